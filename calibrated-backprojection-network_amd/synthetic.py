@@ -1,0 +1,74 @@
+"""Deterministic synthetic frames and weights.
+
+Everything is drawn from `numpy.random.Generator(numpy.random.Philox(seed))`
+so the build container and the GPU box regenerate identical tensors.
+Frame statistics follow the reference's data conventions: images are /255
+normalised (`src/transforms.py:201-204`), sparse depth is a multiple of 1/256 m
+(16-bit PNG / 256, `src/data_utils.py:137-141`), validity = depth > 0
+(`src/kbnet.py:899-902`).
+"""
+
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .config import (KBNetConfig, decoder_param_shapes, encoder_param_shapes,
+                     s2d_param_shapes)
+
+# name -> (density, depth range in metres, intrinsics fx, fy, cx, cy)
+FRAME_STATS = {
+    "kitti": (0.05, (1.0, 80.0), (721.5377, 721.5377, 609.5593, 172.854)),
+    "void": (0.005, (0.3, 5.0), (514.6, 514.6, 320.0, 240.0)),
+    # reference setup/setup_dataset_nyu_v2.py:329-349 (crop-adjusted principal point)
+    "nyu_v2": (0.0063, (0.3, 5.0), (518.8579, 519.4696, 325.5824 - 32.0, 253.7362 - 32.0)),
+}
+
+
+def _rng(seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.Philox(seed))
+
+
+def make_frames(n: int, height: int, width: int, kind: str = "kitti", seed: int = 1,
+                jitter_intrinsics: float = 0.0):
+    """Returns (image N3HW, sparse_depth N1HW, validity N1HW, intrinsics N33), CPU fp32."""
+    density, (lo, hi), (fx, fy, cx, cy) = FRAME_STATS[kind]
+    g = _rng(seed)
+    image = g.random((n, 3, height, width), dtype=np.float32)
+    mask = g.random((n, 1, height, width), dtype=np.float32) < density
+    depth = lo + (hi - lo) * g.random((n, 1, height, width), dtype=np.float32)
+    depth = np.round(depth * 256.0) / 256.0
+    sparse = (depth * mask).astype(np.float32)
+    validity = (sparse > 0).astype(np.float32)
+    k = np.zeros((n, 3, 3), dtype=np.float32)
+    scale = 1.0 + jitter_intrinsics * (2.0 * g.random((n, 4), dtype=np.float32) - 1.0)
+    k[:, 0, 0] = fx * scale[:, 0]
+    k[:, 1, 1] = fy * scale[:, 1]
+    k[:, 0, 2] = cx * scale[:, 2]
+    k[:, 1, 2] = cy * scale[:, 3]
+    k[:, 2, 2] = 1.0
+    return tuple(torch.from_numpy(a) for a in (image, sparse, validity, k))
+
+
+def _xavier_normal(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
+    """N(0, 2/(fan_in+fan_out)) keyed by parameter name (order independent);
+    the reference initialises every conv with `xavier_normal_`
+    (`src/net_utils.py:98-99`)."""
+    fan_in = shape[1] * shape[2] * shape[3]
+    fan_out = shape[0] * shape[2] * shape[3]
+    std = (2.0 / (fan_in + fan_out)) ** 0.5
+    g = _rng((seed << 32) ^ zlib.crc32(name.encode()))
+    return torch.from_numpy((std * g.standard_normal(shape)).astype(np.float32))
+
+
+def make_state_dicts(cfg: KBNetConfig, seed: int = 0, gain: float = 1.0):
+    """Three dicts (S2D, encoder, decoder) keyed like the reference's state_dicts
+    (without the DataParallel `module.` prefix)."""
+    out = []
+    for part, shapes in (("s2d", s2d_param_shapes(cfg)), ("enc", encoder_param_shapes(cfg)),
+                         ("dec", decoder_param_shapes(cfg))):
+        out.append({k: gain * _xavier_normal(part + "/" + k, s, seed) for k, s in shapes.items()})
+    return tuple(out)

@@ -1,0 +1,268 @@
+"""CPU oracle for the KBNet inference hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32) restatement of the reference algorithm
+`KBNetModel.forward` (reference `src/kbnet_model.py:143-186`) and everything below
+it.  It exists to CHECK the HIP path; it is never the thing that is shipped or
+measured as the product:
+
+  * only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline`
+    leg may import it;
+  * the product package (`calibrated-backprojection-network_amd/`) does not
+    import it and raises when its HIP extension is missing.
+
+Pinning (see DESIGN.md "Oracle"): the reference holds no tests or golden
+vectors for this path.  The oracle is pinned against the
+reference ITSELF: `tests/golden/gen_golden.py` imports `/root/reference/src`
+in the build container, runs it on seeded inputs and commits the input/output
+vectors under `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks this
+file against those vectors bit-for-bit, and `tests/test_oracle_vs_reference.py`
+(skipped where `/root/reference` is absent) repeats the comparison at the full
+352x1216 / 480x640 sizes.
+
+Weights are passed as plain dicts keyed exactly like the reference's
+`state_dict()` (without the DataParallel `module.` prefix, which `strip_prefix`
+removes), all OIHW fp32, bias-free.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+NEGATIVE_SLOPE = 0.20  # reference src/net_utils.py:36-37 ('leaky_relu' factory)
+
+
+def strip_prefix(state_dict, prefix="module."):
+    """Checkpoint keys carry `module.` (reference src/kbnet_model.py:392-397)."""
+    return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in state_dict.items()}
+
+
+def conv2d(x, weight, stride=1, slope=NEGATIVE_SLOPE):
+    """Bias-free conv, padding k//2, optional LeakyReLU.
+
+    Reference: net_utils.Conv2d, src/net_utils.py:85-93 (ctor) and :120-141
+    (forward).  `slope=None` is the reference's activation_func=None.
+    """
+    k = weight.shape[-1]
+    y = F.conv2d(x, weight, bias=None, stride=stride, padding=k // 2)
+    if slope is not None:
+        y = F.leaky_relu(y, negative_slope=slope)
+    return y
+
+
+# --------------------------------------------------------------------------- S2D
+def s2d_pool_pyramid(z, min_pool_sizes, max_pool_sizes):
+    """Multi-scale min/max pyramid of the sparse depth channel.
+
+    Reference: SparseToDensePool.forward, src/networks.py:2170-2189, with the
+    pool construction of :2112-2132 (sizes <= 1 dropped, stride 1, pad k//2).
+    Min pool of non-zeros = -maxpool(where(z == 0, -999, -z)), 999 -> 0.
+    """
+    pyramid = []
+    for s in [s for s in min_pool_sizes if s > 1]:
+        neg = torch.where(z == 0, torch.full_like(z, -999.0), -z)
+        p = -F.max_pool2d(neg, kernel_size=s, stride=1, padding=s // 2)
+        p = torch.where(p == 999, torch.zeros_like(z), p)
+        pyramid.append(p)
+    for s in [s for s in max_pool_sizes if s > 1]:
+        pyramid.append(F.max_pool2d(z, kernel_size=s, stride=1, padding=s // 2))
+    return torch.cat(pyramid, dim=1)
+
+
+def sparse_to_dense_pool(x, sd, min_pool_sizes, max_pool_sizes, slope=NEGATIVE_SLOPE,
+                         return_pyramid=False):
+    """S2D: pyramid -> n x conv1x1 -> cat[., x] -> conv3x3.
+
+    Reference: src/networks.py:2168-2196.  `sd` keys: `pool_convs.{i}.conv.weight`,
+    `conv.conv.weight`.
+    """
+    z = x[:, 0:1]
+    pyramid = s2d_pool_pyramid(z, min_pool_sizes, max_pool_sizes)
+    h = pyramid
+    i = 0
+    while f"pool_convs.{i}.conv.weight" in sd:
+        h = conv2d(h, sd[f"pool_convs.{i}.conv.weight"], 1, slope)
+        i += 1
+    h = torch.cat([h, x], dim=1)
+    out = conv2d(h, sd["conv.conv.weight"], 1, slope)
+    return (pyramid, out) if return_pyramid else out
+
+
+# ------------------------------------------------------------------- coordinates
+def pixel_grid(n_batch, height, width):
+    """N x 3 x H x W homogeneous pixel grid (x, y, 1), x in [0, W-1], y in [0, H-1].
+
+    Reference: net_utils.meshgrid, src/net_utils.py:1620-1634.
+    """
+    xs = torch.linspace(start=0.0, end=width - 1, steps=width)
+    ys = torch.linspace(start=0.0, end=height - 1, steps=height)
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    grid = torch.stack([gx, gy, torch.ones_like(gx)], dim=0)
+    return grid.unsqueeze(0).repeat(n_batch, 1, 1, 1)
+
+
+def camera_coordinates(k, height, width):
+    """K^-1 [x y 1]^T for every pixel.  Reference: src/networks.py:317-331."""
+    n = k.shape[0]
+    xy_h = pixel_grid(n, height, width).view(n, 3, -1)
+    return torch.matmul(torch.inverse(k), xy_h).view(n, 3, height, width)
+
+
+def scale_intrinsics(k, height0, width0, height1, width1):
+    """K (.) [[sx,1,sx],[1,sy,sy],[1,1,1]], sx = w1/w0, sy = h1/h0.
+
+    Reference: src/networks.py:333-352.  NOTE the caller (`encoder`) always
+    passes the LEVEL-1 size as (height1, width1): the reference's closure reads
+    `n_width1/n_height1` instead of its arguments (:342-343), so KB levels 2, 3
+    and 4 are all scaled by the half-resolution ratio.
+    """
+    sx = width1 / width0
+    sy = height1 / height0
+    scale = torch.tensor([[sx, 1.0, sx], [1.0, sy, sy], [1.0, 1.0, 1.0]], dtype=torch.float32)
+    return k * scale.view(1, 3, 3)
+
+
+# --------------------------------------------------------------------- KB block
+def kb_block(image, depth, coordinates, fused, sd, slope=NEGATIVE_SLOPE):
+    """Calibrated backprojection block.
+
+    Reference: CalibratedBackprojectionBlock.forward, src/net_utils.py:1343-1371.
+    `sd` keys: conv_image.conv_block.0.conv.weight, conv_depth.conv_block.0.conv.weight,
+    proj_depth.conv.weight, conv_fused.conv.weight.
+    Returns (conv_image, conv_depth, conv_fused), all at ceil(H/2) x ceil(W/2).
+    """
+    conv_image = conv2d(image, sd["conv_image.conv_block.0.conv.weight"], 2, slope)
+    conv_depth = conv2d(torch.cat([depth, coordinates], dim=1),
+                        sd["conv_depth.conv_block.0.conv.weight"], 2, slope)
+    z = conv2d(depth, sd["proj_depth.conv.weight"], 1, slope)
+    xyz = coordinates * z
+    layers = [image, xyz] + ([fused] if fused is not None else [])
+    conv_fused = conv2d(torch.cat(layers, dim=1), sd["conv_fused.conv.weight"], 2, slope)
+    return conv_image, conv_depth, conv_fused
+
+
+def _sub(sd, prefix):
+    p = prefix + "."
+    return {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+
+
+# ---------------------------------------------------------------------- encoder
+def encoder(image, depth, intrinsics, sd, resolutions_backprojection=(0, 1, 2, 3),
+            slope=NEGATIVE_SLOPE, return_trace=False):
+    """KBNetEncoder.forward, reference src/networks.py:301-533.
+
+    Supports the shipped topology family: level 0 must be a KB level (the
+    reference is undefined otherwise); levels 1..3 are KB levels
+    when listed, plain stride-2 VGG blocks otherwise; level 4 is always plain
+    (shipped configs; the reference's level-4 KB branch re-uses block 4, Q3).
+    Returns (latent, [skip1..skip4]).
+    """
+    if 0 not in resolutions_backprojection:
+        raise ValueError("resolution 0 must use calibrated backprojection (reference Q4)")
+    if 4 in resolutions_backprojection:
+        raise ValueError("calibrated backprojection at resolution 4 is not supported")
+    n, _, h0, w0 = image.shape
+    trace = {}
+
+    coords = camera_coordinates(intrinsics, h0, w0)
+    conv_image = conv2d(image, sd["conv0_image.conv.weight"], 1, slope)
+    conv_depth = conv2d(depth, sd["conv0_depth.conv.weight"], 1, slope)
+    trace["coordinates0"] = coords
+    conv_image, conv_depth, conv_fused = kb_block(
+        conv_image, conv_depth, coords, None, _sub(sd, "calibrated_backprojection1"), slope)
+    skips = [torch.cat([conv_fused, conv_depth], dim=1)]
+    h1, w1 = conv_image.shape[-2:]
+
+    for level in (1, 2, 3):
+        hl, wl = conv_image.shape[-2:]
+        if level in resolutions_backprojection:
+            k_l = scale_intrinsics(intrinsics, h0, w0, h1, w1)  # Q1: always level-1 ratio
+            coords = camera_coordinates(k_l, hl, wl)
+            trace[f"intrinsics{level}"] = k_l
+            trace[f"coordinates{level}"] = coords
+            conv_image, conv_depth, conv_fused = kb_block(
+                conv_image, conv_depth, coords, conv_fused,
+                _sub(sd, f"calibrated_backprojection{level + 1}"), slope)
+            skips.append(torch.cat([conv_fused, conv_depth], dim=1))
+        else:
+            src = conv_fused if conv_fused is not None else conv_image
+            conv_image = conv2d(src, sd[f"conv{level + 1}_image.conv_block.0.conv.weight"], 2, slope)
+            conv_depth = conv2d(conv_depth, sd[f"conv{level + 1}_depth.conv_block.0.conv.weight"], 2, slope)
+            conv_fused = None
+            skips.append(torch.cat([conv_image, conv_depth], dim=1))
+
+    src = conv_fused if conv_fused is not None else conv_image
+    conv5_image = conv2d(src, sd["conv5_image.conv_block.0.conv.weight"], 2, slope)
+    conv5_depth = conv2d(conv_depth, sd["conv5_depth.conv_block.0.conv.weight"], 2, slope)
+    latent = torch.cat([conv5_image, conv5_depth], dim=1)
+    if return_trace:
+        return latent, skips, trace
+    return latent, skips
+
+
+# ---------------------------------------------------------------------- decoder
+def decoder_block(x, skip, shape, sd, slope=NEGATIVE_SLOPE):
+    """Nearest-resize -> conv3x3 -> cat skip -> conv3x3.
+
+    Reference: DecoderBlock.forward src/net_utils.py:1453-1487 and
+    UpConv2d.forward :484-499.
+    """
+    if skip is not None:
+        shape = skip.shape[2:4]
+    up = F.interpolate(x, size=tuple(shape), mode="nearest")
+    y = conv2d(up, sd["deconv.conv.conv.weight"], 1, slope)
+    if skip is not None:
+        y = torch.cat([y, skip], dim=1)
+    return conv2d(y, sd["conv.conv.weight"], 1, slope)
+
+
+def decoder(latent, skips, shape, sd, slope=NEGATIVE_SLOPE):
+    """MultiScaleDecoder.forward with n_resolution=1, output_func='linear',
+    deconv_type='up' (reference src/networks.py:1855-1989 as configured at
+    src/kbnet_model.py:127-137).  Returns the full-resolution logits."""
+    x = latent
+    for name, skip in (("deconv4", skips[3]), ("deconv3", skips[2]),
+                       ("deconv2", skips[1]), ("deconv1", skips[0])):
+        x = decoder_block(x, skip, None, _sub(sd, name), slope)
+    x = decoder_block(x, None, shape, _sub(sd, "deconv0"), slope)
+    return conv2d(x, sd["output0.conv.weight"], 1, None)
+
+
+# ---------------------------------------------------------------------- forward
+def depth_head(logits, min_predict_depth, max_predict_depth):
+    """sigmoid then d_min / (s + d_min/d_max).  Reference src/kbnet_model.py:181-184."""
+    s = torch.sigmoid(logits)
+    return min_predict_depth / (s + min_predict_depth / max_predict_depth)
+
+
+def kbnet_forward(image, sparse_depth, validity_map_depth, intrinsics,
+                  sd_s2d, sd_encoder, sd_decoder,
+                  min_pool_sizes, max_pool_sizes,
+                  min_predict_depth, max_predict_depth,
+                  resolutions_backprojection=(0, 1, 2, 3), slope=NEGATIVE_SLOPE):
+    """KBNetModel.forward, reference src/kbnet_model.py:143-186."""
+    with torch.no_grad():
+        x = torch.cat([sparse_depth, validity_map_depth], dim=1)
+        d = sparse_to_dense_pool(x, strip_prefix(sd_s2d), min_pool_sizes, max_pool_sizes, slope)
+        latent, skips = encoder(image, d, intrinsics, strip_prefix(sd_encoder),
+                                resolutions_backprojection, slope)
+        logits = decoder(latent, skips, d.shape[-2:], strip_prefix(sd_decoder), slope)
+        return depth_head(logits, min_predict_depth, max_predict_depth)
+
+
+# ------------------------------------------------------- "next" rows
+def validity_and_outlier_removal(sparse_depth, kernel_size=7, threshold=1.5):
+    """Validity map + outlier removal, reference src/kbnet.py:899-908 and
+    OutlierRemoval.remove_outliers src/net_utils.py:1761-1806.  Note the
+    batch-global `10 * max(sparse_depth)` fill value (:1776)."""
+    validity = torch.where(sparse_depth > 0, torch.ones_like(sparse_depth), sparse_depth)
+    max_value = 10 * torch.max(sparse_depth)
+    filled = torch.where(validity <= 0, torch.full_like(sparse_depth, fill_value=float(max_value)),
+                         sparse_depth)
+    pad = kernel_size // 2
+    filled = F.pad(filled, (pad, pad, pad, pad), mode="constant", value=float(max_value))
+    min_values = -F.max_pool2d(-filled, kernel_size=kernel_size, stride=1, padding=0)
+    keep = torch.where(min_values < sparse_depth - threshold,
+                       torch.zeros_like(validity), torch.ones_like(validity))
+    validity_clean = validity * keep
+    return sparse_depth * validity_clean, validity_clean

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name):
+    """Returns a dict; keys 'group::name' are regrouped into nested dicts of tensors."""
+    raw = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    out = {}
+    for k in raw.files:
+        v = raw[k]
+        val = torch.from_numpy(v) if v.dtype.kind == "f" else v
+        if "::" in k:
+            grp, sub = k.split("::", 1)
+            out.setdefault(grp, {})[sub] = val
+        else:
+            out[k] = val
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|, tiny) over the tensor: the 1e-4 parity gate's metric."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

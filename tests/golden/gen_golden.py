@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING THE REFERENCE on CPU.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/gen_golden.py
+
+It imports `/root/reference/src` (read-only; `torchvision` is stubbed because
+`kbnet_model.py:17` imports it for TensorBoard image grids only), feeds seeded
+synthetic inputs and Philox-keyed weights through the reference's own classes
+and stores {inputs, weights, outputs} as small `.npz` files next to this script.
+Nothing of the reference's source is stored: the fixtures are data.
+
+Cases
+  s2d_*      networks.SparseToDensePool: pyramid (pre-hook on pool_convs) + output,
+             incl. a hand-made map: isolated points, border points, an all-zero
+             window, a depth of exactly 999.0 and one above 999.
+  coords_*   encoder closures camera_coordinates/scale_intrinsics captured through
+             forward pre-hooks on the four KB blocks (pins Q1/Q2/Q9).
+  kb_*       net_utils.CalibratedBackprojectionBlock with / without `fused`, odd size.
+  dec_*      networks.MultiScaleDecoder (n_resolution=1, 'up', linear output).
+  fwd_*      KBNetModel.forward: KITTI preset, VOID preset (both narrow channels)
+             and an odd 70x100 frame.
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+
+import kbnet_amd as kb  # noqa: E402
+import kbnet_model  # noqa: E402  (reference)
+import net_utils  # noqa: E402  (reference)
+import networks  # noqa: E402  (reference)
+
+torch.set_grad_enabled(False)
+
+
+def np_sd(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def load(module, sd):
+    own = module.state_dict()
+    pref = "module." if next(iter(own)).startswith("module.") else ""
+    module.load_state_dict({pref + k: v for k, v in sd.items()}, strict=True)
+
+
+def save(name, **arrays):
+    flat = {}
+    for k, v in arrays.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}::{kk}"] = np.asarray(vv)
+        else:
+            flat[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def build_reference_model(cfg):
+    return kbnet_model.KBNetModel(
+        input_channels_image=cfg.input_channels_image,
+        input_channels_depth=cfg.input_channels_depth,
+        min_pool_sizes_sparse_to_dense_pool=list(cfg.min_pool_sizes_sparse_to_dense_pool),
+        max_pool_sizes_sparse_to_dense_pool=list(cfg.max_pool_sizes_sparse_to_dense_pool),
+        n_convolution_sparse_to_dense_pool=cfg.n_convolution_sparse_to_dense_pool,
+        n_filter_sparse_to_dense_pool=cfg.n_filter_sparse_to_dense_pool,
+        n_filters_encoder_image=list(cfg.n_filters_encoder_image),
+        n_filters_encoder_depth=list(cfg.n_filters_encoder_depth),
+        resolutions_backprojection=list(cfg.resolutions_backprojection),
+        n_filters_decoder=list(cfg.n_filters_decoder),
+        deconv_type=cfg.deconv_type,
+        weight_initializer=cfg.weight_initializer,
+        activation_func=cfg.activation_func,
+        min_predict_depth=cfg.min_predict_depth,
+        max_predict_depth=cfg.max_predict_depth,
+        device=torch.device("cpu"))
+
+
+# ------------------------------------------------------------------------- S2D
+def handmade_depth():
+    z = np.zeros((1, 1, 24, 30), dtype=np.float32)
+    z[0, 0, 0, 0] = 3.5          # corner
+    z[0, 0, 0, 17] = 12.25       # top border
+    z[0, 0, 23, 29] = 7.0        # opposite corner
+    z[0, 0, 11, 0] = 1.0         # left border
+    z[0, 0, 10, 12] = 999.0      # exactly the sentinel value (Q6)
+    z[0, 0, 10, 14] = 1500.0     # above the sentinel
+    z[0, 0, 5, 6] = 2.0
+    z[0, 0, 5, 7] = 40.0         # neighbours: min != max
+    z[0, 0, 18, 20] = 0.00390625  # 1/256, the smallest PNG depth
+    return torch.from_numpy(z)
+
+
+def gen_s2d():
+    for preset in ("kitti", "void"):
+        cfg = kb.PRESETS[preset]()
+        sd = kb.synthetic.make_state_dicts(cfg, seed=3, gain=2.0)[0]
+        m = networks.SparseToDensePool(
+            input_channels=cfg.input_channels_depth,
+            min_pool_sizes=list(cfg.min_pool_sizes_sparse_to_dense_pool),
+            max_pool_sizes=list(cfg.max_pool_sizes_sparse_to_dense_pool),
+            n_convolution=cfg.n_convolution_sparse_to_dense_pool,
+            n_filter=cfg.n_filter_sparse_to_dense_pool,
+            weight_initializer=cfg.weight_initializer,
+            activation_func=cfg.activation_func).eval()
+        load(m, sd)
+        captured = {}
+        m.pool_convs.register_forward_pre_hook(lambda mod, args: captured.__setitem__("p", args[0].clone()))
+        zs = [handmade_depth()]
+        _, sp, _, _ = kb.synthetic.make_frames(2, 40, 56, preset, seed=11)
+        zs.append(sp)
+        # denser map so that min != max almost everywhere
+        zs.append(kb.synthetic.make_frames(1, 33, 47, "kitti", seed=12)[1] *
+                  (torch.rand(1, 1, 33, 47, generator=torch.Generator().manual_seed(5)) < 0.7))
+        for i, z in enumerate(zs):
+            x = torch.cat([z, (z > 0).float()], dim=1)
+            out = m(x)
+            save(f"s2d_{preset}_{i}", x=x, weights=np_sd(sd), pyramid=captured["p"], out=out,
+                 min_pool_sizes=np.array(cfg.min_pool_sizes_sparse_to_dense_pool),
+                 max_pool_sizes=np.array(cfg.max_pool_sizes_sparse_to_dense_pool))
+
+
+# ------------------------------------------------------------------ coordinates
+def gen_coords():
+    cfg = kb.kitti_config().narrow()
+    model = build_reference_model(cfg)
+    enc = model.encoder.module if hasattr(model.encoder, "module") else model.encoder
+    cases = {
+        "kitti": (kb.synthetic.make_frames(2, 64, 96, "kitti", seed=21, jitter_intrinsics=0.1), 64, 96),
+        "nyu": (kb.synthetic.make_frames(1, 96, 128, "nyu_v2", seed=22), 96, 128),
+        "odd": (kb.synthetic.make_frames(1, 70, 100, "void", seed=23), 70, 100),
+    }
+    for name, ((image, sparse, valid, k), h, w) in cases.items():
+        if name == "odd":
+            k = k.clone()
+            k[:, 0, 1] = 0.37  # skew: Q2 leaves it unscaled
+        cap = {}
+        hooks = []
+        for lvl in range(4):
+            blk = getattr(enc, f"calibrated_backprojection{lvl + 1}")
+            hooks.append(blk.register_forward_pre_hook(
+                (lambda lv: lambda mod, args, kwargs: cap.__setitem__(lv, kwargs["coordinates"].clone()))(lvl),
+                with_kwargs=True))
+        model.forward(image, sparse, valid, k)
+        for hk in hooks:
+            hk.remove()
+        save(f"coords_{name}", intrinsics=k, height=np.array(h), width=np.array(w),
+             **{f"coordinates{lv}": cap[lv] for lv in range(4)})
+
+
+# --------------------------------------------------------------------- KB block
+def gen_kb():
+    g = torch.Generator().manual_seed(31)
+    act = net_utils.activation_func("leaky_relu")
+    for name, (ci, cd, cf_prev, fi, fd, ff, h, w, with_fused) in {
+        "nofused": (8, 4, 0, 8, 4, 8, 20, 28, False),
+        "fused": (8, 4, 8, 16, 8, 16, 18, 24, True),
+        "odd": (6, 5, 7, 10, 6, 9, 13, 19, True),
+    }.items():
+        in_fused = ci + cf_prev if with_fused else ci
+        blk = net_utils.CalibratedBackprojectionBlock(
+            in_channels_image=ci, in_channels_depth=cd, in_channels_fused=in_fused,
+            n_filter_image=fi, n_filter_depth=fd, n_filter_fused=ff,
+            weight_initializer="xavier_normal", activation_func=act).eval()
+        sd = {k: torch.randn(v.shape, generator=g) * (2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+              for k, v in blk.state_dict().items()}
+        blk.load_state_dict(sd)
+        n = 2
+        image = torch.randn(n, ci, h, w, generator=g)
+        depth = torch.randn(n, cd, h, w, generator=g)
+        fused = torch.randn(n, cf_prev, h, w, generator=g) if with_fused else None
+        k = kb.synthetic.make_frames(n, h, w, "void", seed=32, jitter_intrinsics=0.2)[3]
+        k[:, 0, 0] = 30.0
+        k[:, 1, 1] = 28.0
+        k[:, 0, 2] = w / 2.0
+        k[:, 1, 2] = h / 2.0
+        xy = net_utils.meshgrid(n, h, w, device=torch.device("cpu"), homogeneous=True).view(n, 3, -1)
+        coords = torch.matmul(torch.inverse(k), xy).view(n, 3, h, w)
+        ci_o, cd_o, cf_o = blk(image=image, depth=depth, coordinates=coords, fused=fused)
+        arrays = dict(image=image, depth=depth, coordinates=coords, intrinsics=k,
+                      weights=np_sd(sd), conv_image=ci_o, conv_depth=cd_o, conv_fused=cf_o)
+        if with_fused:
+            arrays["fused"] = fused
+        save(f"kb_{name}", **arrays)
+
+
+# ---------------------------------------------------------------------- decoder
+def gen_decoder():
+    cfg = kb.kitti_config().narrow()
+    sd = kb.synthetic.make_state_dicts(cfg, seed=4, gain=1.5)[2]
+    enc_ch = [i + z for i, z in zip(cfg.n_filters_encoder_image, cfg.n_filters_encoder_depth)]
+    dec = networks.MultiScaleDecoder(
+        input_channels=enc_ch[-1], output_channels=1, n_resolution=1,
+        n_filters=list(cfg.n_filters_decoder), n_skips=cfg.n_skips,
+        weight_initializer="xavier_normal", activation_func="leaky_relu",
+        output_func="linear", use_batch_norm=False, deconv_type="up").eval()
+    load(dec, sd)
+    g = torch.Generator().manual_seed(41)
+    for name, (h, w) in {"even": (64, 96), "odd": (70, 100)}.items():
+        sizes = [(h, w)]
+        for _ in range(5):
+            sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+        latent = torch.randn(1, enc_ch[4], *sizes[5], generator=g)
+        skips = [torch.randn(1, enc_ch[i], *sizes[i + 1], generator=g) for i in range(4)]
+        out = dec(latent, skips, (h, w))[-1]
+        save(f"dec_{name}", latent=latent, weights=np_sd(sd), logits=out, shape=np.array([h, w]),
+             **{f"skip{i + 1}": s for i, s in enumerate(skips)})
+
+
+# ----------------------------------------------------------------- full forward
+def gen_forward():
+    for name, preset, (h, w), n in (("kitti", "kitti", (64, 96), 2),
+                                    ("void", "void", (96, 128), 1),
+                                    ("odd", "void", (70, 100), 1)):
+        cfg = kb.PRESETS[preset]().narrow()
+        # gain > 1 keeps the logits O(1) (random xavier weights shrink the signal), so the
+        # sigmoid head is exercised off its saturated ends
+        sds = kb.synthetic.make_state_dicts(cfg, seed=5, gain=1.3 if preset == "kitti" else 1.45)
+        model = build_reference_model(cfg)
+        model.eval()
+        load(model.sparse_to_dense_pool, sds[0])
+        load(model.encoder, sds[1])
+        load(model.decoder, sds[2])
+        density_kind = preset
+        image, sparse, valid, k = kb.synthetic.make_frames(n, h, w, density_kind, seed=51,
+                                                           jitter_intrinsics=0.05)
+        if preset == "void":
+            # denser than VOID so small frames still hold a few dozen points
+            g = np.random.Generator(np.random.Philox(52))
+            m = torch.from_numpy((g.random((n, 1, h, w), dtype=np.float32) < 0.03))
+            d = torch.from_numpy(np.round((0.3 + 4.7 * g.random((n, 1, h, w), dtype=np.float32)) * 256) / 256)
+            sparse = (d * m).float()
+            valid = (sparse > 0).float()
+        out = model.forward(image, sparse, valid, k)
+        save(f"fwd_{name}", image=image, sparse_depth=sparse, validity_map=valid, intrinsics=k,
+             output_depth=out, preset=np.array(preset),
+             s2d=np_sd(sds[0]), encoder=np_sd(sds[1]), decoder=np_sd(sds[2]))
+
+
+if __name__ == "__main__":
+    gen_s2d()
+    gen_coords()
+    gen_kb()
+    gen_decoder()
+    gen_forward()

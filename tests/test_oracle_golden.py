@@ -1,0 +1,68 @@
+"""CPU: the oracle restatement reproduces the reference's captured outputs bit-for-bit."""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import kbnet_oracle as orc
+
+import kbnet_amd as kb
+
+
+@pytest.mark.parametrize("name", [f"s2d_{p}_{i}" for p in ("kitti", "void") for i in range(3)])
+def test_s2d_matches_reference(name):
+    g = load_golden(name)
+    pyr, out = orc.sparse_to_dense_pool(g["x"], g["weights"], list(g["min_pool_sizes"]),
+                                        list(g["max_pool_sizes"]), return_pyramid=True)
+    assert torch.equal(pyr, g["pyramid"])
+    assert torch.equal(out, g["out"])
+
+
+def test_s2d_sentinel_quirk():
+    """Q6: a depth of exactly 999 (and a lone depth above it) min-pools to 0."""
+    g = load_golden("s2d_kitti_0")
+    pyr = g["pyramid"]
+    assert g["x"][0, 0, 10, 12] == 999.0 and g["x"][0, 0, 10, 14] == 1500.0
+    assert pyr[0, 0, 10, 12] == 0.0          # k=5 window holds only 999 and 1500
+    assert pyr[0, 5, 10, 12] == 1500.0       # max pool sees it
+
+
+@pytest.mark.parametrize("name", ["coords_kitti", "coords_nyu", "coords_odd"])
+def test_coordinates_match_reference(name):
+    g = load_golden(name)
+    k, h, w = g["intrinsics"], int(g["height"]), int(g["width"])
+    h1, w1 = (h + 1) // 2, (w + 1) // 2
+    hl, wl = h, w
+    for lvl in range(4):
+        kl = k if lvl == 0 else orc.scale_intrinsics(k, h, w, h1, w1)
+        c = orc.camera_coordinates(kl, hl, wl)
+        assert torch.equal(c, g[f"coordinates{lvl}"]), lvl
+        assert torch.all(c[:, 2] == 1.0)  # Q9
+        hl, wl = (hl + 1) // 2, (wl + 1) // 2
+
+
+@pytest.mark.parametrize("name", ["kb_nofused", "kb_fused", "kb_odd"])
+def test_kb_block_matches_reference(name):
+    g = load_golden(name)
+    ci, cd, cf = orc.kb_block(g["image"], g["depth"], g["coordinates"], g.get("fused"), g["weights"])
+    assert torch.equal(ci, g["conv_image"])
+    assert torch.equal(cd, g["conv_depth"])
+    assert torch.equal(cf, g["conv_fused"])
+
+
+@pytest.mark.parametrize("name", ["dec_even", "dec_odd"])
+def test_decoder_matches_reference(name):
+    g = load_golden(name)
+    skips = [g[f"skip{i}"] for i in range(1, 5)]
+    out = orc.decoder(g["latent"], skips, tuple(int(v) for v in g["shape"]), g["weights"])
+    assert torch.equal(out, g["logits"])
+
+
+@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd"])
+def test_forward_matches_reference(name):
+    g = load_golden(name)
+    cfg = kb.PRESETS[str(g["preset"])]().narrow()
+    out = orc.kbnet_forward(g["image"], g["sparse_depth"], g["validity_map"], g["intrinsics"],
+                            g["s2d"], g["encoder"], g["decoder"],
+                            cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+    assert torch.equal(out, g["output_depth"])
+    assert out.min() >= cfg.min_predict_depth * 0.98 and out.max() <= cfg.max_predict_depth * 1.001
