@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the KBNet inference hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one `KBNetModel.forward` over this rank's batch of synthetic KITTI-shaped
+frames (352 x 1216, fp32, inputs resident in HBM), followed -- for N > 1 -- by the RCCL
+all-gather of the depth maps.  Frames shard across ranks (weak scaling: 8 frames per GPU,
+BASELINE.json configs[1]); there is no other collective on the data path.  Rank 0 prints
+ONE JSON line.  `roofline` is measured live with HIP events around every launch of the
+dominant kernel (the fp32 MFMA implicit-GEMM conv variant with the largest total time);
+`cpu_baseline` times the CPU oracle (the port of the reference, bit-identical to it) on
+this box's host cores over a bounded sample.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import kbnet_amd as kb  # noqa: E402
+
+HEIGHT, WIDTH = 352, 1216
+FRAMES_PER_GPU = 8
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32, dense
+HBM_PEAK_GBS = 8000.0
+WEIGHT_GAIN = 1.3  # keeps random-weight logits O(1) so the sigmoid head is off saturation
+
+
+def conv_gflop_per_frame(cfg, h, w):
+    """Algorithmic conv work of one forward (2*MAC), from the parameter shapes and the
+    resolution each conv runs at (100.722 GFLOP at 352x1216)."""
+    sizes = [(h, w)]
+    for _ in range(5):
+        sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+    px = [a * b for a, b in sizes]
+    total = 0.0
+    for k, s in kb.config.s2d_param_shapes(cfg).items():
+        total += 2.0 * px[0] * s[0] * s[1] * s[2] * s[3]
+    for k, s in kb.config.encoder_param_shapes(cfg).items():
+        macs = s[0] * s[1] * s[2] * s[3]
+        if k.startswith("conv0_"):
+            lvl = 0
+        elif k.startswith("conv5_"):
+            lvl = 5
+        elif "proj_depth" in k:
+            lvl = int(k.split(".")[0][-1]) - 1  # evaluated by the reference at full block resolution
+        else:
+            lvl = int(k.split(".")[0][-1]) if "calibrated" in k else int(k[4])
+        total += 2.0 * px[lvl] * macs
+    for k, s in kb.config.decoder_param_shapes(cfg).items():
+        lvl = 0 if k.startswith("output0") else int(k[6])
+        total += 2.0 * px[lvl] * s[0] * s[1] * s[2] * s[3]
+    return total / 1e9
+
+
+def cpu_baseline(cfg, sds, budget_s=15.0, max_frames=6):
+    """Oracle (CPU port of the reference) on this box's host cores, one frame at a time
+    like the reference's own loop (reference src/kbnet.py:887)."""
+    from oracle import kbnet_oracle as orc
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    frames = kb.synthetic.make_frames(1, HEIGHT, WIDTH, "kitti", seed=1)
+    run = lambda: orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools,
+                                    cfg.min_predict_depth, cfg.max_predict_depth)
+    ref = run()  # warm-up (also the parity reference for frame 0 of rank 0)
+    t0 = time.perf_counter()
+    done = 0
+    while done < max_frames and (time.perf_counter() - t0 < budget_s or done == 0):
+        run()
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} KITTI 352x1216 frames, batch 1, fp32, oracle/kbnet_oracle.py (torch CPU)"}, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = kb.dist.init("nccl")
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=WEIGHT_GAIN)
+    model = kb.modules.KBNetModel.from_config(cfg, dev)
+    model.load_state_dicts(*sds)
+    per = args.frames_per_gpu
+    # rank r holds frames [r*per, (r+1)*per) of the global batch (seed 1+rank; frame 0 of
+    # rank 0 is the frame the CPU oracle sees)
+    frames = kb.synthetic.make_frames(per, HEIGHT, WIDTH, "kitti", seed=1 + rank)
+    frames = [f.to(dev) for f in frames]
+    runner = kb.dist.ShardedRunner(model.forward, rank, world)
+
+    for _ in range(args.warmup):
+        out = runner.step(frames, n_total=per * world)
+    torch.cuda.synchronize()
+
+    kb.ops.PROFILE = []
+    kb.dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = runner.step(frames, n_total=per * world)
+    torch.cuda.synchronize()
+    kb.dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof, kb.ops.PROFILE = kb.ops.PROFILE, None
+    elapsed = kb.dist.max_over_ranks(elapsed, dev)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    fps = per * world * args.steps / elapsed
+    gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
+
+    # ---- roofline of the dominant kernel (rank 0's launches) ----
+    groups = {}
+    for name, work, s, e in prof:
+        g = groups.setdefault(name, [0.0, 0.0, 0])
+        g[0] += work
+        g[1] += s.elapsed_time(e) * 1e-3
+        g[2] += 1
+    breakdown = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3),
+                     "avg_us": round(v[1] / v[2] * 1e6, 2)} for k, v in groups.items()}
+    conv_groups = {k: v for k, v in groups.items() if k.startswith("conv_igemm")}
+    dom = max(conv_groups, key=lambda k: conv_groups[k][1])
+    dwork, dtime, dlaunch = conv_groups[dom]
+    achieved = dwork / dtime / 1e12
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": dlaunch, "avg_launch_us": round(dtime / dlaunch * 1e6, 2),
+                "flop_per_launch": dwork / dlaunch,
+                "whole_forward_frac": round(fps / world * gflop_frame / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    s2d = groups.get("s2d")
+    if s2d:
+        gbs = s2d[0] / s2d[1] / 1e9
+        roofline["s2d_hbm"] = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_us": round(s2d[1] / s2d[2] * 1e6, 2)}
+
+    result = {
+        "metric": "depth-completion frames/sec at 352x1216", "value": round(fps, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"KITTI 352x1216, batch {per}/GPU, fp32, full KBNet forward in HIP "
+                               "(S2D + KB layers + MFMA convs + head), random xavier weights",
+                   "frames_per_gpu": per, "global_batch": per * world, "height": HEIGHT, "width": WIDTH,
+                   "gflop_per_frame": round(gflop_frame, 3),
+                   "parallelism": f"frames sharded over {world} rank(s), RCCL all-gather of outputs"},
+        "roofline": roofline, "kernels": breakdown,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, ref = cpu_baseline(cfg, sds)
+        result["cpu_baseline"] = base
+        got = out[0:1].cpu()
+        result["parity"] = {"max_rel_err_vs_oracle": float(((got - ref).abs() / ref.abs()).max()),
+                            "mae_vs_oracle_m": float((got - ref).abs().mean()), "tolerance": 1e-4}
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

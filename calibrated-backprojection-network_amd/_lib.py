@@ -1,0 +1,93 @@
+"""ctypes binding of libkbnet_hip.so (the C ABI declared in include/kbnet_hip.h).
+
+`import torch` happens before `ctypes.CDLL` on purpose: torch bundles its own
+libamdhip64 with the same SONAME as /opt/rocm's, and the extension must bind to the
+HIP runtime that is already loaded so streams and device pointers are shared.
+There is NO fallback: a missing library is an error, never a silent CPU path.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkbnet_hip.so")
+
+KBN_OK = 0
+KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ = 0, 1, 2
+KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
+KBN_MAX_SRC = 3
+ABI_VERSION = 1
+
+
+class KbnError(RuntimeError):
+    pass
+
+
+class ConvSrc(C.Structure):
+    """Mirror of `kbn_conv_src` (include/kbnet_hip.h)."""
+    _fields_ = [
+        ("kind", C.c_int),
+        ("channels", C.c_int),
+        ("data", C.c_void_p),
+        ("batch_stride", C.c_longlong),
+        ("src_height", C.c_int),
+        ("src_width", C.c_int),
+        ("aux_channels", C.c_int),
+        ("proj_weight", C.c_void_p),
+        ("coordinates", C.c_void_p),
+        ("coordinates_batch_stride", C.c_longlong),
+        ("kinv", C.c_void_p),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/kbnet_hip.h declares
+SIGNATURES = {
+    "kbn_version": (_I, []),
+    "kbn_status_string": (C.c_char_p, [_I]),
+    "kbn_s2d_forward": (_I, [_P, C.POINTER(_P), _P, _P, _I, _I, _I, _I, C.POINTER(_I), _I,
+                             C.POINTER(_I), _I, _I, _I, _F, _P]),
+    "kbn_s2d_pyramid": (_I, [_P, _L, _P, _I, _I, _I, C.POINTER(_I), _I, C.POINTER(_I), _I, _P]),
+    "kbn_intrinsics_inverse": (_I, [_P, _P, _I, _F, _F, _P]),
+    "kbn_camera_coordinates": (_I, [_P, _P, _I, _I, _I, _P]),
+    "kbn_conv2d_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
+    "kbn_conv2d_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "kbn_conv2d_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I,
+                                _F, _P]),
+    "kbn_kb_block_forward": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P,
+                                  _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_depth_head_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library once; raises KbnError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KbnError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (needs hipcc).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kbn_version() != ABI_VERSION:
+        raise KbnError(f"libkbnet_hip.so ABI {lib.kbn_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != KBN_OK:
+        msg = load().kbn_status_string(status).decode()
+        raise KbnError(f"{what} failed: {msg} (status {status})")

@@ -1,0 +1,468 @@
+// conv_igemm.hip -- fp32 implicit-GEMM convolution on the gfx950 matrix cores.
+//
+// Replaces net_utils.Conv2d.forward (reference src/net_utils.py:120-141) together with
+// the torch.cat / interpolate(nearest) / coordinate-channel ops the reference runs in
+// front of it (src/net_utils.py:497, 1351-1368, 1483).  NCHW fp32 in, NCHW fp32 out.
+//
+// GEMM view:  M = output pixels, N = output channels, K = (input channel, tap).
+//   D[pixel][oc] += A[pixel][k] * B[k][oc]       v_mfma_f32_16x16x4_f32 (exact fp32)
+// A workgroup (256 threads = 4 waves) owns a TH x TW pixel tile (TW a multiple of 16,
+// TH*TW/16 = 4*MW "m-blocks" of 16 consecutive pixels of one row) times NT = 16*NB output
+// channels.  Each wave owns MW m-blocks x all NB n-blocks (MW*NB accumulators of 4 VGPRs).
+//
+// K loop: channels are consumed CK at a time.  Per chunk the workgroup stages
+//   As[CK][plane]   the input tile incl. halo for CK channels (zero padded), and
+//   Bs[CK*TAPS*NT]  the pre-packed weight slice (a straight 16-byte copy),
+// then runs TAPS * CK/4 MFMA k-steps out of LDS.  All 9 taps re-use one staged tile.
+//
+// LDS layout (bank-conflict free for ds_read_b32, which is serviced per 32-lane half):
+//   A: lane (i = l&15, k = l>>4) reads As[(c4*4+k)*plane + row*pitch + col + i]; plane = 16
+//      (mod 32) puts the k=0 / k=1 rows of a half-wave on disjoint 16-bank groups.
+//      Stride-2 3x3 convs de-interleave the staged columns by parity so that the 16 lanes
+//      of a fragment still read consecutive words.
+//   B: fragment order [k>>1][n][k&1] -> the 32 lanes of a half-wave read 32 consecutive words.
+#include "kbn_common.h"
+
+namespace kbn {
+
+struct SrcDev {
+    const float* data;
+    const float* proj;
+    const float* coords;
+    const float* kinv;
+    long long bstride;
+    long long coords_bstride;
+    int kind, C, H, W, Cd, cstart;
+};
+
+struct ConvParams {
+    SrcDev src[KBN_MAX_SRC];
+    const float* wp;
+    float* out;
+    long long out_bstride;
+    int nsrc, N, OC, Ctot, Cpad;
+    int inH, inW, outH, outW;
+    int resize;
+    int tilesX, tilesY, nTilesN, nblocks;
+    int TWB, TH;
+    int rowsS, colsS;
+    int pitch, plane, PH;
+    int act;
+    float slope;
+};
+
+struct ConvPlan {
+    int CK, NB, MW, nTilesN, Cpad, NT;
+};
+
+__host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks) {
+    ConvPlan pl;
+    pl.CK = (ks == 1) ? 16 : (cin <= 4 ? 4 : 8);
+    int nblk = ceil_div(oc, 16);
+    // pick NB in 1..4 minimising padded n-blocks, ties -> larger NB
+    int best = 1, bestpad = 1 << 30;
+    for (int nb = 1; nb <= 4; ++nb) {
+        int pad = ceil_div(nblk, nb) * nb;
+        if (pad < bestpad || (pad == bestpad && nb > best)) { best = nb; bestpad = pad; }
+    }
+    pl.NB = best;
+    pl.MW = (best >= 3) ? 4 : 8;
+    pl.nTilesN = ceil_div(nblk, best);
+    pl.NT = best * 16;
+    pl.Cpad = round_up(cin, pl.CK);
+    return pl;
+}
+
+// ---------------------------------------------------------------- weight packing
+// packed[nt][chunk][tap][c4][k>>1][n][k&1]  (zero padded in both c and oc)
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int OC,
+                                   int Cin, int taps, ConvPlan pl, long long total) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int NT = pl.NT, CK = pl.CK;
+    long long per_nt = (long long)pl.Cpad * taps * NT;
+    int nt = (int)(e / per_nt);
+    int rem = (int)(e - (long long)nt * per_nt);
+    int per_chunk = CK * taps * NT;
+    int chunk = rem / per_chunk;
+    rem -= chunk * per_chunk;
+    int per_tap = CK * NT;  // (CK/4) * 4 * NT
+    int tap = rem / per_tap;
+    rem -= tap * per_tap;
+    int c4 = rem / (4 * NT);
+    rem -= c4 * 4 * NT;
+    int khalf = rem / (2 * NT);
+    rem -= khalf * 2 * NT;
+    int nn = rem >> 1, klow = rem & 1;
+    int c = chunk * CK + c4 * 4 + khalf * 2 + klow;
+    int oc = nt * NT + nn;
+    float v = 0.f;
+    if (c < Cin && oc < OC) v = w[((long long)oc * Cin + c) * taps + tap];
+    packed[e] = v;
+}
+
+// ------------------------------------------------------------------- the kernel
+template <int KS, int STRIDE, int CK, int NB, int MW, int MAXPOS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int TAPS = KS * KS;
+    constexpr int PAD = KS / 2;
+    constexpr int STEP = (KS == 1) ? STRIDE : 1;  // spacing of staged positions in the input
+    constexpr bool S2 = (KS == 3 && STRIDE == 2);
+    constexpr int NT = NB * 16;
+    constexpr int NC4 = CK / 4;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + CK * p.plane;
+
+    const int tid = threadIdx.x;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int TW = p.TWB * 16;
+    const int oy0 = ty * p.TH, ox0 = tx * TW;
+
+    // ---- staging table: which input element / LDS word each thread moves -------------
+    int goff[MAXPOS], loff[MAXPOS];
+    {
+        const int Y0 = oy0 * STRIDE - PAD, X0 = ox0 * STRIDE - PAD;
+        const int npos = p.rowsS * p.colsS;
+        const int srcH = p.src[0].H, srcW = p.src[0].W;
+#pragma unroll
+        for (int u = 0; u < MAXPOS; ++u) {
+            int pos = tid + u * 256;
+            int g = -1, l = -1;
+            if (pos < npos) {
+                int r = pos / p.colsS;
+                int ci = pos - r * p.colsS;
+                int Y = Y0 + r * STEP, X = X0 + ci * STEP;
+                l = S2 ? (r * p.pitch + (ci & 1) * p.PH + (ci >> 1)) : (r * p.pitch + ci);
+                if (Y >= 0 && Y < p.inH && X >= 0 && X < p.inW) {
+                    if (p.resize) {
+                        g = nearest_src_index(Y, srcH, p.inH) * srcW + nearest_src_index(X, srcW, p.inW);
+                    } else {
+                        g = Y * p.inW + X;
+                    }
+                }
+            }
+            goff[u] = g;
+            loff[u] = l;
+        }
+    }
+
+    // ---- per-lane fragment addressing ----------------------------------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    int mbase[MW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        int mb = wave * MW + mi;
+        int oy = mb / p.TWB;
+        int seg = mb - oy * p.TWB;
+        mbase[mi] = (S2 ? 2 * oy : oy) * p.pitch + seg * 16 + li + lk * p.plane;
+    }
+    const int boff = (lk >> 1) * 2 * NT + li * 2 + (lk & 1);
+
+    f32x4 acc[MW][NB];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* wp_nt = p.wp + (long long)nt * p.Cpad * TAPS * NT;
+
+    for (int c0 = 0; c0 < p.Cpad; c0 += CK) {
+        __syncthreads();  // previous chunk's fragments are consumed
+        // ---- stage B: packed weight slice, straight copy ----
+        {
+            const float4* s4 = reinterpret_cast<const float4*>(wp_nt + (long long)c0 * TAPS * NT);
+            float4* d4 = reinterpret_cast<float4*>(Bs);
+            constexpr int CNT4 = CK * TAPS * NT / 4;
+            for (int e = tid; e < CNT4; e += 256) d4[e] = s4[e];
+        }
+        // ---- stage A: CK channels of the concat [src0 | src1 | src2], zero padded ----
+        for (int s = 0; s < p.nsrc; ++s) {
+            const SrcDev& sd = p.src[s];
+            int lo = c0 > sd.cstart ? c0 : sd.cstart;
+            int hi = (c0 + CK < sd.cstart + sd.C) ? (c0 + CK) : (sd.cstart + sd.C);
+            if (lo >= hi) continue;
+            const int cnt = hi - lo;
+            float* dst = As + (lo - c0) * p.plane;
+            if (sd.kind == KBN_SRC_TENSOR) {
+                const int HW = sd.H * sd.W;
+                const float* base = sd.data + (long long)n * sd.bstride + (long long)(lo - sd.cstart) * HW;
+#pragma unroll
+                for (int u = 0; u < MAXPOS; ++u) {
+                    if (loff[u] < 0) continue;
+                    float v[CK];
+#pragma unroll
+                    for (int q = 0; q < CK; ++q)
+                        v[q] = (q < cnt && goff[u] >= 0) ? base[q * HW + goff[u]] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < CK; ++q)
+                        if (q < cnt) dst[q * p.plane + loff[u]] = v[q];
+                }
+            } else {
+                // synthesized channels (KB layer): coordinates K^-1 [x y 1]^T, optionally times
+                // z = act(proj . depth[:, y, x]) -- reference src/net_utils.py:1351-1360
+                const float* kinv = sd.kinv ? sd.kinv + (long long)n * 9 : nullptr;
+#pragma unroll
+                for (int u = 0; u < MAXPOS; ++u) {
+                    if (loff[u] < 0) continue;
+                    float cv[3] = {0.f, 0.f, 0.f};
+                    float z = 1.f;
+                    if (goff[u] >= 0) {
+                        const int Y = goff[u] / p.inW, X = goff[u] - Y * p.inW;
+                        if (sd.kind == KBN_SRC_XYZ && sd.coords) {
+                            const float* cb = sd.coords + (long long)n * sd.coords_bstride + goff[u];
+                            const int HW = p.inH * p.inW;
+                            cv[0] = cb[0]; cv[1] = cb[HW]; cv[2] = cb[2 * HW];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                cv[j] = fmaf(kinv[j * 3 + 1], (float)Y, kinv[j * 3 + 0] * (float)X) + kinv[j * 3 + 2];
+                        }
+                        if (sd.kind == KBN_SRC_XYZ) {
+                            const int HW = p.inH * p.inW;
+                            const float* db = sd.data + (long long)n * sd.bstride + goff[u];
+                            float a = 0.f;
+                            for (int c = 0; c < sd.Cd; ++c) a = fmaf(sd.proj[c], db[(long long)c * HW], a);
+                            z = p.act ? leaky_relu(a, p.slope) : a;
+                        }
+                    }
+                    for (int q = 0; q < cnt; ++q) {
+                        int j = lo - sd.cstart + q;
+                        float val = (j == 0 ? cv[0] : (j == 1 ? cv[1] : cv[2])) * z;
+                        dst[q * p.plane + loff[u]] = (goff[u] >= 0) ? val : 0.f;
+                    }
+                }
+            }
+        }
+        if (c0 + CK > p.Ctot) {  // zero the channel padding of the last chunk
+            int lo = p.Ctot > c0 ? p.Ctot - c0 : 0;
+#pragma unroll
+            for (int u = 0; u < MAXPOS; ++u) {
+                if (loff[u] < 0) continue;
+                for (int q = lo; q < CK; ++q) As[q * p.plane + loff[u]] = 0.f;
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMA k-steps out of LDS ----
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            const int toff = (KS == 1) ? 0
+                             : (S2 ? (ky * p.pitch + (kx == 1 ? p.PH : (kx == 2 ? 1 : 0)))
+                                   : (ky * p.pitch + kx));
+#pragma unroll
+            for (int c4 = 0; c4 < NC4; ++c4) {
+                const float* Ab = As + c4 * 4 * p.plane + toff;
+                const float* Bb = Bs + (tap * NC4 + c4) * 4 * NT + boff;
+                float a[MW], b[NB];
+#pragma unroll
+                for (int mi = 0; mi < MW; ++mi) a[mi] = Ab[mbase[mi]];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) b[nb] = Bb[nb * 32];
+#pragma unroll
+                for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[nb], acc[mi][nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds 4 consecutive pixels (rows 4*(l>>4)+r of the m-block) of
+    //      output channel (l&15) of each n-block -------------------------------------
+    const int HWo = p.outH * p.outW;
+    float* outn = p.out + (long long)n * p.out_bstride;
+    const bool vec_ok = ((p.outW & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+                        ((p.out_bstride & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        int mb = wave * MW + mi;
+        int oyl = mb / p.TWB;
+        int seg = mb - oyl * p.TWB;
+        int oy = oy0 + oyl;
+        int ox = ox0 + seg * 16 + lk * 4;
+        if (oy >= p.outH || ox >= p.outW) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            int oc = nt * NT + nb * 16 + li;
+            if (oc >= p.OC) continue;
+            f32x4 v = acc[mi][nb];
+            if (p.act) {
+                v[0] = leaky_relu(v[0], p.slope); v[1] = leaky_relu(v[1], p.slope);
+                v[2] = leaky_relu(v[2], p.slope); v[3] = leaky_relu(v[3], p.slope);
+            }
+            float* o = outn + (long long)oc * HWo + (long long)oy * p.outW + ox;
+            if (vec_ok && ox + 3 < p.outW) {
+                *reinterpret_cast<f32x4*>(o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ox + r < p.outW) o[r] = v[r];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------- host dispatch
+template <int KS, int STRIDE, int CK, int NB>
+static int launch_variant(const ConvParams& p, size_t lds_bytes, hipStream_t stream) {
+    constexpr int MW = (NB >= 3) ? 4 : 8;
+    constexpr int MAXPOS = (KS == 1) ? (MW / 4) : (STRIDE == 1 ? (MW == 4 ? 2 : 3) : (MW == 4 ? 5 : 9));
+    auto kern = conv_igemm_kernel<KS, STRIDE, CK, NB, MW, MAXPOS>;
+    static bool attr_set = false;  // benign race: idempotent call
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return KBN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    if (p.rowsS * p.colsS > MAXPOS * 256) return KBN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds_bytes, stream, p);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+template <int KS, int STRIDE, int CK>
+static int launch_nb(const ConvParams& p, int NB, size_t lds, hipStream_t st) {
+    switch (NB) {
+        case 1: return launch_variant<KS, STRIDE, CK, 1>(p, lds, st);
+        case 2: return launch_variant<KS, STRIDE, CK, 2>(p, lds, st);
+        case 3: return launch_variant<KS, STRIDE, CK, 3>(p, lds, st);
+        default: return launch_variant<KS, STRIDE, CK, 4>(p, lds, st);
+    }
+}
+
+int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
+                  long long out_batch_stride, int n, int out_channels, int kernel_size, int stride,
+                  int in_height, int in_width, int resize, int apply_activation, float negative_slope,
+                  hipStream_t stream) {
+    if (!srcs || !packed_weight || !out) return KBN_ERR_INVALID_ARGUMENT;
+    if (n_src < 1 || n_src > KBN_MAX_SRC || n < 1 || out_channels < 1 || in_height < 1 || in_width < 1)
+        return KBN_ERR_INVALID_ARGUMENT;
+    if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
+    if (resize != KBN_RESIZE_NONE && resize != KBN_RESIZE_NEAREST) return KBN_ERR_INVALID_ARGUMENT;
+    if (resize == KBN_RESIZE_NEAREST && (n_src != 1 || srcs[0].kind != KBN_SRC_TENSOR)) return KBN_ERR_UNSUPPORTED;
+    if (in_height > 32767 || in_width > 32767) return KBN_ERR_UNSUPPORTED;
+
+    ConvParams p;
+    int ctot = 0;
+    for (int s = 0; s < n_src; ++s) {
+        const kbn_conv_src& a = srcs[s];
+        SrcDev& d = p.src[s];
+        if (a.channels < 1) return KBN_ERR_INVALID_ARGUMENT;
+        d.kind = a.kind; d.C = a.channels; d.cstart = ctot;
+        d.data = a.data; d.bstride = a.batch_stride;
+        d.H = in_height; d.W = in_width; d.Cd = 0;
+        d.proj = nullptr; d.coords = nullptr; d.kinv = nullptr; d.coords_bstride = 0;
+        if (a.kind == KBN_SRC_TENSOR) {
+            if (!a.data) return KBN_ERR_INVALID_ARGUMENT;
+            if (resize == KBN_RESIZE_NEAREST) {
+                if (a.src_height < 1 || a.src_width < 1) return KBN_ERR_INVALID_ARGUMENT;
+                d.H = a.src_height; d.W = a.src_width;
+            } else if ((a.src_height && a.src_height != in_height) || (a.src_width && a.src_width != in_width)) {
+                return KBN_ERR_INVALID_ARGUMENT;
+            }
+        } else if (a.kind == KBN_SRC_COORDS) {
+            if (!a.kinv || a.channels != 3) return KBN_ERR_INVALID_ARGUMENT;
+            d.kinv = a.kinv;
+        } else if (a.kind == KBN_SRC_XYZ) {
+            if (!a.data || !a.proj_weight || a.aux_channels < 1 || a.channels != 3) return KBN_ERR_INVALID_ARGUMENT;
+            if (!a.coordinates && !a.kinv) return KBN_ERR_INVALID_ARGUMENT;
+            d.proj = a.proj_weight; d.Cd = a.aux_channels;
+            d.coords = a.coordinates; d.coords_bstride = a.coordinates_batch_stride; d.kinv = a.kinv;
+        } else {
+            return KBN_ERR_INVALID_ARGUMENT;
+        }
+        ctot += a.channels;
+    }
+    for (int s = n_src; s < KBN_MAX_SRC; ++s) p.src[s] = p.src[0];
+
+    const ConvPlan pl = make_plan(out_channels, ctot, kernel_size);
+    p.nsrc = n_src; p.N = n; p.OC = out_channels; p.Ctot = ctot; p.Cpad = pl.Cpad;
+    p.wp = packed_weight; p.out = out; p.out_bstride = out_batch_stride;
+    p.inH = in_height; p.inW = in_width;
+    p.outH = ceil_div(in_height, stride); p.outW = ceil_div(in_width, stride);
+    p.resize = resize; p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
+    p.nTilesN = pl.nTilesN;
+
+    // tile geometry: 4*MW m-blocks of 16 pixels as TH rows x TWB segments
+    const int mblocks = 4 * pl.MW;
+    const bool s2 = (kernel_size == 3 && stride == 2);
+    double best_cost = 1e300;
+    int best_twb = 1;
+    for (int twb = 1; twb <= 4; twb *= 2) {
+        int th = mblocks / twb, tw = twb * 16;
+        int tiles = ceil_div(p.outW, tw) * ceil_div(p.outH, th);
+        int rows = (kernel_size == 1) ? th : (s2 ? 2 * th + 1 : th + 2);
+        int cols = (kernel_size == 1) ? tw : (s2 ? 2 * tw + 1 : tw + 2);
+        double cost = (double)tiles * (mblocks * 16.0 + 0.08 * rows * cols);
+        if (cost < best_cost * 0.999 || (cost < best_cost * 1.001 && twb == 2)) { best_cost = cost; best_twb = twb; }
+    }
+    p.TWB = best_twb; p.TH = mblocks / best_twb;
+    const int TW = best_twb * 16;
+    p.tilesX = ceil_div(p.outW, TW); p.tilesY = ceil_div(p.outH, p.TH);
+    if (kernel_size == 1) { p.rowsS = p.TH; p.colsS = TW; p.PH = 0; p.pitch = TW; }
+    else if (s2) { p.rowsS = 2 * p.TH + 1; p.colsS = 2 * TW + 1; p.PH = TW + 1; p.pitch = 2 * p.PH; }
+    else { p.rowsS = p.TH + 2; p.colsS = TW + 2; p.PH = 0; p.pitch = TW + 2; }
+    int plane = p.rowsS * p.pitch;
+    plane = ((plane + 15) / 32) * 32 + 16;  // smallest value >= plane that is 16 (mod 32)
+    if (plane < p.rowsS * p.pitch) plane += 32;
+    p.plane = plane;
+    long long nb64 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
+    if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.nblocks = (int)nb64;
+    const int taps = kernel_size * kernel_size;
+    size_t lds = sizeof(float) * ((size_t)pl.CK * plane + (size_t)pl.CK * taps * pl.NT);
+    if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
+
+    if (kernel_size == 3 && stride == 1)
+        return pl.CK == 4 ? launch_nb<3, 1, 4>(p, pl.NB, lds, stream) : launch_nb<3, 1, 8>(p, pl.NB, lds, stream);
+    if (kernel_size == 3 && stride == 2)
+        return pl.CK == 4 ? launch_nb<3, 2, 4>(p, pl.NB, lds, stream) : launch_nb<3, 2, 8>(p, pl.NB, lds, stream);
+    if (stride == 2) return launch_nb<1, 2, 16>(p, pl.NB, lds, stream);
+    return launch_nb<1, 1, 16>(p, pl.NB, lds, stream);
+}
+
+}  // namespace kbn
+
+extern "C" {
+
+size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int kernel_size) {
+    if (out_channels < 1 || in_channels < 1 || (kernel_size != 1 && kernel_size != 3)) return 0;
+    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size);
+    return sizeof(float) * (size_t)pl.nTilesN * pl.Cpad * kernel_size * kernel_size * pl.NT;
+}
+
+int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
+                           int kernel_size, kbn_stream_t stream) {
+    if (!weight || !packed || out_channels < 1 || in_channels < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if (kernel_size != 1 && kernel_size != 3) return KBN_ERR_UNSUPPORTED;
+    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size);
+    int taps = kernel_size * kernel_size;
+    long long total = (long long)pl.nTilesN * pl.Cpad * taps * pl.NT;
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(kbn::pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight,
+                       packed, out_channels, in_channels, taps, pl, total);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
+                       long long out_batch_stride, int n, int out_channels, int kernel_size,
+                       int stride, int in_height, int in_width, int resize, int apply_activation,
+                       float negative_slope, kbn_stream_t stream) {
+    return kbn::conv2d_launch(srcs, n_src, packed_weight, out, out_batch_stride, n, out_channels,
+                              kernel_size, stride, in_height, in_width, resize, apply_activation,
+                              negative_slope, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,497 @@
+"""Host-side mirror of the reference's operator interface for the inference hot path.
+
+Same class names, constructor arguments, `forward()` signatures and `state_dict()`
+keys as the reference (so its checkpoints load and `kbnet_model.py` can use these as
+drop-ins), but every `forward` is a sequence of HIP launches through the C ABI
+(ops.py).  Inference only: there is no autograd and no CPU path.
+
+  reference class                              here
+  net_utils.Conv2d            src/net_utils.py:51-141      Conv2d
+  net_utils.UpConv2d          src/net_utils.py:441-499     UpConv2d
+  net_utils.VGGNetBlock       src/net_utils.py:878-958     VGGNetBlock
+  net_utils.CalibratedBackprojectionBlock :1269-1371       CalibratedBackprojectionBlock
+  net_utils.DecoderBlock      src/net_utils.py:1377-1487   DecoderBlock
+  networks.SparseToDensePool  src/networks.py:2078-2196    SparseToDensePool
+  networks.KBNetEncoder       src/networks.py:24-533       KBNetEncoder
+  networks.MultiScaleDecoder  src/networks.py:1605-1989    MultiScaleDecoder
+  kbnet_model.KBNetModel      src/kbnet_model.py:24-186    KBNetModel
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from ._lib import KbnError
+from .config import KBNetConfig
+
+
+# ------------------------------------------------------------------- activations
+def activation_func(activation_fn: str):
+    """Same factory contract as reference src/net_utils.py:23-45; the kernels fuse
+    LeakyReLU (slope 0.20 from this factory), ReLU (slope 0) and linear."""
+    if "linear" in activation_fn:
+        return None
+    if "leaky_relu" in activation_fn:
+        return torch.nn.LeakyReLU(negative_slope=0.20, inplace=True)
+    if "relu" in activation_fn:
+        return torch.nn.ReLU()
+    if activation_fn in ("elu", "sigmoid"):
+        raise ValueError("Activation not supported by the fused HIP kernels: {}".format(activation_fn))
+    raise ValueError("Unsupported activation function: {}".format(activation_fn))
+
+
+def _slope(act) -> Optional[float]:
+    if act is None:
+        return None
+    if isinstance(act, torch.nn.LeakyReLU):
+        return float(act.negative_slope)
+    if isinstance(act, torch.nn.ReLU):
+        return 0.0
+    raise ValueError("Activation not supported by the fused HIP kernels: {}".format(type(act).__name__))
+
+
+def _init_weight(weight, weight_initializer):
+    if weight_initializer == "kaiming_normal":
+        torch.nn.init.kaiming_normal_(weight)
+    elif weight_initializer == "xavier_normal":
+        torch.nn.init.xavier_normal_(weight)
+    elif weight_initializer == "xavier_uniform":
+        torch.nn.init.xavier_uniform_(weight)
+    elif weight_initializer == "kaiming_uniform":
+        pass
+    else:
+        raise ValueError("Unsupported weight initializer: {}".format(weight_initializer))
+
+
+class _PackedWeight:
+    """Caches the MFMA-ordered copy of a conv weight; re-packs when the parameter is
+    modified in place (version bump), replaced or moved."""
+
+    def __init__(self):
+        self._key = None
+        self._packed = None
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        key = (weight.data_ptr(), weight._version, weight.device)
+        if key != self._key:
+            self._packed = ops.pack_conv_weight(weight)
+            self._key = key
+        return self._packed
+
+
+# ------------------------------------------------------------------------ layers
+class Conv2d(torch.nn.Module):
+    """Bias-free conv (padding k//2) + activation; kernel sizes 1 and 3, strides 1 and 2."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1,
+                 weight_initializer="kaiming_uniform",
+                 activation_func=torch.nn.LeakyReLU(negative_slope=0.10, inplace=True),
+                 use_batch_norm=False, use_instance_norm=False):
+        super().__init__()
+        if use_batch_norm or use_instance_norm:
+            raise ValueError("normalisation layers are not part of the KBNet inference path")
+        if kernel_size not in (1, 3) or stride not in (1, 2):
+            raise ValueError("HIP conv supports kernel_size in {1,3} and stride in {1,2}")
+        self.conv = torch.nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                    padding=kernel_size // 2, bias=False)
+        _init_weight(self.conv.weight, weight_initializer)
+        self.activation_func = activation_func
+        self.kernel_size, self.stride = kernel_size, stride
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._slope = _slope(activation_func)
+        self._packed = _PackedWeight()
+
+    def packed(self):
+        return self._packed.get(self.conv.weight)
+
+    def run(self, srcs, n, in_h, in_w, out=None, resize=False):
+        oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)
+        if out is None:
+            out = torch.empty((n, self.out_channels, oh, ow), device=self.conv.weight.device,
+                              dtype=torch.float32)
+        return ops.conv2d(srcs, self.packed(), n, self.out_channels, self.kernel_size, self.stride,
+                          in_h, in_w, out, resize=resize, negative_slope=self._slope)
+
+    def forward(self, x):
+        if x.shape[1] != self.in_channels:
+            raise KbnError(f"expected {self.in_channels} input channels, got {x.shape[1]}")
+        x = x if _dense(x) else x.contiguous()
+        return self.run([ops.tensor_src(x, "x")], x.shape[0], x.shape[2], x.shape[3])
+
+
+def _dense(t):
+    return t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == t.shape[2] * t.shape[3]
+
+
+class UpConv2d(torch.nn.Module):
+    """interpolate(nearest, size=shape) -> conv3x3, with the resize folded into the conv's
+    tile staging (no upsampled tensor is materialised)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, weight_initializer="kaiming_uniform",
+                 activation_func=torch.nn.LeakyReLU(negative_slope=0.10, inplace=True),
+                 use_batch_norm=False, use_instance_norm=False):
+        super().__init__()
+        self.conv = Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=1,
+                           weight_initializer=weight_initializer, activation_func=activation_func,
+                           use_batch_norm=use_batch_norm, use_instance_norm=use_instance_norm)
+
+    def forward(self, x, shape):
+        x = x if _dense(x) else x.contiguous()
+        return self.conv.run([ops.tensor_src(x, "x")], x.shape[0], int(shape[0]), int(shape[1]), resize=True)
+
+
+class VGGNetBlock(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, n_convolution=1, stride=1,
+                 weight_initializer="kaiming_uniform",
+                 activation_func=torch.nn.LeakyReLU(negative_slope=0.10, inplace=True),
+                 use_batch_norm=False, use_instance_norm=False, use_depthwise_separable=False):
+        super().__init__()
+        if use_depthwise_separable:
+            raise ValueError("depthwise separable convolutions are not part of the KBNet path")
+        layers = []
+        for _ in range(n_convolution - 1):
+            layers.append(Conv2d(in_channels, out_channels, 3, 1, weight_initializer, activation_func,
+                                 use_batch_norm, use_instance_norm))
+            in_channels = out_channels
+        layers.append(Conv2d(in_channels, out_channels, 3, stride, weight_initializer, activation_func,
+                             use_batch_norm, use_instance_norm))
+        self.conv_block = torch.nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.conv_block(x)
+
+
+class CalibratedBackprojectionBlock(torch.nn.Module):
+    """KB layer.  forward(image, depth, coordinates, fused=None) as in the reference;
+    `coordinates` may also be the N x 3 x 3 inverse intrinsics of this level, in which case
+    K^-1 [x y 1]^T is generated inside the kernels instead of being read from HBM."""
+
+    def __init__(self, in_channels_image, in_channels_depth, in_channels_fused, n_filter_image=48,
+                 n_filter_depth=16, n_filter_fused=48, n_convolution_image=1, n_convolution_depth=1,
+                 n_convolution_fused=1, weight_initializer="kaiming_uniform",
+                 activation_func=torch.nn.LeakyReLU(negative_slope=0.10, inplace=True)):
+        super().__init__()
+        if n_convolution_image != 1 or n_convolution_depth != 1:
+            raise ValueError("the fused KB block supports one convolution per branch (KBNet's setting)")
+        self.conv_image = VGGNetBlock(in_channels_image, n_filter_image, n_convolution_image, 2,
+                                      weight_initializer, activation_func)
+        self.conv_depth = VGGNetBlock(in_channels_depth + 3, n_filter_depth, n_convolution_depth, 2,
+                                      weight_initializer, activation_func)
+        self.proj_depth = Conv2d(in_channels_depth, 1, kernel_size=1, stride=1,
+                                 weight_initializer=weight_initializer, activation_func=activation_func)
+        self.conv_fused = Conv2d(in_channels_fused + 3, n_filter_fused, kernel_size=1, stride=2,
+                                 weight_initializer=weight_initializer, activation_func=activation_func)
+        self.n_filter_image, self.n_filter_depth, self.n_filter_fused = n_filter_image, n_filter_depth, n_filter_fused
+        self._slope = _slope(activation_func)
+        if self._slope is None:
+            raise ValueError("the fused KB block needs a (leaky) ReLU activation")
+
+    def run(self, image, depth, coordinates, fused, out_image=None, out_depth=None, out_fused=None):
+        n, _, h, w = image.shape
+        oh, ow = (h + 1) // 2, (w + 1) // 2
+        dev = image.device
+        mk = lambda c: torch.empty((n, c, oh, ow), device=dev, dtype=torch.float32)
+        out_image = mk(self.n_filter_image) if out_image is None else out_image
+        out_depth = mk(self.n_filter_depth) if out_depth is None else out_depth
+        out_fused = mk(self.n_filter_fused) if out_fused is None else out_fused
+        kinv = coords = None
+        if coordinates.dim() == 3:
+            kinv = coordinates.contiguous()
+        else:
+            coords = coordinates.contiguous()
+        return ops.kb_block(image, depth, coords, kinv, fused,
+                            self.conv_image.conv_block[0].packed(), self.conv_depth.conv_block[0].packed(),
+                            self.proj_depth.conv.weight, self.conv_fused.packed(),
+                            self.n_filter_image, self.n_filter_depth, self.n_filter_fused,
+                            out_image, out_depth, out_fused, self._slope)
+
+    def forward(self, image, depth, coordinates, fused=None):
+        image = image if _dense(image) else image.contiguous()
+        depth = depth if _dense(depth) else depth.contiguous()
+        if fused is not None and not _dense(fused):
+            fused = fused.contiguous()
+        return self.run(image, depth, coordinates, fused)
+
+
+class DecoderBlock(torch.nn.Module):
+    def __init__(self, in_channels, skip_channels, out_channels, weight_initializer="kaiming_uniform",
+                 activation_func=torch.nn.LeakyReLU(negative_slope=0.10, inplace=True),
+                 use_batch_norm=False, use_instance_norm=False, deconv_type="up",
+                 use_depthwise_separable=False):
+        super().__init__()
+        if deconv_type != "up" or use_depthwise_separable:
+            raise ValueError("only deconv_type='up' (KBNet's setting) is implemented")
+        self.skip_channels = skip_channels
+        self.deconv_type = deconv_type
+        self.deconv = UpConv2d(in_channels, out_channels, 3, weight_initializer, activation_func,
+                               use_batch_norm, use_instance_norm)
+        self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer,
+                           activation_func, use_batch_norm, use_instance_norm)
+
+    def forward(self, x, skip=None, shape=None):
+        if skip is not None:
+            shape = skip.shape[2:4]
+        elif shape is None:
+            shape = (2 * x.shape[2], 2 * x.shape[3])
+        deconv = self.deconv(x, shape=shape)
+        srcs = [ops.tensor_src(deconv, "deconv")]
+        if self.skip_channels > 0:
+            skip = skip if _dense(skip) else skip.contiguous()
+            srcs.append(ops.tensor_src(skip, "skip"))  # torch.cat([deconv, skip]) fused into the K loop
+        return self.conv.run(srcs, x.shape[0], int(shape[0]), int(shape[1]))
+
+
+# --------------------------------------------------------------------------- S2D
+class SparseToDensePool(torch.nn.Module):
+    def __init__(self, input_channels, min_pool_sizes=[3, 5, 7, 9], max_pool_sizes=[3, 5, 7, 9],
+                 n_filter=8, n_convolution=3, weight_initializer="kaiming_uniform",
+                 activation_func="leaky_relu"):
+        super().__init__()
+        act = activation_func if not isinstance(activation_func, str) else globals()["activation_func"](activation_func)
+        self.min_pool_sizes = [s for s in min_pool_sizes if s > 1]
+        self.max_pool_sizes = [s for s in max_pool_sizes if s > 1]
+        self.len_pool_sizes = len(self.min_pool_sizes) + len(self.max_pool_sizes)
+        in_channels = self.len_pool_sizes
+        convs = []
+        for _ in range(n_convolution):
+            convs.append(Conv2d(in_channels, n_filter, kernel_size=1, stride=1,
+                                weight_initializer=weight_initializer, activation_func=act))
+            in_channels = n_filter
+        self.pool_convs = torch.nn.Sequential(*convs)
+        self.conv = Conv2d(n_filter + input_channels, n_filter, kernel_size=3, stride=1,
+                           weight_initializer=weight_initializer, activation_func=act)
+        self._slope = _slope(act)
+        if self._slope is None:
+            raise ValueError("the fused S2D kernel needs a (leaky) ReLU activation")
+
+    def forward(self, x):
+        return ops.s2d_forward(x, [c.conv.weight for c in self.pool_convs], self.conv.conv.weight,
+                               self.min_pool_sizes, self.max_pool_sizes, self._slope)
+
+
+# ----------------------------------------------------------------------- encoder
+class KBNetEncoder(torch.nn.Module):
+    """KBNet encoder for the shipped topology family: KB at level 0, KB or plain VGG
+    blocks at levels 1-3, plain level 4.  Skip tensors are written in place: each KB
+    block's conv_fused / conv_depth land in the two channel slices of one buffer, which
+    is both the skip connection and the next block's `fused` / `depth` inputs."""
+
+    def __init__(self, input_channels_image=3, input_channels_depth=1,
+                 n_filters_image=[48, 96, 192, 384, 384], n_filters_depth=[16, 32, 64, 128, 128],
+                 n_filters_fused=[48, 96, 192, 384, 384], n_convolutions_image=[1, 1, 1, 1, 1],
+                 n_convolutions_depth=[1, 1, 1, 1, 1], n_convolutions_fused=[1, 1, 1, 1, 1],
+                 resolutions_backprojection=[0, 1, 2], weight_initializer="kaiming_uniform",
+                 activation_func="leaky_relu"):
+        super().__init__()
+        for lst in (n_convolutions_image, n_convolutions_depth, n_convolutions_fused, n_filters_image,
+                    n_filters_depth, n_filters_fused):
+            assert len(lst) == 5
+        if 0 not in resolutions_backprojection:
+            raise ValueError("resolution 0 must use calibrated backprojection (undefined in the reference otherwise)")
+        if 4 in resolutions_backprojection:
+            raise ValueError("calibrated backprojection at resolution 4 is not supported")
+        self.resolutions_backprojection = list(resolutions_backprojection)
+        act = globals()["activation_func"](activation_func)
+        fi, fd, ff = n_filters_image, n_filters_depth, n_filters_fused
+        self.conv0_image = Conv2d(input_channels_image, fi[0], 3, 1, weight_initializer, act)
+        self.conv0_depth = Conv2d(input_channels_depth, fd[0], 3, 1, weight_initializer, act)
+        self.calibrated_backprojection1 = CalibratedBackprojectionBlock(
+            fi[0], fd[0], fi[0], fi[0], fd[0], ff[0], n_convolutions_image[0], n_convolutions_depth[0],
+            n_convolutions_fused[0], weight_initializer, act)
+        for n in (1, 2, 3):
+            if n in resolutions_backprojection:
+                cf = fi[n - 1] + ff[n - 1] if (n - 1) in resolutions_backprojection else fi[n - 1]
+                setattr(self, f"calibrated_backprojection{n + 1}", CalibratedBackprojectionBlock(
+                    fi[n - 1], fd[n - 1], cf, fi[n], fd[n], ff[n], n_convolutions_image[n],
+                    n_convolutions_depth[n], n_convolutions_fused[n], weight_initializer, act))
+            else:
+                setattr(self, f"conv{n + 1}_image", VGGNetBlock(fi[n - 1], fi[n], n_convolutions_image[n], 2,
+                                                               weight_initializer, act))
+                setattr(self, f"conv{n + 1}_depth", VGGNetBlock(fd[n - 1], fd[n], n_convolutions_depth[n], 2,
+                                                               weight_initializer, act))
+        self.conv5_image = VGGNetBlock(fi[3], fi[4], n_convolutions_image[4], 2, weight_initializer, act)
+        self.conv5_depth = VGGNetBlock(fd[3], fd[4], n_convolutions_depth[4], 2, weight_initializer, act)
+        self._f = (list(fi), list(fd), list(ff))
+
+    def forward(self, image, depth, intrinsics):
+        fi, fd, ff = self._f
+        n, _, h0, w0 = image.shape
+        dev = image.device
+        image = image if _dense(image) else image.contiguous()
+        depth = depth if _dense(depth) else depth.contiguous()
+        intrinsics = intrinsics.contiguous()
+
+        conv_image = self.conv0_image(image)
+        conv_depth = self.conv0_depth(depth)
+        kinv = ops.intrinsics_inverse(intrinsics, 1.0, 1.0)
+        h, w = h0, w0
+        h1, w1 = (h0 + 1) // 2, (w0 + 1) // 2
+        # Q1: every deeper KB level scales K by the level-1 ratio (reference src/networks.py:342-343)
+        sx, sy = w1 / w0, h1 / h0
+        conv_fused = None
+        skips = []
+        for level in range(4):
+            oh, ow = (h + 1) // 2, (w + 1) // 2
+            if level in self.resolutions_backprojection:
+                blk = getattr(self, f"calibrated_backprojection{level + 1}")
+                if level > 0:
+                    kinv = ops.intrinsics_inverse(intrinsics, sx, sy)
+                skip = torch.empty((n, ff[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
+                out_fused, out_depth = skip[:, :ff[level]], skip[:, ff[level]:]
+                conv_image, conv_depth, conv_fused = blk.run(conv_image, conv_depth, kinv, conv_fused,
+                                                             None, out_depth, out_fused)
+            else:
+                src = conv_fused if conv_fused is not None else conv_image
+                skip = torch.empty((n, fi[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
+                ci_blk = getattr(self, f"conv{level + 1}_image").conv_block[0]
+                cd_blk = getattr(self, f"conv{level + 1}_depth").conv_block[0]
+                conv_image = ci_blk.run([ops.tensor_src(src)], n, h, w, out=skip[:, :fi[level]])
+                conv_depth = cd_blk.run([ops.tensor_src(conv_depth)], n, h, w, out=skip[:, fi[level]:])
+                conv_fused = None
+            skips.append(skip)
+            h, w = oh, ow
+        oh, ow = (h + 1) // 2, (w + 1) // 2
+        latent = torch.empty((n, fi[4] + fd[4], oh, ow), device=dev, dtype=torch.float32)
+        src = conv_fused if conv_fused is not None else conv_image
+        self.conv5_image.conv_block[0].run([ops.tensor_src(src)], n, h, w, out=latent[:, :fi[4]])
+        self.conv5_depth.conv_block[0].run([ops.tensor_src(conv_depth)], n, h, w, out=latent[:, fi[4]:])
+        return latent, skips
+
+
+# ----------------------------------------------------------------------- decoder
+class MultiScaleDecoder(torch.nn.Module):
+    """The decoder as KBNet builds it: five 'up' DecoderBlocks, n_resolution=1, linear
+    output0.  `forward` returns `[logits]` like the reference (the caller takes [-1])."""
+
+    def __init__(self, input_channels=256, output_channels=1, n_resolution=1,
+                 n_filters=[256, 128, 64, 32, 16], n_skips=[256, 128, 64, 32, 0],
+                 weight_initializer="kaiming_uniform", activation_func="leaky_relu",
+                 output_func="linear", use_batch_norm=False, use_instance_norm=False, deconv_type="up"):
+        super().__init__()
+        if n_resolution != 1 or output_func != "linear" or len(n_filters) != 5 or output_channels != 1:
+            raise ValueError("implemented for KBNet's decoder: 5 levels, n_resolution=1, linear 1-channel output")
+        if use_batch_norm or use_instance_norm:
+            raise ValueError("normalisation layers are not part of the KBNet inference path")
+        self.n_resolution = n_resolution
+        self.output_func = output_func
+        act = globals()["activation_func"](activation_func)
+        cin = input_channels
+        for i, name in enumerate(("deconv4", "deconv3", "deconv2", "deconv1", "deconv0")):
+            setattr(self, name, DecoderBlock(cin, n_skips[i], n_filters[i], weight_initializer, act,
+                                             deconv_type=deconv_type))
+            cin = n_filters[i]
+        self.output0 = Conv2d(n_filters[4], output_channels, 3, 1, weight_initializer, None)
+
+    def features(self, x, skips, shape):
+        """Everything up to (not including) output0."""
+        x = self.deconv4(x, skips[3])
+        x = self.deconv3(x, skips[2])
+        x = self.deconv2(x, skips[1])
+        x = self.deconv1(x, skips[0])
+        return self.deconv0(x, None, shape=tuple(shape)[-2:])
+
+    def forward(self, x, skips, shape=None):
+        return [self.output0(self.features(x, skips, shape))]
+
+
+# ------------------------------------------------------------------------- model
+class KBNetModel(object):
+    """Inference counterpart of reference `KBNetModel` (src/kbnet_model.py:24-186): same
+    constructor arguments and `forward(image, sparse_depth, validity_map_depth, intrinsics)`.
+    One process drives one GPU; multi-GPU runs shard frames across processes (dist.py)
+    instead of wrapping modules in DataParallel."""
+
+    def __init__(self, input_channels_image, input_channels_depth, min_pool_sizes_sparse_to_dense_pool,
+                 max_pool_sizes_sparse_to_dense_pool, n_convolution_sparse_to_dense_pool,
+                 n_filter_sparse_to_dense_pool, n_filters_encoder_image, n_filters_encoder_depth,
+                 resolutions_backprojection, n_filters_decoder, deconv_type="up",
+                 weight_initializer="xavier_normal", activation_func="leaky_relu",
+                 min_predict_depth=1.5, max_predict_depth=100.0, device=torch.device("cuda")):
+        self.min_predict_depth = min_predict_depth
+        self.max_predict_depth = max_predict_depth
+        self.device = device
+        self.sparse_to_dense_pool = SparseToDensePool(
+            input_channels=input_channels_depth, min_pool_sizes=min_pool_sizes_sparse_to_dense_pool,
+            max_pool_sizes=max_pool_sizes_sparse_to_dense_pool, n_convolution=n_convolution_sparse_to_dense_pool,
+            n_filter=n_filter_sparse_to_dense_pool, weight_initializer=weight_initializer,
+            activation_func=activation_func)
+        n_filters_encoder = [i + z for i, z in zip(n_filters_encoder_image, n_filters_encoder_depth)]
+        n_skips = n_filters_encoder[:-1][::-1] + [0]
+        self.encoder = KBNetEncoder(
+            input_channels_image=input_channels_image, input_channels_depth=n_filter_sparse_to_dense_pool,
+            n_filters_image=list(n_filters_encoder_image), n_filters_depth=list(n_filters_encoder_depth),
+            n_filters_fused=list(n_filters_encoder_image), resolutions_backprojection=list(resolutions_backprojection),
+            weight_initializer=weight_initializer, activation_func=activation_func)
+        self.decoder = MultiScaleDecoder(
+            input_channels=n_filters_encoder[-1], output_channels=1, n_resolution=1,
+            n_filters=list(n_filters_decoder), n_skips=n_skips, weight_initializer=weight_initializer,
+            activation_func=activation_func, output_func="linear", use_batch_norm=False, deconv_type=deconv_type)
+        self.to(device)
+        self.eval()
+
+    @classmethod
+    def from_config(cls, cfg: KBNetConfig, device=torch.device("cuda")):
+        return cls(cfg.input_channels_image, cfg.input_channels_depth,
+                   list(cfg.min_pool_sizes_sparse_to_dense_pool), list(cfg.max_pool_sizes_sparse_to_dense_pool),
+                   cfg.n_convolution_sparse_to_dense_pool, cfg.n_filter_sparse_to_dense_pool,
+                   list(cfg.n_filters_encoder_image), list(cfg.n_filters_encoder_depth),
+                   list(cfg.resolutions_backprojection), list(cfg.n_filters_decoder), cfg.deconv_type,
+                   cfg.weight_initializer, cfg.activation_func, cfg.min_predict_depth, cfg.max_predict_depth,
+                   device)
+
+    # -- forward ---------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, image, sparse_depth, validity_map_depth, intrinsics, return_logits=False):
+        input_depth = torch.cat([sparse_depth, validity_map_depth], dim=1)
+        input_depth = self.sparse_to_dense_pool(input_depth)
+        shape = input_depth.shape[-2:]
+        latent, skips = self.encoder(image, input_depth, intrinsics)
+        feats = self.decoder.features(latent, skips, shape)
+        # output0 conv + sigmoid + d_min / (s + d_min/d_max), one kernel
+        return ops.depth_head(feats, self.decoder.output0.conv.weight, self.min_predict_depth,
+                              self.max_predict_depth, return_logits=return_logits)
+
+    # -- nn.Module-like plumbing the reference driver uses ------------------------
+    def modules(self):
+        return (self.sparse_to_dense_pool, self.encoder, self.decoder)
+
+    def parameters(self):
+        return [p for m in self.modules() for p in m.parameters()]
+
+    def train(self):
+        raise KbnError("the HIP path is inference only")
+
+    def eval(self):
+        for m in self.modules():
+            m.eval()
+
+    def to(self, device):
+        for m in self.modules():
+            m.to(device)
+        self.device = device
+
+    def load_state_dicts(self, sd_s2d, sd_encoder, sd_decoder):
+        """Accepts keys with or without the DataParallel `module.` prefix."""
+        for m, sd in zip(self.modules(), (sd_s2d, sd_encoder, sd_decoder)):
+            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+            m.load_state_dict(sd, strict=True)
+
+    def restore_model(self, checkpoint_path, optimizer=None):
+        """Loads a reference checkpoint (reference src/kbnet_model.py:378-406)."""
+        ckpt = torch.load(checkpoint_path, map_location=self.device)
+        self.load_state_dicts(ckpt["sparse_to_dense_pool_state_dict"], ckpt["encoder_state_dict"],
+                              ckpt["decoder_state_dict"])
+        return ckpt.get("train_step", 0), optimizer
+
+    def save_model(self, checkpoint_path, step=0, optimizer=None):
+        """Writes the reference's checkpoint layout (src/kbnet_model.py:353-376), keys
+        prefixed with `module.` like its DataParallel-wrapped modules produce."""
+        pref = lambda sd: {"module." + k: v for k, v in sd.items()}
+        torch.save({"train_step": step,
+                    "optimizer_state_dict": optimizer.state_dict() if optimizer is not None else {},
+                    "sparse_to_dense_pool_state_dict": pref(self.sparse_to_dense_pool.state_dict()),
+                    "encoder_state_dict": pref(self.encoder.state_dict()),
+                    "decoder_state_dict": pref(self.decoder.state_dict())}, checkpoint_path)

@@ -1,0 +1,262 @@
+"""Tensor-level wrappers over the C ABI.  PyTorch is plumbing here: it owns the
+device memory and the stream; every computation below is a HIP kernel launch
+through libkbnet_hip.so.  CPU tensors are rejected (no fallback).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ConvSrc, KbnError, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# Optional per-launch timing (bench.py): when PROFILE is a list, every ABI call is
+# bracketed by HIP events recorded on the launch stream and (name, work, start, end)
+# is appended.  `work` is the launch's algorithmic FLOPs (convs) or bytes (S2D, head).
+PROFILE = None
+
+
+def _launch(name: str, work: float, fn):
+    if PROFILE is None:
+        return fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    status = fn()
+    end.record()
+    PROFILE.append((name, work, start, end))
+    return status
+
+
+def conv_plan(out_channels: int, in_channels: int, kernel_size: int):
+    """Python mirror of kbn::make_plan (csrc/conv_igemm.hip): (CK, NB, MW)."""
+    ck = 16 if kernel_size == 1 else (4 if in_channels <= 4 else 8)
+    nblk = -(-out_channels // 16)
+    best, bestpad = 1, 1 << 30
+    for nb in range(1, 5):
+        pad = -(-nblk // nb) * nb
+        if pad < bestpad or (pad == bestpad and nb > best):
+            best, bestpad = nb, pad
+    return ck, best, (4 if best >= 3 else 8)
+
+
+def _require(t: torch.Tensor, name: str, ndim: Optional[int] = None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise KbnError(f"{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise KbnError(f"{name}: expected float32, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise KbnError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+
+
+def _planes(t: torch.Tensor, name: str):
+    """(ptr, batch_stride) of an N x C x H x W tensor whose frames are dense C x H x W blocks
+    (a contiguous tensor or a channel slice of one)."""
+    _require(t, name, 4)
+    n, c, h, w = t.shape
+    if t.stride(3) != 1 or t.stride(2) != w or t.stride(1) != h * w:
+        raise KbnError(f"{name}: planes must be dense (got strides {t.stride()})")
+    return t.data_ptr(), (t.stride(0) if n > 1 else c * h * w)
+
+
+def _int_array(values: Sequence[int]):
+    arr = (C.c_int * max(len(values), 1))(*values)
+    return arr
+
+
+# ----------------------------------------------------------------------------- S2D
+def s2d_forward(x, w_pool_convs: List[torch.Tensor], w_conv, min_pool_sizes, max_pool_sizes,
+                negative_slope: float = 0.2):
+    lib = _lib.load()
+    _require(x, "x", 4)
+    x = x.contiguous()
+    n, cin, h, w = x.shape
+    ws = [wt.detach().contiguous() for wt in w_pool_convs]
+    for i, wt in enumerate(ws):
+        _require(wt, f"pool_convs.{i}.weight", 4)
+    wc = w_conv.detach().contiguous()
+    _require(wc, "conv.weight", 4)
+    nf = wc.shape[0]
+    mins = [int(s) for s in min_pool_sizes if s > 1]
+    maxs = [int(s) for s in max_pool_sizes if s > 1]
+    if ws[0].shape[1] != len(mins) + len(maxs) or wc.shape[1] != nf + cin:
+        raise KbnError("S2D weight shapes do not match the pool lists / input channels")
+    out = torch.empty((n, nf, h, w), device=x.device, dtype=torch.float32)
+    wptrs = (C.c_void_p * len(ws))(*[wt.data_ptr() for wt in ws])
+    amin, amax = _int_array(mins), _int_array(maxs)
+    check(_launch("s2d", 4.0 * n * h * w * (cin + nf),
+                  lambda: lib.kbn_s2d_forward(x.data_ptr(), wptrs, wc.data_ptr(), out.data_ptr(), n, h, w, cin,
+                                              amin, len(mins), amax, len(maxs), len(ws), nf,
+                                              float(negative_slope), _stream())), "kbn_s2d_forward")
+    return out
+
+
+def s2d_pyramid(x, min_pool_sizes, max_pool_sizes):
+    lib = _lib.load()
+    _require(x, "x", 4)
+    x = x.contiguous()
+    n, cin, h, w = x.shape
+    mins = [int(s) for s in min_pool_sizes if s > 1]
+    maxs = [int(s) for s in max_pool_sizes if s > 1]
+    out = torch.empty((n, len(mins) + len(maxs), h, w), device=x.device, dtype=torch.float32)
+    check(lib.kbn_s2d_pyramid(x.data_ptr(), cin * h * w, out.data_ptr(), n, h, w, _int_array(mins),
+                              len(mins), _int_array(maxs), len(maxs), _stream()), "kbn_s2d_pyramid")
+    return out
+
+
+# ---------------------------------------------------------------------- intrinsics
+def intrinsics_inverse(intrinsics, scale_x: float = 1.0, scale_y: float = 1.0):
+    lib = _lib.load()
+    _require(intrinsics, "intrinsics", 3)
+    k = intrinsics.contiguous()
+    if k.shape[1:] != (3, 3):
+        raise KbnError("intrinsics must be N x 3 x 3")
+    out = torch.empty_like(k)
+    check(lib.kbn_intrinsics_inverse(k.data_ptr(), out.data_ptr(), k.shape[0], float(scale_x),
+                                     float(scale_y), _stream()), "kbn_intrinsics_inverse")
+    return out
+
+
+def camera_coordinates(kinv, height: int, width: int):
+    lib = _lib.load()
+    _require(kinv, "kinv", 3)
+    kinv = kinv.contiguous()
+    out = torch.empty((kinv.shape[0], 3, height, width), device=kinv.device, dtype=torch.float32)
+    check(lib.kbn_camera_coordinates(kinv.data_ptr(), out.data_ptr(), kinv.shape[0], height, width,
+                                     _stream()), "kbn_camera_coordinates")
+    return out
+
+
+# --------------------------------------------------------------------------- conv2d
+def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
+    """OIHW -> MFMA fragment order (done once per weight; see PackedWeights in modules.py)."""
+    lib = _lib.load()
+    w = weight.detach().contiguous()
+    _require(w, "weight", 4)
+    oc, cin, kh, kw = w.shape
+    if kh != kw:
+        raise KbnError("square kernels only")
+    nbytes = lib.kbn_conv2d_packed_weight_bytes(oc, cin, kh)
+    if nbytes == 0:
+        raise KbnError(f"unsupported conv weight shape {tuple(w.shape)}")
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    check(lib.kbn_conv2d_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, kh, _stream()),
+          "kbn_conv2d_pack_weight")
+    return packed
+
+
+def tensor_src(t: torch.Tensor, name="src") -> ConvSrc:
+    ptr, bs = _planes(t, name)
+    s = ConvSrc()
+    s.kind = _lib.KBN_SRC_TENSOR
+    s.channels = t.shape[1]
+    s.data = ptr
+    s.batch_stride = bs
+    s.src_height, s.src_width = t.shape[2], t.shape[3]
+    return s
+
+
+def coords_src(kinv: torch.Tensor) -> ConvSrc:
+    _require(kinv, "kinv", 3)
+    s = ConvSrc()
+    s.kind = _lib.KBN_SRC_COORDS
+    s.channels = 3
+    s.kinv = kinv.data_ptr()
+    return s
+
+
+def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int,
+           kernel_size: int, stride: int, in_height: int, in_width: int, out: torch.Tensor,
+           resize: bool = False, negative_slope: Optional[float] = 0.2):
+    """`out` is an N x out_channels x ceil(H/s) x ceil(W/s) tensor or channel slice."""
+    lib = _lib.load()
+    arr = (ConvSrc * len(srcs))(*srcs)
+    optr, obs = _planes(out, "out")
+    oh, ow = -(-in_height // stride), -(-in_width // stride)
+    if tuple(out.shape) != (n, out_channels, oh, ow):
+        raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, oh, ow)}")
+    cin = sum(s.channels for s in srcs)
+    ck, nb, _ = conv_plan(out_channels, cin, kernel_size)
+    check(_launch(f"conv_igemm<{kernel_size},{stride},{ck},{nb}>",
+                  2.0 * n * oh * ow * cin * kernel_size * kernel_size * out_channels,
+                  lambda: lib.kbn_conv2d_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
+                                                 out_channels, kernel_size, stride, in_height, in_width,
+                                                 _lib.KBN_RESIZE_NEAREST if resize else _lib.KBN_RESIZE_NONE,
+                                                 0 if negative_slope is None else 1,
+                                                 0.0 if negative_slope is None else float(negative_slope),
+                                                 _stream())), "kbn_conv2d_forward")
+    return out
+
+
+# ------------------------------------------------------------------------ KB block
+def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_depth, proj_weight,
+             packed_w_fused, filters_image: int, filters_depth: int, filters_fused: int,
+             out_image, out_depth, out_fused, negative_slope: float = 0.2):
+    """Inputs/outputs may be channel slices; exactly one of coordinates / kinv may be None."""
+    lib = _lib.load()
+    n, ci, h, w = image.shape
+    iptr, ibs = _planes(image, "image")
+    dptr, dbs = _planes(depth, "depth")
+    cd = depth.shape[1]
+    if fused is not None:
+        fptr, fbs = _planes(fused, "fused")
+        cf = fused.shape[1]
+    else:
+        fptr, fbs, cf = None, 0, 0
+    cptr = None
+    if coordinates is not None:
+        _require(coordinates, "coordinates", 4)
+        if not coordinates.is_contiguous() or tuple(coordinates.shape) != (n, 3, h, w):
+            raise KbnError("coordinates must be a contiguous N x 3 x H x W tensor")
+        cptr = coordinates.data_ptr()
+    kptr = None
+    if kinv is not None:
+        _require(kinv, "kinv", 3)
+        kptr = kinv.data_ptr()
+    pw = proj_weight.detach().contiguous()
+    _require(pw, "proj_weight")
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    for t, f, nm in ((out_image, filters_image, "out_image"), (out_depth, filters_depth, "out_depth"),
+                     (out_fused, filters_fused, "out_fused")):
+        if tuple(t.shape) != (n, f, oh, ow):
+            raise KbnError(f"{nm} has shape {tuple(t.shape)}, expected {(n, f, oh, ow)}")
+    oi, oibs = _planes(out_image, "out_image")
+    od, odbs = _planes(out_depth, "out_depth")
+    of, ofbs = _planes(out_fused, "out_fused")
+    flops = 2.0 * n * oh * ow * (9 * ci * filters_image + 9 * (cd + 3) * filters_depth +
+                                  (ci + 3 + cf) * filters_fused)
+    check(_launch("kb_block", flops,
+                  lambda: lib.kbn_kb_block_forward(iptr, ibs, dptr, dbs, cptr, kptr, fptr, fbs,
+                                                   packed_w_image.data_ptr(), packed_w_depth.data_ptr(),
+                                                   pw.data_ptr(), packed_w_fused.data_ptr(), oi, oibs, od, odbs,
+                                                   of, ofbs, n, h, w, ci, cd, cf, filters_image, filters_depth,
+                                                   filters_fused, float(negative_slope), _stream())),
+          "kbn_kb_block_forward")
+    return out_image, out_depth, out_fused
+
+
+# ---------------------------------------------------------------------- depth head
+def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, return_logits=False):
+    lib = _lib.load()
+    _require(x, "x", 4)
+    x = x.contiguous()
+    w = weight.detach().contiguous()
+    _require(w, "weight", 4)
+    n, c, h, wd = x.shape
+    if tuple(w.shape) != (1, c, 3, 3):
+        raise KbnError(f"depth head weight must be 1 x {c} x 3 x 3")
+    depth = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32)
+    logits = torch.empty_like(depth) if return_logits else None
+    check(_launch("depth_head", 4.0 * n * h * wd * (c + 1),
+                  lambda: lib.kbn_depth_head_forward(x.data_ptr(), w.data_ptr(), depth.data_ptr(),
+                                                     logits.data_ptr() if return_logits else None, n, c, h, wd,
+                                                     float(min_predict_depth), float(max_predict_depth),
+                                                     _stream())), "kbn_depth_head_forward")
+    return (depth, logits) if return_logits else depth

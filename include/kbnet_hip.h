@@ -1,0 +1,176 @@
+/*
+ * kbnet_hip.h -- C ABI of the MI355X (gfx950) KBNet inference hot path.
+ *
+ * The reference (alexklwong/calibrated-backprojection-network) is pure Python on
+ * PyTorch and has no FFI of its own; the entry points below are what a binding for
+ * its hot path would call, one per reference operator.  Each declaration cites the
+ * reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every tensor is fp32, NCHW, W-contiguous, device (HBM) memory owned by the
+ *     caller; the library allocates nothing and keeps no pointer after return;
+ *   - every call only enqueues work on `stream` (a hipStream_t) and returns;
+ *   - return value: KBN_OK (0) or a negative kbn_status; nothing throws across the ABI;
+ *   - the library is re-entrant (no global mutable state besides one-time kernel
+ *     attribute setup).
+ */
+#ifndef KBNET_HIP_H
+#define KBNET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KBN_ABI_VERSION 1
+
+typedef void* kbn_stream_t; /* hipStream_t */
+
+typedef enum kbn_status {
+    KBN_OK = 0,
+    KBN_ERR_INVALID_ARGUMENT = -1, /* null pointer, non-positive size, bad enum      */
+    KBN_ERR_UNSUPPORTED = -2,      /* legal for the reference, outside kernel limits */
+    KBN_ERR_WORKSPACE = -3,        /* caller-provided buffer too small               */
+    KBN_ERR_LAUNCH = -4            /* HIP reported a launch error                    */
+} kbn_status;
+
+int kbn_version(void);
+const char* kbn_status_string(int status);
+
+/* ------------------------------------------------------------------ S2D -------
+ * networks.SparseToDensePool.forward(x)            reference src/networks.py:2168-2196
+ * (pool construction :2112-2132, 1x1 convs :2138-2152, 3x3 conv :2156-2166).
+ *
+ *   x              N x input_channels x H x W; channel 0 is the sparse depth
+ *   w_pool_convs   n_convolution pointers: [0] is n_filter x (n_min+n_max) x 1 x 1,
+ *                  the others n_filter x n_filter x 1 x 1  (pool_convs.{i}.conv.weight)
+ *   w_conv         n_filter x (n_filter+input_channels) x 3 x 3   (conv.conv.weight)
+ *   out            N x n_filter x H x W
+ *   pool sizes     odd kernel sizes > 1 (the caller drops sizes <= 1 like the
+ *                  reference does); min pools ignore zeros (999 sentinel semantics)
+ * Limits: n_filter <= 8, input_channels <= 2, n_min+n_max <= 8, n_convolution <= 4,
+ *         pool size <= 31 and odd.
+ */
+int kbn_s2d_forward(const float* x, const float* const* w_pool_convs, const float* w_conv,
+                    float* out, int n, int height, int width, int input_channels,
+                    const int* min_pool_sizes, int n_min, const int* max_pool_sizes, int n_max,
+                    int n_convolution, int n_filter, float negative_slope, kbn_stream_t stream);
+
+/* Optional debug/parity output of the min/max pyramid alone (the tensor the
+ * reference concatenates at src/networks.py:2189): N x (n_min+n_max) x H x W. */
+int kbn_s2d_pyramid(const float* x_depth, long long batch_stride, float* pyramid, int n,
+                    int height, int width, const int* min_pool_sizes, int n_min,
+                    const int* max_pool_sizes, int n_max, kbn_stream_t stream);
+
+/* ----------------------------------------------------------- intrinsics --------
+ * KBNetEncoder.forward closures scale_intrinsics + torch.inverse
+ *                                                  reference src/networks.py:328, 333-352
+ * kinv[n] = inverse(K[n] (.) [[sx,1,sx],[1,sy,sy],[1,1,1]]); pass sx = sy = 1 for level 0.
+ */
+int kbn_intrinsics_inverse(const float* intrinsics, float* kinv, int n, float scale_x,
+                           float scale_y, kbn_stream_t stream);
+
+/* camera_coordinates closure + net_utils.meshgrid   reference src/networks.py:317-331,
+ * src/net_utils.py:1601-1636.  coordinates: N x 3 x H x W = kinv . [x y 1]^T. */
+int kbn_camera_coordinates(const float* kinv, float* coordinates, int n, int height, int width,
+                           kbn_stream_t stream);
+
+/* ------------------------------------------------------------- conv2d ----------
+ * net_utils.Conv2d.forward (bias-free conv, padding k//2, optional LeakyReLU)
+ *                                                  reference src/net_utils.py:85-93, 120-141
+ * fused with the ops the reference runs around it:
+ *   - torch.cat of the inputs along channels (src/net_utils.py:1351, 1366, 1483):
+ *     up to KBN_MAX_SRC sources, concatenated in order;
+ *   - UpConv2d's nearest interpolate (src/net_utils.py:497): KBN_RESIZE_NEAREST
+ *     (only with a single tensor source);
+ *   - the KB layer's coordinate / backprojection channels (src/net_utils.py:1351-1360),
+ *     synthesized while the input tile is staged (source kinds below).
+ */
+#define KBN_MAX_SRC 3
+
+typedef enum kbn_src_kind {
+    KBN_SRC_TENSOR = 0, /* data: N x channels x src_height x src_width                     */
+    KBN_SRC_COORDS = 1, /* 3 channels kinv.[x y 1]^T, kinv: N x 3 x 3 (data unused)        */
+    KBN_SRC_XYZ = 2     /* 3 channels coords * z, z = act(proj_weight . depth[:, y, x]);   */
+                        /* data = depth N x aux_channels x H x W, proj_weight = aux_channels */
+                        /* floats, coords from `coordinates` (N x 3 x H x W) if non-null,  */
+                        /* else from kinv                                                  */
+} kbn_src_kind;
+
+typedef struct kbn_conv_src {
+    int kind;               /* kbn_src_kind                                       */
+    int channels;           /* channels this source contributes to the concat     */
+    const float* data;
+    long long batch_stride; /* elements between consecutive frames of `data`      */
+    int src_height, src_width; /* size of `data` planes (KBN_SRC_TENSOR)          */
+    int aux_channels;       /* KBN_SRC_XYZ: channels of the depth feature tensor  */
+    const float* proj_weight;  /* KBN_SRC_XYZ                                     */
+    const float* coordinates;  /* KBN_SRC_XYZ, optional                           */
+    long long coordinates_batch_stride;
+    const float* kinv;      /* KBN_SRC_COORDS / KBN_SRC_XYZ without coordinates    */
+} kbn_conv_src;
+
+#define KBN_RESIZE_NONE 0
+#define KBN_RESIZE_NEAREST 1
+
+/* Bytes of the packed weight blob for a conv with these dimensions. */
+size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int kernel_size);
+
+/* Re-orders an OIHW weight (out_channels x in_channels x k x k) into the MFMA
+ * fragment order the kernel consumes.  `packed` must hold
+ * kbn_conv2d_packed_weight_bytes(...) bytes.  Do this once per weight. */
+int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
+                           int kernel_size, kbn_stream_t stream);
+
+/* out[n, :, oy, ox] = act(sum_c,ky,kx W[:, c, ky, kx] * in[n, c, oy*stride+ky-pad, ox*stride+kx-pad])
+ * where `in` is the channel concat of the sources, logically in_height x in_width
+ * (sources are nearest-resized to that size first when resize = KBN_RESIZE_NEAREST).
+ * out: frames `out_batch_stride` elements apart (lets the caller write straight into a
+ * channel slice of a larger skip tensor), out_channels x ceil(in_h/stride) x ceil(in_w/stride).
+ * kernel_size in {1, 3}; stride in {1, 2}. */
+int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
+                       long long out_batch_stride, int n, int out_channels, int kernel_size,
+                       int stride, int in_height, int in_width, int resize, int apply_activation,
+                       float negative_slope, kbn_stream_t stream);
+
+/* ----------------------------------------------------------- KB block ----------
+ * net_utils.CalibratedBackprojectionBlock.forward(image, depth, coordinates, fused)
+ *                                                  reference src/net_utils.py:1343-1371
+ * Three kbn_conv2d_forward launches: conv_image (3x3 s2), conv_depth (3x3 s2 on
+ * cat[depth, coordinates]) and conv_fused (1x1 s2 on cat[image, coordinates*z, fused])
+ * with z = act(proj_depth(depth)) evaluated only where the stride-2 conv samples it.
+ *   coordinates     N x 3 x H x W, or NULL to synthesize them from kinv (N x 3 x 3)
+ *   fused           N x channels_fused x H x W or NULL (level 0)
+ *   packed weights  from kbn_conv2d_pack_weight; proj_weight is the raw (1 x Cd x 1 x 1)
+ *   outputs         each at ceil(H/2) x ceil(W/2), with its own batch stride
+ *   *_batch_stride  elements between frames (inputs/outputs may be channel slices of a
+ *                   larger NCHW tensor, e.g. the encoder's skip buffers; `coordinates`, when
+ *                   given, is contiguous N x 3 x H x W)
+ */
+int kbn_kb_block_forward(const float* image, long long image_batch_stride, const float* depth,
+                         long long depth_batch_stride, const float* coordinates, const float* kinv,
+                         const float* fused, long long fused_batch_stride,
+                         const float* packed_w_image, const float* packed_w_depth,
+                         const float* proj_weight, const float* packed_w_fused, float* out_image,
+                         long long out_image_batch_stride, float* out_depth,
+                         long long out_depth_batch_stride, float* out_fused,
+                         long long out_fused_batch_stride, int n, int height, int width,
+                         int channels_image, int channels_depth, int channels_fused,
+                         int filters_image, int filters_depth, int filters_fused,
+                         float negative_slope, kbn_stream_t stream);
+
+/* ------------------------------------------------------------ depth head -------
+ * MultiScaleDecoder.output0 (3x3, linear)           reference src/networks.py:1842-1851, 1985
+ * + KBNetModel.forward's sigmoid / depth mapping    reference src/kbnet_model.py:181-184
+ *   depth = d_min / (sigmoid(conv3x3(x, w)) + d_min / d_max)
+ * x: N x channels x H x W (channels <= 16), w: 1 x channels x 3 x 3 (raw OIHW).
+ * `logits` may be NULL; when given it receives the pre-sigmoid conv output. */
+int kbn_depth_head_forward(const float* x, const float* weight, float* depth, float* logits, int n,
+                           int channels, int height, int width, float min_predict_depth,
+                           float max_predict_depth, kbn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBNET_HIP_H */

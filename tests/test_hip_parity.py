@@ -1,0 +1,255 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden
+vectors captured from the reference.  Tolerance: north_star's 1e-4 relative (fp32);
+the min/max pyramid is compare/select only and must be bit-exact.
+
+    python -m pytest tests -m gpu -q
+"""
+import math
+
+import pytest
+import torch
+
+import kbnet_amd as kb
+from conftest import load_golden, rel_err
+from oracle import kbnet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north_star: "within 1e-4 relative fp32"
+TIGHT = 2e-5  # single-op checks: fp32 summation-order noise only
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    kb._lib.load()
+    return torch.device("cuda:0")
+
+
+def to(dev, *ts):
+    return [t.to(dev) if torch.is_tensor(t) else t for t in ts]
+
+
+# ------------------------------------------------------------------------------ S2D
+@pytest.mark.parametrize("name", [f"s2d_{p}_{i}" for p in ("kitti", "void") for i in range(3)])
+def test_s2d_golden(dev, name):
+    g = load_golden(name)
+    x = g["x"].to(dev)
+    mins, maxs = list(g["min_pool_sizes"]), list(g["max_pool_sizes"])
+    pyr = kb.ops.s2d_pyramid(x, mins, maxs)
+    assert torch.equal(pyr.cpu(), g["pyramid"]), "min/max pyramid must be bit-exact"
+    w = g["weights"]
+    out = kb.ops.s2d_forward(x, [w[f"pool_convs.{i}.conv.weight"].to(dev) for i in range(3)],
+                             w["conv.conv.weight"].to(dev), mins, maxs, 0.2)
+    assert rel_err(out, g["out"]) < TIGHT
+
+
+@pytest.mark.parametrize("preset,shape", [("kitti", (2, 352, 1216)), ("void", (1, 480, 640)),
+                                          ("void", (3, 37, 45)), ("kitti", (1, 16, 32)), ("kitti", (1, 1, 1))])
+def test_s2d_vs_oracle(dev, preset, shape):
+    cfg = kb.PRESETS[preset]()
+    n, h, w = shape
+    _, sparse, valid, _ = kb.synthetic.make_frames(n, h, w, preset, seed=7)
+    x = torch.cat([sparse, valid], 1)
+    sd = kb.synthetic.make_state_dicts(cfg, seed=2, gain=2.0)[0]
+    pyr_ref, out_ref = orc.sparse_to_dense_pool(x, sd, cfg.min_pools, cfg.max_pools, return_pyramid=True)
+    xd = x.to(dev)
+    assert torch.equal(kb.ops.s2d_pyramid(xd, cfg.min_pools, cfg.max_pools).cpu(), pyr_ref)
+    mod = kb.modules.SparseToDensePool(2, list(cfg.min_pool_sizes_sparse_to_dense_pool),
+                                       list(cfg.max_pool_sizes_sparse_to_dense_pool), 8, 3,
+                                       "xavier_normal", "leaky_relu").to(dev)
+    mod.load_state_dict(sd)
+    assert rel_err(mod(xd), out_ref) < TIGHT
+
+
+def test_s2d_dense_and_empty_maps(dev):
+    cfg = kb.kitti_config()
+    sd = kb.synthetic.make_state_dicts(cfg, seed=2, gain=2.0)[0]
+    g = torch.Generator().manual_seed(0)
+    dense = torch.rand(1, 1, 40, 70, generator=g) * 50 + 0.5
+    for z in (dense, torch.zeros(1, 1, 40, 70)):
+        x = torch.cat([z, (z > 0).float()], 1)
+        pyr_ref, out_ref = orc.sparse_to_dense_pool(x, sd, cfg.min_pools, cfg.max_pools, return_pyramid=True)
+        assert torch.equal(kb.ops.s2d_pyramid(x.to(dev), cfg.min_pools, cfg.max_pools).cpu(), pyr_ref)
+        out = kb.ops.s2d_forward(x.to(dev), [sd[f"pool_convs.{i}.conv.weight"].to(dev) for i in range(3)],
+                                 sd["conv.conv.weight"].to(dev), cfg.min_pools, cfg.max_pools)
+        assert (out.cpu() - out_ref).abs().max() <= TIGHT * max(1.0, float(out_ref.abs().max()))
+
+
+# ---------------------------------------------------------------------- coordinates
+@pytest.mark.parametrize("name", ["coords_kitti", "coords_nyu", "coords_odd"])
+def test_coordinates_golden(dev, name):
+    g = load_golden(name)
+    k, h, w = g["intrinsics"].to(dev), int(g["height"]), int(g["width"])
+    sx, sy = ((w + 1) // 2) / w, ((h + 1) // 2) / h
+    hl, wl = h, w
+    for lvl in range(4):
+        kinv = kb.ops.intrinsics_inverse(k, 1.0 if lvl == 0 else sx, 1.0 if lvl == 0 else sy)
+        c = kb.ops.camera_coordinates(kinv, hl, wl)
+        ref = g[f"coordinates{lvl}"]
+        assert (c.cpu() - ref).abs().max() <= 2e-6 * float(ref.abs().max()), lvl
+        assert torch.all(c[:, 2] == 1.0)
+        hl, wl = (hl + 1) // 2, (wl + 1) // 2
+
+
+# --------------------------------------------------------------------------- conv2d
+CONV_CASES = [
+    # cin, cout, k, stride, n, h, w
+    (3, 48, 3, 1, 2, 40, 72), (8, 16, 3, 1, 1, 33, 47), (48, 48, 3, 2, 2, 38, 70), (19, 16, 3, 2, 1, 21, 35),
+    (19, 32, 3, 2, 1, 44, 64), (64, 12, 3, 1, 1, 32, 64), (12, 12, 3, 1, 1, 17, 130), (12, 1, 3, 1, 1, 20, 20),
+    (51, 48, 1, 2, 2, 30, 50), (99, 96, 1, 2, 1, 23, 31), (16, 1, 1, 1, 1, 9, 9), (128, 64, 3, 1, 1, 22, 38),
+    (96, 192, 3, 2, 1, 11, 19), (35, 64, 3, 2, 1, 16, 16), (5, 80, 3, 1, 1, 7, 5), (4, 20, 1, 1, 3, 5, 70),
+    (24, 130, 3, 1, 1, 18, 18),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,n,h,w", CONV_CASES)
+@pytest.mark.parametrize("slope", [0.2, None])
+def test_conv2d_vs_oracle(dev, cin, cout, k, stride, n, h, w, slope):
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    ref = orc.conv2d(x, wt, stride, slope)
+    conv = kb.modules.Conv2d(cin, cout, k, stride, "xavier_normal",
+                             torch.nn.LeakyReLU(slope) if slope is not None else None).to(dev)
+    conv.conv.weight.data.copy_(wt)
+    out = conv(x.to(dev))
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TIGHT
+
+
+def test_conv2d_repacks_after_weight_update(dev):
+    conv = kb.modules.Conv2d(8, 8, 3, 1, "xavier_normal", None).to(dev)
+    x = torch.randn(1, 8, 12, 12)
+    a = conv(x.to(dev)).cpu()
+    with torch.no_grad():
+        conv.conv.weight.mul_(2.0)
+    b = conv(x.to(dev)).cpu()
+    assert rel_err(b, 2 * a) < 1e-6
+
+
+@pytest.mark.parametrize("shapes", [((5, 7), (10, 14)), ((5, 7), (9, 13)), ((11, 38), (22, 76)), ((3, 4), (5, 7)),
+                                    ((6, 6), (6, 6))])
+def test_upconv_nearest_resize_vs_oracle(dev, shapes):
+    (h, w), (oh, ow) = shapes
+    g = torch.Generator().manual_seed(h * 100 + ow)
+    x = torch.randn(2, 24, h, w, generator=g)
+    wt = torch.randn(16, 24, 3, 3, generator=g) / math.sqrt(24 * 9)
+    ref = orc.conv2d(torch.nn.functional.interpolate(x, size=(oh, ow), mode="nearest"), wt, 1, 0.2)
+    up = kb.modules.UpConv2d(24, 16, 3, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+    up.conv.conv.weight.data.copy_(wt)
+    assert rel_err(up(x.to(dev), (oh, ow)), ref) < TIGHT
+
+
+def test_decoder_block_concat_and_slice_output(dev):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 32, 9, 13, generator=g)
+    skip_full = torch.randn(2, 40, 18, 25, generator=g)
+    skip = skip_full[:, 8:32]  # a channel slice: dense planes, larger batch stride
+    sd = {"deconv.conv.conv.weight": torch.randn(16, 32, 3, 3, generator=g) / 17,
+          "conv.conv.weight": torch.randn(16, 16 + 24, 3, 3, generator=g) / 19}
+    ref = orc.decoder_block(x, skip, None, sd)
+    blk = kb.modules.DecoderBlock(32, 24, 16, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+    blk.load_state_dict(sd)
+    out = blk(x.to(dev), skip_full.to(dev)[:, 8:32])
+    assert rel_err(out, ref) < TIGHT
+
+
+# ------------------------------------------------------------------------- KB block
+def _kb_module(g, dev):
+    w = g["weights"]
+    fi, ci = w["conv_image.conv_block.0.conv.weight"].shape[:2]
+    fd, cd3 = w["conv_depth.conv_block.0.conv.weight"].shape[:2]
+    ff, cf3 = w["conv_fused.conv.weight"].shape[:2]
+    blk = kb.modules.CalibratedBackprojectionBlock(ci, cd3 - 3, cf3 - 3, fi, fd, ff, 1, 1, 1, "xavier_normal",
+                                                   torch.nn.LeakyReLU(0.2)).to(dev)
+    blk.load_state_dict(w)
+    return blk
+
+
+@pytest.mark.parametrize("name", ["kb_nofused", "kb_fused", "kb_odd"])
+@pytest.mark.parametrize("mode", ["coordinates", "kinv"])
+def test_kb_block_golden(dev, name, mode):
+    g = load_golden(name)
+    blk = _kb_module(g, dev)
+    image, depth = g["image"].to(dev), g["depth"].to(dev)
+    fused = g["fused"].to(dev) if "fused" in g else None
+    if mode == "coordinates":  # the reference's signature: dense N x 3 x H x W coordinates
+        coords = g["coordinates"].to(dev)
+    else:                       # fast path: K^-1, coordinates generated in-kernel
+        coords = kb.ops.intrinsics_inverse(g["intrinsics"].to(dev))
+    ci, cd, cf = blk(image=image, depth=depth, coordinates=coords, fused=fused)
+    assert rel_err(ci, g["conv_image"]) < TIGHT
+    assert rel_err(cd, g["conv_depth"]) < TIGHT
+    assert rel_err(cf, g["conv_fused"]) < TIGHT
+
+
+# -------------------------------------------------------------------------- decoder
+@pytest.mark.parametrize("name", ["dec_even", "dec_odd"])
+def test_decoder_golden(dev, name):
+    g = load_golden(name)
+    cfg = kb.kitti_config().narrow()
+    enc_ch = [i + z for i, z in zip(cfg.n_filters_encoder_image, cfg.n_filters_encoder_depth)]
+    dec = kb.modules.MultiScaleDecoder(enc_ch[-1], 1, 1, list(cfg.n_filters_decoder), cfg.n_skips,
+                                       "xavier_normal", "leaky_relu", "linear", False, False, "up").to(dev)
+    dec.load_state_dict(g["weights"])
+    skips = [g[f"skip{i}"].to(dev) for i in range(1, 5)]
+    out = dec(g["latent"].to(dev), skips, tuple(int(v) for v in g["shape"]))[-1]
+    assert rel_err(out, g["logits"]) < TOL
+
+
+def test_depth_head_vs_oracle(dev):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 12, 37, 70, generator=g)
+    w = torch.randn(1, 12, 3, 3, generator=g) / 4
+    logits = orc.conv2d(x, w, 1, None)
+    ref = orc.depth_head(logits, 1.5, 100.0)
+    d, lg = kb.ops.depth_head(x.to(dev), w.to(dev), 1.5, 100.0, return_logits=True)
+    assert rel_err(lg, logits) < TIGHT
+    assert float(((d.cpu() - ref).abs() / ref).max()) < TOL
+
+
+# --------------------------------------------------------------------- full forward
+def _check_forward(out, ref):
+    err = ((out.cpu() - ref).abs() / ref.abs()).max()
+    assert float(err) < TOL, f"max relative error {float(err):.3e}"
+
+
+@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd"])
+def test_forward_golden(dev, name):
+    g = load_golden(name)
+    cfg = kb.PRESETS[str(g["preset"])]().narrow()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(g["s2d"], g["encoder"], g["decoder"])
+    out = m.forward(*to(dev, g["image"], g["sparse_depth"], g["validity_map"], g["intrinsics"]))
+    _check_forward(out, g["output_depth"])
+
+
+@pytest.mark.parametrize("preset,shape", [("kitti", (352, 1216)), ("void", (480, 640)), ("nyu_v2", (416, 576))])
+def test_forward_full_size_vs_oracle(dev, preset, shape):
+    """BASELINE.json sizes, full-width network, one frame on the oracle (seconds on CPU)."""
+    cfg = kb.PRESETS[preset]()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3 if preset == "kitti" else 1.45)
+    frames = kb.synthetic.make_frames(2, *shape, preset, seed=1, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    out, logits = m.forward(*to(dev, *frames), return_logits=True)
+    ref = orc.kbnet_forward(*[f[1:2] for f in frames], *sds, cfg.min_pools, cfg.max_pools,
+                            cfg.min_predict_depth, cfg.max_predict_depth)
+    _check_forward(out[1:2], ref)
+    assert float(logits.std()) > 0.1  # the head is exercised off saturation
+    # batching property: frames are independent (no cross-frame state) -> a frame alone
+    # gives the bits it gave inside the batch
+    alone = m.forward(*to(dev, *[f[1:2] for f in frames]))
+    assert torch.equal(alone, out[1:2])
+
+
+def test_drop_in_modules_inside_reference_style_forward(dev):
+    """The two north-star modules used the way reference kbnet_model.py uses them:
+    positional S2D call, keyword KB-block call with a dense coordinates tensor."""
+    g = load_golden("kb_fused")
+    blk = _kb_module(g, dev)
+    outs = blk(image=g["image"].to(dev), depth=g["depth"].to(dev), coordinates=g["coordinates"].to(dev),
+               fused=g["fused"].to(dev))
+    assert len(outs) == 3 and all(o.is_contiguous() for o in outs)
+    assert outs[0].shape[-2:] == ((g["image"].shape[2] + 1) // 2, (g["image"].shape[3] + 1) // 2)
