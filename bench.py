@@ -63,13 +63,16 @@ def conv_gflop_per_frame(cfg, h, w):
     return total / 1e9
 
 
-def cpu_baseline(cfg, sds, budget_s=15.0, max_frames=6):
+def cpu_baseline(cfg, sds, frames, budget_s=15.0, max_frames=6):
     """Oracle (CPU port of the reference) on this box's host cores, one frame at a time
-    like the reference's own loop (reference src/kbnet.py:887)."""
+    like the reference's own loop (reference src/kbnet.py:887).  Thread count: the
+    reference's single-channel MaxPool2d / strided 1x1 conv do not scale past a few
+    dozen threads (measured on the 256-core GPU box: 16 threads 0.98 s/frame, 64: 1.19, 128: 1.71,
+    256: 33), so use
+    min(cores, KBNET_CPU_THREADS or 16) and report that number as `cores`."""
     from oracle import kbnet_oracle as orc
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, int(os.environ.get("KBNET_CPU_THREADS", "16")))
     torch.set_num_threads(threads)
-    frames = kb.synthetic.make_frames(1, HEIGHT, WIDTH, "kitti", seed=1)
     run = lambda: orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools,
                                     cfg.min_predict_depth, cfg.max_predict_depth)
     ref = run()  # warm-up (also the parity reference for frame 0 of rank 0)
@@ -169,7 +172,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, ref = cpu_baseline(cfg, sds)
+        base, ref = cpu_baseline(cfg, sds, [f[0:1].cpu() for f in frames])
         result["cpu_baseline"] = base
         got = out[0:1].cpu()
         result["parity"] = {"max_rel_err_vs_oracle": float(((got - ref).abs() / ref.abs()).max()),
