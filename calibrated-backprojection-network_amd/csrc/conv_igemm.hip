@@ -102,7 +102,35 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 }
 
 // ------------------------------------------------------------------- the kernel
-template <int KS, int STRIDE, int CK, int NB, int MW, int MAXPOS>
+__host__ __device__ constexpr int conv_maxpos(int KS, int STRIDE, int MW) {
+    // staged positions per thread, worst case over the tile shapes conv2d_launch may pick
+    return (KS == 1) ? (MW >= 4 ? MW / 4 : 1)
+           : (STRIDE == 1) ? (MW == 1 ? 1 : (MW <= 4 ? 2 : 3))
+                           : (MW == 1 ? 2 : (MW == 2 ? 3 : (MW == 4 ? 5 : 9)));
+}
+
+// Which source / plane feeds concat channel c (all wave-uniform -> scalar registers).
+struct ChanRef {
+    const float* ptr;  // tensor plane of this frame, or nullptr
+    int kind;          // kbn_src_kind, or -1 for zero padding
+    int j;             // channel index inside the source
+};
+
+__device__ __forceinline__ ChanRef chan_lookup(const ConvParams& p, int n, int c) {
+    ChanRef r{nullptr, -1, 0};
+#pragma unroll
+    for (int s = 0; s < KBN_MAX_SRC; ++s) {
+        if (s < p.nsrc && c >= p.src[s].cstart && c < p.src[s].cstart + p.src[s].C) {
+            r.kind = p.src[s].kind;
+            r.j = c - p.src[s].cstart;
+            if (r.kind == KBN_SRC_TENSOR)
+                r.ptr = p.src[s].data + (long long)n * p.src[s].bstride + (long long)r.j * (p.src[s].H * p.src[s].W);
+        }
+    }
+    return r;
+}
+
+template <int KS, int STRIDE, int CK, int NB, int MW, int MAXPOS, bool PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int TAPS = KS * KS;
     constexpr int PAD = KS / 2;
@@ -110,10 +138,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr bool S2 = (KS == 3 && STRIDE == 2);
     constexpr int NT = NB * 16;
     constexpr int NC4 = CK / 4;
+    constexpr int B_FLOATS = CK * TAPS * NT;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + CK * p.plane;
+    const int a_floats = CK * p.plane;
+    const int buf_floats = a_floats + B_FLOATS;  // one stage: [As | Bs]; PIPE uses two stages
 
     const int tid = threadIdx.x;
     int bid = xcd_remap(blockIdx.x, p.nblocks);
@@ -153,6 +182,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             loff[u] = l;
         }
     }
+    // synthesized source (KB layer), if any: coordinates K^-1 [x y 1]^T, optionally times
+    // z = act(proj . depth[:, y, x]) -- reference src/net_utils.py:1351-1360
+    int syn = -1;
+#pragma unroll
+    for (int s = 0; s < KBN_MAX_SRC; ++s)
+        if (s < p.nsrc && p.src[s].kind != KBN_SRC_TENSOR) syn = s;
 
     // ---- per-lane fragment addressing ----------------------------------------------
     const int lane = tid & 63, wave = tid >> 6;
@@ -175,84 +210,99 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     const float* wp_nt = p.wp + (long long)nt * p.Cpad * TAPS * NT;
 
-    for (int c0 = 0; c0 < p.Cpad; c0 += CK) {
-        __syncthreads();  // previous chunk's fragments are consumed
-        // ---- stage B: packed weight slice, straight copy ----
-        {
-            const float4* s4 = reinterpret_cast<const float4*>(wp_nt + (long long)c0 * TAPS * NT);
-            float4* d4 = reinterpret_cast<float4*>(Bs);
-            constexpr int CNT4 = CK * TAPS * NT / 4;
-            for (int e = tid; e < CNT4; e += 256) d4[e] = s4[e];
-        }
-        // ---- stage A: CK channels of the concat [src0 | src1 | src2], zero padded ----
-        for (int s = 0; s < p.nsrc; ++s) {
-            const SrcDev& sd = p.src[s];
-            int lo = c0 > sd.cstart ? c0 : sd.cstart;
-            int hi = (c0 + CK < sd.cstart + sd.C) ? (c0 + CK) : (sd.cstart + sd.C);
-            if (lo >= hi) continue;
-            const int cnt = hi - lo;
-            float* dst = As + (lo - c0) * p.plane;
-            if (sd.kind == KBN_SRC_TENSOR) {
-                const int HW = sd.H * sd.W;
-                const float* base = sd.data + (long long)n * sd.bstride + (long long)(lo - sd.cstart) * HW;
+    // Values of the CK chunk channels at every staged position of this thread (zero outside the
+    // image and in the channel padding).  Fast path: the chunk lies inside one tensor source
+    // (or runs off the end of the last one into padding) -> MAXPOS*CK unconditional, independent
+    // loads that the compiler can issue back to back and wait for late.  Generic path: the chunk
+    // straddles sources or holds synthesized KB channels.
+    auto load_chunk = [&](int c0, float (&va)[MAXPOS][CK]) -> int {
+        int s = 0;
 #pragma unroll
-                for (int u = 0; u < MAXPOS; ++u) {
-                    if (loff[u] < 0) continue;
-                    float v[CK];
-#pragma unroll
-                    for (int q = 0; q < CK; ++q)
-                        v[q] = (q < cnt && goff[u] >= 0) ? base[q * HW + goff[u]] : 0.f;
-#pragma unroll
-                    for (int q = 0; q < CK; ++q)
-                        if (q < cnt) dst[q * p.plane + loff[u]] = v[q];
-                }
-            } else {
-                // synthesized channels (KB layer): coordinates K^-1 [x y 1]^T, optionally times
-                // z = act(proj . depth[:, y, x]) -- reference src/net_utils.py:1351-1360
-                const float* kinv = sd.kinv ? sd.kinv + (long long)n * 9 : nullptr;
-#pragma unroll
-                for (int u = 0; u < MAXPOS; ++u) {
-                    if (loff[u] < 0) continue;
-                    float cv[3] = {0.f, 0.f, 0.f};
-                    float z = 1.f;
-                    if (goff[u] >= 0) {
-                        const int Y = goff[u] / p.inW, X = goff[u] - Y * p.inW;
-                        if (sd.kind == KBN_SRC_XYZ && sd.coords) {
-                            const float* cb = sd.coords + (long long)n * sd.coords_bstride + goff[u];
-                            const int HW = p.inH * p.inW;
-                            cv[0] = cb[0]; cv[1] = cb[HW]; cv[2] = cb[2 * HW];
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 3; ++j)
-                                cv[j] = fmaf(kinv[j * 3 + 1], (float)Y, kinv[j * 3 + 0] * (float)X) + kinv[j * 3 + 2];
-                        }
-                        if (sd.kind == KBN_SRC_XYZ) {
-                            const int HW = p.inH * p.inW;
-                            const float* db = sd.data + (long long)n * sd.bstride + goff[u];
-                            float a = 0.f;
-                            for (int c = 0; c < sd.Cd; ++c) a = fmaf(sd.proj[c], db[(long long)c * HW], a);
-                            z = p.act ? leaky_relu(a, p.slope) : a;
-                        }
-                    }
-                    for (int q = 0; q < cnt; ++q) {
-                        int j = lo - sd.cstart + q;
-                        float val = (j == 0 ? cv[0] : (j == 1 ? cv[1] : cv[2])) * z;
-                        dst[q * p.plane + loff[u]] = (goff[u] >= 0) ? val : 0.f;
-                    }
-                }
-            }
-        }
-        if (c0 + CK > p.Ctot) {  // zero the channel padding of the last chunk
-            int lo = p.Ctot > c0 ? p.Ctot - c0 : 0;
+        for (int t = 1; t < KBN_MAX_SRC; ++t)
+            if (t < p.nsrc && c0 >= p.src[t].cstart) s = t;
+        const int cend = p.src[s].cstart + p.src[s].C;
+        const bool fast = (c0 < cend) && p.src[s].kind == KBN_SRC_TENSOR && (c0 + CK <= cend || cend == p.Ctot);
+        if (fast) {
+            const int HW = p.src[s].H * p.src[s].W;
+            const float* base = p.src[s].data + (long long)n * p.src[s].bstride +
+                                (long long)(c0 - p.src[s].cstart) * HW;
+            const int nvalid = (cend - c0 < CK) ? (cend - c0) : CK;
 #pragma unroll
             for (int u = 0; u < MAXPOS; ++u) {
-                if (loff[u] < 0) continue;
-                for (int q = lo; q < CK; ++q) As[q * p.plane + loff[u]] = 0.f;
+                const int g = goff[u];
+                const int gi = g < 0 ? 0 : g;
+#pragma unroll
+                for (int q = 0; q < CK; ++q) {
+                    const int qq = (q < nvalid) ? q : 0;
+                    va[u][q] = base[qq * HW + gi];  // raw: masked in store_pos, so that nothing
+                }                                   // consumes the load before the MFMAs have run
+            }
+            return nvalid;
+        }
+#pragma unroll
+        for (int u = 0; u < MAXPOS; ++u) {
+            const int g = goff[u];
+            float cv[3] = {0.f, 0.f, 0.f};
+            float z = 1.f;
+            if (syn >= 0 && c0 + CK > p.src[syn].cstart && c0 < p.src[syn].cstart + 3 && g >= 0) {
+                const SrcDev& sd = p.src[syn];
+                const int HW = p.inH * p.inW;
+                if (sd.kind == KBN_SRC_XYZ && sd.coords) {
+                    const float* cb = sd.coords + (long long)n * sd.coords_bstride + g;
+                    cv[0] = cb[0]; cv[1] = cb[HW]; cv[2] = cb[2 * HW];
+                } else {
+                    const float* kinv = sd.kinv + (long long)n * 9;
+                    const int Y = g / p.inW, X = g - Y * p.inW;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        cv[j] = fmaf(kinv[j * 3 + 1], (float)Y, kinv[j * 3 + 0] * (float)X) + kinv[j * 3 + 2];
+                }
+                if (sd.kind == KBN_SRC_XYZ) {
+                    const float* db = sd.data + (long long)n * sd.bstride + g;
+                    float a = 0.f;
+                    for (int c = 0; c < sd.Cd; ++c) a = fmaf(sd.proj[c], db[(long long)c * HW], a);
+                    z = p.act ? leaky_relu(a, p.slope) : a;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CK; ++q) {
+                const ChanRef cr = chan_lookup(p, n, c0 + q);
+                float val = 0.f;
+                if (g >= 0) {
+                    if (cr.kind == KBN_SRC_TENSOR) val = cr.ptr[g];
+                    else if (cr.kind >= 0) val = (cr.j == 0 ? cv[0] : (cr.j == 1 ? cv[1] : cv[2])) * z;
+                }
+                va[u][q] = val;
             }
         }
-        __syncthreads();
-
-        // ---- MFMA k-steps out of LDS ----
+        return CK;
+    };
+    auto store_pos = [&](float* As, int u, const float (&v)[CK], int nvalid) {
+        if (loff[u] >= 0) {
+            const bool inb = goff[u] >= 0;
+#pragma unroll
+            for (int q = 0; q < CK; ++q) As[q * p.plane + loff[u]] = (inb && q < nvalid) ? v[q] : 0.f;
+        }
+    };
+    // packed weight slice of chunk c0 -> LDS (a straight copy; PIPE: LDS-DMA, no VGPR round trip)
+    auto stage_B = [&](float* Bs, int c0) {
+        constexpr int CNT4 = B_FLOATS / 4;
+        const float4* s4 = reinterpret_cast<const float4*>(wp_nt + (long long)c0 * TAPS * NT);
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int e0 = 0; e0 < CNT4; e0 += 256) {
+                const int eb = e0 + wave * 64;  // wave-uniform
+                if (eb + lane < CNT4)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(s4 + eb + lane),
+                        (__attribute__((address_space(3))) void*)(Bs + eb * 4), 16, 0, 0);
+            }
+        } else {
+            float4* d4 = reinterpret_cast<float4*>(Bs);
+            for (int e = tid; e < CNT4; e += 256) d4[e] = s4[e];
+        }
+    };
+    auto compute = [&](const float* As, const float* Bs) {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
@@ -274,6 +324,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     for (int nb = 0; nb < NB; ++nb)
                         acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[nb], acc[mi][nb], 0, 0, 0);
             }
+        }
+    };
+
+    if constexpr (PIPE) {
+        // Double-buffered: the next chunk's global loads (A -> VGPRs, B -> LDS by DMA) are in
+        // flight while the MFMAs of the current chunk run; one barrier per chunk.
+        float va[MAXPOS][CK];
+        stage_B(smem + a_floats, 0);
+        int nv = load_chunk(0, va);
+#pragma unroll
+        for (int u = 0; u < MAXPOS; ++u) store_pos(smem, u, va[u], nv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int c0 = 0; c0 < p.Cpad; c0 += CK) {
+            float* curA = smem + cur * buf_floats;
+            float* nxtA = smem + (cur ^ 1) * buf_floats;
+            const bool more = (c0 + CK < p.Cpad);
+            if (more) {
+                nv = load_chunk(c0 + CK, va);       // A loads first: the DMA below has no register
+                stage_B(nxtA + a_floats, c0 + CK);  // result, so nothing waits on it before the barrier
+            }
+            compute(curA, curA + a_floats);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < MAXPOS; ++u) store_pos(nxtA, u, va[u], nv);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (int c0 = 0; c0 < p.Cpad; c0 += CK) {
+            __syncthreads();  // previous chunk's fragments are consumed
+            stage_B(smem + a_floats, c0);
+            {
+                float va[MAXPOS][CK];
+                const int nv = load_chunk(c0, va);
+#pragma unroll
+                for (int u = 0; u < MAXPOS; ++u) store_pos(smem, u, va[u], nv);
+            }
+            __syncthreads();
+            compute(smem, smem + a_floats);
         }
     }
 
@@ -313,11 +406,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 }
 
 // ----------------------------------------------------------------- host dispatch
-template <int KS, int STRIDE, int CK, int NB>
-static int launch_variant(const ConvParams& p, size_t lds_bytes, hipStream_t stream) {
-    constexpr int MW = (NB >= 3) ? 4 : 8;
-    constexpr int MAXPOS = (KS == 1) ? (MW / 4) : (STRIDE == 1 ? (MW == 4 ? 2 : 3) : (MW == 4 ? 5 : 9));
-    auto kern = conv_igemm_kernel<KS, STRIDE, CK, NB, MW, MAXPOS>;
+struct TileChoice { int MW, TWB; };
+
+template <int KS, int STRIDE, int CK, int NB, int MW>
+static int launch_variant(const ConvParams& p, size_t stage_bytes, hipStream_t stream) {
+    constexpr int MAXPOS = conv_maxpos(KS, STRIDE, MW);
+    constexpr bool PIPE = (MAXPOS * CK <= 48);
+    auto kern = conv_igemm_kernel<KS, STRIDE, CK, NB, MW, MAXPOS, PIPE>;
     static bool attr_set = false;  // benign race: idempotent call
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -326,19 +421,63 @@ static int launch_variant(const ConvParams& p, size_t lds_bytes, hipStream_t str
         attr_set = true;
     }
     if (p.rowsS * p.colsS > MAXPOS * 256) return KBN_ERR_UNSUPPORTED;
+    size_t lds_bytes = stage_bytes * (PIPE ? 2 : 1);
+    if (lds_bytes > 160 * 1024) return KBN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds_bytes, stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
 
-template <int KS, int STRIDE, int CK>
-static int launch_nb(const ConvParams& p, int NB, size_t lds, hipStream_t st) {
-    switch (NB) {
-        case 1: return launch_variant<KS, STRIDE, CK, 1>(p, lds, st);
-        case 2: return launch_variant<KS, STRIDE, CK, 2>(p, lds, st);
-        case 3: return launch_variant<KS, STRIDE, CK, 3>(p, lds, st);
-        default: return launch_variant<KS, STRIDE, CK, 4>(p, lds, st);
+template <int KS, int STRIDE, int CK, int NB>
+static int launch_mw(const ConvParams& p, int MW, size_t lds, hipStream_t st) {
+    if constexpr (NB >= 3) {
+        switch (MW) {
+            case 1: return launch_variant<KS, STRIDE, CK, NB, 1>(p, lds, st);
+            case 2: return launch_variant<KS, STRIDE, CK, NB, 2>(p, lds, st);
+            default: return launch_variant<KS, STRIDE, CK, NB, 4>(p, lds, st);
+        }
+    } else {
+        switch (MW) {
+            case 1: return launch_variant<KS, STRIDE, CK, NB, 1>(p, lds, st);
+            case 2: return launch_variant<KS, STRIDE, CK, NB, 2>(p, lds, st);
+            case 4: return launch_variant<KS, STRIDE, CK, NB, 4>(p, lds, st);
+            default: return launch_variant<KS, STRIDE, CK, NB, 8>(p, lds, st);
+        }
     }
+}
+
+template <int KS, int STRIDE, int CK>
+static int launch_nb(const ConvParams& p, int NB, int MW, size_t lds, hipStream_t st) {
+    switch (NB) {
+        case 1: return launch_mw<KS, STRIDE, CK, 1>(p, MW, lds, st);
+        case 2: return launch_mw<KS, STRIDE, CK, 2>(p, MW, lds, st);
+        case 3: return launch_mw<KS, STRIDE, CK, 3>(p, MW, lds, st);
+        default: return launch_mw<KS, STRIDE, CK, 4>(p, MW, lds, st);
+    }
+}
+
+// Tile choice: 4*MW m-blocks of 16 pixels arranged as TH rows x TWB segments.  Cost model:
+// the chip runs ~256 workgroups at a time (one per CU, MFMA bound), each costing MW units
+// plus a fixed staging overhead; small feature maps pick small tiles so all CUs get work.
+static TileChoice choose_tile(int outH, int outW, int n, int nTilesN, int kernel_size, bool s2, int max_mw) {
+    double best_cost = 1e300;
+    TileChoice best{max_mw, 2};
+    for (int mw = max_mw; mw >= 1; mw /= 2) {
+        const int mblocks = 4 * mw;
+        for (int twb = 1; twb <= 4 && twb <= mblocks; twb *= 2) {
+            int th = mblocks / twb, tw = twb * 16;
+            long long tiles = (long long)ceil_div(outW, tw) * ceil_div(outH, th) * n * nTilesN;
+            int rows = (kernel_size == 1) ? th : (s2 ? 2 * th + 1 : th + 2);
+            int cols = (kernel_size == 1) ? tw : (s2 ? 2 * tw + 1 : tw + 2);
+            double rounds = (double)((tiles + 255) / 256);
+            double cost = rounds * (mw * 64.0 + 12.0 + 0.02 * rows * cols);
+            if (cost < best_cost * 0.98 || (cost < best_cost && mw == best.MW)) {
+                best_cost = cost;
+                best = TileChoice{mw, twb};
+            }
+        }
+    }
+    return best;
 }
 
 int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
@@ -394,42 +533,32 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     p.resize = resize; p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.nTilesN = pl.nTilesN;
 
-    // tile geometry: 4*MW m-blocks of 16 pixels as TH rows x TWB segments
-    const int mblocks = 4 * pl.MW;
     const bool s2 = (kernel_size == 3 && stride == 2);
-    double best_cost = 1e300;
-    int best_twb = 1;
-    for (int twb = 1; twb <= 4; twb *= 2) {
-        int th = mblocks / twb, tw = twb * 16;
-        int tiles = ceil_div(p.outW, tw) * ceil_div(p.outH, th);
-        int rows = (kernel_size == 1) ? th : (s2 ? 2 * th + 1 : th + 2);
-        int cols = (kernel_size == 1) ? tw : (s2 ? 2 * tw + 1 : tw + 2);
-        double cost = (double)tiles * (mblocks * 16.0 + 0.08 * rows * cols);
-        if (cost < best_cost * 0.999 || (cost < best_cost * 1.001 && twb == 2)) { best_cost = cost; best_twb = twb; }
-    }
-    p.TWB = best_twb; p.TH = mblocks / best_twb;
-    const int TW = best_twb * 16;
+    const TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, s2, pl.MW);
+    const int mblocks = 4 * tc.MW;
+    p.TWB = tc.TWB; p.TH = mblocks / tc.TWB;
+    const int TW = tc.TWB * 16;
     p.tilesX = ceil_div(p.outW, TW); p.tilesY = ceil_div(p.outH, p.TH);
     if (kernel_size == 1) { p.rowsS = p.TH; p.colsS = TW; p.PH = 0; p.pitch = TW; }
     else if (s2) { p.rowsS = 2 * p.TH + 1; p.colsS = 2 * TW + 1; p.PH = TW + 1; p.pitch = 2 * p.PH; }
     else { p.rowsS = p.TH + 2; p.colsS = TW + 2; p.PH = 0; p.pitch = TW + 2; }
     int plane = p.rowsS * p.pitch;
     plane = ((plane + 15) / 32) * 32 + 16;  // smallest value >= plane that is 16 (mod 32)
-    if (plane < p.rowsS * p.pitch) plane += 32;
     p.plane = plane;
     long long nb64 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
     if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
     p.nblocks = (int)nb64;
     const int taps = kernel_size * kernel_size;
     size_t lds = sizeof(float) * ((size_t)pl.CK * plane + (size_t)pl.CK * taps * pl.NT);
-    if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
 
     if (kernel_size == 3 && stride == 1)
-        return pl.CK == 4 ? launch_nb<3, 1, 4>(p, pl.NB, lds, stream) : launch_nb<3, 1, 8>(p, pl.NB, lds, stream);
+        return pl.CK == 4 ? launch_nb<3, 1, 4>(p, pl.NB, tc.MW, lds, stream)
+                          : launch_nb<3, 1, 8>(p, pl.NB, tc.MW, lds, stream);
     if (kernel_size == 3 && stride == 2)
-        return pl.CK == 4 ? launch_nb<3, 2, 4>(p, pl.NB, lds, stream) : launch_nb<3, 2, 8>(p, pl.NB, lds, stream);
-    if (stride == 2) return launch_nb<1, 2, 16>(p, pl.NB, lds, stream);
-    return launch_nb<1, 1, 16>(p, pl.NB, lds, stream);
+        return pl.CK == 4 ? launch_nb<3, 2, 4>(p, pl.NB, tc.MW, lds, stream)
+                          : launch_nb<3, 2, 8>(p, pl.NB, tc.MW, lds, stream);
+    if (stride == 2) return launch_nb<1, 2, 16>(p, pl.NB, tc.MW, lds, stream);
+    return launch_nb<1, 1, 16>(p, pl.NB, tc.MW, lds, stream);
 }
 
 }  // namespace kbn
@@ -453,6 +582,25 @@ int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels,
     hipLaunchKernelGGL(kbn::pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight,
                        packed, out_channels, in_channels, taps, pl, total);
     KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, int stride, int in_height,
+                     int in_width, int* info) {
+    using namespace kbn;
+    if (!info || n < 1 || out_channels < 1 || in_channels < 1 || in_height < 1 || in_width < 1)
+        return KBN_ERR_INVALID_ARGUMENT;
+    if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
+    const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size);
+    const bool s2 = (kernel_size == 3 && stride == 2);
+    const int outH = ceil_div(in_height, stride), outW = ceil_div(in_width, stride);
+    const TileChoice tc = choose_tile(outH, outW, n, pl.nTilesN, kernel_size, s2, pl.MW);
+    const int th = 4 * tc.MW / tc.TWB, tw = tc.TWB * 16;
+    const int maxpos = conv_maxpos(kernel_size, stride, tc.MW);
+    info[0] = pl.CK; info[1] = pl.NB; info[2] = tc.MW; info[3] = tc.TWB; info[4] = th;
+    info[5] = ceil_div(outW, tw) * ceil_div(outH, th) * n * pl.nTilesN;
+    info[6] = maxpos;
+    info[7] = (maxpos * pl.CK <= 48) ? 1 : 0;
     return KBN_OK;
 }
 

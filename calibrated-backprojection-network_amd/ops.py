@@ -35,16 +35,19 @@ def _launch(name: str, work: float, fn):
     return status
 
 
-def conv_plan(out_channels: int, in_channels: int, kernel_size: int):
-    """Python mirror of kbn::make_plan (csrc/conv_igemm.hip): (CK, NB, MW)."""
-    ck = 16 if kernel_size == 1 else (4 if in_channels <= 4 else 8)
-    nblk = -(-out_channels // 16)
-    best, bestpad = 1, 1 << 30
-    for nb in range(1, 5):
-        pad = -(-nblk // nb) * nb
-        if pad < bestpad or (pad == bestpad and nb > best):
-            best, bestpad = nb, pad
-    return ck, best, (4 if best >= 3 else 8)
+_PLAN_CACHE = {}
+
+
+def conv_plan(n: int, out_channels: int, in_channels: int, kernel_size: int, stride: int, in_height: int,
+              in_width: int):
+    """Kernel variant the library picks (kbn_conv2d_query): dict with CK, NB, MW, TWB, TH,
+    workgroups, maxpos, pipelined."""
+    key = (n, out_channels, in_channels, kernel_size, stride, in_height, in_width)
+    if key not in _PLAN_CACHE:
+        info = (C.c_int * 8)()
+        check(_lib.load().kbn_conv2d_query(*key, info), "kbn_conv2d_query")
+        _PLAN_CACHE[key] = dict(zip(("CK", "NB", "MW", "TWB", "TH", "workgroups", "maxpos", "pipelined"), info))
+    return _PLAN_CACHE[key]
 
 
 def _require(t: torch.Tensor, name: str, ndim: Optional[int] = None):
@@ -183,8 +186,11 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
     if tuple(out.shape) != (n, out_channels, oh, ow):
         raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, oh, ow)}")
     cin = sum(s.channels for s in srcs)
-    ck, nb, _ = conv_plan(out_channels, cin, kernel_size)
-    check(_launch(f"conv_igemm<{kernel_size},{stride},{ck},{nb}>",
+    name = "conv_igemm"
+    if PROFILE is not None:
+        pl = conv_plan(n, out_channels, cin, kernel_size, stride, in_height, in_width)
+        name = f"conv_igemm<{kernel_size},{stride},{pl['CK']},{pl['NB']},{pl['MW']}>"
+    check(_launch(name,
                   2.0 * n * oh * ow * cin * kernel_size * kernel_size * out_channels,
                   lambda: lib.kbn_conv2d_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
                                                  out_channels, kernel_size, stride, in_height, in_width,

@@ -134,6 +134,12 @@ int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_
                        int stride, int in_height, int in_width, int resize, int apply_activation,
                        float negative_slope, kbn_stream_t stream);
 
+/* Which kernel variant / tile geometry kbn_conv2d_forward picks for a problem (diagnostics,
+ * profiling): info[8] = {CK, NB, MW, TWB, TH, workgroups, staged positions per thread,
+ * pipelined (1/0)}; the launched kernel is conv_igemm_kernel<kernel_size, stride, CK, NB, MW, ...>. */
+int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, int stride,
+                     int in_height, int in_width, int* info);
+
 /* ----------------------------------------------------------- KB block ----------
  * net_utils.CalibratedBackprojectionBlock.forward(image, depth, coordinates, fused)
  *                                                  reference src/net_utils.py:1343-1371

@@ -92,6 +92,10 @@ def test_library_exports_every_declared_symbol():
     assert loaded.kbn_conv2d_packed_weight_bytes(12, 64, 3) == 4 * 1 * 64 * 9 * 16
     assert loaded.kbn_conv2d_packed_weight_bytes(96, 99, 1) == 4 * 2 * 112 * 1 * 48
     assert loaded.kbn_conv2d_packed_weight_bytes(5, 5, 5) == 0
+    # tile choice: big maps keep the largest tile, small maps shrink it so every CU gets work
+    big = kb.ops.conv_plan(8, 64, 128, 3, 1, 176, 608)
+    small = kb.ops.conv_plan(8, 256, 512, 3, 1, 22, 76)
+    assert (big["NB"], big["MW"]) == (4, 4) and small["MW"] < 4 and small["workgroups"] >= 256
 
 
 def test_synthetic_frames_are_deterministic_and_well_formed():
