@@ -21,6 +21,8 @@
 //      Stride-2 3x3 convs de-interleave the staged columns by parity so that the 16 lanes
 //      of a fragment still read consecutive words.
 //   B: fragment order [k>>1][n][k&1] -> the 32 lanes of a half-wave read 32 consecutive words.
+#include <stdlib.h>
+
 #include "kbn_common.h"
 
 namespace kbn {
@@ -49,6 +51,7 @@ struct ConvParams {
     int pitch, plane, PH;
     int act;
     float slope;
+    int dbg;  // ablation switches for tools/conv_bench.py (KBN_DEBUG): 1 no A staging, 2 no B staging, 4 no MFMA
 };
 
 struct ConvPlan {
@@ -343,11 +346,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             float* nxtA = smem + (cur ^ 1) * buf_floats;
             const bool more = (c0 + CK < p.Cpad);
             if (more) {
-                nv = load_chunk(c0 + CK, va);       // A loads first: the DMA below has no register
-                stage_B(nxtA + a_floats, c0 + CK);  // result, so nothing waits on it before the barrier
+                if (!(p.dbg & 1)) nv = load_chunk(c0 + CK, va);  // A loads first: the DMA below has no register
+                if (!(p.dbg & 2)) stage_B(nxtA + a_floats, c0 + CK);  // result: nothing waits on it before the barrier
             }
-            compute(curA, curA + a_floats);
-            if (more) {
+            if (!(p.dbg & 4)) compute(curA, curA + a_floats);
+            if (more && !(p.dbg & 1)) {
 #pragma unroll
                 for (int u = 0; u < MAXPOS; ++u) store_pos(nxtA, u, va[u], nv);
             }
@@ -459,12 +462,21 @@ static int launch_nb(const ConvParams& p, int NB, int MW, size_t lds, hipStream_
 // Tile choice: 4*MW m-blocks of 16 pixels arranged as TH rows x TWB segments.  Cost model:
 // the chip runs ~256 workgroups at a time (one per CU, MFMA bound), each costing MW units
 // plus a fixed staging overhead; small feature maps pick small tiles so all CUs get work.
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
 static TileChoice choose_tile(int outH, int outW, int n, int nTilesN, int kernel_size, bool s2, int max_mw) {
+    // experiment hooks (tools/conv_bench.py): KBN_FORCE_MW / KBN_FORCE_TWB pin the tile
+    const int force_mw = env_int("KBN_FORCE_MW"), force_twb = env_int("KBN_FORCE_TWB");
     double best_cost = 1e300;
     TileChoice best{max_mw, 2};
     for (int mw = max_mw; mw >= 1; mw /= 2) {
+        if (force_mw && mw != force_mw && !(force_mw > max_mw && mw == max_mw)) continue;
         const int mblocks = 4 * mw;
         for (int twb = 1; twb <= 4 && twb <= mblocks; twb *= 2) {
+            if (force_twb && twb != force_twb) continue;
             int th = mblocks / twb, tw = twb * 16;
             long long tiles = (long long)ceil_div(outW, tw) * ceil_div(outH, th) * n * nTilesN;
             int rows = (kernel_size == 1) ? th : (s2 ? 2 * th + 1 : th + 2);
@@ -532,6 +544,7 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     p.outH = ceil_div(in_height, stride); p.outW = ceil_div(in_width, stride);
     p.resize = resize; p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.nTilesN = pl.nTilesN;
+    p.dbg = env_int("KBN_DEBUG");
 
     const bool s2 = (kernel_size == 3 && stride == 2);
     const TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, s2, pl.MW);

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     float* zmin = smem;
     float* zmax = zmin + ZH * ZW;
     float* hbuf = zmax + ZH * ZW;
-    float* feat = hbuf + ZH * S2D_FW;  // [(nf + inC)][FH][FW]
+    float* feat = smem;  // [(nf + inC)][FH][FW]; overlays the pool buffers, which are dead by then
 
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
@@ -228,8 +228,9 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
     p.tilesX = ceil_div(p.W, S2D_TW);
     p.tilesY = ceil_div(p.H, S2D_TH);
     const int ZW = S2D_FW + 2 * R, ZH = S2D_FH + 2 * R;
-    size_t lds = sizeof(float) * ((size_t)2 * ZH * ZW + (size_t)ZH * S2D_FW +
-                                  (size_t)(S2D_MAXF + S2D_MAXIN) * S2D_FH * S2D_FW);
+    size_t lds_pool = sizeof(float) * ((size_t)2 * ZH * ZW + (size_t)ZH * S2D_FW);
+    size_t lds_feat = sizeof(float) * (size_t)(S2D_MAXF + S2D_MAXIN) * S2D_FH * S2D_FW;
+    size_t lds = lds_pool > lds_feat ? lds_pool : lds_feat;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(s2d_kernel),
