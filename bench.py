@@ -144,7 +144,7 @@ def main():
         g[2] += 1
     breakdown = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3),
                      "avg_us": round(v[1] / v[2] * 1e6, 2)} for k, v in groups.items()}
-    conv_groups = {k: v for k, v in groups.items() if k.startswith("conv_igemm")}
+    conv_groups = {k: v for k, v in groups.items() if k.startswith("conv_")}
     dom = max(conv_groups, key=lambda k: conv_groups[k][1])
     dwork, dtime, dlaunch = conv_groups[dom]
     achieved = dwork / dtime / 1e12

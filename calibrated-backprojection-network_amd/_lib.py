@@ -59,7 +59,7 @@ SIGNATURES = {
     "kbn_conv2d_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "kbn_conv2d_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I,
                                 _F, _P]),
-    "kbn_conv2d_query": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
+    "kbn_conv2d_query": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_kb_block_forward": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P,
                                   _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "kbn_depth_head_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),

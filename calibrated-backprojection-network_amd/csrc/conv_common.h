@@ -1,0 +1,152 @@
+// conv_common.h -- types shared by the two implicit-GEMM conv kernels
+// (conv_igemm.hip: register-staged, any shape; conv_dma.hip: LDS-DMA staged, aligned shapes).
+#pragma once
+
+#include "kbn_common.h"
+
+namespace kbn {
+
+struct SrcDev {
+    const float* data;
+    const float* proj;
+    const float* coords;
+    const float* kinv;
+    long long bstride;
+    long long coords_bstride;
+    int kind, C, H, W, Cd, cstart;
+};
+
+struct ConvParams {
+    SrcDev src[KBN_MAX_SRC];
+    const float* wp;
+    float* out;
+    long long out_bstride;
+    int nsrc, N, OC, Ctot, Cpad;
+    int inH, inW, outH, outW;
+    int resize;
+    int tilesX, tilesY, nTilesN, nblocks;
+    int TWB, TH;
+    int rowsS, colsS;
+    int pitch, plane, PH;
+    int act;
+    float slope;
+    int dbg;  // ablation switches for tools/conv_bench.py (KBN_DEBUG): 1 no A staging, 2 no B staging, 4 no MFMA
+};
+
+struct ConvPlan {
+    int CK, NB, MW, nTilesN, Cpad, NT;
+};
+
+__host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks) {
+    ConvPlan pl;
+    pl.CK = (ks == 1) ? 16 : (cin <= 4 ? 4 : 8);
+    int nblk = ceil_div(oc, 16);
+    // pick NB in 1..4 minimising padded n-blocks, ties -> larger NB
+    int best = 1, bestpad = 1 << 30;
+    for (int nb = 1; nb <= 4; ++nb) {
+        int pad = ceil_div(nblk, nb) * nb;
+        if (pad < bestpad || (pad == bestpad && nb > best)) { best = nb; bestpad = pad; }
+    }
+    pl.NB = best;
+    pl.MW = (best >= 3) ? 4 : 8;
+    pl.nTilesN = ceil_div(nblk, best);
+    pl.NT = best * 16;
+    pl.Cpad = round_up(cin, pl.CK);
+    return pl;
+}
+
+__host__ __device__ constexpr int conv_maxpos(int KS, int STRIDE, int MW) {
+    // staged positions per thread, worst case over the tile shapes conv2d_launch may pick
+    return (KS == 1) ? (MW >= 4 ? MW / 4 : 1)
+           : (STRIDE == 1) ? (MW == 1 ? 1 : (MW <= 4 ? 2 : 3))
+                           : (MW == 1 ? 2 : (MW == 2 ? 3 : (MW == 4 ? 5 : 9)));
+}
+
+// Which source / plane feeds concat channel c (all wave-uniform -> scalar registers).
+struct ChanRef {
+    const float* ptr;  // tensor plane of this frame, or nullptr
+    int kind;          // kbn_src_kind, or -1 for zero padding
+    int j;             // channel index inside the source
+};
+
+__device__ __forceinline__ ChanRef chan_lookup(const ConvParams& p, int n, int c) {
+    ChanRef r{nullptr, -1, 0};
+#pragma unroll
+    for (int s = 0; s < KBN_MAX_SRC; ++s) {
+        if (s < p.nsrc && c >= p.src[s].cstart && c < p.src[s].cstart + p.src[s].C) {
+            r.kind = p.src[s].kind;
+            r.j = c - p.src[s].cstart;
+            if (r.kind == KBN_SRC_TENSOR)
+                r.ptr = p.src[s].data + (long long)n * p.src[s].bstride + (long long)r.j * (p.src[s].H * p.src[s].W);
+        }
+    }
+    return r;
+}
+
+
+// Epilogue shared by both kernels: each lane holds 4 consecutive pixels (rows 4*(l>>4)+r of
+// the m-block) of output channel (l&15) of each n-block; fused LeakyReLU; float4 stores.
+template <int NB, int MW>
+__device__ __forceinline__ void store_tile(const ConvParams& p, const f32x4 (&acc)[MW][NB], int n, int nt,
+                                           int oy0, int ox0, int wave, int li, int lk) {
+    constexpr int NT = NB * 16;
+    const int HWo = p.outH * p.outW;
+    float* outn = p.out + (long long)n * p.out_bstride;
+    const bool vec_ok = ((p.outW & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+                        ((p.out_bstride & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        int mb = wave * MW + mi;
+        int oyl = mb / p.TWB;
+        int seg = mb - oyl * p.TWB;
+        int oy = oy0 + oyl;
+        int ox = ox0 + seg * 16 + lk * 4;
+        if (oy >= p.outH || ox >= p.outW) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            int oc = nt * NT + nb * 16 + li;
+            if (oc >= p.OC) continue;
+            f32x4 v = acc[mi][nb];
+            if (p.act) {
+                v[0] = leaky_relu(v[0], p.slope); v[1] = leaky_relu(v[1], p.slope);
+                v[2] = leaky_relu(v[2], p.slope); v[3] = leaky_relu(v[3], p.slope);
+            }
+            float* o = outn + (long long)oc * HWo + (long long)oy * p.outW + ox;
+            if (vec_ok && ox + 3 < p.outW) {
+                *reinterpret_cast<f32x4*>(o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ox + r < p.outW) o[r] = v[r];
+            }
+        }
+    }
+}
+
+// One 16-byte-per-lane LDS-DMA: lane l copies gsrc[0..3] to LDS byte address lds_base + 16*l.
+// Inline asm on purpose: hipcc's waitcnt pass makes every later ds_read wait vmcnt(0) for a
+// builtin LDS-DMA it cannot disambiguate, which would serialise staging and MFMAs; issued from
+// asm the DMA is invisible to it and completion is awaited by the kernels' own
+// `s_waitcnt vmcnt(0)` in front of the stage barrier.  M0 (the DMA's LDS base) is compiler
+// reserved, so it is saved and restored inside the statement (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_base_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_base_uniform)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+
+struct TileChoice { int MW, TWB; };
+
+// conv_dma.hip: LDS-DMA staged kernel for 16-byte aligned, non-resized tensor sources.
+// Fills the staging geometry of `p` itself.  Returns KBN_ERR_UNSUPPORTED if not eligible.
+int conv_dma_launch(ConvParams& p, const ConvPlan& pl, TileChoice tc, int kernel_size, int stride,
+                    hipStream_t stream);
+
+}  // namespace kbn

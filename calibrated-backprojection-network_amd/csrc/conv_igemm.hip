@@ -23,58 +23,9 @@
 //   B: fragment order [k>>1][n][k&1] -> the 32 lanes of a half-wave read 32 consecutive words.
 #include <stdlib.h>
 
-#include "kbn_common.h"
+#include "conv_common.h"
 
 namespace kbn {
-
-struct SrcDev {
-    const float* data;
-    const float* proj;
-    const float* coords;
-    const float* kinv;
-    long long bstride;
-    long long coords_bstride;
-    int kind, C, H, W, Cd, cstart;
-};
-
-struct ConvParams {
-    SrcDev src[KBN_MAX_SRC];
-    const float* wp;
-    float* out;
-    long long out_bstride;
-    int nsrc, N, OC, Ctot, Cpad;
-    int inH, inW, outH, outW;
-    int resize;
-    int tilesX, tilesY, nTilesN, nblocks;
-    int TWB, TH;
-    int rowsS, colsS;
-    int pitch, plane, PH;
-    int act;
-    float slope;
-    int dbg;  // ablation switches for tools/conv_bench.py (KBN_DEBUG): 1 no A staging, 2 no B staging, 4 no MFMA
-};
-
-struct ConvPlan {
-    int CK, NB, MW, nTilesN, Cpad, NT;
-};
-
-__host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks) {
-    ConvPlan pl;
-    pl.CK = (ks == 1) ? 16 : (cin <= 4 ? 4 : 8);
-    int nblk = ceil_div(oc, 16);
-    // pick NB in 1..4 minimising padded n-blocks, ties -> larger NB
-    int best = 1, bestpad = 1 << 30;
-    for (int nb = 1; nb <= 4; ++nb) {
-        int pad = ceil_div(nblk, nb) * nb;
-        if (pad < bestpad || (pad == bestpad && nb > best)) { best = nb; bestpad = pad; }
-    }
-    pl.NB = best;
-    pl.MW = (best >= 3) ? 4 : 8;
-    pl.nTilesN = ceil_div(nblk, best);
-    pl.NT = best * 16;
-    pl.Cpad = round_up(cin, pl.CK);
-    return pl;
-}
 
 // ---------------------------------------------------------------- weight packing
 // packed[nt][chunk][tap][c4][k>>1][n][k&1]  (zero padded in both c and oc)
@@ -105,34 +56,6 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 }
 
 // ------------------------------------------------------------------- the kernel
-__host__ __device__ constexpr int conv_maxpos(int KS, int STRIDE, int MW) {
-    // staged positions per thread, worst case over the tile shapes conv2d_launch may pick
-    return (KS == 1) ? (MW >= 4 ? MW / 4 : 1)
-           : (STRIDE == 1) ? (MW == 1 ? 1 : (MW <= 4 ? 2 : 3))
-                           : (MW == 1 ? 2 : (MW == 2 ? 3 : (MW == 4 ? 5 : 9)));
-}
-
-// Which source / plane feeds concat channel c (all wave-uniform -> scalar registers).
-struct ChanRef {
-    const float* ptr;  // tensor plane of this frame, or nullptr
-    int kind;          // kbn_src_kind, or -1 for zero padding
-    int j;             // channel index inside the source
-};
-
-__device__ __forceinline__ ChanRef chan_lookup(const ConvParams& p, int n, int c) {
-    ChanRef r{nullptr, -1, 0};
-#pragma unroll
-    for (int s = 0; s < KBN_MAX_SRC; ++s) {
-        if (s < p.nsrc && c >= p.src[s].cstart && c < p.src[s].cstart + p.src[s].C) {
-            r.kind = p.src[s].kind;
-            r.j = c - p.src[s].cstart;
-            if (r.kind == KBN_SRC_TENSOR)
-                r.ptr = p.src[s].data + (long long)n * p.src[s].bstride + (long long)r.j * (p.src[s].H * p.src[s].W);
-        }
-    }
-    return r;
-}
-
 template <int KS, int STRIDE, int CK, int NB, int MW, int MAXPOS, bool PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int TAPS = KS * KS;
@@ -373,44 +296,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
     }
 
-    // ---- epilogue: lane holds 4 consecutive pixels (rows 4*(l>>4)+r of the m-block) of
-    //      output channel (l&15) of each n-block -------------------------------------
-    const int HWo = p.outH * p.outW;
-    float* outn = p.out + (long long)n * p.out_bstride;
-    const bool vec_ok = ((p.outW & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
-                        ((p.out_bstride & 3) == 0);
-#pragma unroll
-    for (int mi = 0; mi < MW; ++mi) {
-        int mb = wave * MW + mi;
-        int oyl = mb / p.TWB;
-        int seg = mb - oyl * p.TWB;
-        int oy = oy0 + oyl;
-        int ox = ox0 + seg * 16 + lk * 4;
-        if (oy >= p.outH || ox >= p.outW) continue;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            int oc = nt * NT + nb * 16 + li;
-            if (oc >= p.OC) continue;
-            f32x4 v = acc[mi][nb];
-            if (p.act) {
-                v[0] = leaky_relu(v[0], p.slope); v[1] = leaky_relu(v[1], p.slope);
-                v[2] = leaky_relu(v[2], p.slope); v[3] = leaky_relu(v[3], p.slope);
-            }
-            float* o = outn + (long long)oc * HWo + (long long)oy * p.outW + ox;
-            if (vec_ok && ox + 3 < p.outW) {
-                *reinterpret_cast<f32x4*>(o) = v;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ox + r < p.outW) o[r] = v[r];
-            }
-        }
-    }
+    store_tile<NB, MW>(p, acc, n, nt, oy0, ox0, wave, li, lk);
 }
 
 // ----------------------------------------------------------------- host dispatch
-struct TileChoice { int MW, TWB; };
-
 template <int KS, int STRIDE, int CK, int NB, int MW>
 static int launch_variant(const ConvParams& p, size_t stage_bytes, hipStream_t stream) {
     constexpr int MAXPOS = conv_maxpos(KS, STRIDE, MW);
@@ -467,9 +356,11 @@ static int env_int(const char* name) {
     return v ? atoi(v) : 0;
 }
 
-static TileChoice choose_tile(int outH, int outW, int n, int nTilesN, int kernel_size, bool s2, int max_mw) {
+static TileChoice choose_tile(int outH, int outW, int n, int nTilesN, int kernel_size, int stride, int max_mw,
+                              int CK, int NT) {
     // experiment hooks (tools/conv_bench.py): KBN_FORCE_MW / KBN_FORCE_TWB pin the tile
     const int force_mw = env_int("KBN_FORCE_MW"), force_twb = env_int("KBN_FORCE_TWB");
+    const bool s2 = (kernel_size == 3 && stride == 2);
     double best_cost = 1e300;
     TileChoice best{max_mw, 2};
     for (int mw = max_mw; mw >= 1; mw /= 2) {
@@ -480,9 +371,14 @@ static TileChoice choose_tile(int outH, int outW, int n, int nTilesN, int kernel
             int th = mblocks / twb, tw = twb * 16;
             long long tiles = (long long)ceil_div(outW, tw) * ceil_div(outH, th) * n * nTilesN;
             int rows = (kernel_size == 1) ? th : (s2 ? 2 * th + 1 : th + 2);
-            int cols = (kernel_size == 1) ? tw : (s2 ? 2 * tw + 1 : tw + 2);
+            int cols = (kernel_size == 1) ? stride * tw : (s2 ? 2 * tw + 4 : tw + 8);
+            // double-buffered stage size -> resident workgroups per CU (a lone workgroup cannot
+            // overlap its barrier / staging bubbles with another one's MFMAs)
+            double lds = 2.0 * 4.0 * (CK * (rows * cols + 32.0) + CK * kernel_size * kernel_size * NT);
+            int resident = (int)(160.0 * 1024.0 / lds);
+            double occ_penalty = resident >= 2 ? 1.0 : 1.18;
             double rounds = (double)((tiles + 255) / 256);
-            double cost = rounds * (mw * 64.0 + 12.0 + 0.02 * rows * cols);
+            double cost = rounds * (mw * 64.0 + 12.0 + 0.02 * rows * cols) * occ_penalty;
             if (cost < best_cost * 0.98 || (cost < best_cost && mw == best.MW)) {
                 best_cost = cost;
                 best = TileChoice{mw, twb};
@@ -547,7 +443,11 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     p.dbg = env_int("KBN_DEBUG");
 
     const bool s2 = (kernel_size == 3 && stride == 2);
-    const TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, s2, pl.MW);
+    const TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
+    if (!env_int("KBN_NO_DMA")) {  // fast path: LDS-DMA staging (aligned tensor sources, no resize)
+        int rc = conv_dma_launch(p, pl, tc, kernel_size, stride, stream);
+        if (rc != KBN_ERR_UNSUPPORTED) return rc;
+    }
     const int mblocks = 4 * tc.MW;
     p.TWB = tc.TWB; p.TH = mblocks / tc.TWB;
     const int TW = tc.TWB * 16;
@@ -599,21 +499,21 @@ int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels,
 }
 
 int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, int stride, int in_height,
-                     int in_width, int* info) {
+                     int in_width, int resize, int* info) {
     using namespace kbn;
     if (!info || n < 1 || out_channels < 1 || in_channels < 1 || in_height < 1 || in_width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
     if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
     const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size);
-    const bool s2 = (kernel_size == 3 && stride == 2);
     const int outH = ceil_div(in_height, stride), outW = ceil_div(in_width, stride);
-    const TileChoice tc = choose_tile(outH, outW, n, pl.nTilesN, kernel_size, s2, pl.MW);
+    const TileChoice tc = choose_tile(outH, outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
     const int th = 4 * tc.MW / tc.TWB, tw = tc.TWB * 16;
     const int maxpos = conv_maxpos(kernel_size, stride, tc.MW);
     info[0] = pl.CK; info[1] = pl.NB; info[2] = tc.MW; info[3] = tc.TWB; info[4] = th;
     info[5] = ceil_div(outW, tw) * ceil_div(outH, th) * n * pl.nTilesN;
     info[6] = maxpos;
-    info[7] = (maxpos * pl.CK <= 48) ? 1 : 0;
+    // 2: conv_dma_kernel (assuming 16-byte aligned planes), 1: conv_igemm_kernel pipelined, 0: not pipelined
+    info[7] = (!resize && (in_width & 3) == 0 && !env_int("KBN_NO_DMA")) ? 2 : ((maxpos * pl.CK <= 48) ? 1 : 0);
     return KBN_OK;
 }
 

@@ -39,10 +39,10 @@ _PLAN_CACHE = {}
 
 
 def conv_plan(n: int, out_channels: int, in_channels: int, kernel_size: int, stride: int, in_height: int,
-              in_width: int):
+              in_width: int, resize: bool = False):
     """Kernel variant the library picks (kbn_conv2d_query): dict with CK, NB, MW, TWB, TH,
-    workgroups, maxpos, pipelined."""
-    key = (n, out_channels, in_channels, kernel_size, stride, in_height, in_width)
+    workgroups, maxpos, pipelined (2 = conv_dma_kernel, 1/0 = conv_igemm_kernel)."""
+    key = (n, out_channels, in_channels, kernel_size, stride, in_height, in_width, int(resize))
     if key not in _PLAN_CACHE:
         info = (C.c_int * 8)()
         check(_lib.load().kbn_conv2d_query(*key, info), "kbn_conv2d_query")
@@ -188,8 +188,9 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
     cin = sum(s.channels for s in srcs)
     name = "conv_igemm"
     if PROFILE is not None:
-        pl = conv_plan(n, out_channels, cin, kernel_size, stride, in_height, in_width)
-        name = f"conv_igemm<{kernel_size},{stride},{pl['CK']},{pl['NB']},{pl['MW']}>"
+        pl = conv_plan(n, out_channels, cin, kernel_size, stride, in_height, in_width, resize)
+        name = ("conv_dma" if pl["pipelined"] == 2 else "conv_igemm") + \
+            f"<{kernel_size},{stride},{pl['CK']},{pl['NB']},{pl['MW']}>"
     check(_launch(name,
                   2.0 * n * oh * ow * cin * kernel_size * kernel_size * out_channels,
                   lambda: lib.kbn_conv2d_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,

@@ -135,10 +135,12 @@ int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_
                        float negative_slope, kbn_stream_t stream);
 
 /* Which kernel variant / tile geometry kbn_conv2d_forward picks for a problem (diagnostics,
- * profiling): info[8] = {CK, NB, MW, TWB, TH, workgroups, staged positions per thread,
- * pipelined (1/0)}; the launched kernel is conv_igemm_kernel<kernel_size, stride, CK, NB, MW, ...>. */
+ * profiling): info[8] = {CK, NB, MW, TWB, TH, workgroups, staged positions per thread, kernel};
+ * kernel 2 = conv_dma_kernel<kernel_size, stride, CK, NB, MW, ...> (LDS-DMA staging; needs
+ * W % 4 == 0, 16-byte aligned planes, no resize), 1 / 0 = conv_igemm_kernel<...> with / without
+ * register prefetch. */
 int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, int stride,
-                     int in_height, int in_width, int* info);
+                     int in_height, int in_width, int resize, int* info);
 
 /* ----------------------------------------------------------- KB block ----------
  * net_utils.CalibratedBackprojectionBlock.forward(image, depth, coordinates, fused)

@@ -61,7 +61,7 @@ def run_one(name, batch=8, iters=8):
     torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / iters
     flops = 2.0 * batch * oh * ow * cin * k * k * cout
-    pl = kb.ops.conv_plan(batch, cout, cin, k, stride, h, w)
+    pl = kb.ops.conv_plan(batch, cout, cin, k, stride, h, w, rs is not None)
     return {"layer": name, "us": round(us, 1), "tflops": round(flops / us / 1e6, 1), **pl}
 
 
