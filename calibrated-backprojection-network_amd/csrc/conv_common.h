@@ -37,9 +37,10 @@ struct ConvPlan {
     int CK, NB, MW, nTilesN, Cpad, NT;
 };
 
-__host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks) {
+__host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks, int force_ck = 0) {
     ConvPlan pl;
     pl.CK = (ks == 1) ? 16 : (cin <= 4 ? 4 : 8);
+    if (force_ck == 4 && ks == 3) pl.CK = 4;  // experiment hook (KBN_FORCE_CK)
     int nblk = ceil_div(oc, 16);
     // pick NB in 1..4 minimising padded n-blocks, ties -> larger NB
     int best = 1, bestpad = 1 << 30;

@@ -29,7 +29,7 @@ LAYERS = {
 }
 
 
-def run_one(name, batch=8, iters=8):
+def run_one(name, batch=int(os.environ.get("KBN_BATCH", "8")), iters=8):
     import torch
     import kbnet_amd as kb
     cins, cout, k, stride, h, w, rs = LAYERS[name]
