@@ -13,6 +13,9 @@
 // chain runs in registers, its outputs (plus the raw x channels) go to LDS as the 3x3
 // conv's input tile, zero outside the image exactly like the reference's zero padding.
 #include <math.h>
+#include <stdlib.h>
+
+#include <initializer_list>
 
 #include "kbn_common.h"
 
@@ -20,8 +23,13 @@ namespace kbn {
 
 constexpr int S2D_TW = 32, S2D_TH = 16;
 constexpr int S2D_FW = S2D_TW + 2, S2D_FH = S2D_TH + 2;
-constexpr int S2D_NPOS = (S2D_FW * S2D_FH + 255) / 256;  // feature positions per thread (3)
+constexpr int S2D_NF = S2D_FW * S2D_FH;                  // feature positions per tile (612)
+constexpr int S2D_NPOS = (S2D_NF + 255) / 256;           // feature positions per thread (3)
 constexpr int S2D_MAXPOOL = 8, S2D_MAXF = 8, S2D_MAXCONV = 4, S2D_MAXIN = 2;
+constexpr int S2D_MAXCH = S2D_MAXF + S2D_MAXIN;
+// LDS weight block (floats): 3x3 conv as [ch][tap][8 filters], 1x1 convs as [input][8 filters]
+constexpr int S2D_WC = S2D_MAXCH * 9 * 8, S2D_WP = 8 * 8;
+constexpr int S2D_WFLOATS = S2D_WC + S2D_MAXCONV * S2D_WP;
 
 struct S2DParams {
     const float* x;
@@ -33,19 +41,57 @@ struct S2DParams {
     int N, H, W, inC;
     int nmin, npool;
     int ksize[S2D_MAXPOOL];
-    int nconv, nf, R;
+    int hoff[S2D_MAXPOOL];  // LDS offset (floats) of each pool's row-pass buffer
+    int nconv, nf, R, Rmin, Rmax;
     int tilesX, tilesY;
+    int pool_floats;        // zmin + zmax + row-pass buffers
+    int dbg;                // ablation (KBN_S2D_DEBUG): 1 no row pass, 2 no column pass, 4 no 1x1, 8 no 3x3, 16 no staging
     float slope;
 };
 
+// Pool configuration: compile-time lists for the reference's shipped presets (every pool loop
+// unrolls to straight-line code: all LDS reads of a window issue back to back with immediate
+// offsets), a run-time list for anything else.
+template <int NMIN, int... KS>
+struct StaticPools {
+    static constexpr bool is_static = true;
+    static constexpr int NP = sizeof...(KS);
+    static constexpr int K[NP] = {KS...};
+    static constexpr int cmax(int lo, int hi) {
+        int m = 0;
+        for (int i = lo; i < hi; ++i) m = (K[i] / 2 > m) ? K[i] / 2 : m;
+        return m;
+    }
+    static constexpr int RMIN = cmax(0, NMIN), RMAX = cmax(NMIN, NP);
+    __device__ static constexpr int nmin(const S2DParams&) { return NMIN; }
+    __device__ static constexpr int npool(const S2DParams&) { return NP; }
+    __device__ static constexpr int ksize(const S2DParams&, int pi) { return pi < NP ? K[pi] : 1; }
+    __device__ static constexpr int rmin(const S2DParams&) { return RMIN; }
+    __device__ static constexpr int rmax(const S2DParams&) { return RMAX; }
+};
+struct DynamicPools {
+    static constexpr bool is_static = false;
+    static constexpr int RMIN = 15, RMAX = 15;
+    __device__ static int nmin(const S2DParams& p) { return p.nmin; }
+    __device__ static int npool(const S2DParams& p) { return p.npool; }
+    __device__ static int ksize(const S2DParams& p, int pi) { return p.ksize[pi]; }
+    __device__ static int rmin(const S2DParams& p) { return p.Rmin; }
+    __device__ static int rmax(const S2DParams& p) { return p.Rmax; }
+};
+using KittiPools = StaticPools<5, 5, 7, 9, 11, 13, 15, 17>;   // bash/kitti/run_kbnet_kitti_validation.sh:15-16
+using VoidPools = StaticPools<2, 15, 17, 23, 27, 29>;         // bash/void/run_kbnet_void1500.sh:15-16
+using VoidTrainPools = StaticPools<3, 15, 17, 19, 23, 27>;    // bash/void/train_kbnet_void1500.sh:21-22
+
+template <typename CFG>
 __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int R = p.R;
     const int ZW = S2D_FW + 2 * R, ZH = S2D_FH + 2 * R;
-    float* zmin = smem;
+    float* wl = smem;                      // weights, live for the whole kernel
+    float* zmin = smem + S2D_WFLOATS;
     float* zmax = zmin + ZH * ZW;
-    float* hbuf = zmax + ZH * ZW;
-    float* feat = smem;  // [(nf + inC)][FH][FW]; overlays the pool buffers, which are dead by then
+    float* hb = zmax + ZH * ZW;            // row-pass buffers, one per pool
+    float* feat = smem + S2D_WFLOATS;      // [(nf + inC)][FH][FW]; overlays the pool buffers (dead by then)
 
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
@@ -55,8 +101,22 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     const int n = bid / p.tilesY;
     const int oy0 = ty * S2D_TH, ox0 = tx * S2D_TW;
     const float* xz = p.x + (long long)n * p.x_bstride;  // channel 0 = sparse depth
+    const int nch = p.nf + p.inC;
 
+    // ---- weights -> LDS, transposed so that the 8 filters of one (input, tap) are contiguous --
+    if (!p.pyramid) {
+        for (int e = tid; e < S2D_WC; e += 256) {
+            const int f = e & 7, t = (e >> 3) % 9, ch = e / 72;
+            wl[e] = (f < p.nf && ch < nch) ? p.wconv[((long long)f * nch + ch) * 9 + t] : 0.f;
+        }
+        for (int e = tid; e < S2D_MAXCONV * S2D_WP; e += 256) {
+            const int f = e & 7, q = (e >> 3) & 7, i = e >> 6;
+            const int cin = (i == 0) ? CFG::npool(p) : p.nf;
+            wl[S2D_WC + e] = (i < p.nconv && f < p.nf && q < cin) ? p.wpool[i][f * cin + q] : 0.f;
+        }
+    }
     // ---- stage the depth tile (+halo) -------------------------------------------------
+    if (!(p.dbg & 16))
     for (int e = tid; e < ZH * ZW; e += 256) {
         int r = e / ZW, c = e - r * ZW;
         int Y = oy0 - 1 - R + r, X = ox0 - 1 - R + c;
@@ -71,139 +131,168 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     }
     __syncthreads();
 
-    // ---- pools: separable min / max, results for this thread's feature positions ------
+    // ---- row pass, nested: one sweep outwards gives every min pool, another every max pool ----
+    const int nmin = CFG::nmin(p), npool = CFG::npool(p);
+    if (!(p.dbg & 1))
+    for (int e = tid; e < ZH * S2D_FW; e += 256) {
+        const int r = e / S2D_FW, c = e - r * S2D_FW;
+        {
+            const float* s = zmin + r * ZW + c + R;
+            float a = s[0];
+#pragma unroll
+            for (int d = 1; d <= CFG::RMIN; ++d) {
+                if (d > CFG::rmin(p)) break;
+                a = fminf(a, fminf(s[-d], s[d]));
+#pragma unroll
+                for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
+                    if (pi < nmin && (CFG::ksize(p, pi) >> 1) == d) {
+                        const int rr = r - (R - d);
+                        if (rr >= 0 && rr < S2D_FH + 2 * d) hb[p.hoff[pi] + rr * S2D_FW + c] = a;
+                    }
+                }
+            }
+        }
+        {
+            const float* s = zmax + r * ZW + c + R;
+            float a = s[0];
+#pragma unroll
+            for (int d = 1; d <= CFG::RMAX; ++d) {
+                if (d > CFG::rmax(p)) break;
+                a = fmaxf(a, fmaxf(s[-d], s[d]));
+#pragma unroll
+                for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
+                    if (pi >= nmin && pi < npool && (CFG::ksize(p, pi) >> 1) == d) {
+                        const int rr = r - (R - d);
+                        if (rr >= 0 && rr < S2D_FH + 2 * d) hb[p.hoff[pi] + rr * S2D_FW + c] = a;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- column pass: pooled values of this thread's feature positions -> registers ------
     float pooled[S2D_NPOS][S2D_MAXPOOL];
 #pragma unroll
-    for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
-        if (pi >= p.npool) break;
-        const bool is_min = pi < p.nmin;
-        const int rad = p.ksize[pi] >> 1;
-        const float* src = is_min ? zmin : zmax;
-        // row pass over the rows the column pass will touch: [R-rad, R+FH+rad)
-        const int rows = S2D_FH + 2 * rad;
-        for (int e = tid; e < rows * S2D_FW; e += 256) {
-            int rr = e / S2D_FW, c = e - rr * S2D_FW;
-            int r = rr + R - rad;
-            const float* s = src + r * ZW + c + R;
-            float a = s[0];
-            if (is_min) {
-                for (int d = 1; d <= rad; ++d) a = fminf(a, fminf(s[-d], s[d]));
-            } else {
-                for (int d = 1; d <= rad; ++d) a = fmaxf(a, fmaxf(s[-d], s[d]));
-            }
-            hbuf[r * S2D_FW + c] = a;
-        }
-        __syncthreads();
+    for (int u = 0; u < S2D_NPOS; ++u) {
+        const int e = tid + u * 256;
 #pragma unroll
-        for (int u = 0; u < S2D_NPOS; ++u) {
-            int e = tid + u * 256;
+        for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
             float a = 0.f;
-            if (e < S2D_FH * S2D_FW) {
-                int fy = e / S2D_FW, fx = e - fy * S2D_FW;
-                const float* s = hbuf + (fy + R) * S2D_FW + fx;
+            if (pi < npool && e < S2D_NF && !(p.dbg & 2)) {
+                const int k = CFG::ksize(p, pi);
+                const float* s = hb + p.hoff[pi] + e;  // rows fy .. fy+k-1 of this pool's buffer
                 a = s[0];
-                if (is_min) {
-                    for (int d = 1; d <= rad; ++d) a = fminf(a, fminf(s[-d * S2D_FW], s[d * S2D_FW]));
+                if (pi < nmin) {
+                    if constexpr (CFG::is_static) {
+#pragma unroll
+                        for (int d = 1; d < 2 * CFG::RMIN + 1; ++d)
+                            if (d < k) a = fminf(a, s[d * S2D_FW]);
+                    } else {
+#pragma unroll 4
+                        for (int d = 1; d < k; ++d) a = fminf(a, s[d * S2D_FW]);
+                    }
                     a = (a == 999.f) ? 0.f : a;  // where(pool == 999, 0, pool)
                 } else {
-                    for (int d = 1; d <= rad; ++d) a = fmaxf(a, fmaxf(s[-d * S2D_FW], s[d * S2D_FW]));
+                    if constexpr (CFG::is_static) {
+#pragma unroll
+                        for (int d = 1; d < 2 * CFG::RMAX + 1; ++d)
+                            if (d < k) a = fmaxf(a, s[d * S2D_FW]);
+                    } else {
+#pragma unroll 4
+                        for (int d = 1; d < k; ++d) a = fmaxf(a, s[d * S2D_FW]);
+                    }
                 }
             }
             pooled[u][pi] = a;
         }
-        __syncthreads();
     }
+    __syncthreads();  // the pool buffers are dead from here on: `feat` overlays them
 
-    const int nch = p.nf + p.inC;
     // ---- 1x1 conv chain in registers; features + raw x channels to LDS ----------------
 #pragma unroll
     for (int u = 0; u < S2D_NPOS; ++u) {
-        int e = tid + u * 256;
-        if (e >= S2D_FH * S2D_FW) continue;
-        int fy = e / S2D_FW, fx = e - fy * S2D_FW;
-        int Y = oy0 - 1 + fy, X = ox0 - 1 + fx;
+        const int e = tid + u * 256;
+        if (e >= S2D_NF) continue;
+        const int fy = e / S2D_FW, fx = e - fy * S2D_FW;
+        const int Y = oy0 - 1 + fy, X = ox0 - 1 + fx;
         const bool inb = (Y >= 0 && Y < p.H && X >= 0 && X < p.W);
         if (p.pyramid) {
             if (inb && fy >= 1 && fy <= S2D_TH && fx >= 1 && fx <= S2D_TW) {
-                float* py = p.pyramid + ((long long)n * p.npool) * p.H * p.W + (long long)Y * p.W + X;
+                float* py = p.pyramid + ((long long)n * npool) * p.H * p.W + (long long)Y * p.W + X;
 #pragma unroll
                 for (int pi = 0; pi < S2D_MAXPOOL; ++pi)
-                    if (pi < p.npool) py[(long long)pi * p.H * p.W] = pooled[u][pi];
+                    if (pi < npool) py[(long long)pi * p.H * p.W] = pooled[u][pi];
             }
             continue;
         }
         float h[S2D_MAXF], g[S2D_MAXF];
 #pragma unroll
-        for (int f = 0; f < S2D_MAXF; ++f) {
-            float a = 0.f;
-            if (f < p.nf) {
+        for (int q = 0; q < S2D_MAXPOOL; ++q) h[q] = pooled[u][q];  // inputs of layer 0 (zero beyond npool)
 #pragma unroll
-                for (int pi = 0; pi < S2D_MAXPOOL; ++pi)
-                    if (pi < p.npool) a = fmaf(p.wpool[0][f * p.npool + pi], pooled[u][pi], a);
-                a = leaky_relu(a, p.slope);
-            }
-            h[f] = a;
-        }
+        for (int i = 0; i < S2D_MAXCONV; ++i) {
+            if (i >= p.nconv || (p.dbg & 4)) break;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + S2D_WC + i * S2D_WP);
 #pragma unroll
-        for (int i = 1; i < S2D_MAXCONV; ++i) {
-            if (i >= p.nconv) break;
-            const float* w = p.wpool[i];
+            for (int f = 0; f < S2D_MAXF; ++f) g[f] = 0.f;
 #pragma unroll
-            for (int f = 0; f < S2D_MAXF; ++f) {
-                float a = 0.f;
-                if (f < p.nf) {
-#pragma unroll
-                    for (int q = 0; q < S2D_MAXF; ++q)
-                        if (q < p.nf) a = fmaf(w[f * p.nf + q], h[q], a);
-                    a = leaky_relu(a, p.slope);
-                }
-                g[f] = a;
+            for (int q = 0; q < 8; ++q) {  // zero weights beyond the real fan-in
+                const f32x4 wa = w4[q * 2], wb = w4[q * 2 + 1];
+                g[0] = fmaf(wa[0], h[q], g[0]); g[1] = fmaf(wa[1], h[q], g[1]);
+                g[2] = fmaf(wa[2], h[q], g[2]); g[3] = fmaf(wa[3], h[q], g[3]);
+                g[4] = fmaf(wb[0], h[q], g[4]); g[5] = fmaf(wb[1], h[q], g[5]);
+                g[6] = fmaf(wb[2], h[q], g[6]); g[7] = fmaf(wb[3], h[q], g[7]);
             }
 #pragma unroll
-            for (int f = 0; f < S2D_MAXF; ++f) h[f] = g[f];
+            for (int f = 0; f < S2D_MAXF; ++f) h[f] = leaky_relu(g[f], p.slope);
         }
 #pragma unroll
         for (int f = 0; f < S2D_MAXF; ++f)
-            if (f < p.nf) feat[f * (S2D_FH * S2D_FW) + e] = inb ? h[f] : 0.f;
+            if (f < p.nf) feat[f * S2D_NF + e] = inb ? h[f] : 0.f;
 #pragma unroll
         for (int ci = 0; ci < S2D_MAXIN; ++ci)
             if (ci < p.inC)
-                feat[(p.nf + ci) * (S2D_FH * S2D_FW) + e] =
-                    inb ? xz[(long long)ci * p.H * p.W + (long long)Y * p.W + X] : 0.f;
+                feat[(p.nf + ci) * S2D_NF + e] = inb ? xz[(long long)ci * p.H * p.W + (long long)Y * p.W + X] : 0.f;
     }
     if (p.pyramid) return;
     __syncthreads();
 
-    // ---- 3x3 conv over [features | x] + LeakyReLU --------------------------------------
+    // ---- 3x3 conv over [features | x] + LeakyReLU: each thread two pixels (rows oy, oy+8), the
+    //      weights of a (channel, tap) are read once (LDS broadcast) and used for both ----------
+    {
+        const int oy = tid / S2D_TW, ox = tid - oy * S2D_TW;
+        float acc0[S2D_MAXF], acc1[S2D_MAXF];
 #pragma unroll
-    for (int u = 0; u < (S2D_TW * S2D_TH) / 256; ++u) {
-        int e = tid + u * 256;
-        int oy = e / S2D_TW, ox = e - oy * S2D_TW;
-        float acc[S2D_MAXF];
+        for (int f = 0; f < S2D_MAXF; ++f) acc0[f] = acc1[f] = 0.f;
+        for (int ch = 0; ch < ((p.dbg & 8) ? 0 : nch); ++ch) {
+            const float* f0 = feat + ch * S2D_NF + oy * S2D_FW + ox;
+            const float* f1 = f0 + 8 * S2D_FW;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ch * 72);
 #pragma unroll
-        for (int f = 0; f < S2D_MAXF; ++f) acc[f] = 0.f;
-        for (int ch = 0; ch < nch; ++ch) {
-            const float* fb = feat + ch * (S2D_FH * S2D_FW) + oy * S2D_FW + ox;
-            float v[9];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = fb[ky * S2D_FW + kx];
-#pragma unroll
-            for (int f = 0; f < S2D_MAXF; ++f) {
-                if (f < p.nf) {
-                    const float* w = p.wconv + ((long long)f * nch + ch) * 9;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) acc[f] = fmaf(w[t], v[t], acc[f]);
-                }
+            for (int t = 0; t < 9; ++t) {
+                const int o = (t / 3) * S2D_FW + (t % 3);
+                const float v0 = f0[o], v1 = f1[o];
+                const f32x4 wa = w4[t * 2], wb = w4[t * 2 + 1];
+                acc0[0] = fmaf(wa[0], v0, acc0[0]); acc0[1] = fmaf(wa[1], v0, acc0[1]);
+                acc0[2] = fmaf(wa[2], v0, acc0[2]); acc0[3] = fmaf(wa[3], v0, acc0[3]);
+                acc0[4] = fmaf(wb[0], v0, acc0[4]); acc0[5] = fmaf(wb[1], v0, acc0[5]);
+                acc0[6] = fmaf(wb[2], v0, acc0[6]); acc0[7] = fmaf(wb[3], v0, acc0[7]);
+                acc1[0] = fmaf(wa[0], v1, acc1[0]); acc1[1] = fmaf(wa[1], v1, acc1[1]);
+                acc1[2] = fmaf(wa[2], v1, acc1[2]); acc1[3] = fmaf(wa[3], v1, acc1[3]);
+                acc1[4] = fmaf(wb[0], v1, acc1[4]); acc1[5] = fmaf(wb[1], v1, acc1[5]);
+                acc1[6] = fmaf(wb[2], v1, acc1[6]); acc1[7] = fmaf(wb[3], v1, acc1[7]);
             }
         }
-        int Y = oy0 + oy, X = ox0 + ox;
-        if (Y < p.H && X < p.W) {
-            float* o = p.out + ((long long)n * p.nf) * p.H * p.W + (long long)Y * p.W + X;
+        const int X = ox0 + ox;
 #pragma unroll
-            for (int f = 0; f < S2D_MAXF; ++f)
-                if (f < p.nf) o[(long long)f * p.H * p.W] = leaky_relu(acc[f], p.slope);
+        for (int half = 0; half < 2; ++half) {
+            const int Y = oy0 + oy + half * 8;
+            if (Y < p.H && X < p.W) {
+                float* o = p.out + ((long long)n * p.nf) * p.H * p.W + (long long)Y * p.W + X;
+#pragma unroll
+                for (int f = 0; f < S2D_MAXF; ++f)
+                    if (f < p.nf) o[(long long)f * p.H * p.W] = leaky_relu(half ? acc1[f] : acc0[f], p.slope);
+            }
         }
     }
 }
@@ -221,26 +310,49 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
         p.ksize[i] = k;
         if (k / 2 > R) R = k / 2;
     }
-    for (int i = n_min + n_max; i < S2D_MAXPOOL; ++i) p.ksize[i] = 1;
+    for (int i = n_min + n_max; i < S2D_MAXPOOL; ++i) { p.ksize[i] = 1; p.hoff[i] = 0; }
     p.nmin = n_min;
     p.npool = n_min + n_max;
     p.R = R;
+    p.Rmin = 0; p.Rmax = 0;
+    const int ZW = S2D_FW + 2 * R, ZH = S2D_FH + 2 * R;
+    int off = 0;
+    for (int i = 0; i < p.npool; ++i) {
+        const int rad = p.ksize[i] / 2;
+        if (i < n_min) { if (rad > p.Rmin) p.Rmin = rad; } else { if (rad > p.Rmax) p.Rmax = rad; }
+        p.hoff[i] = off;
+        off += (S2D_FH + 2 * rad) * S2D_FW;
+    }
     p.tilesX = ceil_div(p.W, S2D_TW);
     p.tilesY = ceil_div(p.H, S2D_TH);
-    const int ZW = S2D_FW + 2 * R, ZH = S2D_FH + 2 * R;
-    size_t lds_pool = sizeof(float) * ((size_t)2 * ZH * ZW + (size_t)ZH * S2D_FW);
-    size_t lds_feat = sizeof(float) * (size_t)(S2D_MAXF + S2D_MAXIN) * S2D_FH * S2D_FW;
-    size_t lds = lds_pool > lds_feat ? lds_pool : lds_feat;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(s2d_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
-        attr_set = true;
-    }
+    size_t pool_floats = (size_t)2 * ZH * ZW + (size_t)off;
+    size_t feat_floats = (size_t)S2D_MAXCH * S2D_NF;
+    p.pool_floats = (int)pool_floats;
+    { const char* v = getenv("KBN_S2D_DEBUG"); p.dbg = v ? atoi(v) : 0; }
+    size_t lds = sizeof(float) * (S2D_WFLOATS + (pool_floats > feat_floats ? pool_floats : feat_floats));
+    if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
     long long blocks = (long long)p.tilesX * p.tilesY * p.N;
     if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(s2d_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    auto matches = [&](int nm, std::initializer_list<int> ks) {
+        if (p.nmin != nm || p.npool != (int)ks.size()) return false;
+        int i = 0;
+        for (int k : ks)
+            if (p.ksize[i++] != k) return false;
+        return true;
+    };
+    auto launch = [&](auto kern) -> int {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return KBN_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+        return KBN_OK;
+    };
+    int rc;
+    if (matches(5, {5, 7, 9, 11, 13, 15, 17})) rc = launch(s2d_kernel<KittiPools>);
+    else if (matches(2, {15, 17, 23, 27, 29})) rc = launch(s2d_kernel<VoidPools>);
+    else if (matches(3, {15, 17, 19, 23, 27})) rc = launch(s2d_kernel<VoidTrainPools>);
+    else rc = launch(s2d_kernel<DynamicPools>);
+    if (rc != KBN_OK) return rc;
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }

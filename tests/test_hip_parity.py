@@ -62,6 +62,23 @@ def test_s2d_vs_oracle(dev, preset, shape):
     assert rel_err(mod(xd), out_ref) < TIGHT
 
 
+@pytest.mark.parametrize("mins,maxs", [([3, 5], [7]), ([9], [3, 31]), ([15, 17, 19], [23, 27]), ([], [5, 9]), ([7, 1], [1, 11])])
+def test_s2d_generic_pool_lists(dev, mins, maxs):
+    """Pool lists other than the two shipped presets (run-time pool loops); sizes <= 1 are dropped."""
+    g = torch.Generator().manual_seed(sum(mins) + 7 * sum(maxs))
+    z = (torch.rand(2, 1, 45, 70, generator=g) * 30 + 0.25) * (torch.rand(2, 1, 45, 70, generator=g) < 0.08)
+    x = torch.cat([z, (z > 0).float()], 1)
+    npool = len([s for s in mins if s > 1]) + len([s for s in maxs if s > 1])
+    sd = {"pool_convs.0.conv.weight": torch.randn(8, npool, 1, 1, generator=g) / 2,
+          "pool_convs.1.conv.weight": torch.randn(8, 8, 1, 1, generator=g) / 2,
+          "conv.conv.weight": torch.randn(8, 10, 3, 3, generator=g) / 6}
+    pyr_ref, out_ref = orc.sparse_to_dense_pool(x, sd, mins, maxs, return_pyramid=True)
+    assert torch.equal(kb.ops.s2d_pyramid(x.to(dev), mins, maxs).cpu(), pyr_ref)
+    mod = kb.modules.SparseToDensePool(2, mins, maxs, 8, 2, "xavier_normal", "leaky_relu").to(dev)
+    mod.load_state_dict(sd)
+    assert rel_err(mod(x.to(dev)), out_ref) < TIGHT
+
+
 def test_s2d_dense_and_empty_maps(dev):
     cfg = kb.kitti_config()
     sd = kb.synthetic.make_state_dicts(cfg, seed=2, gain=2.0)[0]

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Times kbn_s2d_forward alone (KITTI preset, batch 8) under the KBN_S2D_DEBUG ablation switches."""
+import os, sys, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1 and sys.argv[1] == "--one":
+    import torch, kbnet_amd as kb
+    preset = os.environ.get("S2D_PRESET", "kitti")
+    cfg = kb.PRESETS[preset]()
+    h, w = (352, 1216) if preset == "kitti" else (480, 640)
+    dev = torch.device("cuda:0")
+    _, sp, va, _ = kb.synthetic.make_frames(8, h, w, preset, seed=1)
+    x = torch.cat([sp, va], 1).to(dev)
+    sd = kb.synthetic.make_state_dicts(cfg, seed=0)[0]
+    ws = [sd[f"pool_convs.{i}.conv.weight"].to(dev) for i in range(3)]
+    wc = sd["conv.conv.weight"].to(dev)
+    f = lambda: kb.ops.s2d_forward(x, ws, wc, cfg.min_pools, cfg.max_pools)
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10): f()
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 100
+    print(json.dumps({"us": round(us, 1), "GBps": round(8 * h * w * 40 / us / 1e3, 1)}))
+    sys.exit(0)
+for dbg, tag in ((0, "full"), (16, "no z staging"), (1, "no row pass"), (2, "no column pass"), (4, "no 1x1 chain"), (8, "no 3x3 conv"), (31, "skeleton only"), (15, "staging+stores only")):
+    r = subprocess.run([sys.executable, __file__, "--one"], env=dict(os.environ, KBN_S2D_DEBUG=str(dbg)), capture_output=True, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    print(f"{tag:22s}", line[-1] if line else r.stderr[-300:], flush=True)
