@@ -55,8 +55,8 @@ SIGNATURES = {
     "kbn_s2d_pyramid": (_I, [_P, _L, _P, _I, _I, _I, C.POINTER(_I), _I, C.POINTER(_I), _I, _P]),
     "kbn_intrinsics_inverse": (_I, [_P, _P, _I, _F, _F, _P]),
     "kbn_camera_coordinates": (_I, [_P, _P, _I, _I, _I, _P]),
-    "kbn_conv2d_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
-    "kbn_conv2d_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "kbn_conv2d_packed_weight_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "kbn_conv2d_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "kbn_conv2d_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I,
                                 _F, _P]),
     "kbn_conv2d_query": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I)]),

@@ -37,10 +37,14 @@ struct ConvPlan {
     int CK, NB, MW, nTilesN, Cpad, NT;
 };
 
-__host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks, int force_ck = 0) {
+__host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks, int stride, int force_ck = 0) {
     ConvPlan pl;
-    pl.CK = (ks == 1) ? 16 : (cin <= 4 ? 4 : 8);
+    // Channels per K chunk (the packed weight layout depends on it, hence on the stride the
+    // weight is used with).  Stride-2 3x3 convs stage 4x the pixels per output pixel: CK = 4
+    // halves their LDS stage so that two workgroups stay resident per CU.
+    pl.CK = (ks == 1) ? 16 : ((cin <= 4 || stride == 2) ? 4 : 8);
     if (force_ck == 4 && ks == 3) pl.CK = 4;  // experiment hook (KBN_FORCE_CK)
+    if (force_ck == 8 && ks == 3 && cin > 4) pl.CK = 8;
     int nblk = ceil_div(oc, 16);
     // pick NB in 1..4 minimising padded n-blocks, ties -> larger NB
     int best = 1, bestpad = 1 << 30;

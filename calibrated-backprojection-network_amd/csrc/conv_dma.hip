@@ -126,8 +126,11 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p) {
                 const SrcDev& sd = p.src[syn];
                 const int HW = p.inH * p.inW;
                 const float* kinv = sd.kinv ? sd.kinv + (long long)n * 9 : nullptr;
-                for (int e = tid; e < p.rowsS * p.colsS; e += 256) {
-                    const int r = e / p.colsS, cx = e - r * p.colsS;
+                // only the columns the fragments read: every one for 3x3, every STRIDE-th for 1x1
+                constexpr int CSTEP = (KS == 1) ? STRIDE : 1;
+                const int ncols = p.colsS / CSTEP;
+                for (int e = tid; e < p.rowsS * ncols; e += 256) {
+                    const int r = e / ncols, cx = (e - r * ncols) * CSTEP;
                     const int Y = Y0 + r * YSTEP, X = XA + cx;
                     float cv[3] = {0.f, 0.f, 0.f};
                     float z = 1.f;
@@ -144,8 +147,16 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p) {
                         }
                         if (sd.kind == KBN_SRC_XYZ) {
                             const float* db = sd.data + (long long)n * sd.bstride + g;
-                            float a = 0.f;
-                            for (int c = 0; c < sd.Cd; ++c) a = fmaf(sd.proj[c], db[(long long)c * HW], a);
+                            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 chains: loads issue ahead of the FMAs
+                            int c = 0;
+                            for (; c + 3 < sd.Cd; c += 4) {
+                                a0 = fmaf(sd.proj[c], db[(long long)c * HW], a0);
+                                a1 = fmaf(sd.proj[c + 1], db[(long long)(c + 1) * HW], a1);
+                                a2 = fmaf(sd.proj[c + 2], db[(long long)(c + 2) * HW], a2);
+                                a3 = fmaf(sd.proj[c + 3], db[(long long)(c + 3) * HW], a3);
+                            }
+                            for (; c < sd.Cd; ++c) a0 = fmaf(sd.proj[c], db[(long long)c * HW], a0);
+                            const float a = (a0 + a1) + (a2 + a3);
                             z = p.act ? leaky_relu(a, p.slope) : a;
                         }
                     }
@@ -270,10 +281,10 @@ static int dma_nb_syn(const ConvParams& p, int NB, int MW, size_t lds, hipStream
 }
 
 // The computed-source (KB layer) variants only exist for the two convs that use them:
-// conv_depth (3x3 s2, CK 8) and conv_fused (1x1 s2, CK 16).
+// conv_depth (3x3 s2) and conv_fused (1x1 s2).
 template <int KS, int STRIDE, int CK>
 static int dma_nb(const ConvParams& p, int NB, int MW, size_t lds, hipStream_t st, bool syn) {
-    if constexpr (STRIDE == 2 && CK != 4) {
+    if constexpr (STRIDE == 2) {
         if (syn) return dma_nb_syn<KS, STRIDE, CK, true>(p, NB, MW, lds, st);
     } else {
         if (syn) return KBN_ERR_UNSUPPORTED;

@@ -433,7 +433,7 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     }
     for (int s = n_src; s < KBN_MAX_SRC; ++s) p.src[s] = p.src[0];
 
-    const ConvPlan pl = make_plan(out_channels, ctot, kernel_size, env_int("KBN_FORCE_CK"));
+    const ConvPlan pl = make_plan(out_channels, ctot, kernel_size, stride, env_int("KBN_FORCE_CK"));
     p.nsrc = n_src; p.N = n; p.OC = out_channels; p.Ctot = ctot; p.Cpad = pl.Cpad;
     p.wp = packed_weight; p.out = out; p.out_bstride = out_batch_stride;
     p.inH = in_height; p.inW = in_width;
@@ -478,17 +478,18 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
 
 extern "C" {
 
-size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int kernel_size) {
+size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int kernel_size, int stride) {
     if (out_channels < 1 || in_channels < 1 || (kernel_size != 1 && kernel_size != 3)) return 0;
-    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, kbn::env_int("KBN_FORCE_CK"));
+    if (stride != 1 && stride != 2) return 0;
+    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::env_int("KBN_FORCE_CK"));
     return sizeof(float) * (size_t)pl.nTilesN * pl.Cpad * kernel_size * kernel_size * pl.NT;
 }
 
 int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
-                           int kernel_size, kbn_stream_t stream) {
+                           int kernel_size, int stride, kbn_stream_t stream) {
     if (!weight || !packed || out_channels < 1 || in_channels < 1) return KBN_ERR_INVALID_ARGUMENT;
-    if (kernel_size != 1 && kernel_size != 3) return KBN_ERR_UNSUPPORTED;
-    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, kbn::env_int("KBN_FORCE_CK"));
+    if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
+    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::env_int("KBN_FORCE_CK"));
     int taps = kernel_size * kernel_size;
     long long total = (long long)pl.nTilesN * pl.Cpad * taps * pl.NT;
     int blocks = (int)((total + 255) / 256);
@@ -504,7 +505,7 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
     if (!info || n < 1 || out_channels < 1 || in_channels < 1 || in_height < 1 || in_width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
     if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
-    const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size, env_int("KBN_FORCE_CK"));
+    const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size, stride, env_int("KBN_FORCE_CK"));
     const int outH = ceil_div(in_height, stride), outW = ceil_div(in_width, stride);
     const TileChoice tc = choose_tile(outH, outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
     const int th = 4 * tc.MW / tc.TWB, tw = tc.TWB * 16;

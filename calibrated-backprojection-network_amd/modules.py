@@ -74,10 +74,10 @@ class _PackedWeight:
         self._key = None
         self._packed = None
 
-    def get(self, weight: torch.Tensor) -> torch.Tensor:
-        key = (weight.data_ptr(), weight._version, weight.device)
+    def get(self, weight: torch.Tensor, stride: int) -> torch.Tensor:
+        key = (weight.data_ptr(), weight._version, weight.device, stride)
         if key != self._key:
-            self._packed = ops.pack_conv_weight(weight)
+            self._packed = ops.pack_conv_weight(weight, stride)
             self._key = key
         return self._packed
 
@@ -105,7 +105,7 @@ class Conv2d(torch.nn.Module):
         self._packed = _PackedWeight()
 
     def packed(self):
-        return self._packed.get(self.conv.weight)
+        return self._packed.get(self.conv.weight, self.stride)
 
     def run(self, srcs, n, in_h, in_w, out=None, resize=False):
         oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)

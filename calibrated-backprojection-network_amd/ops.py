@@ -138,19 +138,20 @@ def camera_coordinates(kinv, height: int, width: int):
 
 
 # --------------------------------------------------------------------------- conv2d
-def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
-    """OIHW -> MFMA fragment order (done once per weight; see PackedWeights in modules.py)."""
+def pack_conv_weight(weight: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """OIHW -> MFMA fragment order for a conv of this stride (done once per weight; see
+    _PackedWeight in modules.py)."""
     lib = _lib.load()
     w = weight.detach().contiguous()
     _require(w, "weight", 4)
     oc, cin, kh, kw = w.shape
     if kh != kw:
         raise KbnError("square kernels only")
-    nbytes = lib.kbn_conv2d_packed_weight_bytes(oc, cin, kh)
+    nbytes = lib.kbn_conv2d_packed_weight_bytes(oc, cin, kh, stride)
     if nbytes == 0:
         raise KbnError(f"unsupported conv weight shape {tuple(w.shape)}")
     packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    check(lib.kbn_conv2d_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, kh, _stream()),
+    check(lib.kbn_conv2d_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, kh, stride, _stream()),
           "kbn_conv2d_pack_weight")
     return packed
 

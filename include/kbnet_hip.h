@@ -114,14 +114,15 @@ typedef struct kbn_conv_src {
 #define KBN_RESIZE_NONE 0
 #define KBN_RESIZE_NEAREST 1
 
-/* Bytes of the packed weight blob for a conv with these dimensions. */
-size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int kernel_size);
+/* Bytes of the packed weight blob for a conv with these dimensions (0 if unsupported).  The
+ * blob layout depends on the stride the weight will be used with. */
+size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int kernel_size, int stride);
 
 /* Re-orders an OIHW weight (out_channels x in_channels x k x k) into the MFMA
  * fragment order the kernel consumes.  `packed` must hold
- * kbn_conv2d_packed_weight_bytes(...) bytes.  Do this once per weight. */
+ * kbn_conv2d_packed_weight_bytes(...) bytes.  Do this once per weight (and stride). */
 int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
-                           int kernel_size, kbn_stream_t stream);
+                           int kernel_size, int stride, kbn_stream_t stream);
 
 /* out[n, :, oy, ox] = act(sum_c,ky,kx W[:, c, ky, kx] * in[n, c, oy*stride+ky-pad, ox*stride+kx-pad])
  * where `in` is the channel concat of the sources, logically in_height x in_width

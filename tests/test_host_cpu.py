@@ -88,10 +88,11 @@ def test_library_exports_every_declared_symbol():
     assert loaded.kbn_version() == kb._lib.ABI_VERSION
     assert loaded.kbn_status_string(-2) == b"configuration outside the kernel limits"
     # pure host arithmetic, no GPU needed
-    assert loaded.kbn_conv2d_packed_weight_bytes(48, 3, 3) == 4 * 1 * 4 * 9 * 48
-    assert loaded.kbn_conv2d_packed_weight_bytes(12, 64, 3) == 4 * 1 * 64 * 9 * 16
-    assert loaded.kbn_conv2d_packed_weight_bytes(96, 99, 1) == 4 * 2 * 112 * 1 * 48
-    assert loaded.kbn_conv2d_packed_weight_bytes(5, 5, 5) == 0
+    assert loaded.kbn_conv2d_packed_weight_bytes(48, 3, 3, 1) == 4 * 1 * 4 * 9 * 48
+    assert loaded.kbn_conv2d_packed_weight_bytes(12, 64, 3, 1) == 4 * 1 * 64 * 9 * 16
+    assert loaded.kbn_conv2d_packed_weight_bytes(96, 99, 1, 2) == 4 * 2 * 112 * 1 * 48
+    assert loaded.kbn_conv2d_packed_weight_bytes(16, 19, 3, 2) == 4 * 1 * 20 * 9 * 16  # stride 2: 4-channel chunks
+    assert loaded.kbn_conv2d_packed_weight_bytes(5, 5, 5, 1) == 0
     # tile choice: big maps keep the largest tile, small maps shrink it so every CU gets work
     big = kb.ops.conv_plan(8, 64, 128, 3, 1, 176, 608)
     small = kb.ops.conv_plan(8, 256, 512, 3, 1, 22, 76)

@@ -46,7 +46,7 @@ def run_one(name, batch=int(os.environ.get("KBN_BATCH", "8")), iters=8):
         srcs.append(kb.ops.tensor_src(t))
     cin = sum(cins)
     wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
-    pw = kb.ops.pack_conv_weight(wt)
+    pw = kb.ops.pack_conv_weight(wt, stride)
     oh, ow = -(-h // stride), -(-w // stride)
     out = torch.empty(batch, cout, oh, ow, device=dev)
     f = lambda: kb.ops.conv2d(srcs, pw, batch, cout, k, stride, h, w, out, resize=rs is not None, negative_slope=0.2)
