@@ -59,6 +59,9 @@ SIGNATURES = {
     "kbn_conv2d_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "kbn_conv2d_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I,
                                 _F, _P]),
+    "kbn_upconv2x_packed_weight_bytes": (C.c_size_t, [_I, _I]),
+    "kbn_upconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
+    "kbn_upconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P]),
     "kbn_conv2d_query": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_kb_block_forward": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P,
                                   _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),

@@ -1,0 +1,364 @@
+// conv_up2x.hip -- UpConv2d for an exact 2x nearest upsample: interpolate(nearest, 2x) followed
+// by a 3x3 conv (reference net_utils.UpConv2d.forward, src/net_utils.py:484-499) evaluated as
+// four 2x2 convs on the LOW-resolution input, one per output phase (a, b) = (Y & 1, X & 1):
+//
+//   out[2y+a, 2x+b] = sum_{dy,dx in {0,1}} W'_{ab}[dy][dx] . in[y-1+a+dy, x-1+b+dx]
+//   W'_{ab}[dy][dx] = sum_{ky in S_a(dy)} sum_{kx in S_b(dx)} W[ky][kx]
+//   S_0(0) = {0}, S_0(1) = {1,2}, S_1(0) = {0,1}, S_1(1) = {2}
+//
+// (two of the three taps of the 3x3 window always land on the same low-res pixel).  That is
+// 4 instead of 9 MACs per output and channel -- 2.25x fewer MFMAs for the five up-convs of the
+// decoder (37.5 of KBNet's 100.7 GFLOP) -- and the upsampled tensor is never formed.  The
+// pre-summed weights change rounding at the 1e-7 level only.  Zero padding carries over
+// exactly: an out-of-image upsampled row/column corresponds to an out-of-image low-res one.
+//
+// Same MFMA machinery as conv_igemm.hip (v_mfma_f32_16x16x4_f32, LDS-staged tile + packed
+// weights, double buffered: A by register prefetch, B by LDS-DMA).  A workgroup owns a
+// TH x TW low-res tile, ONE row phase `a` and BOTH column phases: each lane ends up with 4
+// consecutive low-res x for b = 0 and b = 1, i.e. 8 consecutive output pixels -> two 16-byte
+// stores.  Weights are packed per row phase as [a][n-tile][chunk][dy][c/4][dx][b][k>>1][n][k&1].
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace kbn {
+
+struct Up2xPlan {
+    int CK, NB, MW, NT, nTilesN, Cpad;
+};
+
+__host__ __device__ inline Up2xPlan make_up2x_plan(int oc, int cin) {
+    Up2xPlan pl;
+    pl.CK = 8;
+    int nblk = ceil_div(oc, 16);
+    int best = 1, bestpad = 1 << 30;
+    for (int nb = 1; nb <= 4; ++nb) {
+        int pad = ceil_div(nblk, nb) * nb;
+        if (pad < bestpad || (pad == bestpad && nb > best)) { best = nb; bestpad = pad; }
+    }
+    pl.NB = best;
+    pl.MW = (best >= 3) ? 2 : 4;  // 2 * MW * NB accumulators (both column phases)
+    pl.NT = best * 16;
+    pl.nTilesN = ceil_div(nblk, best);
+    pl.Cpad = round_up(cin, pl.CK);
+    return pl;
+}
+
+__global__ void pack_up2x_kernel(const float* __restrict__ w, float* __restrict__ packed, int OC, int Cin,
+                                 Up2xPlan pl, long long total) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int NT = pl.NT, CK = pl.CK, NC4 = CK / 4;
+    const long long per_nt = (long long)pl.Cpad * 8 * NT;  // 2 dy * 2 dx * 2 b taps per channel
+    const long long per_a = per_nt * pl.nTilesN;
+    const int a = (int)(e / per_a);
+    long long rem = e - a * per_a;
+    const int nt = (int)(rem / per_nt);
+    int r = (int)(rem - nt * per_nt);
+    const int per_chunk = CK * 8 * NT;
+    const int chunk = r / per_chunk; r -= chunk * per_chunk;
+    const int per_dy = NC4 * 4 * 4 * NT;
+    const int dy = r / per_dy; r -= dy * per_dy;
+    const int per_c4 = 4 * 4 * NT;
+    const int c4 = r / per_c4; r -= c4 * per_c4;
+    const int dx = r / (2 * 4 * NT); r -= dx * 2 * 4 * NT;
+    const int b = r / (4 * NT); r -= b * 4 * NT;
+    const int khalf = r / (2 * NT); r -= khalf * 2 * NT;
+    const int nn = r >> 1, klow = r & 1;
+    const int c = chunk * CK + c4 * 4 + khalf * 2 + klow;
+    const int oc = nt * NT + nn;
+    float v = 0.f;
+    if (c < Cin && oc < OC) {
+        const float* wk = w + ((long long)oc * Cin + c) * 9;
+        const int ky0 = (a == 0) ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2);
+        const int ky1 = (a == 0) ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+        const int kx0 = (b == 0) ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2);
+        const int kx1 = (b == 0) ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) v += wk[ky * 3 + kx];
+    }
+    packed[e] = v;
+}
+
+struct Up2xParams {
+    const float* src;
+    const float* wp;
+    float* out;
+    long long src_bstride, out_bstride;
+    int N, Cin, Cpad, OC, srcH, srcW;
+    int tilesX, tilesY, nTilesN, nblocks;
+    int TWB, TH, rowsS, colsS, pitch, plane;
+    int act;
+    float slope;
+};
+
+template <int CK, int NB, int MW, int MAXPOS>
+__global__ __launch_bounds__(256) void conv_up2x_kernel(const Up2xParams p) {
+    constexpr int NT = NB * 16;
+    constexpr int NC4 = CK / 4;
+    constexpr int B_FLOATS = CK * 8 * NT;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int a_floats = CK * p.plane;
+    const int buf_floats = a_floats + B_FLOATS;
+
+    const int tid = threadIdx.x;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int a = bid & 1;  // row phase
+    bid >>= 1;
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int TW = p.TWB * 16;
+    const int y0 = ty * p.TH, x0 = tx * TW;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+
+    // ---- staging table (low-res rows y0-1+a .. y0+TH-1+a, cols x0-1 .. x0+TW) ----
+    int goff[MAXPOS], loff[MAXPOS];
+#pragma unroll
+    for (int u = 0; u < MAXPOS; ++u) {
+        const int pos = tid + u * 256;
+        int g = -1, l = -1;
+        if (pos < p.rowsS * p.colsS) {
+            const int r = pos / p.colsS, ci = pos - r * p.colsS;
+            const int Y = y0 - 1 + a + r, X = x0 - 1 + ci;
+            l = r * p.pitch + ci;
+            if (Y >= 0 && Y < p.srcH && X >= 0 && X < p.srcW) g = Y * p.srcW + X;
+        }
+        goff[u] = g;
+        loff[u] = l;
+    }
+
+    int mbase[MW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int mb = wave * MW + mi;
+        const int oy = mb / p.TWB, seg = mb - oy * p.TWB;
+        mbase[mi] = oy * p.pitch + seg * 16 + li + lk * p.plane;
+    }
+    const int boff = (lk >> 1) * 2 * NT + li * 2 + (lk & 1);
+
+    f32x4 acc[2][MW][NB];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[b][mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int HW = p.srcH * p.srcW;
+    const float* srcn = p.src + (long long)n * p.src_bstride;
+    const float* wp_a = p.wp + ((long long)a * p.nTilesN + nt) * p.Cpad * 8 * NT;
+
+    auto load_chunk = [&](int c0, float (&va)[MAXPOS][CK]) -> int {
+        const int nvalid = (p.Cin - c0 < CK) ? (p.Cin - c0) : CK;
+        const float* base = srcn + (long long)c0 * HW;
+#pragma unroll
+        for (int u = 0; u < MAXPOS; ++u) {
+            const int gi = goff[u] < 0 ? 0 : goff[u];
+#pragma unroll
+            for (int q = 0; q < CK; ++q) va[u][q] = base[(q < nvalid ? q : 0) * HW + gi];  // masked at the store
+        }
+        return nvalid;
+    };
+    auto store_chunk = [&](float* As, const float (&va)[MAXPOS][CK], int nvalid) {
+#pragma unroll
+        for (int u = 0; u < MAXPOS; ++u) {
+            if (loff[u] >= 0) {
+                const bool inb = goff[u] >= 0;
+#pragma unroll
+                for (int q = 0; q < CK; ++q) As[q * p.plane + loff[u]] = (inb && q < nvalid) ? va[u][q] : 0.f;
+            }
+        }
+    };
+    auto stage_B = [&](float* Bs, int c0) {
+        constexpr int CNT4 = B_FLOATS / 4;
+        const float4* s4 = reinterpret_cast<const float4*>(wp_a + (long long)c0 * 8 * NT);
+        const unsigned bs = __builtin_amdgcn_readfirstlane(lds_addr(Bs));
+#pragma unroll
+        for (int e0 = 0; e0 < CNT4; e0 += 256) {
+            const int eb = e0 + __builtin_amdgcn_readfirstlane(wave) * 64;
+            if (eb + lane < CNT4) lds_dma16(reinterpret_cast<const float*>(s4 + eb + lane), bs + eb * 16);
+        }
+    };
+    auto compute = [&](const float* As, const float* Bs) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+            for (int c4 = 0; c4 < NC4; ++c4) {
+                const float* Ab = As + c4 * 4 * p.plane + dy * p.pitch;
+                const float* Bb = Bs + (dy * NC4 + c4) * 16 * NT + boff;
+                float av[MW][3], bv[2][2][NB];
+#pragma unroll
+                for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) av[mi][j] = Ab[mbase[mi] + j];
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) bv[dx][b][nb] = Bb[(dx * 2 + b) * 4 * NT + nb * 32];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[b][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][b + dx], bv[dx][b][nb],
+                                                                                     acc[b][mi][nb], 0, 0, 0);
+            }
+        }
+    };
+
+    float va[MAXPOS][CK];
+    stage_B(smem + a_floats, 0);
+    int nv = load_chunk(0, va);
+    store_chunk(smem, va, nv);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < p.Cpad; c0 += CK) {
+        float* curA = smem + cur * buf_floats;
+        float* nxtA = smem + (cur ^ 1) * buf_floats;
+        const bool more = (c0 + CK < p.Cpad);
+        if (more) {
+            nv = load_chunk(c0 + CK, va);
+            stage_B(nxtA + a_floats, c0 + CK);
+        }
+        compute(curA, curA + a_floats);
+        if (more) store_chunk(nxtA, va, nv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: interleave the two column phases -> 8 consecutive output pixels per lane ----
+    const int outH = 2 * p.srcH, outW = 2 * p.srcW;
+    const long long HWo = (long long)outH * outW;
+    float* outn = p.out + (long long)n * p.out_bstride;
+    const bool vec_ok = ((outW & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) && ((p.out_bstride & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int mb = wave * MW + mi;
+        const int oyl = mb / p.TWB, seg = mb - oyl * p.TWB;
+        const int y = y0 + oyl;
+        const int xl = x0 + seg * 16 + lk * 4;
+        if (y >= p.srcH || xl >= p.srcW) continue;
+        const int Y = 2 * y + a, X = 2 * xl;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int oc = nt * NT + nb * 16 + li;
+            if (oc >= p.OC) continue;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e0 = acc[0][mi][nb][r], e1 = acc[1][mi][nb][r];
+                if (p.act) { e0 = leaky_relu(e0, p.slope); e1 = leaky_relu(e1, p.slope); }
+                v[2 * r] = e0;
+                v[2 * r + 1] = e1;
+            }
+            float* o = outn + (long long)oc * HWo + (long long)Y * outW + X;
+            if (vec_ok && xl + 3 < p.srcW) {
+                reinterpret_cast<f32x4*>(o)[0] = (f32x4){v[0], v[1], v[2], v[3]};
+                reinterpret_cast<f32x4*>(o)[1] = (f32x4){v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (xl + (r >> 1) < p.srcW) o[r] = v[r];
+            }
+        }
+    }
+}
+
+template <int NB, int MW, int MAXPOS>
+static int up2x_variant(const Up2xParams& p, size_t lds, hipStream_t stream) {
+    auto kern = conv_up2x_kernel<8, NB, MW, MAXPOS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return KBN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    if (p.rowsS * p.colsS > MAXPOS * 256) return KBN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, stream, p);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+}  // namespace kbn
+
+extern "C" {
+
+size_t kbn_upconv2x_packed_weight_bytes(int out_channels, int in_channels) {
+    if (out_channels < 1 || in_channels < 1) return 0;
+    kbn::Up2xPlan pl = kbn::make_up2x_plan(out_channels, in_channels);
+    return sizeof(float) * 2 * (size_t)pl.nTilesN * pl.Cpad * 8 * pl.NT;
+}
+
+int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
+                             kbn_stream_t stream) {
+    if (!weight || !packed || out_channels < 1 || in_channels < 1) return KBN_ERR_INVALID_ARGUMENT;
+    kbn::Up2xPlan pl = kbn::make_up2x_plan(out_channels, in_channels);
+    long long total = 2LL * pl.nTilesN * pl.Cpad * 8 * pl.NT;
+    hipLaunchKernelGGL(kbn::pack_up2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, weight, packed, out_channels, in_channels, pl, total);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const float* packed_weight, float* out,
+                         long long out_batch_stride, int n, int in_channels, int out_channels, int src_height,
+                         int src_width, int apply_activation, float negative_slope, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!src || !packed_weight || !out || n < 1 || in_channels < 1 || out_channels < 1 || src_height < 1 ||
+        src_width < 1)
+        return KBN_ERR_INVALID_ARGUMENT;
+    if (src_height > 16383 || src_width > 16383) return KBN_ERR_UNSUPPORTED;
+    const Up2xPlan pl = make_up2x_plan(out_channels, in_channels);
+    Up2xParams p;
+    p.src = src; p.wp = packed_weight; p.out = out;
+    p.src_bstride = src_batch_stride; p.out_bstride = out_batch_stride;
+    p.N = n; p.Cin = in_channels; p.Cpad = pl.Cpad; p.OC = out_channels;
+    p.srcH = src_height; p.srcW = src_width;
+    p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
+    p.nTilesN = pl.nTilesN;
+    // tile: 4*MW m-blocks of 16 low-res pixels, 16 or 32 wide; a lone workgroup round is avoided
+    const int mblocks = 4 * pl.MW;
+    double best_cost = 1e300;
+    int best_twb = 1;
+    const char* ft = getenv("KBN_FORCE_TWB");
+    for (int twb = 1; twb <= 2; ++twb) {
+        if (ft && atoi(ft) && atoi(ft) != twb) continue;
+        const int th = mblocks / twb, tw = twb * 16;
+        long long tiles = (long long)ceil_div(src_width, tw) * ceil_div(src_height, th) * n * pl.nTilesN * 2;
+        double cost = (double)((tiles + 255) / 256) * (mblocks * 16.0 + 0.1 * (th + 1) * (tw + 2));
+        if (cost < best_cost) { best_cost = cost; best_twb = twb; }
+    }
+    p.TWB = best_twb; p.TH = mblocks / best_twb;
+    const int TW = best_twb * 16;
+    p.tilesX = ceil_div(src_width, TW); p.tilesY = ceil_div(src_height, p.TH);
+    p.rowsS = p.TH + 1; p.colsS = TW + 2; p.pitch = TW + 2;
+    int plane = p.rowsS * p.pitch;
+    p.plane = ((plane + 15) / 32) * 32 + 16;
+    long long nb64 = (long long)p.tilesX * p.tilesY * n * pl.nTilesN * 2;
+    if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.nblocks = (int)nb64;
+    size_t lds = 2 * sizeof(float) * ((size_t)pl.CK * p.plane + (size_t)pl.CK * 8 * pl.NT);
+    hipStream_t st = (hipStream_t)stream;
+    switch (pl.NB) {
+        case 1: return up2x_variant<1, 4, 2>(p, lds, st);
+        case 2: return up2x_variant<2, 4, 2>(p, lds, st);
+        case 3: return up2x_variant<3, 2, 1>(p, lds, st);
+        default: return up2x_variant<4, 2, 1>(p, lds, st);
+    }
+}
+
+}  // extern "C"

@@ -203,6 +203,39 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
     return out
 
 
+# ---------------------------------------------------------------------- up-conv 2x
+def pack_upconv2x_weight(weight: torch.Tensor) -> torch.Tensor:
+    """OIHW 3x3 weight -> phase-summed MFMA blob for `upconv2x` (once per weight)."""
+    lib = _lib.load()
+    w = weight.detach().contiguous()
+    _require(w, "weight", 4)
+    oc, cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise KbnError("upconv2x needs a 3x3 weight")
+    packed = torch.empty(lib.kbn_upconv2x_packed_weight_bytes(oc, cin) // 4, device=w.device, dtype=torch.float32)
+    check(lib.kbn_upconv2x_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, _stream()),
+          "kbn_upconv2x_pack_weight")
+    return packed
+
+
+def upconv2x(x: torch.Tensor, packed_weight: torch.Tensor, out_channels: int, out: torch.Tensor,
+             negative_slope: Optional[float] = 0.2):
+    """nearest 2x upsample + conv3x3 (+ LeakyReLU): x N x C x h x w -> out N x out_channels x 2h x 2w."""
+    lib = _lib.load()
+    xptr, xbs = _planes(x, "x")
+    n, cin, h, w = x.shape
+    optr, obs = _planes(out, "out")
+    if tuple(out.shape) != (n, out_channels, 2 * h, 2 * w):
+        raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, 2 * h, 2 * w)}")
+    # algorithmic work of the reference formulation (9 taps at the upsampled resolution)
+    check(_launch("conv_up2x", 2.0 * n * 4 * h * w * cin * 9 * out_channels,
+                  lambda: lib.kbn_upconv2x_forward(xptr, xbs, packed_weight.data_ptr(), optr, obs, n, cin,
+                                                   out_channels, h, w, 0 if negative_slope is None else 1,
+                                                   0.0 if negative_slope is None else float(negative_slope),
+                                                   _stream())), "kbn_upconv2x_forward")
+    return out
+
+
 # ------------------------------------------------------------------------ KB block
 def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_depth, proj_weight,
              packed_w_fused, filters_image: int, filters_depth: int, filters_fused: int,

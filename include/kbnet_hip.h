@@ -135,6 +135,23 @@ int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_
                        int stride, int in_height, int in_width, int resize, int apply_activation,
                        float negative_slope, kbn_stream_t stream);
 
+/* ------------------------------------------------------------ up-conv 2x -------
+ * net_utils.UpConv2d.forward when the target size is exactly twice the input:
+ * interpolate(nearest) + conv3x3 (+ activation)       reference src/net_utils.py:484-499
+ * evaluated as four 2x2 convs on the low-resolution input (one per output phase) with
+ * pre-summed weights: 4 instead of 9 MACs per output and input channel, no upsampled tensor.
+ *   src   N x in_channels x src_height x src_width (frames src_batch_stride apart)
+ *   out   N x out_channels x 2*src_height x 2*src_width (frames out_batch_stride apart)
+ *   packed_weight from kbn_upconv2x_pack_weight (OIHW 3x3 weight in, phase-summed blob out).
+ * Other target sizes go through kbn_conv2d_forward(..., KBN_RESIZE_NEAREST). */
+size_t kbn_upconv2x_packed_weight_bytes(int out_channels, int in_channels);
+int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
+                             kbn_stream_t stream);
+int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const float* packed_weight,
+                         float* out, long long out_batch_stride, int n, int in_channels,
+                         int out_channels, int src_height, int src_width, int apply_activation,
+                         float negative_slope, kbn_stream_t stream);
+
 /* Which kernel variant / tile geometry kbn_conv2d_forward picks for a problem (diagnostics,
  * profiling): info[8] = {CK, NB, MW, TWB, TH, workgroups, staged positions per thread, kernel};
  * kernel 2 = conv_dma_kernel<kernel_size, stride, CK, NB, MW, ...> (LDS-DMA staging; needs
