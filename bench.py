@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="time plain launches instead of HIP-graph replay")
     args = ap.parse_args()
 
     rank, local_rank, world = kb.dist.init("nccl")
@@ -113,13 +114,15 @@ def main():
     # rank 0 is the frame the CPU oracle sees)
     frames = kb.synthetic.make_frames(per, HEIGHT, WIDTH, "kitti", seed=1 + rank)
     frames = [f.to(dev) for f in frames]
-    runner = kb.dist.ShardedRunner(model.forward, rank, world)
+    # The forward of this batch shape is captured once into a HIP graph; a step replays it (same
+    # kernels, no per-launch host round trips).  --eager times the plain launch sequence instead.
+    forward = model.forward if args.eager else model.capture(*frames)
+    runner = kb.dist.ShardedRunner(forward, rank, world)
 
     for _ in range(args.warmup):
         out = runner.step(frames, n_total=per * world)
     torch.cuda.synchronize()
 
-    kb.ops.PROFILE = []
     kb.dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -128,8 +131,18 @@ def main():
     torch.cuda.synchronize()
     kb.dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof, kb.ops.PROFILE = kb.ops.PROFILE, None
     elapsed = kb.dist.max_over_ranks(elapsed, dev)
+    out = out.clone()
+
+    # Per-kernel durations for the roofline: the same K steps launched eagerly, every ABI call
+    # bracketed by HIP events on the launch stream (graph nodes cannot be timed individually).
+    kb.ops.PROFILE = []
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        model.forward(*frames)
+    torch.cuda.synchronize()
+    eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+    prof, kb.ops.PROFILE = kb.ops.PROFILE, None
 
     ms_per_step = 1e3 * elapsed / args.steps
     fps = per * world * args.steps / elapsed
@@ -167,7 +180,9 @@ def main():
                                "(S2D + KB layers + MFMA convs + head), random xavier weights",
                    "frames_per_gpu": per, "global_batch": per * world, "height": HEIGHT, "width": WIDTH,
                    "gflop_per_frame": round(gflop_frame, 3),
-                   "parallelism": f"frames sharded over {world} rank(s), RCCL all-gather of outputs"},
+                   "parallelism": f"frames sharded over {world} rank(s), RCCL all-gather of outputs",
+                   "launch": "eager" if args.eager else "HIP graph replay",
+                   "eager_ms_per_step_with_event_timing": round(eager_ms, 4)},
         "roofline": roofline, "kernels": breakdown,
     }
 

@@ -103,19 +103,41 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p) {
 
     const float* wp_nt = p.wp + (long long)nt * p.Cpad * TAPS * NT;
 
+    // current source of the K loop (wave-uniform; chunks are staged in increasing c0 order)
+    int cs_idx = 0, cs_start = 0, cs_end = p.src[0].C, cs_hw = p.src[0].H * p.src[0].W;
+    bool cs_tensor = p.src[0].kind == KBN_SRC_TENSOR;
+    const float* cs_base = p.src[0].data + (long long)n * p.src[0].bstride;
+
     // ---- stage one chunk: A tile (CK channels) + B slice, all by LDS-DMA ----------------
     auto stage = [&](float* As, int c0) {
         if (!(p.dbg & 1)) {
-            // wave w moves channels w, w+4, ... of the chunk
+            // wave w moves channels w, w+4, ... of the chunk.  Fast path: the chunk lies inside the
+            // current source (tracked in scalar registers across chunks) -> no kernarg lookups.
+            while (c0 >= cs_end && cs_idx + 1 < p.nsrc) {  // advance to the source that holds c0
+                ++cs_idx;
+                cs_start = p.src[cs_idx].cstart;
+                cs_end = cs_start + p.src[cs_idx].C;
+                cs_tensor = p.src[cs_idx].kind == KBN_SRC_TENSOR;
+                cs_hw = p.src[cs_idx].H * p.src[cs_idx].W;
+                cs_base = p.src[cs_idx].data + (long long)n * p.src[cs_idx].bstride;
+            }
+            const bool inside = cs_tensor && c0 >= cs_start && c0 + CK <= cs_end;
 #pragma unroll
             for (int t = 0; t < NC4; ++t) {
                 const int q = wave + 4 * t;
-                const ChanRef cr = chan_lookup(p, n, c0 + q);  // wave-uniform
-                if (cr.kind == KBN_SRC_TENSOR) {
+                const float* cptr = nullptr;
+                if (inside) {
+                    cptr = cs_base + (long long)(c0 + q - cs_start) * cs_hw;
+                } else {
+                    const ChanRef cr = chan_lookup(p, n, c0 + q);  // wave-uniform
+                    if (cr.kind == KBN_SRC_TENSOR) cptr = cr.ptr;
+                }
+                if (cptr) {
                     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(As + q * p.plane));
 #pragma unroll
                     for (int j = 0; j < MAXJ; ++j) {
-                        if (j * 64 < nf4 && goff[j] >= 0) lds_dma16(cr.ptr + goff[j], dst + j * 1024);
+                        if (j * 64 < nf4 && goff[j] >= 0)
+                            lds_dma16(cptr + ((p.dbg & 8) ? (lane * 4) : goff[j]), dst + j * 1024);
                     }
                 }
             }

@@ -340,18 +340,22 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
             if (p.ksize[i++] != k) return false;
         return true;
     };
-    auto launch = [&](auto kern) -> int {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
+    auto launch = [&](auto kern, bool& attr_set) -> int {
+        if (!attr_set) {  // once per kernel (not a stream operation: keep it out of graph captures)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return KBN_ERR_LAUNCH;
+            attr_set = true;
+        }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
         return KBN_OK;
     };
+    static bool set_kitti = false, set_void = false, set_voidtrain = false, set_dyn = false;
     int rc;
-    if (matches(5, {5, 7, 9, 11, 13, 15, 17})) rc = launch(s2d_kernel<KittiPools>);
-    else if (matches(2, {15, 17, 23, 27, 29})) rc = launch(s2d_kernel<VoidPools>);
-    else if (matches(3, {15, 17, 19, 23, 27})) rc = launch(s2d_kernel<VoidTrainPools>);
-    else rc = launch(s2d_kernel<DynamicPools>);
+    if (matches(5, {5, 7, 9, 11, 13, 15, 17})) rc = launch(s2d_kernel<KittiPools>, set_kitti);
+    else if (matches(2, {15, 17, 23, 27, 29})) rc = launch(s2d_kernel<VoidPools>, set_void);
+    else if (matches(3, {15, 17, 19, 23, 27})) rc = launch(s2d_kernel<VoidTrainPools>, set_voidtrain);
+    else rc = launch(s2d_kernel<DynamicPools>, set_dyn);
     if (rc != KBN_OK) return rc;
     KBN_CHECK_LAUNCH();
     return KBN_OK;

@@ -261,6 +261,19 @@ def test_forward_full_size_vs_oracle(dev, preset, shape):
     assert torch.equal(alone, out[1:2])
 
 
+def test_graph_replay_matches_eager(dev):
+    cfg = kb.kitti_config().narrow()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    a = to(dev, *kb.synthetic.make_frames(2, 64, 96, "kitti", seed=1))
+    b = to(dev, *kb.synthetic.make_frames(2, 64, 96, "kitti", seed=2))
+    eager_a, eager_b = m.forward(*a).clone(), m.forward(*b).clone()
+    replay = m.capture(*a)
+    assert torch.equal(replay(*a), eager_a)
+    assert torch.equal(replay(*b), eager_b)   # new inputs are copied into the static buffers
+    assert torch.equal(replay(*a), eager_a)
+
+
 def test_drop_in_modules_inside_reference_style_forward(dev):
     """The two north-star modules used the way reference kbnet_model.py uses them:
     positional S2D call, keyword KB-block call with a dense coordinates tensor."""

@@ -71,7 +71,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--ablate":
         for n in sys.argv[2:]:
-            for dbg, tag in ((0, "full"), (1, "no-A-staging"), (2, "no-B-staging"), (3, "no-staging"), (4, "no-MFMA"), (7, "barriers-only")):
+            for dbg, tag in ((0, "full"), (1, "no-A-staging"), (2, "no-B-staging"), (3, "no-staging"), (4, "no-MFMA"), (7, "barriers-only"), (8, "A-from-cache"), (12, "A-from-cache-noMFMA")):
                 env = dict(os.environ, KBN_DEBUG=str(dbg))
                 r = subprocess.run([sys.executable, __file__, "--one", n], env=env, capture_output=True, text=True)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
