@@ -63,6 +63,25 @@ def conv_gflop_per_frame(cfg, h, w):
     return total / 1e9
 
 
+def lookup_traffic(kernel, launches):
+    """HBM bytes per launch of `kernel` from the committed PMC collection (tools/collect_traffic.py:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled on gfx950), or None."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None
+    table = json.load(open(files[-1]))["kernels"]
+    m = re.match(r"(conv_\w+)<([\d,]+)>", kernel)
+    if not m:
+        return None
+    want = m.group(1) + "_kernel<" + m.group(2).replace(",", ", ")
+    for name, e in table.items():
+        if want in name:
+            return {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
+    return None
+
+
 def cpu_baseline(cfg, sds, frames, budget_s=15.0, max_frames=6):
     """Oracle (CPU port of the reference) on this box's host cores, one frame at a time
     like the reference's own loop (reference src/kbnet.py:887).  Thread count: the
@@ -166,6 +185,7 @@ def main():
                 "launches": dlaunch, "avg_launch_us": round(dtime / dlaunch * 1e6, 2),
                 "flop_per_launch": dwork / dlaunch,
                 "whole_forward_frac": round(fps / world * gflop_frame / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    roofline["traffic"] = lookup_traffic(dom, dlaunch)
     s2d = groups.get("s2d")
     if s2d:
         gbs = s2d[0] / s2d[1] / 1e9
