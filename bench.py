@@ -163,6 +163,17 @@ def main():
     eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
     prof, kb.ops.PROFILE = kb.ops.PROFILE, None
 
+    # "Reference-style" region (reference src/kbnet.py:896-921 times validity map + outlier removal +
+    # image/255 + forward per sample): the same steps with the pre-model kernels in front.
+    image255 = frames[0] * 255.0
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        img, valid, _ = kb.ops.preprocess(image255, frames[1])
+        model.forward(img, frames[1], valid, frames[3])
+    torch.cuda.synchronize()
+    refstyle_ms = 1e3 * (time.perf_counter() - t2) / args.steps
+
     ms_per_step = 1e3 * elapsed / args.steps
     fps = per * world * args.steps / elapsed
     gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
@@ -202,7 +213,8 @@ def main():
                    "gflop_per_frame": round(gflop_frame, 3),
                    "parallelism": f"frames sharded over {world} rank(s), RCCL all-gather of outputs",
                    "launch": "eager" if args.eager else "HIP graph replay",
-                   "eager_ms_per_step_with_event_timing": round(eager_ms, 4)},
+                   "eager_ms_per_step_with_event_timing": round(eager_ms, 4),
+                   "reference_style_region_ms_per_step": round(refstyle_ms, 4)},
         "roofline": roofline, "kernels": breakdown,
     }
 

@@ -65,6 +65,8 @@ SIGNATURES = {
     "kbn_conv2d_query": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_kb_block_forward": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P,
                                   _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_preprocess_forward": (_I, [_P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_eval_accumulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "kbn_depth_head_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
 }
 

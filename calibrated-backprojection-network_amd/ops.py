@@ -301,3 +301,51 @@ def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, re
                                                      float(min_predict_depth), float(max_predict_depth),
                                                      _stream())), "kbn_depth_head_forward")
     return (depth, logits) if return_logits else depth
+
+
+# ------------------------------------------------------- pre-model stage / evaluation
+def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5, normalize_image: bool = True):
+    """Validity map + outlier removal (+ image / 255): what reference src/kbnet.py:899-912 does
+    before calling the model.  Returns (image_normalized or None, filtered_validity, filtered_sparse)."""
+    lib = _lib.load()
+    _require(sparse_depth, "sparse_depth", 4)
+    sd = sparse_depth.contiguous()
+    n, _, h, w = sd.shape
+    img = out_img = None
+    c = 0
+    if image is not None and normalize_image:
+        _require(image, "image", 4)
+        img = image.contiguous()
+        c = img.shape[1]
+        out_img = torch.empty_like(img)
+    validity = torch.empty_like(sd)
+    filtered = torch.empty_like(sd)
+    ws = torch.empty(1, device=sd.device, dtype=torch.int32)
+    check(lib.kbn_preprocess_forward(img.data_ptr() if img is not None else None, sd.data_ptr(),
+                                     out_img.data_ptr() if out_img is not None else None, validity.data_ptr(),
+                                     filtered.data_ptr(), ws.data_ptr(), 4, n, c, h, w, int(kernel_size),
+                                     float(threshold), _stream()), "kbn_preprocess_forward")
+    return out_img, validity, filtered
+
+
+def eval_metrics(output_depth, ground_truth, ground_truth_validity, min_evaluate_depth: float,
+                 max_evaluate_depth: float):
+    """Per-frame (MAE [mm], RMSE [mm], iMAE [1/km], iRMSE [1/km]) as an N x 4 fp64 tensor, computed on
+    the device (reference src/kbnet.py:932-950 does this on the host after a D2H copy)."""
+    lib = _lib.load()
+    o = output_depth.contiguous()
+    _require(o, "output_depth")
+    g = ground_truth.contiguous()
+    v = ground_truth_validity.contiguous()
+    _require(g, "ground_truth")
+    _require(v, "ground_truth_validity")
+    n, h, w = o.shape[0], o.shape[-2], o.shape[-1]
+    if g.numel() != o.numel() or v.numel() != o.numel():
+        raise KbnError("ground truth must have one value per output pixel")
+    sums = torch.zeros((n, 5), device=o.device, dtype=torch.float64)
+    check(lib.kbn_eval_accumulate(o.data_ptr(), g.data_ptr(), v.data_ptr(), sums.data_ptr(), n, h, w,
+                                  float(min_evaluate_depth), float(max_evaluate_depth), _stream()),
+          "kbn_eval_accumulate")
+    cnt = sums[:, 4:5].clamp_min(1.0)
+    mean = sums[:, :4] / cnt
+    return torch.stack([mean[:, 0], mean[:, 1].sqrt(), mean[:, 2], mean[:, 3].sqrt()], dim=1)

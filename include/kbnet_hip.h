@@ -196,6 +196,34 @@ int kbn_depth_head_forward(const float* x, const float* weight, float* depth, fl
                            int channels, int height, int width, float min_predict_depth,
                            float max_predict_depth, kbn_stream_t stream);
 
+/* ------------------------------------------------- pre-model stage --
+ * What the reference's run loop does between the host->device copy and the model call:
+ *   validity = where(sparse > 0, 1, sparse)                        reference src/kbnet.py:899-902
+ *   OutlierRemoval(kernel_size, threshold).remove_outliers          reference src/net_utils.py:1761-1806
+ *     (k x k min filter over the depth with invalid pixels and the padding set to
+ *      10 * max(sparse_depth) -- a BATCH-global maximum; a point is dropped if
+ *      min < depth - threshold)
+ *   image / 255                                                     reference src/transforms.py:201-204
+ * image/out_image: N x image_channels x H x W (both may be NULL to skip the normalisation);
+ * out_validity: the filtered validity map the model is fed; out_sparse_depth (may be NULL): the
+ * filtered sparse depth.  workspace: >= 4 bytes of device memory.  kernel_size odd, <= 15. */
+int kbn_preprocess_forward(const float* image, const float* sparse_depth, float* out_image,
+                           float* out_validity, float* out_sparse_depth, void* workspace,
+                           size_t workspace_bytes, int n, int image_channels, int height, int width,
+                           int kernel_size, float threshold, kbn_stream_t stream);
+
+/* ------------------------------------------------- on-device evaluation
+ * The reference's per-sample metrics                  reference src/kbnet.py:932-950,
+ *                                                     src/eval_utils.py:20-78
+ * over the pixels with ground_truth_validity > 0 and min < ground_truth < max.  ADDS into
+ * sums[n*5 + k] (fp64, caller zeroes): k=0 sum|1000(o-g)|, 1 sum(1000(g-o))^2,
+ * 2 sum|1/(.001g) - 1/(.001o)|, 3 its square, 4 pixel count.  MAE = s0/s4 (mm),
+ * RMSE = sqrt(s1/s4), iMAE = s2/s4 (1/km), iRMSE = sqrt(s3/s4). */
+int kbn_eval_accumulate(const float* output_depth, const float* ground_truth,
+                        const float* ground_truth_validity, double* sums, int n, int height,
+                        int width, float min_evaluate_depth, float max_evaluate_depth,
+                        kbn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

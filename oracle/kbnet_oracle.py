@@ -266,3 +266,23 @@ def validity_and_outlier_removal(sparse_depth, kernel_size=7, threshold=1.5):
                        torch.zeros_like(validity), torch.ones_like(validity))
     validity_clean = validity * keep
     return sparse_depth * validity_clean, validity_clean
+
+
+def evaluation_metrics(output_depth, ground_truth, validity_map, min_evaluate_depth, max_evaluate_depth):
+    """(MAE mm, RMSE mm, iMAE 1/km, iRMSE 1/km) of ONE frame, in numpy like the reference:
+    mask and scaling from src/kbnet.py:932-950, formulas from src/eval_utils.py:20-78."""
+    import numpy as np
+    o = np.squeeze(np.asarray(output_depth))
+    g = np.squeeze(np.asarray(ground_truth))
+    v = np.squeeze(np.asarray(validity_map))
+    validity_mask = np.where(v > 0, 1, 0)
+    min_max_mask = np.logical_and(g > min_evaluate_depth, g < max_evaluate_depth)
+    mask = np.where(np.logical_and(validity_mask, min_max_mask) > 0)
+    o, g = o[mask], g[mask]
+    src, tgt = 1000.0 * o, 1000.0 * g
+    isrc, itgt = 0.001 * o, 0.001 * g
+    mae = np.mean(np.abs(tgt - src))
+    rmse = np.sqrt(np.mean((tgt - src) ** 2))
+    imae = np.mean(np.abs((1.0 / itgt) - (1.0 / isrc)))
+    irmse = np.sqrt(np.mean(((1.0 / itgt) - (1.0 / isrc)) ** 2))
+    return float(mae), float(rmse), float(imae), float(irmse)

@@ -249,7 +249,47 @@ def gen_forward():
              s2d=np_sd(sds[0]), encoder=np_sd(sds[1]), decoder=np_sd(sds[2]))
 
 
+# ------------------------------------------- pre-model stage and evaluation (f1, f2)
+def gen_pre_eval():
+    import eval_utils  # reference
+    g = np.random.Generator(np.random.Philox(71))
+    n, h, w = 2, 40, 64
+    sparse = kb.synthetic.make_frames(n, h, w, "kitti", seed=72)[1]
+    dense_mask = torch.from_numpy(g.random((n, 1, h, w), dtype=np.float32) < 0.25)
+    sparse = torch.where(dense_mask, torch.from_numpy(np.round((5 + 3 * g.random((n, 1, h, w), dtype=np.float32)) * 256) / 256), sparse)
+    # outliers: far points sitting inside a near neighbourhood
+    sparse[0, 0, 10, 10] = 60.0
+    sparse[1, 0, 0, 0] = 75.5
+    sparse[1, 0, 39, 63] = 0.5
+    image = torch.from_numpy(np.floor(256 * g.random((n, 3, h, w), dtype=np.float32)))
+    validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)           # src/kbnet.py:899-902
+    removal = net_utils.OutlierRemoval(7, 1.5)
+    f_sparse, f_valid = removal.remove_outliers(sparse_depth=sparse, validity_map=validity)
+    image_n = image / 255.0                                                      # src/transforms.py:201-204
+    save("pre_outlier", image=image, sparse_depth=sparse, validity_map=validity, filtered_sparse_depth=f_sparse,
+         filtered_validity_map=f_valid, image_normalized=image_n, kernel_size=np.array(7), threshold=np.array(1.5))
+
+    # evaluation: reference src/kbnet.py:932-950 on one frame
+    h, w = 48, 80
+    gt = (1.0 + 79.0 * g.random((h, w), dtype=np.float32)).astype(np.float32)
+    gtv = (g.random((h, w), dtype=np.float32) < 0.3).astype(np.float32)
+    gt = gt * gtv
+    pred = (gt + g.standard_normal((h, w)).astype(np.float32) * 0.8 + 2.0 * (1 - gtv)).clip(1.5, 100).astype(np.float32)
+    vmask = np.where(gtv > 0, 1, 0)
+    mm = np.logical_and(gt > 0.0, gt < 100.0)
+    mask = np.where(np.logical_and(vmask, mm) > 0)
+    o, t = pred[mask], gt[mask]
+    metrics = np.array([eval_utils.mean_abs_err(1000.0 * o, 1000.0 * t), eval_utils.root_mean_sq_err(1000.0 * o, 1000.0 * t),
+                        eval_utils.inv_mean_abs_err(0.001 * o, 0.001 * t), eval_utils.inv_root_mean_sq_err(0.001 * o, 0.001 * t)],
+                       dtype=np.float64)
+    save("eval_metrics", output_depth=pred, ground_truth=gt, validity_map=gtv, metrics=metrics,
+         min_evaluate_depth=np.array(0.0), max_evaluate_depth=np.array(100.0))
+
+
 if __name__ == "__main__":
+    gen_pre_eval()
+    if "--only-pre-eval" in sys.argv:
+        sys.exit(0)
     gen_s2d()
     gen_coords()
     gen_kb()

@@ -283,3 +283,48 @@ def test_drop_in_modules_inside_reference_style_forward(dev):
                fused=g["fused"].to(dev))
     assert len(outs) == 3 and all(o.is_contiguous() for o in outs)
     assert outs[0].shape[-2:] == ((g["image"].shape[2] + 1) // 2, (g["image"].shape[3] + 1) // 2)
+
+
+# ------------------------------------------------- next rows: pre-model stage, evaluation
+def test_preprocess_golden_bit_exact(dev):
+    """f1: validity + outlier removal + image/255 are compare/select/exact-division only."""
+    g = load_golden("pre_outlier")
+    img, valid, fsparse = kb.ops.preprocess(g["image"].to(dev), g["sparse_depth"].to(dev),
+                                            int(g["kernel_size"]), float(g["threshold"]))
+    assert torch.equal(valid.cpu(), g["filtered_validity_map"])
+    assert torch.equal(fsparse.cpu(), g["filtered_sparse_depth"])
+    assert torch.equal(img.cpu(), g["image_normalized"])
+
+
+@pytest.mark.parametrize("shape", [(2, 352, 1216), (1, 37, 45), (3, 16, 64)])
+def test_preprocess_vs_oracle(dev, shape):
+    n, h, w = shape
+    _, sparse, _, _ = kb.synthetic.make_frames(n, h, w, "kitti", seed=5)
+    g = torch.Generator().manual_seed(3)
+    sparse = torch.where(torch.rand(sparse.shape, generator=g) < 0.02, sparse + 30.0 * (sparse > 0), sparse)
+    fs_ref, fv_ref = orc.validity_and_outlier_removal(sparse)
+    _, valid, fsparse = kb.ops.preprocess(None, sparse.to(dev))
+    assert torch.equal(valid.cpu(), fv_ref)
+    assert torch.equal(fsparse.cpu(), fs_ref)
+    assert float(fv_ref.sum()) < float((sparse > 0).sum())  # something was filtered
+
+
+def test_eval_metrics_golden(dev):
+    g = load_golden("eval_metrics")
+    m = kb.ops.eval_metrics(g["output_depth"].to(dev)[None, None], g["ground_truth"].to(dev)[None],
+                            g["validity_map"].to(dev)[None], float(g["min_evaluate_depth"]),
+                            float(g["max_evaluate_depth"]))
+    ref = torch.as_tensor(g["metrics"] if not torch.is_tensor(g["metrics"]) else g["metrics"]).double()
+    assert torch.allclose(m.cpu()[0], ref, rtol=2e-5)
+
+
+def test_eval_metrics_batch_vs_oracle(dev):
+    g = torch.Generator().manual_seed(8)
+    n, h, w = 3, 70, 100
+    gt = 1 + 60 * torch.rand(n, h, w, generator=g)
+    gtv = (torch.rand(n, h, w, generator=g) < 0.2).float()
+    pred = (gt + torch.randn(n, h, w, generator=g)).clamp(1.5, 100.0)
+    m = kb.ops.eval_metrics(pred[:, None].to(dev), gt.to(dev), gtv.to(dev), 1e-3, 50.0).cpu()
+    for i in range(n):
+        ref = orc.evaluation_metrics(pred[i].numpy(), gt[i].numpy(), gtv[i].numpy(), 1e-3, 50.0)
+        assert torch.allclose(m[i], torch.tensor(ref, dtype=torch.float64), rtol=2e-5), i

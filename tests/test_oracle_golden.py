@@ -66,3 +66,22 @@ def test_forward_matches_reference(name):
                             cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
     assert torch.equal(out, g["output_depth"])
     assert out.min() >= cfg.min_predict_depth * 0.98 and out.max() <= cfg.max_predict_depth * 1.001
+
+
+def test_outlier_removal_matches_reference():
+    """validity map + OutlierRemoval (batch-global fill value) + image / 255."""
+    g = load_golden("pre_outlier")
+    fs, fv = orc.validity_and_outlier_removal(g["sparse_depth"], int(g["kernel_size"]), float(g["threshold"]))
+    assert torch.equal(fv, g["filtered_validity_map"])
+    assert torch.equal(fs, g["filtered_sparse_depth"])
+    assert float((g["validity_map"] - g["filtered_validity_map"]).sum()) >= 2  # the planted outliers are dropped
+    assert torch.equal(g["image"] / 255.0, g["image_normalized"])
+
+
+def test_evaluation_metrics_match_reference():
+    """MAE / RMSE / iMAE / iRMSE with the reference's masks and scaling."""
+    g = load_golden("eval_metrics")
+    m = orc.evaluation_metrics(g["output_depth"].numpy(), g["ground_truth"].numpy(), g["validity_map"].numpy(),
+                               float(g["min_evaluate_depth"]), float(g["max_evaluate_depth"]))
+    import numpy as np
+    assert np.allclose(m, g["metrics"].numpy() if hasattr(g["metrics"], "numpy") else g["metrics"], rtol=1e-6)
