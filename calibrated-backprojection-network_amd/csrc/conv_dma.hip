@@ -347,6 +347,7 @@ int conv_dma_launch(ConvParams& p, const ConvPlan& pl, TileChoice tc, int kernel
     p.nblocks = (int)nb64;
     const int taps = kernel_size * kernel_size;
     size_t lds = 2 * sizeof(float) * ((size_t)pl.CK * plane + (size_t)pl.CK * taps * pl.NT);
+    { const char* v = getenv("KBN_LDS_PAD"); if (v) lds += (size_t)atoi(v); }  // experiment: force lower residency
     if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
 
     bool syn = false;

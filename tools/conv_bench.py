@@ -50,6 +50,9 @@ def run_one(name, batch=int(os.environ.get("KBN_BATCH", "8")), iters=8):
     oh, ow = -(-h // stride), -(-w // stride)
     out = torch.empty(batch, cout, oh, ow, device=dev)
     f = lambda: kb.ops.conv2d(srcs, pw, batch, cout, k, stride, h, w, out, resize=rs is not None, negative_slope=0.2)
+    if rs is not None and (h, w) == (2 * rs[0], 2 * rs[1]) and not os.environ.get("KBN_NO_UP2X"):
+        pw2 = kb.ops.pack_upconv2x_weight(wt)
+        f = lambda: kb.ops.upconv2x(tens[0], pw2, cout, out, 0.2)
     for _ in range(3):
         f()
     torch.cuda.synchronize()
