@@ -76,7 +76,7 @@ def _int_array(values: Sequence[int]):
 
 # ----------------------------------------------------------------------------- S2D
 def s2d_forward(x, w_pool_convs: List[torch.Tensor], w_conv, min_pool_sizes, max_pool_sizes,
-                negative_slope: float = 0.2):
+                negative_slope: float = 0.2, out: Optional[torch.Tensor] = None):
     lib = _lib.load()
     _require(x, "x", 4)
     x = x.contiguous()
@@ -91,7 +91,10 @@ def s2d_forward(x, w_pool_convs: List[torch.Tensor], w_conv, min_pool_sizes, max
     maxs = [int(s) for s in max_pool_sizes if s > 1]
     if ws[0].shape[1] != len(mins) + len(maxs) or wc.shape[1] != nf + cin:
         raise KbnError("S2D weight shapes do not match the pool lists / input channels")
-    out = torch.empty((n, nf, h, w), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n, nf, h, w), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (n, nf, h, w) or not out.is_contiguous():
+        raise KbnError("s2d_forward: `out` must be a contiguous N x n_filter x H x W tensor")
     wptrs = (C.c_void_p * len(ws))(*[wt.data_ptr() for wt in ws])
     amin, amax = _int_array(mins), _int_array(maxs)
     check(_launch("s2d", 4.0 * n * h * w * (cin + nf),
@@ -172,6 +175,21 @@ def coords_src(kinv: torch.Tensor) -> ConvSrc:
     s = ConvSrc()
     s.kind = _lib.KBN_SRC_COORDS
     s.channels = 3
+    s.kinv = kinv.data_ptr()
+    return s
+
+
+def xyz_src(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: torch.Tensor) -> ConvSrc:
+    """The KB layer's backprojection channels K^-1 [x y 1]^T * act(proj . depth), computed in-kernel."""
+    ptr, bs = _planes(depth, "depth")
+    _require(kinv, "kinv", 3)
+    s = ConvSrc()
+    s.kind = _lib.KBN_SRC_XYZ
+    s.channels = 3
+    s.data = ptr
+    s.batch_stride = bs
+    s.aux_channels = depth.shape[1]
+    s.proj_weight = proj_weight.data_ptr()
     s.kinv = kinv.data_ptr()
     return s
 
