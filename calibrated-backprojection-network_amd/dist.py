@@ -61,6 +61,43 @@ class ShardedRunner:
         self.forward_fn = forward_fn
         self.rank, self.world = rank, world
         self._buf = None
+        self._ring = None      # pipelined mode: [(staging, gathered, work)] x 2
+        self._step = 0
+
+    def step_pipelined(self, local_inputs):
+        """Forward of this step + an ASYNCHRONOUS all-gather of its outputs, overlapped with the
+        next step's forward (RCCL runs on its own stream; xGMI traffic hides behind the MFMAs).
+        Equal shard sizes only.  Returns the gathered N_total x 1 x H x W tensor of the PREVIOUS
+        step (None on the first call); call `drain()` to get the last one."""
+        out = self.forward_fn(*local_inputs)
+        if self.world == 1:
+            prev, self._last = getattr(self, "_last", None), out
+            return prev
+        if self._ring is None:
+            mk = lambda: [torch.empty_like(out), torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]),
+                                                             device=out.device, dtype=out.dtype), None]
+            self._ring = [mk(), mk()]
+        slot = self._ring[self._step & 1]
+        if slot[2] is not None:
+            slot[2].wait()                      # the gather that used this slot two steps ago
+        slot[0].copy_(out)                      # `out` may be a graph's static buffer: detach it
+        slot[2] = dist.all_gather_into_tensor(slot[1], slot[0], async_op=True)
+        prev = self._ring[(self._step & 1) ^ 1]
+        self._step += 1
+        if prev[2] is not None:
+            prev[2].wait()                      # orders the consumer after the previous gather
+            return prev[1]
+        return None
+
+    def drain(self):
+        if self.world == 1:
+            return getattr(self, "_last", None)
+        last = self._ring[(self._step - 1) & 1] if self._ring else None
+        if last is None:
+            return None
+        if last[2] is not None:
+            last[2].wait()
+        return last[1]
 
     def step(self, local_inputs, n_total: Optional[int] = None, gather: bool = True):
         out = self.forward_fn(*local_inputs)

@@ -37,6 +37,12 @@ def _worker(rank, world, port, n_total, q):
         out = runner.step(local, n_total=n_total)
     ref = _fake_forward(*frames)
     ok = torch.equal(out, ref)
+    if n_total % world == 0:  # pipelined mode: result of step i arrives with step i+1 / drain()
+        prunner = kb.dist.ShardedRunner(_fake_forward, rank, world)
+        assert prunner.step_pipelined(local) is None
+        ok = ok and torch.equal(prunner.step_pipelined(local), ref)
+        ok = ok and torch.equal(prunner.step_pipelined(local), ref)
+        ok = ok and torch.equal(prunner.drain(), ref)
     t = kb.dist.max_over_ranks(float(rank), torch.device("cpu"))
     kb.dist.barrier()
     q.put((rank, ok, t))
