@@ -31,7 +31,7 @@ __host__ __device__ constexpr int dma_maxj(int KS, int STRIDE, int MW) {
 }
 
 template <int KS, int STRIDE, int CK, int NB, int MW, int MAXJ, bool SYN>
-__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const ConvParams p) {
     constexpr int TAPS = KS * KS;
     constexpr int PAD = KS / 2;
     constexpr int YSTEP = (KS == 1) ? STRIDE : 1;  // input rows per staged row

@@ -62,7 +62,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 // ------------------------------------------------------------------- the kernel
 template <int KS, int STRIDE, int CK, int NB, int MW, int MAXPOS, bool PIPE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_igemm_kernel(const ConvParams p) {
     constexpr int TAPS = KS * KS;
     constexpr int PAD = KS / 2;
     constexpr int STEP = (KS == 1) ? STRIDE : 1;  // spacing of staged positions in the input

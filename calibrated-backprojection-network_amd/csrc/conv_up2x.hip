@@ -93,7 +93,7 @@ struct Up2xParams {
 };
 
 template <int CK, int NB, int MW, int MAXPOS>
-__global__ __launch_bounds__(256) void conv_up2x_kernel(const Up2xParams p) {
+__global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_kernel(const Up2xParams p) {
     constexpr int NT = NB * 16;
     constexpr int NC4 = CK / 4;
     constexpr int B_FLOATS = CK * 8 * NT;
