@@ -38,6 +38,9 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
+    extra = os.environ.get("KBN_HIPCC_FLAGS", "").split()  # experiments, e.g. -DKBN_WAVES_PER_SIMD=3
+    if extra:
+        force = True
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
@@ -47,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

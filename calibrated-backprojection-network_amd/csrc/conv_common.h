@@ -149,6 +149,17 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_base_u
         : "memory");
 }
 
+// Same with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset (the
+// instruction's saddr + vaddr form): no 64-bit VALU address arithmetic per DMA.
+__device__ __forceinline__ void lds_dma16_s(const float* sbase_uniform, unsigned voff_bytes, unsigned lds_base_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff_bytes), "s"(sbase_uniform), "s"(lds_base_uniform)
+        : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }

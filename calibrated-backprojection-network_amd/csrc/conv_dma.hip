@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const
     const int n = bid / p.tilesY;
     const int TW = p.TWB * 16;
     const int oy0 = ty * p.TH, ox0 = tx * TW;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar staging code
     const int li = lane & 15, lk = lane >> 4;
 
     // first staged input row / column (column aligned down to a multiple of 4)
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const
         if (f < nf4) {
             const int r = f / cv4, cv = f - r * cv4;
             const int Y = Y0 + r * YSTEP, X = XA + cv * 4;
-            if (Y >= 0 && Y < p.inH && X >= 0 && X < p.inW) g = Y * p.inW + X;
+            if (Y >= 0 && Y < p.inH && X >= 0 && X < p.inW) g = (Y * p.inW + X) * 4;  // byte offset in the plane
         }
         goff[j] = g;
     }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const
 #pragma unroll
                     for (int j = 0; j < MAXJ; ++j) {
                         if (j * 64 < nf4 && goff[j] >= 0)
-                            lds_dma16(cptr + ((p.dbg & 8) ? (lane * 4) : goff[j]), dst + j * 1024);
+                            lds_dma16_s(cptr, (p.dbg & 8) ? (unsigned)(lane * 16) : (unsigned)goff[j], dst + j * 1024);
                     }
                 }
             }
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const
             const unsigned bs = __builtin_amdgcn_readfirstlane(lds_addr(As + a_floats));
 #pragma unroll
             for (int e0 = 0; e0 < CNT4; e0 += 256) {
-                const int eb = e0 + __builtin_amdgcn_readfirstlane(wave) * 64;
-                if (eb + lane < CNT4) lds_dma16(reinterpret_cast<const float*>(s4 + eb + lane), bs + eb * 16);
+                const int eb = e0 + wave * 64;
+                if (eb + lane < CNT4) lds_dma16_s(reinterpret_cast<const float*>(s4 + eb), (unsigned)(lane * 16), bs + eb * 16);
             }
         }
     };
