@@ -105,15 +105,42 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const
     const float* wp_nt = p.wp + (long long)nt * p.Cpad * TAPS * NT;
 
     // current source of the K loop (wave-uniform; chunks are staged in increasing c0 order)
+    // Source tracking for the K loop (wave-uniform scalars; chunks are staged in increasing c0
+    // order).  !SYN launches are "aligned": every source but the last ends on a chunk boundary
+    // (conv_dma_launch checks), so one running pointer per wave is all the staging needs.
     int cs_idx = 0, cs_start = 0, cs_end = p.src[0].C, cs_hw = p.src[0].H * p.src[0].W;
     bool cs_tensor = p.src[0].kind == KBN_SRC_TENSOR;
     const float* cs_base = p.src[0].data + (long long)n * p.src[0].bstride;
+    const int HWin = p.inH * p.inW;
+    const float* wptr = cs_base + (long long)wave * HWin;  // channel (c0 + wave) of the current source
+    int s_left = p.src[0].C;                               // channels of the current source from c0 on
 
     // ---- stage one chunk: A tile (CK channels) + B slice, all by LDS-DMA ----------------
     auto stage = [&](float* As, int c0) {
         if (!(p.dbg & 1)) {
-            // wave w moves channels w, w+4, ... of the chunk.  Fast path: the chunk lies inside the
-            // current source (tracked in scalar registers across chunks) -> no kernarg lookups.
+            if constexpr (!SYN) {
+                if (s_left <= 0 && cs_idx + 1 < p.nsrc) {
+                    ++cs_idx;
+                    wptr = p.src[cs_idx].data + (long long)n * p.src[cs_idx].bstride + (long long)wave * HWin;
+                    s_left = p.src[cs_idx].C;
+                }
+#pragma unroll
+                for (int t = 0; t < NC4; ++t) {  // wave w moves channels w, w+4, ... of the chunk
+                    const int q = wave + 4 * t;
+                    if (q < s_left) {
+                        const float* cptr = wptr + (long long)(4 * t) * HWin;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(As + q * p.plane));
+#pragma unroll
+                        for (int j = 0; j < MAXJ; ++j) {
+                            if (j * 64 < nf4 && goff[j] >= 0)
+                                lds_dma16_s(cptr, (p.dbg & 8) ? (unsigned)(lane * 16) : (unsigned)goff[j], dst + j * 1024);
+                        }
+                    }
+                }
+                wptr += (long long)CK * HWin;
+                s_left -= CK;
+            } else {
+            // generic: chunks may straddle sources / hold computed channels
             while (c0 >= cs_end && cs_idx + 1 < p.nsrc) {  // advance to the source that holds c0
                 ++cs_idx;
                 cs_start = p.src[cs_idx].cstart;
@@ -141,6 +168,7 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const
                             lds_dma16_s(cptr, (p.dbg & 8) ? (unsigned)(lane * 16) : (unsigned)goff[j], dst + j * 1024);
                     }
                 }
+            }
             }
             // computed channels (KB layer) and channel padding: plain stores, rare
             bool has_syn = false;
@@ -303,15 +331,9 @@ static int dma_nb_syn(const ConvParams& p, int NB, int MW, size_t lds, hipStream
     }
 }
 
-// The computed-source (KB layer) variants only exist for the two convs that use them:
-// conv_depth (3x3 s2) and conv_fused (1x1 s2).
 template <int KS, int STRIDE, int CK>
 static int dma_nb(const ConvParams& p, int NB, int MW, size_t lds, hipStream_t st, bool syn) {
-    if constexpr (STRIDE == 2) {
-        if (syn) return dma_nb_syn<KS, STRIDE, CK, true>(p, NB, MW, lds, st);
-    } else {
-        if (syn) return KBN_ERR_UNSUPPORTED;
-    }
+    if (syn) return dma_nb_syn<KS, STRIDE, CK, true>(p, NB, MW, lds, st);
     return dma_nb_syn<KS, STRIDE, CK, false>(p, NB, MW, lds, st);
 }
 
@@ -351,8 +373,12 @@ int conv_dma_launch(ConvParams& p, const ConvPlan& pl, TileChoice tc, int kernel
     { const char* v = getenv("KBN_LDS_PAD"); if (v) lds += (size_t)atoi(v); }  // experiment: force lower residency
     if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
 
+    // generic staging (SYN) if a source is computed, or a chunk would straddle two sources
     bool syn = false;
-    for (int s = 0; s < p.nsrc; ++s) syn = syn || p.src[s].kind != KBN_SRC_TENSOR;
+    for (int s = 0; s < p.nsrc; ++s) {
+        syn = syn || p.src[s].kind != KBN_SRC_TENSOR;
+        if (s + 1 < p.nsrc && (p.src[s].cstart + p.src[s].C) % pl.CK != 0) syn = true;
+    }
     if (kernel_size == 3 && stride == 1)
         return pl.CK == 4 ? dma_nb<3, 1, 4>(p, pl.NB, tc.MW, lds, stream, syn)
                           : dma_nb<3, 1, 8>(p, pl.NB, tc.MW, lds, stream, syn);
