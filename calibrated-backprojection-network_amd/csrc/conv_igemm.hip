@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_igemm_kernel(con
         if (s < p.nsrc && p.src[s].kind != KBN_SRC_TENSOR) syn = s;
 
     // ---- per-lane fragment addressing ----------------------------------------------
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     int mbase[MW];
 #pragma unroll
@@ -220,13 +221,12 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_igemm_kernel(con
         constexpr int CNT4 = B_FLOATS / 4;
         const float4* s4 = reinterpret_cast<const float4*>(wp_nt + (long long)c0 * TAPS * NT);
         if constexpr (PIPE) {
+            const unsigned bs = __builtin_amdgcn_readfirstlane(lds_addr(Bs));
 #pragma unroll
             for (int e0 = 0; e0 < CNT4; e0 += 256) {
                 const int eb = e0 + wave * 64;  // wave-uniform
                 if (eb + lane < CNT4)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(s4 + eb + lane),
-                        (__attribute__((address_space(3))) void*)(Bs + eb * 4), 16, 0, 0);
+                    lds_dma16_s(reinterpret_cast<const float*>(s4 + eb), (unsigned)(lane * 16), bs + eb * 16);
             }
         } else {
             float4* d4 = reinterpret_cast<float4*>(Bs);

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_kernel(cons
     const int n = bid / p.tilesY;
     const int TW = p.TWB * 16;
     const int y0 = ty * p.TH, x0 = tx * TW;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
 
     // ---- staging table (low-res rows y0-1+a .. y0+TH-1+a, cols x0-1 .. x0+TW) ----
@@ -181,8 +182,8 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_kernel(cons
         const unsigned bs = __builtin_amdgcn_readfirstlane(lds_addr(Bs));
 #pragma unroll
         for (int e0 = 0; e0 < CNT4; e0 += 256) {
-            const int eb = e0 + __builtin_amdgcn_readfirstlane(wave) * 64;
-            if (eb + lane < CNT4) lds_dma16(reinterpret_cast<const float*>(s4 + eb + lane), bs + eb * 16);
+            const int eb = e0 + wave * 64;
+            if (eb + lane < CNT4) lds_dma16_s(reinterpret_cast<const float*>(s4 + eb), (unsigned)(lane * 16), bs + eb * 16);
         }
     };
     auto compute = [&](const float* As, const float* Bs) {
