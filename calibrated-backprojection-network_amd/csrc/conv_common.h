@@ -59,7 +59,9 @@ __host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks, int strid
         if (pad < bestpad || (pad == bestpad && nb > best)) { best = nb; bestpad = pad; }
     }
     pl.NB = best;
-    pl.MW = (best >= 3) ? 4 : 8;
+    // 16-channel outputs (NB = 1) measured 18% faster with MW = 4 than with 8 (tools/conv_bench.py):
+    // their workgroups are staging-bound and a smaller tile keeps more of them in flight.
+    pl.MW = (best >= 3 || best == 1) ? 4 : 8;
     pl.nTilesN = ceil_div(nblk, best);
     pl.NT = best * 16;
     pl.Cpad = round_up(cin, pl.CK);
@@ -165,6 +167,24 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 }
 
 struct TileChoice { int MW, TWB; };
+
+// conv_wino.hip: Winograd F(2x2,3x3) path for wide 3x3 stride-1 convs.  Eligibility by shape only
+// (pack time and launch time must agree): the transformed weights live behind the direct-conv
+// weights in the packed blob.
+struct WinoPlan { int ok, nTilesN; };
+__host__ __device__ inline WinoPlan wino_plan(int oc, int cin, int ks, int stride) {
+    WinoPlan wp;
+    wp.ok = (ks == 3 && stride == 1 && cin >= 32 && (cin % 8) == 0 && oc >= 32) ? 1 : 0;
+    wp.nTilesN = ceil_div(oc, 64);
+    return wp;
+}
+long long wino_packed_floats(int oc, int cin, int ks, int stride);
+int wino_pack(const float* weight, float* packed, int oc, int cin, hipStream_t stream);
+// Launches the Winograd kernel for a prepared ConvParams (sources, weights, output, act) or
+// returns KBN_ERR_UNSUPPORTED (computed / unaligned sources, W % 4 != 0, ...).
+int conv_wino_launch(const ConvParams& p, hipStream_t stream);
+// workgroups (0 = not eligible) and region shape the launch would use
+int wino_query(int n, int oc, int cin, int H, int W, int* RT, int* CT);
 
 // conv_dma.hip: LDS-DMA staged kernel for 16-byte aligned, non-resized tensor sources.
 // Fills the staging geometry of `p` itself.  Returns KBN_ERR_UNSUPPORTED if not eligible.

@@ -444,6 +444,10 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
 
     const bool s2 = (kernel_size == 3 && stride == 2);
     const TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
+    if (kernel_size == 3 && stride == 1 && !env_int("KBN_NO_WINO")) {  // wide 3x3: Winograd F(2x2,3x3)
+        int rc = conv_wino_launch(p, stream);
+        if (rc != KBN_ERR_UNSUPPORTED) return rc;
+    }
     if (!env_int("KBN_NO_DMA")) {  // fast path: LDS-DMA staging (aligned tensor sources, no resize)
         int rc = conv_dma_launch(p, pl, tc, kernel_size, stride, stream);
         if (rc != KBN_ERR_UNSUPPORTED) return rc;
@@ -482,7 +486,8 @@ size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int ker
     if (out_channels < 1 || in_channels < 1 || (kernel_size != 1 && kernel_size != 3)) return 0;
     if (stride != 1 && stride != 2) return 0;
     kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::env_int("KBN_FORCE_CK"));
-    return sizeof(float) * (size_t)pl.nTilesN * pl.Cpad * kernel_size * kernel_size * pl.NT;
+    return sizeof(float) * ((size_t)pl.nTilesN * pl.Cpad * kernel_size * kernel_size * pl.NT +
+                            (size_t)kbn::wino_packed_floats(out_channels, in_channels, kernel_size, stride));
 }
 
 int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
@@ -496,6 +501,8 @@ int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels,
     hipLaunchKernelGGL(kbn::pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight,
                        packed, out_channels, in_channels, taps, pl, total);
     KBN_CHECK_LAUNCH();
+    if (kbn::wino_plan(out_channels, in_channels, kernel_size, stride).ok)  // + G g G^T behind it
+        return kbn::wino_pack(weight, packed + total, out_channels, in_channels, (hipStream_t)stream);
     return KBN_OK;
 }
 
@@ -515,6 +522,11 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
     info[6] = maxpos;
     // 2: conv_dma_kernel (assuming 16-byte aligned planes), 1: conv_igemm_kernel pipelined, 0: not pipelined
     info[7] = (!resize && (in_width & 3) == 0 && !env_int("KBN_NO_DMA")) ? 2 : ((maxpos * pl.CK <= 48) ? 1 : 0);
+    if (kernel_size == 3 && stride == 1 && !resize && !env_int("KBN_NO_WINO")) {
+        int rt = 0, ct = 0;
+        const int wgs = wino_query(n, out_channels, in_channels, in_height, in_width, &rt, &ct);
+        if (wgs > 0) { info[7] = 3; info[2] = rt; info[3] = ct; info[4] = 2 * rt; info[5] = wgs; }
+    }
     return KBN_OK;
 }
 

@@ -41,12 +41,15 @@ _PLAN_CACHE = {}
 def conv_plan(n: int, out_channels: int, in_channels: int, kernel_size: int, stride: int, in_height: int,
               in_width: int, resize: bool = False):
     """Kernel variant the library picks (kbn_conv2d_query): dict with CK, NB, MW, TWB, TH,
-    workgroups, maxpos, pipelined (2 = conv_dma_kernel, 1/0 = conv_igemm_kernel)."""
+    workgroups, maxpos, pipelined (3 = conv_wino_kernel, where MW x TWB is the region's tile
+    rows x columns; 2 = conv_dma_kernel; 1/0 = conv_igemm_kernel) and `kernel` (its name)."""
     key = (n, out_channels, in_channels, kernel_size, stride, in_height, in_width, int(resize))
     if key not in _PLAN_CACHE:
         info = (C.c_int * 8)()
         check(_lib.load().kbn_conv2d_query(*key, info), "kbn_conv2d_query")
-        _PLAN_CACHE[key] = dict(zip(("CK", "NB", "MW", "TWB", "TH", "workgroups", "maxpos", "pipelined"), info))
+        d = dict(zip(("CK", "NB", "MW", "TWB", "TH", "workgroups", "maxpos", "pipelined"), info))
+        d["kernel"] = {3: "wino", 2: "dma"}.get(d["pipelined"], "igemm")
+        _PLAN_CACHE[key] = d
     return _PLAN_CACHE[key]
 
 

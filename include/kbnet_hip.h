@@ -120,7 +120,9 @@ size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int ker
 
 /* Re-orders an OIHW weight (out_channels x in_channels x k x k) into the MFMA
  * fragment order the kernel consumes.  `packed` must hold
- * kbn_conv2d_packed_weight_bytes(...) bytes.  Do this once per weight (and stride). */
+ * kbn_conv2d_packed_weight_bytes(...) bytes.  Do this once per weight (and stride).  For wide
+ * 3x3 stride-1 convs the blob also carries the Winograd-domain weights G g G^T behind the
+ * fragment-order copy; kbn_conv2d_forward picks the kernel per launch. */
 int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
                            int kernel_size, int stride, kbn_stream_t stream);
 
@@ -156,7 +158,9 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
  * profiling): info[8] = {CK, NB, MW, TWB, TH, workgroups, staged positions per thread, kernel};
  * kernel 2 = conv_dma_kernel<kernel_size, stride, CK, NB, MW, ...> (LDS-DMA staging; needs
  * W % 4 == 0, 16-byte aligned planes, no resize), 1 / 0 = conv_igemm_kernel<...> with / without
- * register prefetch. */
+ * register prefetch, 3 = conv_wino_kernel (Winograd F(2x2,3x3) for 3x3 stride-1 convs with
+ * in_channels % 8 == 0, in_channels >= 32, out_channels >= 32 and the conv_dma alignment rules;
+ * then MW x TWB = tile rows x columns of a workgroup's region and TH = its pixel rows). */
 int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, int stride,
                      int in_height, int in_width, int resize, int* info);
 

@@ -93,10 +93,18 @@ def test_library_exports_every_declared_symbol():
     assert loaded.kbn_conv2d_packed_weight_bytes(96, 99, 1, 2) == 4 * 2 * 112 * 1 * 48
     assert loaded.kbn_conv2d_packed_weight_bytes(16, 19, 3, 2) == 4 * 1 * 20 * 9 * 16  # stride 2: 4-channel chunks
     assert loaded.kbn_conv2d_packed_weight_bytes(5, 5, 5, 1) == 0
+    # wide 3x3 stride-1 convs carry the Winograd-domain weights (16 per channel pair) behind the direct ones
+    assert loaded.kbn_conv2d_packed_weight_bytes(64, 128, 3, 1) == 4 * (128 * 9 * 64 + 128 * 16 * 64)
+    assert loaded.kbn_conv2d_packed_weight_bytes(40, 104, 3, 1) == 4 * (104 * 9 * 48 + 104 * 16 * 64)
     # tile choice: big maps keep the largest tile, small maps shrink it so every CU gets work
-    big = kb.ops.conv_plan(8, 64, 128, 3, 1, 176, 608)
-    small = kb.ops.conv_plan(8, 256, 512, 3, 1, 22, 76)
-    assert (big["NB"], big["MW"]) == (4, 4) and small["MW"] < 4 and small["workgroups"] >= 256
+    big = kb.ops.conv_plan(8, 96, 96, 3, 2, 176, 608)
+    small = kb.ops.conv_plan(8, 384, 384, 3, 2, 22, 76)
+    assert (big["NB"], big["MW"]) == (3, 4) and small["MW"] < 4 and small["workgroups"] >= 256
+    # Winograd regions: 4 x 16 tiles on big maps; 6 x 10 on the 22 x 76 map fills exactly one round of 256 CUs
+    wide = kb.ops.conv_plan(8, 64, 128, 3, 1, 176, 608)
+    assert (wide["kernel"], wide["MW"], wide["TWB"], wide["workgroups"]) == ("wino", 4, 16, 3344)
+    deep = kb.ops.conv_plan(8, 256, 768, 3, 1, 22, 76)
+    assert (deep["kernel"], deep["MW"], deep["TWB"], deep["workgroups"]) == ("wino", 6, 10, 256)
 
 
 def test_synthetic_frames_are_deterministic_and_well_formed():

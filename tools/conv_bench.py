@@ -81,6 +81,15 @@ if __name__ == "__main__":
                 d = json.loads(line[-1])
                 print(f"{n:14s} {tag:14s} {d['us']:8.1f} us {d['tflops']:6.1f} TF-equivalent", flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--dbg":  # --dbg 0,1,2,3 layer...: KBN_DEBUG values, raw table
+        for n in sys.argv[3:]:
+            for dbg in sys.argv[2].split(","):
+                env = dict(os.environ, KBN_DEBUG=dbg)
+                r = subprocess.run([sys.executable, __file__, "--one", n], env=env, capture_output=True, text=True, timeout=120)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                d = json.loads(line[-1])
+                print(f"{n:14s} dbg={dbg:3s} {d['us']:8.1f} us {d['tflops']:6.1f} TF-equivalent  {d['kernel']} wgs={d['workgroups']} MW={d['MW']} TWB={d['TWB']}", flush=True)
+        sys.exit(0)
     pats = sys.argv[1:]
     names = [n for n in LAYERS if not pats or any(p in n for p in pats)]
     for n in names:
