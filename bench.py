@@ -72,10 +72,13 @@ def lookup_traffic(kernel, launches):
     if not files:
         return None
     table = json.load(open(files[-1]))["kernels"]
-    m = re.match(r"(conv_\w+)<([\d,]+)>", kernel)
-    if not m:
-        return None
-    want = m.group(1) + "_kernel<" + m.group(2).replace(",", ", ")
+    if kernel == "conv_wino":
+        want = "conv_wino_kernel<0>"
+    else:
+        m = re.match(r"(conv_\w+)<([\d,]+)>", kernel)
+        if not m:
+            return None
+        want = m.group(1) + "_kernel<" + m.group(2).replace(",", ", ")
     for name, e in table.items():
         if want in name:
             return {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
@@ -200,6 +203,13 @@ def main():
                 "launches": dlaunch, "avg_launch_us": round(dtime / dlaunch * 1e6, 2),
                 "flop_per_launch": dwork / dlaunch,
                 "whole_forward_frac": round(fps / world * gflop_frame / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    if dom == "conv_wino":
+        # Winograd F(2x2,3x3) issues 16 multiplies per 2x2 output tile and channel pair instead of the
+        # direct form's 36: `achieved` counts ALGORITHMIC (direct-conv) FLOPs as the contract asks and can
+        # exceed the matrix-pipe peak; `executed` is what the MFMAs really do (the pipe's utilisation).
+        roofline["algorithm"] = "Winograd F(2x2,3x3) in fp32: 4/9 of the algorithmic multiply-adds reach the MFMAs"
+        roofline["executed"] = round(achieved * 4.0 / 9.0, 3)
+        roofline["executed_frac"] = round(achieved * 4.0 / 9.0 / FP32_MFMA_PEAK_TFLOPS, 4)
     roofline["traffic"] = lookup_traffic(dom, dlaunch)
     s2d = groups.get("s2d")
     if s2d:

@@ -162,6 +162,30 @@ __device__ __forceinline__ void lds_dma16_s(const float* sbase_uniform, unsigned
         : "memory");
 }
 
+// Same, executed under an explicit lane mask (wave-uniform 64-bit value): EXEC is swapped inside the
+// statement, so masked-off lanes need no branch around the DMA and the caller's code stays one
+// basic block.  A zero mask makes the instruction a no-op.
+__device__ __forceinline__ void lds_dma16_sm(const float* sbase_uniform, unsigned voff_bytes, unsigned lds_base_uniform,
+                                             unsigned long long lane_mask_uniform) {
+    unsigned keep;
+    unsigned long long keepx;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %5\n\ts_mov_b64 exec, %4\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(keepx)
+        : "v"(voff_bytes), "s"(sbase_uniform), "s"(lane_mask_uniform), "s"(lds_base_uniform)
+        : "memory");
+}
+
+// Pins a wave-uniform pointer into SGPRs (for the "s" operands above when the compiler's divergence
+// analysis cannot prove uniformity).
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }
@@ -174,7 +198,7 @@ struct TileChoice { int MW, TWB; };
 struct WinoPlan { int ok, nTilesN; };
 __host__ __device__ inline WinoPlan wino_plan(int oc, int cin, int ks, int stride) {
     WinoPlan wp;
-    wp.ok = (ks == 3 && stride == 1 && cin >= 32 && (cin % 8) == 0 && oc >= 32) ? 1 : 0;
+    wp.ok = (ks == 3 && stride == 1 && cin >= 32 && (cin % 16) == 0 && oc >= 32) ? 1 : 0;  // even number of 8-channel chunks
     wp.nTilesN = ceil_div(oc, 64);
     return wp;
 }

@@ -30,6 +30,8 @@
 // out [n-tile][chunk][xi][c/4][k>>1][n][k&1] so that a chunk is one contiguous 32 KiB DMA.
 #include <stdlib.h>
 
+#include <utility>
+
 #include "conv_common.h"
 
 namespace kbn {
@@ -41,6 +43,12 @@ constexpr int WNT = 64;                     // output channels per workgroup
 constexpr int U_CHUNK = 16 * WCK * WNT;     // floats of U per chunk
 constexpr int V_CHUNK = 16 * WCK * 64;      // floats of V per chunk
 constexpr int M_NSTRIDE = 68;               // epilogue exchange buffer: [xi][16 n][64 tiles + 4]
+
+template <int I> struct IC { static constexpr int value = I; };
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct WinoParams {
     const float* src[KBN_MAX_SRC];
@@ -88,7 +96,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     packed[e] = (float)u;
 }
 
-template <bool DBG>
+template <int DBG>  // compile-time ablation mask (0 in production; see WinoParams::dbg)
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int raw_floats = WCK * p.plane;          // one raw stage
@@ -149,84 +157,92 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
 
     const int HW = p.H * p.W;
     const int nch = p.Cin / WCK;
-    const float* up_nt = p.up + (long long)nt * nch * U_CHUNK;
 
-    // running source pointer: channel (c0 + wave) of the current source (every source holds a
-    // multiple of 8 channels, so a chunk never straddles two)
-    int cs_idx = 0, s_left = p.srcC[0];
-    const float* wptr = p.src[0] + (long long)n * p.src_bstride[0] + (long long)wave * HW;
+    // ---- wave-uniform state of the staging streams, kept in SGPRs (VALU instructions between MFMAs
+    // are not free -- tools/probe/issue_probe.hip -- so nothing uniform may end up on the vector ALU) ----
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned rdst0 = lds0 + 4u * (unsigned)(wave * p.plane), rdst1 = rdst0 + 4u * (unsigned)raw_floats;
+    const unsigned udst0 = lds0 + 4u * (unsigned)(2 * raw_floats + wave * 256), udst1 = udst0 + 4u * U_CHUNK;
+    const float* usrc = uniform_ptr(p.up + (long long)nt * nch * U_CHUNK + wave * 256);  // U of the chunk to stage next
+    // Plane of channel (gch + wave) of the concatenated input (every source holds a multiple of 8
+    // channels, so a chunk never straddles two); `advance_src` moves to the next chunk and stays on the
+    // last one at the end (the surplus DMAs of the last iterations re-stage it into a dead buffer).
+    const float* s1w = uniform_ptr(p.src[1] + (long long)n * p.src_bstride[1] + (long long)wave * HW);
+    const float* s2w = uniform_ptr(p.src[2] + (long long)n * p.src_bstride[2] + (long long)wave * HW);
+    const float* gsrc = uniform_ptr(p.src[0] + (long long)n * p.src_bstride[0] + (long long)wave * HW);
+    const int C0 = __builtin_amdgcn_readfirstlane(p.srcC[0]);
+    const int C01 = __builtin_amdgcn_readfirstlane(p.srcC[0] + p.srcC[1]);
+    const int Cin = __builtin_amdgcn_readfirstlane(p.Cin);
+    int gch = 0;
+    auto advance_src = [&]() {
+        const int nx = gch + WCK;
+        const bool adv = nx < Cin;
+        const float* cand = nx == C0 ? s1w : (nx == C01 ? s2w : gsrc + (long long)WCK * HW);
+        gsrc = adv ? cand : gsrc;
+        gch = adv ? nx : gch;
+    };
+    // lanes whose granule j is inside the image (loop invariant)
+    const unsigned long long gm0 = __ballot(goff[0] >= 0), gm1 = (64 < nf4) ? __ballot(goff[1] >= 0) : 0ull;
+    const unsigned gv0 = goff[0] < 0 ? 0u : (unsigned)goff[0], gv1 = goff[1] < 0 ? 0u : (unsigned)goff[1];
+    const unsigned uv = (unsigned)(lane * 16);
 
-    auto stage_raw = [&](float* dstbuf) {
-        if (s_left <= 0 && cs_idx + 1 < p.nsrc) {
-            ++cs_idx;
-            wptr = p.src[cs_idx] + (long long)n * p.src_bstride[cs_idx] + (long long)wave * HW;
-            s_left = p.srcC[cs_idx];
-        }
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(dstbuf + wave * p.plane));
-        if (!(DBG && (p.dbg & 1))) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (j * 64 < nf4 && goff[j] >= 0) lds_dma16_s(wptr, (unsigned)goff[j], dst + j * 1024);
-        }
-        wptr += (long long)WCK * HW;
-        s_left -= WCK;
+    // one DMA instruction of the raw tile (j = 0, 1) / of the U slice (j = 0..3) per call
+    auto dma_raw = [&](unsigned dst, int j) {
+        if ((DBG & 1) != 0) return;
+        lds_dma16_sm(gsrc, j ? gv1 : gv0, dst + j * 1024, j ? gm1 : gm0);
     };
-    auto stage_u = [&](float* dstbuf, int chunk) {
-        if (DBG && (p.dbg & 2)) return;
-        const float* s = up_nt + (long long)chunk * U_CHUNK + wave * 256;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(dstbuf + wave * 256));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16_s(s + j * 2048, (unsigned)(lane * 16), dst + j * 8192);
+    auto dma_u = [&](unsigned dst, int j) {
+        if ((DBG & 2) != 0) return;
+        lds_dma16_s(usrc + j * 2048, uv, dst + j * 8192);
     };
-    auto transform = [&](const float* raw, float* V) {
-        if (DBG && (p.dbg & 16)) return;
-        const float* d = raw + raw_off;
-        float t[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {   // rows of B^T d: (d0-d2, d1+d2, d2-d1, d1-d3) along the row index
-            // column pass first on each raw row: t[i][j] = (d_i B)_j
-            const float d0 = d[i * p.colsS], d1 = d[i * p.colsS + 1], d2 = d[i * p.colsS + 2], d3 = d[i * p.colsS + 3];
-            t[i][0] = d0 - d2; t[i][1] = d1 + d2; t[i][2] = d2 - d1; t[i][3] = d1 - d3;
-        }
-        float* v = V + v_off;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[(0 * 4 + j) * 512] = t[0][j] - t[2][j];
-            v[(1 * 4 + j) * 512] = t[1][j] + t[2][j];
-            v[(2 * 4 + j) * 512] = t[2][j] - t[1][j];
-            v[(3 * 4 + j) * 512] = t[1][j] - t[3][j];
-        }
+
+    // Input transform of (channel = wave, tile = lane): d = raw 4x4 patch, t = d B, V = B^T t, on packed
+    // fp32 (v_pk_add_f32: 16 VALU instructions instead of 32).  Register pairs hold two adjacent COLUMNS
+    // of a row -- what one ds_read2_b32 delivers: P[r][h] = (d[r][2h], d[r][2h+1]), same for T.
+    f32x2 P[4][2], T[4][2];
+    auto xf_read = [&](const float* raw, int e) {   // e = 4 * row + column
+        const float v = raw[(e >> 2) * p.colsS + (e & 3)];
+        if (e & 1) P[e >> 2][(e >> 1) & 1].y = v; else P[e >> 2][(e >> 1) & 1].x = v;
     };
-    // MFMAs of one chunk in 4 groups (frequency x, k-step c4) of 16.  The fragments of group g+1 are
-    // read from LDS before the MFMAs of group g are issued (pinned with sched_barrier: all 8 waves run
-    // in step, so an exposed ds_read latency is paid by the whole CU); group 0 is read by `frags0`
-    // right after the chunk's barrier, ahead of the transform.
+    auto xf_col = [&](int o) {                      // o = 2 * row + half: (t0,t1) = (d0-d2, d1+d2) or (t2,t3) = (d2-d1, d1-d3)
+        const int r = o >> 1;
+        if ((o & 1) == 0)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(T[r][0]) : "v"(P[r][0]), "v"(P[r][1]));
+        else
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(T[r][1]) : "v"(P[r][0]), "v"(P[r][1]));
+    };
+    auto xf_row = [&](float* V, int o) {            // o = 2 * i + h: frequencies (i, 2h) and (i, 2h+1)
+        const int i = o >> 1, h = o & 1;
+        f32x2 v;
+        if (i == 0) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(T[0][h]), "v"(T[2][h]));
+        else if (i == 1) asm("v_pk_add_f32 %0, %1, %2" : "=v"(v) : "v"(T[1][h]), "v"(T[2][h]));
+        else if (i == 2) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(T[2][h]), "v"(T[1][h]));
+        else asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(T[1][h]), "v"(T[3][h]));
+        const int xi = i * 4 + 2 * h;
+        V[xi * 512] = v.x;
+        V[(xi + 1) * 512] = v.y;
+    };
+    auto transform = [&](const float* raw, float* V) {   // un-pipelined form (prologue)
+        if ((DBG & 16) != 0) return;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xf_read(raw + raw_off, e);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) xf_col(o);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) xf_row(V + v_off, o);
+    };
+
+    // MFMA fragments: group g = (frequency x = g >> 1, k-step c4 = g & 1), 4 A + 4 B values, 16 MFMAs
     float fa[2][4], fb[2][4];
-    auto load_frags = [&](const float* V, const float* U, int g, float (&a)[4], float (&b)[4]) {
-        const float* Ab = V + a_off + (g >> 1) * 512 + (g & 1) * 256;
-        const float* Bb = U + b_off + (g >> 1) * 512 + (g & 1) * 256;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) a[mb] = Ab[a_mb[mb]];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) b[nb] = Bb[nb * 32];
+    auto frag_read = [&](const float* V, const float* U, int g, int q) {
+        if ((DBG & 4) != 0) return;
+        if (q < 4) fa[g & 1][q] = V[a_off + (g >> 1) * 512 + (g & 1) * 256 + a_mb[q]];
+        else fb[g & 1][q - 4] = U[b_off + (g >> 1) * 512 + (g & 1) * 256 + (q - 4) * 32];
     };
-    auto frags0 = [&](const float* V, const float* U) {
-        if (DBG && (p.dbg & 4)) return;
-        load_frags(V, U, 0, fa[0], fb[0]);
-    };
-    auto compute = [&](const float* V, const float* U) {
-        if (DBG && (p.dbg & 4)) return;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < 3) load_frags(V, U, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    acc[g >> 1][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][mb], fb[g & 1][nb], acc[g >> 1][mb][nb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    auto mfma = [&](int i) {
+        if ((DBG & 4) != 0) return;
+        const int g = i >> 4, mb = (i >> 2) & 3, nb = i & 3;
+        acc[g >> 1][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][mb], fb[g & 1][nb], acc[g >> 1][mb][nb], 0, 0, 0);
     };
 
     // ---- clear both raw stages once (out-of-image granules are never written afterwards) ----
@@ -235,34 +251,74 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         for (int e = tid * 4; e < 2 * raw_floats; e += 2048) *reinterpret_cast<f32x4*>(rawS + e) = zero;
     }
     __syncthreads();
-    stage_raw(rawS);
-    stage_u(Us, 0);
-    if (nch > 1) stage_raw(rawS + raw_floats);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dma_raw(rdst0, 0); dma_raw(rdst0, 1);                // raw(0)
+    advance_src();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_u(udst0, j);         // U(0)
+    usrc += U_CHUNK;                                     // -> U(1)
+    int uleft = nch - 2;                                 // further advances before usrc reaches the last chunk
+    dma_raw(rdst1, 0); dma_raw(rdst1, 1);                // raw(1)
+    advance_src();
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // all but raw(1)
     transform(rawS, Vs);
 
-    for (int c = 0; c + 1 < nch; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- K loop.  One basic block per chunk with a fixed instruction interleave: all 8 waves run in
+    // step, and an in-order wave only keeps the matrix pipe fed if its LDS / VALU / DMA work sits
+    // BETWEEN its MFMAs.  Slot i follows MFMA i of chunk c and carries a piece of: the fragment reads of
+    // the next MFMA group, the DMA of U(c+1) and raw(c+2), the input transform of chunk c+1.
+    // sched_barrier(0) pins the order; buffer parity is a template argument so that every LDS address
+    // is a loop-invariant register plus an immediate.  DMAs in flight are counted, not drained:
+    // at the top only U(c) must have landed (vmcnt(2): raw(c+1) may still fly), raw(c+1) is awaited
+    // (vmcnt(6): U(c+1), raw(c+2) behind it) just before the transform reads it -- a full iteration
+    // plus 24 MFMA slots after it was issued, which covers the loaded HBM latency.
+    auto body = [&](auto par) {
+        constexpr int PAR = decltype(par)::value;
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __syncthreads();
-        stage_u(Us + ((c + 1) & 1) * U_CHUNK, c + 1);
-        if (c + 2 < nch) stage_raw(rawS + (c & 1) * raw_floats);
-        // The two waves of a SIMD (w and w+4) run the two halves of the iteration in opposite order:
-        // one transforms chunk c+1 (LDS + VALU) while the other keeps the matrix pipe busy with chunk c.
-        frags0(Vs + (c & 1) * V_CHUNK, Us + (c & 1) * U_CHUNK);
+        const float* Vc = Vs + PAR * V_CHUNK;
+        const float* Uc = Us + PAR * U_CHUNK;
+        float* Vn = Vs + (PAR ^ 1) * V_CHUNK + v_off;
+        const float* rawn = rawS + (PAR ^ 1) * raw_floats + raw_off;
+        const unsigned rdst = PAR ? rdst1 : rdst0, udst = PAR ? udst0 : udst1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) frag_read(Vc, Uc, 0, q);
         __builtin_amdgcn_sched_barrier(0);
-        if (wave < 4) transform(rawS + ((c + 1) & 1) * raw_floats, Vs + ((c + 1) & 1) * V_CHUNK);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(Vs + (c & 1) * V_CHUNK, Us + (c & 1) * U_CHUNK);
-        __builtin_amdgcn_sched_barrier(0);
-        if (wave >= 4) transform(rawS + ((c + 1) & 1) * raw_floats, Vs + ((c + 1) & 1) * V_CHUNK);
+        static_for<64>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            mfma(i);
+            if constexpr (i < 8) frag_read(Vc, Uc, 1, i);
+            if constexpr (i < 4) dma_u(udst, i);
+            if constexpr (i == 4 || i == 5) dma_raw(rdst, i - 4);
+            if constexpr (i >= 16 && i < 24) frag_read(Vc, Uc, 2, i - 16);
+            if constexpr (i == 23) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (i >= 24 && i < 32) {
+                if ((DBG & 16) == 0) { xf_read(rawn, 2 * (i - 24)); xf_read(rawn, 2 * (i - 24) + 1); }
+            }
+            if constexpr (i >= 32 && i < 40) frag_read(Vc, Uc, 3, i - 32);
+            if constexpr (i >= 34 && i < 42) {
+                if ((DBG & 16) == 0) xf_col(i - 34);
+            }
+            if constexpr (i >= 42 && i < 50) {
+                if ((DBG & 16) == 0) xf_row(Vn, i - 42);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if ((DBG & 8) == 0) {                        // (ablation 8: always re-stage the same, cache-hot chunk)
+            usrc = uleft > 0 ? usrc + U_CHUNK : usrc;   // stays on the last chunk at the end, like gsrc
+            --uleft;
+            advance_src();
+        }
+    };
+    // nch is even (wino_plan): every chunk goes through `body`; the last one stages and transforms a
+    // surplus copy of itself into dead buffers, which keeps the loop free of special cases.
+    for (int c = 0; c < nch; c += 2) {
+        body(IC<0>{});
+        body(IC<1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    frags0(Vs + ((nch - 1) & 1) * V_CHUNK, Us + ((nch - 1) & 1) * U_CHUNK);
-    compute(Vs + ((nch - 1) & 1) * V_CHUNK, Us + ((nch - 1) & 1) * U_CHUNK);
-    __syncthreads();
 
-    if (DBG && (p.dbg & 32)) {
+    if ((DBG & 32) != 0) {
         if (acc[0][0][0][0] == 12345.f) p.out[0] = 0.f;  // keep the loop alive
         return;
     }
@@ -343,6 +399,20 @@ static void choose_region(int H, int W, int n, int nTilesN, int& RT, int& CT) {
     }
 }
 
+template <int DBG>
+static int wino_variant(const WinoParams& p, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<DBG>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return KBN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(p.nblocks), dim3(512), lds, stream, p);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
 int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
     const WinoPlan wp = wino_plan(cp.OC, cp.Ctot, 3, 1);
     if (!wp.ok || cp.resize || (cp.inW & 3)) return KBN_ERR_UNSUPPORTED;
@@ -376,23 +446,20 @@ int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
     const size_t lds_epi = sizeof(float) * (size_t)16 * 16 * M_NSTRIDE;
     if (lds < lds_epi) lds = lds_epi;
     if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
-        attr_set = true;
+    switch (p.dbg) {  // ablation builds of the same kernel (tools/conv_bench.py --dbg)
+        case 1: return wino_variant<1>(p, lds, stream);
+        case 2: return wino_variant<2>(p, lds, stream);
+        case 3: return wino_variant<3>(p, lds, stream);
+        case 4: return wino_variant<4>(p, lds, stream);
+        case 8: return wino_variant<8>(p, lds, stream);
+        case 16: return wino_variant<16>(p, lds, stream);
+        case 19: return wino_variant<19>(p, lds, stream);
+        case 23: return wino_variant<23>(p, lds, stream);
+        case 32: return wino_variant<32>(p, lds, stream);
+        case 55: return wino_variant<55>(p, lds, stream);
+        default: return wino_variant<0>(p, lds, stream);
     }
-    if (p.dbg)  // ablation build of the same kernel (tools/conv_bench.py --dbg)
-        hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(p.nblocks), dim3(512), lds, stream, p);
-    else
-        hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(p.nblocks), dim3(512), lds, stream, p);
-    KBN_CHECK_LAUNCH();
-    return KBN_OK;
 }
-
 int wino_query(int n, int oc, int cin, int H, int W, int* RT, int* CT) {
     const WinoPlan wp = wino_plan(oc, cin, 3, 1);
     if (!wp.ok || (W & 3)) return 0;

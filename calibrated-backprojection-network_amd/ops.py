@@ -211,8 +211,11 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
     name = "conv_igemm"
     if PROFILE is not None:
         pl = conv_plan(n, out_channels, cin, kernel_size, stride, in_height, in_width, resize)
-        name = ("conv_dma" if pl["pipelined"] == 2 else "conv_igemm") + \
-            f"<{kernel_size},{stride},{pl['CK']},{pl['NB']},{pl['MW']}>"
+        if pl["kernel"] == "wino":
+            name = "conv_wino"
+        else:
+            name = ("conv_dma" if pl["pipelined"] == 2 else "conv_igemm") + \
+                f"<{kernel_size},{stride},{pl['CK']},{pl['NB']},{pl['MW']}>"
     check(_launch(name,
                   2.0 * n * oh * ow * cin * kernel_size * kernel_size * out_channels,
                   lambda: lib.kbn_conv2d_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,

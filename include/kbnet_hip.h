@@ -159,7 +159,7 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
  * kernel 2 = conv_dma_kernel<kernel_size, stride, CK, NB, MW, ...> (LDS-DMA staging; needs
  * W % 4 == 0, 16-byte aligned planes, no resize), 1 / 0 = conv_igemm_kernel<...> with / without
  * register prefetch, 3 = conv_wino_kernel (Winograd F(2x2,3x3) for 3x3 stride-1 convs with
- * in_channels % 8 == 0, in_channels >= 32, out_channels >= 32 and the conv_dma alignment rules;
+ * in_channels % 16 == 0, in_channels >= 32, out_channels >= 32, every source a multiple of 8 channels and the conv_dma alignment rules;
  * then MW x TWB = tile rows x columns of a workgroup's region and TH = its pixel rows). */
 int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, int stride,
                      int in_height, int in_width, int resize, int* info);

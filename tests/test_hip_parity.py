@@ -117,10 +117,10 @@ CONV_CASES = [
     (51, 48, 1, 2, 2, 30, 50), (99, 96, 1, 2, 1, 23, 31), (16, 1, 1, 1, 1, 9, 9), (128, 64, 3, 1, 1, 22, 38),
     (96, 192, 3, 2, 1, 11, 19), (35, 64, 3, 2, 1, 16, 16), (5, 80, 3, 1, 1, 7, 5), (4, 20, 1, 1, 3, 5, 70),
     (24, 130, 3, 1, 1, 18, 18),
-    # Winograd F(2x2,3x3) path (cin % 8 == 0, cin >= 32, cout >= 32, w % 4 == 0): partial regions,
+    # Winograd F(2x2,3x3) path (cin % 16 == 0, cin >= 32, cout >= 32, w % 4 == 0): partial regions,
     # odd height, padded / several n-tiles, single tile row
-    (128, 64, 3, 1, 2, 22, 76), (64, 48, 3, 1, 1, 33, 40), (32, 130, 3, 1, 1, 18, 20), (72, 64, 3, 1, 1, 1, 8),
-    (40, 32, 3, 1, 3, 7, 132),
+    (128, 64, 3, 1, 2, 22, 76), (64, 48, 3, 1, 1, 33, 40), (32, 130, 3, 1, 1, 18, 20), (80, 64, 3, 1, 1, 1, 8),
+    (48, 32, 3, 1, 3, 7, 132), (72, 64, 3, 1, 1, 9, 12),
 ]
 
 
@@ -183,13 +183,13 @@ def test_decoder_block_winograd_concat(dev):
     x = torch.randn(2, 48, 11, 18, generator=g)
     skip_full = torch.randn(2, 80, 22, 36, generator=g)
     sd = {"deconv.conv.conv.weight": torch.randn(40, 48, 3, 3, generator=g) / 20,
-          "conv.conv.weight": torch.randn(40, 40 + 64, 3, 3, generator=g) / 30}
-    ref = orc.decoder_block(x, skip_full[:, 8:72], None, sd)
-    blk = kb.modules.DecoderBlock(48, 64, 40, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+          "conv.conv.weight": torch.randn(40, 40 + 56, 3, 3, generator=g) / 30}
+    ref = orc.decoder_block(x, skip_full[:, 8:64], None, sd)
+    blk = kb.modules.DecoderBlock(48, 56, 40, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
     blk.load_state_dict(sd)
-    out = blk(x.to(dev), skip_full.to(dev)[:, 8:72])
+    out = blk(x.to(dev), skip_full.to(dev)[:, 8:64])
     assert rel_err(out, ref) < TIGHT
-    assert kb.ops.conv_plan(2, 40, 104, 3, 1, 22, 36)["kernel"] == "wino"
+    assert kb.ops.conv_plan(2, 40, 96, 3, 1, 22, 36)["kernel"] == "wino"
 
 
 def test_winograd_matches_direct_kernel(dev, monkeypatch):

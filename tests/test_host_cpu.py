@@ -95,7 +95,8 @@ def test_library_exports_every_declared_symbol():
     assert loaded.kbn_conv2d_packed_weight_bytes(5, 5, 5, 1) == 0
     # wide 3x3 stride-1 convs carry the Winograd-domain weights (16 per channel pair) behind the direct ones
     assert loaded.kbn_conv2d_packed_weight_bytes(64, 128, 3, 1) == 4 * (128 * 9 * 64 + 128 * 16 * 64)
-    assert loaded.kbn_conv2d_packed_weight_bytes(40, 104, 3, 1) == 4 * (104 * 9 * 48 + 104 * 16 * 64)
+    assert loaded.kbn_conv2d_packed_weight_bytes(40, 96, 3, 1) == 4 * (96 * 9 * 48 + 96 * 16 * 64)
+    assert loaded.kbn_conv2d_packed_weight_bytes(40, 104, 3, 1) == 4 * 104 * 9 * 48  # odd number of 8-channel chunks: direct only
     # tile choice: big maps keep the largest tile, small maps shrink it so every CU gets work
     big = kb.ops.conv_plan(8, 96, 96, 3, 2, 176, 608)
     small = kb.ops.conv_plan(8, 384, 384, 3, 2, 22, 76)

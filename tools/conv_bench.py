@@ -53,16 +53,19 @@ def run_one(name, batch=int(os.environ.get("KBN_BATCH", "8")), iters=8):
     if rs is not None and (h, w) == (2 * rs[0], 2 * rs[1]) and not os.environ.get("KBN_NO_UP2X"):
         pw2 = kb.ops.pack_upconv2x_weight(wt)
         f = lambda: kb.ops.upconv2x(tens[0], pw2, cout, out, 0.2)
-    for _ in range(3):
+    for _ in range(10):
         f()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        f()
-    e.record()
-    torch.cuda.synchronize()
-    us = s.elapsed_time(e) * 1e3 / iters
+    samples = []
+    for _ in range(5):   # median of 5 timing blocks (clock ramp / co-tenant noise)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            f()
+        e.record()
+        torch.cuda.synchronize()
+        samples.append(s.elapsed_time(e) * 1e3 / iters)
+    us = sorted(samples)[2]
     flops = 2.0 * batch * oh * ow * cin * k * k * cout
     pl = kb.ops.conv_plan(batch, cout, cin, k, stride, h, w, rs is not None)
     return {"layer": name, "us": round(us, 1), "tflops": round(flops / us / 1e6, 1), **pl}
