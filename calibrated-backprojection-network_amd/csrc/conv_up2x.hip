@@ -92,6 +92,51 @@ struct Up2xParams {
     float slope;
 };
 
+template <int I> struct IC2 { static constexpr int value = I; };
+
+// Epilogue shared by both kernels: interleave the two column phases -> 8 consecutive output pixels per
+// lane (two 16-byte stores), fused LeakyReLU.
+template <int NB, int MW>
+__device__ __forceinline__ void up2x_store(const Up2xParams& p, const f32x4 (&acc)[2][MW][NB], int n, int nt, int a,
+                                           int y0, int x0, int twb, int wave, int li, int lk) {
+    constexpr int NT = NB * 16;
+    const int outH = 2 * p.srcH, outW = 2 * p.srcW;
+    const long long HWo = (long long)outH * outW;
+    float* outn = p.out + (long long)n * p.out_bstride;
+    const bool vec_ok = ((outW & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) && ((p.out_bstride & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int mb = wave * MW + mi;
+        const int oyl = mb / twb, seg = mb - oyl * twb;
+        const int y = y0 + oyl;
+        const int xl = x0 + seg * 16 + lk * 4;
+        if (y >= p.srcH || xl >= p.srcW) continue;
+        const int Y = 2 * y + a, X = 2 * xl;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int oc = nt * NT + nb * 16 + li;
+            if (oc >= p.OC) continue;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e0 = acc[0][mi][nb][r], e1 = acc[1][mi][nb][r];
+                if (p.act) { e0 = leaky_relu(e0, p.slope); e1 = leaky_relu(e1, p.slope); }
+                v[2 * r] = e0;
+                v[2 * r + 1] = e1;
+            }
+            float* o = outn + (long long)oc * HWo + (long long)Y * outW + X;
+            if (vec_ok && xl + 3 < p.srcW) {
+                reinterpret_cast<f32x4*>(o)[0] = (f32x4){v[0], v[1], v[2], v[3]};
+                reinterpret_cast<f32x4*>(o)[1] = (f32x4){v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (xl + (r >> 1) < p.srcW) o[r] = v[r];
+            }
+        }
+    }
+}
+
 template <int CK, int NB, int MW, int MAXPOS>
 __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_kernel(const Up2xParams p) {
     constexpr int NT = NB * 16;
@@ -240,42 +285,182 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_kernel(cons
         cur ^= 1;
     }
 
-    // ---- epilogue: interleave the two column phases -> 8 consecutive output pixels per lane ----
-    const int outH = 2 * p.srcH, outW = 2 * p.srcW;
-    const long long HWo = (long long)outH * outW;
-    float* outn = p.out + (long long)n * p.out_bstride;
-    const bool vec_ok = ((outW & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) && ((p.out_bstride & 3) == 0);
+    up2x_store<NB, MW>(p, acc, n, nt, a, y0, x0, p.TWB, wave, li, lk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path: same 4-phase GEMM, but (a) the low-res tile reaches LDS by LDS-DMA as in conv_dma.hip
+// (row-major image of the tile, 16-byte granules, out-of-image granules never written into the
+// pre-zeroed stages; needs srcW % 4 == 0 and 16-byte aligned planes), (b) the tile geometry (MW, TWB)
+// is a template argument and the K loop is unrolled by the stage parity, so that every LDS address is
+// a loop-invariant register plus an immediate, and (c) the staging pointers live in SGPRs.  Vector-ALU
+// instructions between MFMAs cost matrix-pipe time (tools/probe/issue_probe.hip); the general kernel
+// above spends ~0.3 of them per MFMA on addresses and masks, this one none.
+template <int NB, int MW, int TWB>
+struct Up2xGeom {
+    static constexpr int NT = NB * 16;
+    static constexpr int TH = 4 * MW / TWB, TW = TWB * 16;
+    static constexpr int ROWS = TH + 1, COLS = TW + 8;          // staged rows / columns (x0-4 .. x0+TW+3)
+    static constexpr int PLANE = ((ROWS * COLS + 15) / 32) * 32 + 16;
+    static constexpr int NF4 = ROWS * COLS / 4;                  // granules per channel
+    static constexpr int MAXJ = (NF4 + 63) / 64;
+    static constexpr int A_FLOATS = 8 * PLANE, B_FLOATS = 8 * 8 * NT, BUF = A_FLOATS + B_FLOATS;
+};
+
+template <int NB, int MW, int TWB>
+__global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(const Up2xParams p) {
+    using G = Up2xGeom<NB, MW, TWB>;
+    constexpr int NT = G::NT, PLANE = G::PLANE, PITCH = G::COLS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int a = bid & 1;  // row phase
+    bid >>= 1;
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int y0 = ty * G::TH, x0 = tx * G::TW;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+
+    // this lane's granules of a channel tile: byte offset inside the source plane, or masked off
+    unsigned gv[G::MAXJ];
+    unsigned long long gm[G::MAXJ];
+#pragma unroll
+    for (int j = 0; j < G::MAXJ; ++j) {
+        const int f = j * 64 + lane;
+        int g = -1;
+        if (f < G::NF4) {
+            const int r = f / (PITCH / 4), cv = f - r * (PITCH / 4);
+            const int Y = y0 - 1 + a + r, X = x0 - 4 + cv * 4;
+            if (Y >= 0 && Y < p.srcH && X >= 0 && X < p.srcW) g = (Y * p.srcW + X) * 4;
+        }
+        gv[j] = g < 0 ? 0u : (unsigned)g;
+        gm[j] = __ballot(g >= 0);
+    }
+
+    int mbase[MW];
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         const int mb = wave * MW + mi;
-        const int oyl = mb / p.TWB, seg = mb - oyl * p.TWB;
-        const int y = y0 + oyl;
-        const int xl = x0 + seg * 16 + lk * 4;
-        if (y >= p.srcH || xl >= p.srcW) continue;
-        const int Y = 2 * y + a, X = 2 * xl;
+        const int oy = mb / TWB, seg = mb - oy * TWB;
+        mbase[mi] = oy * PITCH + seg * 16 + li + 3 + lk * PLANE;   // column x-1 of the lane's pixel
+    }
+    const int boff = G::A_FLOATS + (lk >> 1) * 2 * NT + li * 2 + (lk & 1);
+
+    f32x4 acc[2][MW][NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int oc = nt * NT + nb * 16 + li;
-            if (oc >= p.OC) continue;
-            float v[8];
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float e0 = acc[0][mi][nb][r], e1 = acc[1][mi][nb][r];
-                if (p.act) { e0 = leaky_relu(e0, p.slope); e1 = leaky_relu(e1, p.slope); }
-                v[2 * r] = e0;
-                v[2 * r + 1] = e1;
-            }
-            float* o = outn + (long long)oc * HWo + (long long)Y * outW + X;
-            if (vec_ok && xl + 3 < p.srcW) {
-                reinterpret_cast<f32x4*>(o)[0] = (f32x4){v[0], v[1], v[2], v[3]};
-                reinterpret_cast<f32x4*>(o)[1] = (f32x4){v[4], v[5], v[6], v[7]};
-            } else {
+        for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    if (xl + (r >> 1) < p.srcW) o[r] = v[r];
+            for (int nb = 0; nb < NB; ++nb) acc[b][mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int HW = p.srcH * p.srcW;
+    // wave-uniform staging state (SGPRs): plane of channel (c0 + wave) and this wave's weight granules
+    const float* aptr = uniform_ptr(p.src + (long long)n * p.src_bstride + (long long)wave * HW);
+    const float* bptr = uniform_ptr(p.wp + ((long long)a * p.nTilesN + nt) * p.Cpad * 8 * NT + wave * 256);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned uv = (unsigned)(lane * 16);
+
+    auto stage = [&](int buf) {   // chunk at aptr / bptr -> stage `buf`; wave w moves channels w and w + 4
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned dst = lds0 + 4u * (unsigned)(buf * G::BUF + (wave + 4 * t) * PLANE);
+#pragma unroll
+            for (int j = 0; j < G::MAXJ; ++j) lds_dma16_sm(aptr + (long long)(4 * t) * HW, gv[j], dst + j * 1024, gm[j]);
+        }
+        const unsigned bdst = lds0 + 4u * (unsigned)(buf * G::BUF + G::A_FLOATS + wave * 256);
+#pragma unroll
+        for (int e = 0; e < G::B_FLOATS / 1024; ++e) lds_dma16_s(bptr + e * 1024, uv, bdst + e * 4096);
+        aptr += (long long)8 * HW;
+        bptr += G::B_FLOATS;
+    };
+    auto compute = [&](auto par) {
+        constexpr int PAR = decltype(par)::value;
+        const float* S = smem + PAR * G::BUF;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+            for (int c4 = 0; c4 < 2; ++c4) {
+                const float* Ab = S + c4 * 4 * PLANE + dy * PITCH;
+                const float* Bb = S + (dy * 2 + c4) * 16 * NT + boff;
+                float av[MW][3], bv[2][2][NB];
+#pragma unroll
+                for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) av[mi][j] = Ab[mbase[mi] + j];
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) bv[dx][b][nb] = Bb[(dx * 2 + b) * 4 * NT + nb * 32];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[b][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][b + dx], bv[dx][b][nb],
+                                                                                     acc[b][mi][nb], 0, 0, 0);
             }
         }
+    };
+
+    // clear the A part of both stages once (out-of-image granules are never written afterwards)
+    {
+        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int e = tid * 4; e < G::A_FLOATS; e += 1024) {
+            *reinterpret_cast<f32x4*>(smem + e) = zero;
+            *reinterpret_cast<f32x4*>(smem + G::BUF + e) = zero;
+        }
     }
+    __syncthreads();
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nch = p.Cpad / 8;   // even (launcher)
+    for (int c = 0; c < nch; c += 2) {
+        stage(1);
+        compute(IC2<0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 2 < nch) stage(0);
+        compute(IC2<1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    up2x_store<NB, MW>(p, acc, n, nt, a, y0, x0, TWB, wave, li, lk);
+}
+
+template <int NB, int MW, int TWB>
+static int up2x_dma_variant(Up2xParams& p, hipStream_t stream) {
+    using G = Up2xGeom<NB, MW, TWB>;
+    auto kern = conv_up2x_dma_kernel<NB, MW, TWB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return KBN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    p.TWB = TWB; p.TH = G::TH;
+    p.tilesX = ceil_div(p.srcW, G::TW); p.tilesY = ceil_div(p.srcH, G::TH);
+    const long long nb64 = (long long)p.tilesX * p.tilesY * p.N * p.nTilesN * 2;
+    if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.nblocks = (int)nb64;
+    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), 2 * sizeof(float) * G::BUF, stream, p);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
 }
 
 template <int NB, int MW, int MAXPOS>
@@ -331,8 +516,45 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
     p.srcH = src_height; p.srcW = src_width;
     p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.nTilesN = pl.nTilesN;
-    // tile: 4*MW m-blocks of 16 low-res pixels, 16 or 32 wide; a lone workgroup round is avoided
-    const int mblocks = 4 * pl.MW;
+    hipStream_t st = (hipStream_t)stream;
+    // fast path: LDS-DMA staging, compile-time tile geometry
+    const bool aligned = (src_width & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+                         (src_batch_stride & 3) == 0 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad;
+    if (aligned && !getenv("KBN_NO_UP2X_DMA")) {
+        const char* ftw = getenv("KBN_FORCE_TWB");
+        int twb = 1;   // 16-wide tiles unless 32-wide ones waste fewer pixels / fill the rounds better
+        {
+            double best = 1e300;
+            for (int t = 1; t <= 2; ++t) {
+                if (ftw && atoi(ftw) && atoi(ftw) != t) continue;
+                const int th = 4 * pl.MW / t, tw = t * 16;
+                const long long tiles = (long long)ceil_div(src_width, tw) * ceil_div(src_height, th) * n * pl.nTilesN * 2;
+                const double cost = (double)((tiles + 511) / 512) * (4 * pl.MW * 16.0 + 0.1 * (th + 1) * (tw + 8));
+                if (cost < best) { best = cost; twb = t; }
+            }
+        }
+        switch (pl.NB * 10 + twb) {
+            case 11: return up2x_dma_variant<1, 4, 1>(p, st);
+            case 12: return up2x_dma_variant<1, 4, 2>(p, st);
+            case 21: return up2x_dma_variant<2, 4, 1>(p, st);
+            case 22: return up2x_dma_variant<2, 4, 2>(p, st);
+            case 31: return up2x_dma_variant<3, 2, 1>(p, st);
+            case 32: return up2x_dma_variant<3, 2, 2>(p, st);
+            case 41: return up2x_dma_variant<4, 2, 1>(p, st);
+            default: return up2x_dma_variant<4, 2, 2>(p, st);
+        }
+    }
+    // tile: 4*MW m-blocks of 16 low-res pixels, 16 or 32 wide; a lone workgroup round is avoided.
+    // Small maps (every tile of the launch resident at once) halve the tile: twice the workgroups, and the
+    // waves sharing a SIMD finish sooner than one wave with the double tile.
+    int mw = pl.MW;
+    {
+        const long long tiles2 = (long long)ceil_div(src_width, 16) * ceil_div(src_height, 4 * pl.MW) * n * pl.nTilesN * 2;
+        if (pl.NB >= 3 && tiles2 <= 512) mw = 1;
+        const char* fm = getenv("KBN_UP_MW");
+        if (fm && atoi(fm) && pl.NB >= 3) mw = atoi(fm) == 1 ? 1 : pl.MW;
+    }
+    const int mblocks = 4 * mw;
     double best_cost = 1e300;
     int best_twb = 1;
     const char* ft = getenv("KBN_FORCE_TWB");
@@ -353,12 +575,11 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
     if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
     p.nblocks = (int)nb64;
     size_t lds = 2 * sizeof(float) * ((size_t)pl.CK * p.plane + (size_t)pl.CK * 8 * pl.NT);
-    hipStream_t st = (hipStream_t)stream;
     switch (pl.NB) {
         case 1: return up2x_variant<1, 4, 2>(p, lds, st);
         case 2: return up2x_variant<2, 4, 2>(p, lds, st);
-        case 3: return up2x_variant<3, 2, 1>(p, lds, st);
-        default: return up2x_variant<4, 2, 1>(p, lds, st);
+        case 3: return mw == 1 ? up2x_variant<3, 1, 1>(p, lds, st) : up2x_variant<3, 2, 1>(p, lds, st);
+        default: return mw == 1 ? up2x_variant<4, 1, 1>(p, lds, st) : up2x_variant<4, 2, 1>(p, lds, st);
     }
 }
 

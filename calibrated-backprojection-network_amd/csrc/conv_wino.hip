@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         const int nx = gch + WCK;
         const bool adv = nx < Cin;
         const float* cand = nx == C0 ? s1w : (nx == C01 ? s2w : gsrc + (long long)WCK * HW);
-        gsrc = adv ? cand : gsrc;
+        gsrc = uniform_ptr(adv ? cand : gsrc);   // (pinned: the compiler does not always prove the select chain uniform)
         gch = adv ? nx : gch;
     };
     // lanes whose granule j is inside the image (loop invariant)
@@ -318,25 +318,42 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    if ((DBG & 32) != 0) {
-        if (acc[0][0][0][0] == 12345.f) p.out[0] = 0.f;  // keep the loop alive
+    if ((DBG & 32) != 0) {  // ablation: no epilogue (every accumulator stays live)
+        f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) sum += acc[x][mb][nb];
+        if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.f) p.out[0] = 0.f;
         return;
     }
     // ---- output transform: 16 frequencies meet in LDS, one pass per 16 output channels ----
-    float* const Ms = smem;  // [16 xi][16 n][M_NSTRIDE]
-    float* outn = p.out + (long long)n * p.out_bstride;
+    // The exchange buffer is double buffered (2 x 68 KiB) and the barriers are bare s_barrier behind an
+    // lgkmcnt wait: __syncthreads() would also drain vmcnt, i.e. wait for the previous pass's global
+    // stores to be acknowledged -- four exposed store latencies per workgroup.
+    // Addressing is hoisted: a lane's pixel offset is one 32-bit value, the channel plane a wave-uniform
+    // base (SGPR) -- the epilogue is instruction-issue bound, not bandwidth bound.
+    const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
+    const bool in0 = lane < ntile && ox < p.W && oy < p.H, in1 = in0 && oy + 1 < p.H;
+    const unsigned o0 = (unsigned)(oy * p.W + ox), o1 = o0 + (unsigned)p.W;
+    float* const outn = p.out + (long long)n * p.out_bstride;
+    const float slope = p.act ? p.slope : 1.f;   // act off == slope 1
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
+        float* const Ms = smem + (nb & 1) * (16 * 16 * M_NSTRIDE);  // [16 xi][16 n][M_NSTRIDE]
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
                 *reinterpret_cast<f32x4*>(Ms + ((2 * wave + x) * 16 + li) * M_NSTRIDE + mb * 16 + 4 * lk) = acc[x][mb][nb];
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int nloc = (tid >> 6) + 8 * k;    // wave-uniform
-            const int oc = nt * WNT + nb * 16 + nloc;
+            const int nloc = wave + 8 * k;
+            const int oc = nt * WNT + nb * 16 + nloc;    // wave-uniform
+            if (oc >= p.OC) continue;
             const float* m = Ms + nloc * M_NSTRIDE + lane;
             float s[2][4];
 #pragma unroll
@@ -346,25 +363,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
                 s[0][j] = m0 + m1 + m2;
                 s[1][j] = m1 - m2 - m3;
             }
-            const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
-            if (lane < ntile && oc < p.OC && ox < p.W) {
+            float* const oplane = outn + (long long)oc * HW;
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    if (oy + a >= p.H) continue;
-                    float v0 = s[a][0] + s[a][1] + s[a][2];
-                    float v1 = s[a][1] - s[a][2] - s[a][3];
-                    if (p.act) { v0 = leaky_relu(v0, p.slope); v1 = leaky_relu(v1, p.slope); }
-                    float* o = outn + (long long)oc * HW + (long long)(oy + a) * p.W + ox;
-                    if (p.vec_ok && ox + 1 < p.W) {
-                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
-                    } else {
-                        o[0] = v0;
-                        if (ox + 1 < p.W) o[1] = v1;
-                    }
+            for (int a = 0; a < 2; ++a) {
+                float v0 = s[a][0] + s[a][1] + s[a][2];
+                float v1 = s[a][1] - s[a][2] - s[a][3];
+                v0 = v0 > 0.f ? v0 : v0 * slope;
+                v1 = v1 > 0.f ? v1 : v1 * slope;
+                if ((DBG & 64) != 0) {   // ablation: epilogue without its global stores
+                    if (v0 + v1 == 12345.f) oplane[0] = 0.f;
+                } else if (a ? in1 : in0) {
+                    *reinterpret_cast<float2*>(oplane + (a ? o1 : o0)) = make_float2(v0, v1);  // W, ox even; 8-byte aligned (launcher)
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -442,8 +454,9 @@ int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
     p.nblocks = (int)nb64;
     p.act = cp.act; p.slope = cp.slope; p.dbg = cp.dbg;
     p.vec_ok = ((reinterpret_cast<uintptr_t>(cp.out) & 7) == 0) && ((cp.out_bstride & 1) == 0) && ((p.W & 1) == 0);
+    if (!p.vec_ok) return KBN_ERR_UNSUPPORTED;  // the epilogue stores float2
     size_t lds = sizeof(float) * ((size_t)2 * WCK * p.plane + 2 * U_CHUNK + 2 * V_CHUNK);
-    const size_t lds_epi = sizeof(float) * (size_t)16 * 16 * M_NSTRIDE;
+    const size_t lds_epi = 2 * sizeof(float) * (size_t)16 * 16 * M_NSTRIDE;
     if (lds < lds_epi) lds = lds_epi;
     if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
     switch (p.dbg) {  // ablation builds of the same kernel (tools/conv_bench.py --dbg)
@@ -457,6 +470,7 @@ int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
         case 23: return wino_variant<23>(p, lds, stream);
         case 32: return wino_variant<32>(p, lds, stream);
         case 55: return wino_variant<55>(p, lds, stream);
+        case 64: return wino_variant<64>(p, lds, stream);
         default: return wino_variant<0>(p, lds, stream);
     }
 }
