@@ -2,6 +2,9 @@
 // (conv_igemm.hip: register-staged, any shape; conv_dma.hip: LDS-DMA staged, aligned shapes).
 #pragma once
 
+#include <array>
+#include <functional>
+
 #include "kbn_common.h"
 
 // Second __launch_bounds__ argument of the MFMA conv kernels (minimum waves per SIMD): 2 lets the
@@ -191,6 +194,14 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 }
 
 struct TileChoice { int MW, TWB; };
+
+// tune.hip: first-use tuning of launch geometry.  `key` = {kernel family, problem shape...};
+// candidates are 0..ncand-1, `launch(c)` launches the real problem with candidate c (KBN_OK, or an error
+// for an invalid candidate), `model` is the analytic choice (used while capturing / when disabled).
+typedef std::array<int, 10> TuneKey;
+bool tune_enabled();
+bool tune_lookup(const TuneKey& key, int* cand);
+int tune_pick(const TuneKey& key, int ncand, int model, const std::function<int(int)>& launch, hipStream_t stream);
 
 // conv_wino.hip: Winograd F(2x2,3x3) path for wide 3x3 stride-1 convs.  Eligibility by shape only
 // (pack time and launch time must agree): the transformed weights live behind the direct-conv

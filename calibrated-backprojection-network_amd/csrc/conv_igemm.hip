@@ -388,6 +388,15 @@ static TileChoice choose_tile(int outH, int outW, int n, int nTilesN, int kernel
     return best;
 }
 
+// candidate index <-> tile shape for the tuner (tune.hip): MW in {1,2,4,8} x TWB in {1,2,4}
+static TileChoice tile_of_cand(int c) { return TileChoice{1 << (c / 3), 1 << (c % 3)}; }
+static int cand_of_tile(TileChoice t) {
+    int a = 0, b2 = 0;
+    while ((1 << a) < t.MW) ++a;
+    while ((1 << b2) < t.TWB) ++b2;
+    return a * 3 + b2;
+}
+
 int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
                   long long out_batch_stride, int n, int out_channels, int kernel_size, int stride,
                   int in_height, int in_width, int resize, int apply_activation, float negative_slope,
@@ -443,13 +452,29 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     p.dbg = env_int("KBN_DEBUG");
 
     const bool s2 = (kernel_size == 3 && stride == 2);
-    const TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
+    TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
     if (kernel_size == 3 && stride == 1 && !env_int("KBN_NO_WINO")) {  // wide 3x3: Winograd F(2x2,3x3)
         int rc = conv_wino_launch(p, stream);
         if (rc != KBN_ERR_UNSUPPORTED) return rc;
     }
     if (!env_int("KBN_NO_DMA")) {  // fast path: LDS-DMA staging (aligned tensor sources, no resize)
-        int rc = conv_dma_launch(p, pl, tc, kernel_size, stride, stream);
+        const bool forced = env_int("KBN_FORCE_MW") || env_int("KBN_FORCE_TWB");
+        int sig = n_src;
+        for (int s = 0; s < n_src; ++s) sig = sig * 4 + srcs[s].kind;
+        const TuneKey key{1, n, out_channels, ctot, kernel_size, stride, in_height, in_width, sig, 0};
+        const bool tuning = !forced && tune_enabled();
+        int cand = cand_of_tile(tc);
+        if (tuning && tune_lookup(key, &cand)) tc = tile_of_cand(cand);     // tuned earlier
+        ConvParams q = p;
+        int rc = conv_dma_launch(q, pl, tc, kernel_size, stride, stream);   // also the eligibility check
+        if (rc == KBN_OK && tuning && !tune_lookup(key, &cand)) {           // first eligible launch of this shape
+            cand = tune_pick(key, 12, cand_of_tile(tc), [&](int c) {
+                const TileChoice t = tile_of_cand(c);
+                if (t.MW > pl.MW || t.TWB > 4 * t.MW) return (int)KBN_ERR_UNSUPPORTED;
+                ConvParams r = p;
+                return conv_dma_launch(r, pl, t, kernel_size, stride, stream);
+            }, stream);
+        }
         if (rc != KBN_ERR_UNSUPPORTED) return rc;
     }
     const int mblocks = 4 * tc.MW;
@@ -514,7 +539,17 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
     if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
     const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size, stride, env_int("KBN_FORCE_CK"));
     const int outH = ceil_div(in_height, stride), outW = ceil_div(in_width, stride);
-    const TileChoice tc = choose_tile(outH, outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
+    TileChoice tc = choose_tile(outH, outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
+    {   // a tuned choice, if this shape has run already (tensor sources only: the common signatures)
+        for (int nsrc = 1; nsrc <= KBN_MAX_SRC; ++nsrc) {
+            int sig = nsrc, cand = 0;
+            for (int s = 0; s < nsrc; ++s) sig = sig * 4 + KBN_SRC_TENSOR;
+            if (tune_lookup(TuneKey{1, n, out_channels, in_channels, kernel_size, stride, in_height, in_width, sig, 0}, &cand)) {
+                tc = tile_of_cand(cand);
+                break;
+            }
+        }
+    }
     const int th = 4 * tc.MW / tc.TWB, tw = tc.TWB * 16;
     const int maxpos = conv_maxpos(kernel_size, stride, tc.MW);
     info[0] = pl.CK; info[1] = pl.NB; info[2] = tc.MW; info[3] = tc.TWB; info[4] = th;

@@ -533,16 +533,22 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
                 if (cost < best) { best = cost; twb = t; }
             }
         }
-        switch (pl.NB * 10 + twb) {
-            case 11: return up2x_dma_variant<1, 4, 1>(p, st);
-            case 12: return up2x_dma_variant<1, 4, 2>(p, st);
-            case 21: return up2x_dma_variant<2, 4, 1>(p, st);
-            case 22: return up2x_dma_variant<2, 4, 2>(p, st);
-            case 31: return up2x_dma_variant<3, 2, 1>(p, st);
-            case 32: return up2x_dma_variant<3, 2, 2>(p, st);
-            case 41: return up2x_dma_variant<4, 2, 1>(p, st);
-            default: return up2x_dma_variant<4, 2, 2>(p, st);
-        }
+        auto launch = [&](int cand) -> int {   // candidate = TWB - 1
+            Up2xParams q = p;
+            switch (pl.NB * 10 + cand + 1) {
+                case 11: return up2x_dma_variant<1, 4, 1>(q, st);
+                case 12: return up2x_dma_variant<1, 4, 2>(q, st);
+                case 21: return up2x_dma_variant<2, 4, 1>(q, st);
+                case 22: return up2x_dma_variant<2, 4, 2>(q, st);
+                case 31: return up2x_dma_variant<3, 2, 1>(q, st);
+                case 32: return up2x_dma_variant<3, 2, 2>(q, st);
+                case 41: return up2x_dma_variant<4, 2, 1>(q, st);
+                default: return up2x_dma_variant<4, 2, 2>(q, st);
+            }
+        };
+        int cand = twb - 1;
+        if (!ftw) cand = tune_pick(TuneKey{3, n, out_channels, in_channels, src_height, src_width, 0, 0, 0, 0}, 2, cand, launch, st);
+        return launch(cand);
     }
     // tile: 4*MW m-blocks of 16 low-res pixels, 16 or 32 wide; a lone workgroup round is avoided.
     // Small maps (every tile of the launch resident at once) halve the tile: twice the workgroups, and the

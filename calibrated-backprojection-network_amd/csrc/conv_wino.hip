@@ -396,19 +396,24 @@ int wino_pack(const float* weight, float* packed, int oc, int cin, hipStream_t s
 
 // Region shape: RT x CT tiles (CT even so that regions start on a 4-pixel boundary), chosen to
 // minimise the number of 256-workgroup rounds (one workgroup per CU), then the workgroup count.
-static void choose_region(int H, int W, int n, int nTilesN, int& RT, int& CT) {
-    static const int cand[][2] = {{4, 16}, {8, 8}, {2, 32}, {6, 10}, {5, 12}, {3, 20}, {7, 8}, {10, 6}, {16, 4}};
+static const int kRegions[][2] = {{4, 16}, {8, 8}, {2, 32}, {6, 10}, {5, 12}, {3, 20}, {7, 8}, {10, 6}, {16, 4}};
+constexpr int kNumRegions = 9;
+
+static int choose_region(int H, int W, int n, int nTilesN) {   // index into kRegions
     const int th = ceil_div(H, 2), tw = ceil_div(W, 2);
     long long best_rounds = 1LL << 60, best_wgs = 1LL << 60;
+    int best = 0;
     const int force_rt = getenv("KBN_WINO_RT") ? atoi(getenv("KBN_WINO_RT")) : 0;
-    for (const auto& c : cand) {
+    for (int i = 0; i < kNumRegions; ++i) {
+        const int* c = kRegions[i];
         if (force_rt && c[0] != force_rt) continue;
         const long long wgs = (long long)ceil_div(th, c[0]) * ceil_div(tw, c[1]) * n * nTilesN;
         const long long rounds = (wgs + 255) / 256;
         if (rounds < best_rounds || (rounds == best_rounds && wgs < best_wgs)) {
-            best_rounds = rounds; best_wgs = wgs; RT = c[0]; CT = c[1];
+            best_rounds = rounds; best_wgs = wgs; best = i;
         }
     }
+    return best;
 }
 
 template <int DBG>
@@ -424,6 +429,8 @@ static int wino_variant(const WinoParams& p, size_t lds, hipStream_t stream) {
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
+
+static int wino_dispatch(const WinoParams& p, size_t lds, hipStream_t stream);
 
 int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
     const WinoPlan wp = wino_plan(cp.OC, cp.Ctot, 3, 1);
@@ -442,23 +449,36 @@ int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
     p.out = cp.out; p.out_bstride = cp.out_bstride;
     p.N = cp.N; p.OC = cp.OC; p.Cin = cp.Ctot; p.H = cp.inH; p.W = cp.inW;
     p.nTilesN = wp.nTilesN;
-    choose_region(p.H, p.W, p.N, p.nTilesN, p.RT, p.CT);
-    p.regionsX = ceil_div(ceil_div(p.W, 2), p.CT);
-    p.regionsY = ceil_div(ceil_div(p.H, 2), p.RT);
-    p.rowsS = 2 * p.RT + 2;
-    p.colsS = round_up(2 * p.CT + 5, 4);
-    p.plane = p.rowsS * p.colsS;  // multiple of 4
-    if (p.plane > 512) return KBN_ERR_UNSUPPORTED;
-    const long long nb64 = (long long)p.regionsX * p.regionsY * p.N * p.nTilesN;
-    if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
-    p.nblocks = (int)nb64;
     p.act = cp.act; p.slope = cp.slope; p.dbg = cp.dbg;
     p.vec_ok = ((reinterpret_cast<uintptr_t>(cp.out) & 7) == 0) && ((cp.out_bstride & 1) == 0) && ((p.W & 1) == 0);
     if (!p.vec_ok) return KBN_ERR_UNSUPPORTED;  // the epilogue stores float2
-    size_t lds = sizeof(float) * ((size_t)2 * WCK * p.plane + 2 * U_CHUNK + 2 * V_CHUNK);
-    const size_t lds_epi = 2 * sizeof(float) * (size_t)16 * 16 * M_NSTRIDE;
-    if (lds < lds_epi) lds = lds_epi;
-    if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
+    const int model = choose_region(p.H, p.W, p.N, p.nTilesN);
+    auto launch = [&](int cand) -> int {
+        WinoParams q = p;
+        q.RT = kRegions[cand][0]; q.CT = kRegions[cand][1];
+        q.regionsX = ceil_div(ceil_div(q.W, 2), q.CT);
+        q.regionsY = ceil_div(ceil_div(q.H, 2), q.RT);
+        q.rowsS = 2 * q.RT + 2;
+        q.colsS = round_up(2 * q.CT + 5, 4);
+        q.plane = q.rowsS * q.colsS;  // multiple of 4
+        if (q.plane > 512) return KBN_ERR_UNSUPPORTED;
+        const long long nb64 = (long long)q.regionsX * q.regionsY * q.N * q.nTilesN;
+        if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+        q.nblocks = (int)nb64;
+        size_t lds = sizeof(float) * ((size_t)2 * WCK * q.plane + 2 * U_CHUNK + 2 * V_CHUNK);
+        const size_t lds_epi = 2 * sizeof(float) * (size_t)16 * 16 * M_NSTRIDE;
+        if (lds < lds_epi) lds = lds_epi;
+        if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
+        return wino_dispatch(q, lds, stream);
+    };
+    int cand = model;
+    if (!getenv("KBN_WINO_RT") && !p.dbg) {
+        cand = tune_pick(TuneKey{2, p.N, p.OC, p.Cin, p.H, p.W, 0, 0, 0, 0}, kNumRegions, model, launch, stream);
+    }
+    return launch(cand);
+}
+
+static int wino_dispatch(const WinoParams& p, size_t lds, hipStream_t stream) {
     switch (p.dbg) {  // ablation builds of the same kernel (tools/conv_bench.py --dbg)
         case 1: return wino_variant<1>(p, lds, stream);
         case 2: return wino_variant<2>(p, lds, stream);
@@ -477,7 +497,9 @@ int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
 int wino_query(int n, int oc, int cin, int H, int W, int* RT, int* CT) {
     const WinoPlan wp = wino_plan(oc, cin, 3, 1);
     if (!wp.ok || (W & 3)) return 0;
-    choose_region(H, W, n, wp.nTilesN, *RT, *CT);
+    int cand = choose_region(H, W, n, wp.nTilesN);
+    tune_lookup(TuneKey{2, n, oc, cin, H, W, 0, 0, 0, 0}, &cand);   // a tuned choice, if this shape has run already
+    *RT = kRegions[cand][0]; *CT = kRegions[cand][1];
     return ceil_div(ceil_div(W, 2), *CT) * ceil_div(ceil_div(H, 2), *RT) * n * wp.nTilesN;
 }
 

@@ -1,0 +1,69 @@
+// tune.hip -- first-use tuning of launch geometry (tile shape of the direct convs, region shape of the
+// Winograd kernel, tile shape of the up-convs).
+//
+// The analytic cost models are within 10-15 % of the best geometry on some layers (workgroup-round
+// quantisation, HBM-bound stores; profiles/r01/v6_tile_sweep.txt).  The first launch of a problem
+// shape therefore times every candidate on the caller's stream (HIP events; the output is simply
+// rewritten with identical values -- geometry never changes an accumulation order) and the winner is
+// cached for the process.  No tuning while the stream is being captured into a graph (the model's
+// choice is used and nothing is cached) or with KBN_AUTOTUNE=0.  The cache holds integers only.
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+
+#include "conv_common.h"
+
+namespace kbn {
+
+static std::map<TuneKey, int> g_cache;
+static std::mutex g_mutex;
+
+bool tune_enabled() {
+    static const bool on = !(getenv("KBN_AUTOTUNE") && atoi(getenv("KBN_AUTOTUNE")) == 0);
+    return on;
+}
+
+bool tune_lookup(const TuneKey& key, int* cand) {
+    std::lock_guard<std::mutex> g(g_mutex);
+    auto it = g_cache.find(key);
+    if (it == g_cache.end()) return false;
+    *cand = it->second;
+    return true;
+}
+
+int tune_pick(const TuneKey& key, int ncand, int model, const std::function<int(int)>& launch, hipStream_t stream) {
+    if (!tune_enabled()) return model;
+    int cand = model;
+    if (tune_lookup(key, &cand)) return cand;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return model;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return model;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return model; }
+    int best = model;
+    float best_ms = 1e30f;
+    for (int c = 0; c < ncand; ++c) {
+        if (launch(c) != KBN_OK) continue;  // warm (kernel attributes, caches); also filters invalid candidates
+        float ms = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0, stream);
+            const int rc = launch(c);
+            (void)hipEventRecord(e1, stream);
+            float t = 1e30f;
+            if (rc != KBN_OK || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) t = 1e30f;
+            ms = t < ms ? t : ms;
+        }
+        const float score = ms * (c == model ? 0.98f : 1.0f);  // keep the model's choice unless something is clearly faster
+        if (score < best_ms) { best_ms = score; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (best_ms < 1e29f) {
+        std::lock_guard<std::mutex> g(g_mutex);
+        g_cache[key] = best;
+    }
+    return best;
+}
+
+}  // namespace kbn
