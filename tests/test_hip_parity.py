@@ -204,6 +204,23 @@ def test_winograd_matches_direct_kernel(dev, monkeypatch):
     assert not torch.equal(a, b)  # two different kernels did run
 
 
+def test_first_use_tuning_keeps_results_bitwise(dev):
+    """The first launch of a shape times every tile / region candidate (csrc/tune.hip); geometry never
+    changes an accumulation order, so the tuned launches must reproduce the first result bit for bit."""
+    g = torch.Generator().manual_seed(12)
+    for cin, cout, k, stride, h, w in ((48, 96, 3, 2, 46, 88), (64, 64, 3, 1, 26, 52), (51, 48, 1, 2, 30, 52)):
+        x = torch.randn(2, cin, h, w, generator=g).to(dev)
+        conv = kb.modules.Conv2d(cin, cout, k, stride, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+        first = conv(x).clone()          # model's choice, then the candidates are timed
+        for _ in range(3):
+            assert torch.equal(conv(x), first)
+    up = kb.modules.UpConv2d(32, 48, 3, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+    x = torch.randn(2, 32, 12, 20, generator=g).to(dev)
+    first = up(x, (24, 40)).clone()
+    for _ in range(3):
+        assert torch.equal(up(x, (24, 40)), first)
+
+
 # ------------------------------------------------------------------------- KB block
 def _kb_module(g, dev):
     w = g["weights"]
