@@ -68,6 +68,10 @@ SIGNATURES = {
     "kbn_preprocess_forward": (_I, [_P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _P]),
     "kbn_eval_accumulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "kbn_depth_head_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "kbn_png_info": (_I, [_P, C.c_size_t, _P, _P, _P, _P]),
+    "kbn_png_decode": (_I, [_P, C.c_size_t, _P, C.c_size_t]),
+    "kbn_png_decode_batch": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "kbn_unpack_frames_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

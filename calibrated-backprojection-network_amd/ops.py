@@ -352,6 +352,44 @@ def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5
     return out_img, validity, filtered
 
 
+def unpack_frames(image_u8, depth_raw, width: Optional[int] = None, x_offset: int = 0):
+    """Decoded PNG pixels on the device -> (image N x 3 x H x W float32 in 0..255, sparse depth
+    N x 1 x H x W float32 = raw / 256): the tensors reference src/datasets.py:259-283 returns.
+    image_u8: N x H x Wraw x C uint8 (C in 1, 3, 4) or None; `width` / `x_offset` select the columns (the
+    middle third of a triplet: width = Wraw // 3, x_offset = width).  depth_raw: N x H x W int16 (bit
+    pattern of the 16-bit PNG samples) or uint8, or None."""
+    lib = _lib.load()
+    if image_u8 is None and depth_raw is None:
+        raise KbnError("unpack_frames: nothing to unpack")
+    image = depth = None
+    n = h = wraw = c = 0
+    if image_u8 is not None:
+        if not image_u8.is_cuda or image_u8.dtype != torch.uint8 or image_u8.dim() != 4:
+            raise KbnError("image_u8: expected a CUDA/HIP uint8 tensor N x H x W x C")
+        image_u8 = image_u8.contiguous()
+        n, h, wraw, c = image_u8.shape
+        if width is None:
+            width = wraw
+        image = torch.empty((n, 3, h, width), device=image_u8.device, dtype=torch.float32)
+    bits = 16
+    if depth_raw is not None:
+        if not depth_raw.is_cuda or depth_raw.dim() != 3 or depth_raw.dtype not in (torch.int16, torch.uint8):
+            raise KbnError("depth_raw: expected a CUDA/HIP int16 (16-bit samples) or uint8 tensor N x H x W")
+        depth_raw = depth_raw.contiguous()
+        bits = 16 if depth_raw.dtype == torch.int16 else 8
+        if image_u8 is not None and (depth_raw.shape[0] != n or depth_raw.shape[1] != h or depth_raw.shape[2] != width):
+            raise KbnError(f"depth_raw has shape {tuple(depth_raw.shape)}, expected {(n, h, width)}")
+        n, h, width = depth_raw.shape
+        depth = torch.empty((n, 1, h, width), device=depth_raw.device, dtype=torch.float32)
+    check(lib.kbn_unpack_frames_forward(image_u8.data_ptr() if image_u8 is not None else None,
+                                        depth_raw.data_ptr() if depth_raw is not None else None,
+                                        image.data_ptr() if image is not None else None,
+                                        depth.data_ptr() if depth is not None else None,
+                                        n, h, width, wraw if image_u8 is not None else width, int(x_offset),
+                                        c if image_u8 is not None else 3, bits, _stream()), "kbn_unpack_frames_forward")
+    return image, depth
+
+
 def eval_metrics(output_depth, ground_truth, ground_truth_validity, min_evaluate_depth: float,
                  max_evaluate_depth: float):
     """Per-frame (MAE [mm], RMSE [mm], iMAE [1/km], iRMSE [1/km]) as an N x 4 fp64 tensor, computed on

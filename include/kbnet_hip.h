@@ -228,6 +228,40 @@ int kbn_eval_accumulate(const float* output_depth, const float* ground_truth,
                         int width, float min_evaluate_depth, float max_evaluate_depth,
                         kbn_stream_t stream);
 
+/* ------------------------------------------------- input pipeline ----
+ * The reference reads every sample through PIL on one DataLoader worker:
+ *   data_utils.load_image   Image.open(path).convert('RGB') -> float32   reference src/data_utils.py:58-85
+ *   data_utils.load_depth   16-bit PNG / 256                              reference src/data_utils.py:123-152
+ *   datasets.KBNetInferenceDataset.__getitem__: middle third of the image triplet
+ *   (load_image_triplet), depth as 1 x H x W, intrinsics from .npy       reference src/datasets.py:22-46, 259-283
+ *
+ * kbn_png_info / kbn_png_decode: HOST-side PNG reader (zlib inflate + scanline filters; 8-bit
+ * gray / RGB / RGBA / palette and 16-bit gray, non-interlaced) for pools of loader threads filling
+ * pinned staging buffers.  `pixels` receives height x width x channels uint8 (palette expanded to
+ * RGB), or height x width uint16 in host byte order for 16-bit files; *channels / *bit_depth say which.
+ * KBN_ERR_UNSUPPORTED for interlaced files and other colour types / depths,
+ * KBN_ERR_INVALID_ARGUMENT for damaged or truncated files and short output buffers. */
+int kbn_png_info(const unsigned char* file, size_t file_bytes, int* width, int* height, int* channels,
+                 int* bit_depth);
+int kbn_png_decode(const unsigned char* file, size_t file_bytes, void* pixels, size_t pixels_bytes);
+/* `n` files at once on `threads` host threads of the library's own (no interpreter lock involved);
+ * status[i] (may be NULL) receives the per-file code, the return value is the first failure. */
+int kbn_png_decode_batch(const unsigned char* const* files, const size_t* file_bytes, void* const* pixels,
+                         const size_t* pixels_bytes, int n, int threads, int* status);
+
+/* Decoded pixels (device buffers) -> the tensors the reference's dataset returns:
+ *   image_u8     N x height x raw_width x image_channels uint8 (1 gray, 3 RGB, 4 RGBA); columns
+ *                [x_offset, x_offset + width) are taken (x_offset = width, raw_width = 3 * width for
+ *                the middle image of a triplet)  ->  image N x 3 x height x width float32, values 0..255
+ *                (normalize=False; gray replicated, alpha dropped = convert('RGB'))
+ *   depth_raw    N x height x width uint16 (depth_bits 16) or uint8 (8)  ->  sparse_depth
+ *                N x 1 x height x width float32 = value / 256
+ * Either pair may be NULL.  kbn_preprocess_forward then derives the validity map, removes
+ * outliers and normalises the image. */
+int kbn_unpack_frames_forward(const unsigned char* image_u8, const void* depth_raw, float* image,
+                              float* sparse_depth, int n, int height, int width, int raw_width,
+                              int x_offset, int image_channels, int depth_bits, kbn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

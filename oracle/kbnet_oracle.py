@@ -286,3 +286,24 @@ def evaluation_metrics(output_depth, ground_truth, validity_map, min_evaluate_de
     imae = np.mean(np.abs((1.0 / itgt) - (1.0 / isrc)))
     irmse = np.sqrt(np.mean(((1.0 / itgt) - (1.0 / isrc)) ** 2))
     return float(mae), float(rmse), float(imae), float(irmse)
+
+
+# ------------------------------------------------------- "next" row f4: input pipeline
+def load_inference_sample(image_path, sparse_depth_path, intrinsics_path, use_image_triplet=True):
+    """datasets.KBNetInferenceDataset.__getitem__ (reference src/datasets.py:259-283): the image
+    through PIL's `Image.open(path).convert('RGB')` un-normalised (data_utils.load_image,
+    src/data_utils.py:58-85), the middle third of a triplet (load_image_triplet, src/datasets.py:22-46),
+    the 16-bit depth PNG / 256 as 1 x H x W (data_utils.load_depth, src/data_utils.py:123-152), the
+    intrinsics .npy as float32.  Returns numpy (image 3 x H x W, sparse_depth 1 x H x W, intrinsics 3 x 3)."""
+    import numpy as np
+    from PIL import Image
+    image = np.asarray(Image.open(image_path).convert("RGB"), np.float32)
+    image = np.transpose(image, (2, 0, 1))
+    if use_image_triplet:
+        _, image, _ = np.split(image, indices_or_sections=3, axis=-1)
+    z = np.array(Image.open(sparse_depth_path), dtype=np.float32)
+    z = z / 256.0
+    z[z <= 0] = 0.0
+    z = np.expand_dims(z, axis=0)
+    intrinsics = np.load(intrinsics_path).astype(np.float32)
+    return image.astype(np.float32), z.astype(np.float32), intrinsics

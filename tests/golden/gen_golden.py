@@ -21,6 +21,10 @@ Cases
   dec_*      networks.MultiScaleDecoder (n_resolution=1, 'up', linear output).
   fwd_*      KBNetModel.forward: KITTI preset, VOID preset (both narrow channels)
              and an odd 70x100 frame.
+  io/*       input pipeline: small PNG / .npy files written by this script's own PNG writer
+             (every scanline filter type, split IDAT, gray / RGB / RGBA / palette / 16-bit gray) and what the
+             reference's data_utils.load_image, datasets.load_image_triplet / load_depth and
+             datasets.KBNetInferenceDataset.__getitem__ read from them (io_expected.npz).
 """
 
 import os
@@ -286,7 +290,110 @@ def gen_pre_eval():
          min_evaluate_depth=np.array(0.0), max_evaluate_depth=np.array(100.0))
 
 
+def _png_bytes(arr, color_type, palette=None, filters=(0, 1, 2, 3, 4), idat_split=1):
+    """Minimal PNG writer: `arr` H x W (x C) uint8 or H x W uint16; the scanline filter cycles through
+    `filters` row by row so that every filter type of the spec appears in the fixtures."""
+    import struct
+    import zlib
+    h, w = arr.shape[:2]
+    bit_depth = 16 if arr.dtype == np.uint16 else 8
+    rows = arr.astype(">u2").tobytes() if bit_depth == 16 else arr.astype(np.uint8).tobytes()
+    bpp = (arr.shape[2] if arr.ndim == 3 else 1) * (bit_depth // 8)
+    stride = w * bpp
+    raw, prev = bytearray(), bytes(stride)
+    for y in range(h):
+        cur = rows[y * stride:(y + 1) * stride]
+        f = filters[y % len(filters)]
+        out = bytearray(stride)
+        for i in range(stride):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if f == 0:
+                pred = 0
+            elif f == 1:
+                pred = a
+            elif f == 2:
+                pred = b
+            elif f == 3:
+                pred = (a + b) >> 1
+            else:
+                p_ = a + b - c
+                pa, pb, pc = abs(p_ - a), abs(p_ - b), abs(p_ - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (cur[i] - pred) & 255
+        raw += bytes([f]) + out
+        prev = cur
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    z = zlib.compress(bytes(raw), 6)
+    cuts = [len(z) * i // idat_split for i in range(idat_split + 1)]
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bit_depth, color_type, 0, 0, 0))
+    if palette is not None:
+        png += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    for i in range(idat_split):
+        png += chunk(b"IDAT", z[cuts[i]:cuts[i + 1]])
+    return png + chunk(b"IEND", b"")
+
+
+def gen_io():
+    import data_utils  # noqa: E402  (reference)
+    import datasets  # noqa: E402  (reference)
+    d = os.path.join(HERE, "io")
+    os.makedirs(d, exist_ok=True)
+    g = np.random.Generator(np.random.Philox(77))
+    h, w = 24, 40
+    exp = {}
+
+    def put(name, data):
+        with open(os.path.join(d, name), "wb") as f:
+            f.write(data)
+        return os.path.join(d, name)
+
+    image_paths, depth_paths, k_paths = [], [], []
+    for i in range(3):
+        trip = g.integers(0, 256, size=(h, 3 * w, 3), dtype=np.uint8)
+        image_paths.append(put(f"triplet_{i}.png", _png_bytes(trip, 2, filters=(i, 1, 2, 3, 4, 0), idat_split=1 + i)))
+        dep = (g.integers(0, 65536, size=(h, w)) * (g.random((h, w)) < 0.2)).astype(np.uint16)
+        dep[0, 0], dep[0, 1], dep[1, 0] = 65535, 1, 256
+        depth_paths.append(put(f"depth_{i}.png", _png_bytes(dep, 0, filters=(4, 3, 2, 1, 0), idat_split=2)))
+        k = np.array([[721.5377 + i, 0, 609.5593], [0, 721.5377, 172.854 - i], [0, 0, 1]], dtype=np.float64)
+        np.save(os.path.join(d, f"k_{i}.npy"), k)
+        k_paths.append(os.path.join(d, f"k_{i}.npy"))
+    gray = put("gray8.png", _png_bytes(g.integers(0, 256, size=(10, 12), dtype=np.uint8), 0))
+    rgba = put("rgba.png", _png_bytes(g.integers(0, 256, size=(7, 9, 4), dtype=np.uint8), 6, filters=(4, 4, 1)))
+    pal = put("palette.png", _png_bytes(g.integers(0, 16, size=(6, 8), dtype=np.uint8), 3,
+                                        palette=g.integers(0, 256, size=(16, 3), dtype=np.uint8), filters=(0, 2)))
+    depth8 = put("depth8.png", _png_bytes(g.integers(0, 256, size=(5, 8), dtype=np.uint8), 0, filters=(1,)))
+
+    # what the reference reads from those files
+    for name, path in (("gray8", gray), ("rgba", rgba), ("palette", pal)):
+        exp[f"load_image_{name}_hwc"] = data_utils.load_image(path, normalize=True, data_format="HWC")
+        exp[f"load_image_{name}_chw_raw"] = data_utils.load_image(path, normalize=False, data_format="CHW")
+    t1, t0, t2 = datasets.load_image_triplet(image_paths[0], normalize=True)
+    exp["triplet_0_t"], exp["triplet_0_tm1"], exp["triplet_0_tp1"] = t0, t1, t2
+    exp["load_depth_0_hw"] = data_utils.load_depth(depth_paths[0], data_format="HW")
+    exp["load_depth8_chw"] = data_utils.load_depth(depth8, data_format="CHW")
+    z, v = data_utils.load_depth_with_validity_map(depth_paths[1], data_format="CHW")
+    exp["depth_1_z"], exp["depth_1_v"] = z, v
+    ds = datasets.KBNetInferenceDataset(image_paths=image_paths, sparse_depth_paths=depth_paths,
+                                        intrinsics_paths=k_paths, use_image_triplet=True)
+    for i in range(len(ds)):
+        image, sparse_depth, intrinsics = ds[i]
+        exp[f"sample_{i}_image"], exp[f"sample_{i}_sparse_depth"], exp[f"sample_{i}_intrinsics"] = image, sparse_depth, intrinsics
+    ds1 = datasets.KBNetInferenceDataset(image_paths=[rgba], sparse_depth_paths=[depth8], intrinsics_paths=k_paths[:1],
+                                         use_image_triplet=False)
+    exp["single_image"] = ds1[0][0]
+    np.savez_compressed(os.path.join(HERE, "io_expected.npz"), **exp)
+    print("io: %d files, %d expected arrays" % (len(os.listdir(d)), len(exp)))
+
+
 if __name__ == "__main__":
+    if "--only-io" in sys.argv:
+        gen_io()
+        sys.exit(0)
     gen_pre_eval()
     if "--only-pre-eval" in sys.argv:
         sys.exit(0)

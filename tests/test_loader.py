@@ -1,0 +1,151 @@
+"""Input pipeline: the library's PNG reader, the reference-named loader functions
+and the batched device loader against what the REFERENCE reads from the same files
+(tests/golden/io/* written and read by tests/golden/gen_golden.py --only-io)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import kbnet_amd as kb
+from conftest import GOLDEN_DIR
+from oracle import kbnet_oracle as orc
+
+IO = os.path.join(GOLDEN_DIR, "io")
+EXP = dict(np.load(os.path.join(GOLDEN_DIR, "io_expected.npz")))
+IMAGES = [os.path.join(IO, f"triplet_{i}.png") for i in range(3)]
+DEPTHS = [os.path.join(IO, f"depth_{i}.png") for i in range(3)]
+KS = [os.path.join(IO, f"k_{i}.npy") for i in range(3)]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    kb._lib.load()
+    return torch.device("cuda:0")
+
+
+def read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+# ------------------------------------------------------------------ host side (no GPU)
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(IO, "*.png"))))
+def test_png_reader_matches_pil_bit_for_bit(path):
+    from PIL import Image
+    got = kb.loader.decode_png(read(path))
+    im = Image.open(path)
+    want = np.asarray(im.convert("RGB")) if im.mode == "P" else np.asarray(im)
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_reference_named_loaders_match_the_reference():
+    for name in ("gray8", "rgba", "palette"):
+        p = os.path.join(IO, name + ".png")
+        assert np.array_equal(kb.loader.load_image(p, normalize=True, data_format="HWC"), EXP[f"load_image_{name}_hwc"])
+        assert np.array_equal(kb.loader.load_image(p, normalize=False, data_format="CHW"), EXP[f"load_image_{name}_chw_raw"])
+    t1, t0, t2 = kb.loader.load_image_triplet(IMAGES[0], normalize=True)
+    assert np.array_equal(t0, EXP["triplet_0_t"]) and np.array_equal(t1, EXP["triplet_0_tm1"]) and np.array_equal(t2, EXP["triplet_0_tp1"])
+    assert np.array_equal(kb.loader.load_depth(DEPTHS[0]), EXP["load_depth_0_hw"])
+    assert np.array_equal(kb.loader.load_depth(os.path.join(IO, "depth8.png"), data_format="CHW"), EXP["load_depth8_chw"])
+    with pytest.raises(ValueError):
+        kb.loader.load_depth(DEPTHS[0], data_format="NCHW")
+
+
+def test_oracle_loader_matches_the_reference():
+    for i in range(3):
+        image, z, k = orc.load_inference_sample(IMAGES[i], DEPTHS[i], KS[i])
+        assert np.array_equal(image, EXP[f"sample_{i}_image"])
+        assert np.array_equal(z, EXP[f"sample_{i}_sparse_depth"])
+        assert np.array_equal(k, EXP[f"sample_{i}_intrinsics"])
+        assert image.dtype == z.dtype == k.dtype == np.float32
+
+
+def test_batch_decode_matches_single_decode():
+    files = [read(p) for p in IMAGES + DEPTHS]
+    outs = [np.empty_like(kb.loader.decode_png(f)) for f in files]
+    kb.loader.decode_png_batch(files, outs, threads=4)
+    for f, o in zip(files, outs):
+        assert np.array_equal(o, kb.loader.decode_png(f))
+    with pytest.raises(kb._lib.KbnError):
+        kb.loader.decode_png_batch([files[0][:100]], [outs[0]], threads=2)
+
+
+def test_png_reader_error_behaviour():
+    data = read(IMAGES[0])
+    with pytest.raises(kb._lib.KbnError):
+        kb.loader.decode_png(data[:200])                     # truncated
+    with pytest.raises(kb._lib.KbnError):
+        kb.loader.decode_png(b"not a png at all" * 4)
+    bad = bytearray(data)
+    bad[28] = 1                                              # IHDR interlace method -> Adam7: unsupported
+    with pytest.raises(kb._lib.KbnError):
+        kb.loader.png_info(bytes(bad))
+    with pytest.raises(kb._lib.KbnError):
+        kb.loader.decode_png(data, np.empty(10, np.uint8))   # short output buffer
+    with pytest.raises(kb._lib.KbnError):
+        kb.loader.InferenceFrameLoader(IMAGES, DEPTHS, KS, device=torch.device("cpu"))   # no CPU fallback
+
+
+# ------------------------------------------------------------------------- device side
+@pytest.mark.gpu
+def test_unpack_frames_bit_exact(dev):
+    raw = np.stack([kb.loader.decode_png(read(p)) for p in IMAGES])            # 3 x H x 3W x 3 uint8
+    dep = np.stack([kb.loader.decode_png(read(p)) for p in DEPTHS])            # 3 x H x W uint16
+    w = raw.shape[2] // 3
+    image, depth = kb.ops.unpack_frames(torch.from_numpy(raw).to(dev), torch.from_numpy(dep.view(np.int16)).to(dev),
+                                        width=w, x_offset=w)
+    for i in range(3):
+        assert np.array_equal(image[i].cpu().numpy(), EXP[f"sample_{i}_image"])
+        assert np.array_equal(depth[i].cpu().numpy(), EXP[f"sample_{i}_sparse_depth"])
+    # RGBA input without a crop, 8-bit depth
+    rgba = kb.loader.decode_png(read(os.path.join(IO, "rgba.png")))[None]
+    image, _ = kb.ops.unpack_frames(torch.from_numpy(rgba).to(dev), None)
+    assert np.array_equal(image[0].cpu().numpy(), EXP["single_image"])
+    d8 = kb.loader.decode_png(read(os.path.join(IO, "depth8.png")))[None]
+    _, depth = kb.ops.unpack_frames(None, torch.from_numpy(d8).to(dev))
+    assert np.array_equal(depth[0].cpu().numpy(), EXP["load_depth8_chw"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 2, 3])
+def test_frame_loader_batches_match_the_reference_dataset(dev, batch):
+    loader = kb.loader.InferenceFrameLoader(IMAGES, DEPTHS, KS, use_image_triplet=True, batch_size=batch,
+                                            device=dev, workers=3)
+    assert len(loader) == -(-3 // batch)
+    i = 0
+    for image, sparse_depth, intrinsics in loader:
+        assert image.is_cuda and image.shape[1:] == (3, 24, 40) and sparse_depth.shape[1:] == (1, 24, 40)
+        for j in range(image.shape[0]):
+            assert np.array_equal(image[j].cpu().numpy(), EXP[f"sample_{i}_image"])
+            assert np.array_equal(sparse_depth[j].cpu().numpy(), EXP[f"sample_{i}_sparse_depth"])
+            assert np.array_equal(intrinsics[j].cpu().numpy(), EXP[f"sample_{i}_intrinsics"])
+            i += 1
+    assert i == 3
+
+
+@pytest.mark.gpu
+def test_loader_feeds_the_forward(dev):
+    """Files -> loader -> preprocess (row f1) -> forward: the reference's inference loop body
+    (src/kbnet.py:887-921) on the device, against the oracle fed by the oracle's own loader."""
+    cfg = kb.kitti_config().narrow()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=3)
+    model = kb.modules.KBNetModel.from_config(cfg, dev)
+    model.load_state_dicts(*sds)
+    # the 24 x 40 fixtures are too small for five stride-2 levels: tile them to 96 x 160 on the device
+    loader = kb.loader.InferenceFrameLoader(IMAGES, DEPTHS, KS, batch_size=3, device=dev)
+    image, sparse, k = next(iter(loader))
+    image, sparse = image.repeat(1, 1, 4, 4), sparse.repeat(1, 1, 4, 4)
+    img, valid, filtered = kb.ops.preprocess(image, sparse)
+    out = model.forward(img, filtered, valid, k)
+    samples = [orc.load_inference_sample(IMAGES[i], DEPTHS[i], KS[i]) for i in range(3)]
+    oimg = torch.from_numpy(np.stack([s[0] for s in samples])).repeat(1, 1, 4, 4)
+    osp = torch.from_numpy(np.stack([s[1] for s in samples])).repeat(1, 1, 4, 4)
+    ok = torch.from_numpy(np.stack([s[2] for s in samples]))
+    ofilt, ovalid = orc.validity_and_outlier_removal(osp)
+    ref = orc.kbnet_forward(oimg / 255.0, ofilt, ovalid, ok, *sds, cfg.min_pools, cfg.max_pools,
+                            cfg.min_predict_depth, cfg.max_predict_depth)
+    assert float((out.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
