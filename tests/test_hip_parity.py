@@ -323,6 +323,30 @@ def test_graph_replay_matches_eager(dev):
     assert torch.equal(replay(*a), eager_a)
 
 
+def test_mixed_shape_stream_two_weight_sets(dev):
+    """BASELINE.json config 4 in miniature: an interleaved stream of VOID 480x640, NYUv2 416x576 (both on
+    the VOID preset) and KITTI 352x1216 frames with per-frame intrinsics, two weight sets resident, one
+    captured graph per shape.  Every frame must come out bit-identical to its stand-alone eager forward:
+    no state (tile caches, packed weights, graph buffers) leaks between shapes or models."""
+    models, alone, replays, frames = {}, {}, {}, {}
+    for preset in ("kitti", "void"):
+        cfg = kb.PRESETS[preset]()
+        m = kb.modules.KBNetModel.from_config(cfg, dev)
+        m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=5, gain=1.3))
+        models[preset] = m
+    stream = [("void", "void", (480, 640)), ("void", "nyu_v2", (416, 576)), ("kitti", "kitti", (352, 1216))]
+    for preset, stats, shape in stream:
+        f = to(dev, *kb.synthetic.make_frames(1, *shape, stats, seed=hash(shape) % 97, jitter_intrinsics=0.1))
+        frames[shape] = f
+        alone[shape] = models[preset].forward(*f).clone()
+    for preset, stats, shape in stream:
+        replays[shape] = models[preset].capture(*frames[shape])
+    for _ in range(2):
+        for preset, stats, shape in stream + stream[::-1]:
+            assert torch.equal(replays[shape](*frames[shape]), alone[shape])
+            assert torch.equal(models[preset].forward(*frames[shape]), alone[shape])
+
+
 def test_drop_in_modules_inside_reference_style_forward(dev):
     """The two north-star modules used the way reference kbnet_model.py uses them:
     positional S2D call, keyword KB-block call with a dense coordinates tensor."""
