@@ -533,21 +533,27 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
                 if (cost < best) { best = cost; twb = t; }
             }
         }
-        auto launch = [&](int cand) -> int {   // candidate = TWB - 1
+        auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
             Up2xParams q = p;
-            switch (pl.NB * 10 + cand + 1) {
-                case 11: return up2x_dma_variant<1, 4, 1>(q, st);
-                case 12: return up2x_dma_variant<1, 4, 2>(q, st);
-                case 21: return up2x_dma_variant<2, 4, 1>(q, st);
-                case 22: return up2x_dma_variant<2, 4, 2>(q, st);
-                case 31: return up2x_dma_variant<3, 2, 1>(q, st);
-                case 32: return up2x_dma_variant<3, 2, 2>(q, st);
-                case 41: return up2x_dma_variant<4, 2, 1>(q, st);
-                default: return up2x_dma_variant<4, 2, 2>(q, st);
+            const int t = (cand & 1) + 1, half = cand >> 1;
+            if (half && pl.NB < 3) return (int)KBN_ERR_UNSUPPORTED;
+            switch (pl.NB * 100 + half * 10 + t) {
+                case 101: return up2x_dma_variant<1, 4, 1>(q, st);
+                case 102: return up2x_dma_variant<1, 4, 2>(q, st);
+                case 201: return up2x_dma_variant<2, 4, 1>(q, st);
+                case 202: return up2x_dma_variant<2, 4, 2>(q, st);
+                case 301: return up2x_dma_variant<3, 2, 1>(q, st);
+                case 302: return up2x_dma_variant<3, 2, 2>(q, st);
+                case 311: return up2x_dma_variant<3, 1, 1>(q, st);
+                case 312: return up2x_dma_variant<3, 1, 2>(q, st);
+                case 401: return up2x_dma_variant<4, 2, 1>(q, st);
+                case 402: return up2x_dma_variant<4, 2, 2>(q, st);
+                case 411: return up2x_dma_variant<4, 1, 1>(q, st);
+                default: return up2x_dma_variant<4, 1, 2>(q, st);
             }
         };
         int cand = twb - 1;
-        if (!ftw) cand = tune_pick(TuneKey{3, n, out_channels, in_channels, src_height, src_width, 0, 0, 0, 0}, 2, cand, launch, st);
+        if (!ftw) cand = tune_pick(TuneKey{3, n, out_channels, in_channels, src_height, src_width, 0, 0, 0, 0}, 4, cand, launch, st);
         return launch(cand);
     }
     // tile: 4*MW m-blocks of 16 low-res pixels, 16 or 32 wide; a lone workgroup round is avoided.

@@ -239,11 +239,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         if (q < 4) fa[g & 1][q] = V[a_off + (g >> 1) * 512 + (g & 1) * 256 + a_mb[q]];
         else fb[g & 1][q - 4] = U[b_off + (g >> 1) * 512 + (g & 1) * 256 + (q - 4) * 32];
     };
+    // MFMA slot i of an iteration runs group (i/16 + 3) % 4: the LAST group of the previous chunk first --
+    // its fragments are already in registers, so the matrix pipe has work while the first fragment reads
+    // after the chunk's barrier are still in flight -- then groups 0..2 of this chunk.
     auto mfma = [&](int i) {
         if ((DBG & 4) != 0) return;
-        const int g = i >> 4, mb = (i >> 2) & 3, nb = i & 3;
+        const int g = ((i >> 4) + 3) & 3, mb = (i >> 2) & 3, nb = i & 3;
         acc[g >> 1][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][mb], fb[g & 1][nb], acc[g >> 1][mb][nb], 0, 0, 0);
     };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fa[1][q] = fb[1][q] = 0.f;   // "group 3 of chunk -1": adds zeros
 
     // ---- clear both raw stages once (out-of-image granules are never written afterwards) ----
     {
@@ -286,15 +291,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         static_for<64>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             mfma(i);
-            if constexpr (i < 8) frag_read(Vc, Uc, 1, i);
             if constexpr (i < 4) dma_u(udst, i);
             if constexpr (i == 4 || i == 5) dma_raw(rdst, i - 4);
-            if constexpr (i >= 16 && i < 24) frag_read(Vc, Uc, 2, i - 16);
+            if constexpr (i >= 16 && i < 24) frag_read(Vc, Uc, 1, i - 16);   // (its registers were group 3's until slot 15)
             if constexpr (i == 23) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             if constexpr (i >= 24 && i < 32) {
                 if ((DBG & 16) == 0) { xf_read(rawn, 2 * (i - 24)); xf_read(rawn, 2 * (i - 24) + 1); }
             }
-            if constexpr (i >= 32 && i < 40) frag_read(Vc, Uc, 3, i - 32);
+            if constexpr (i >= 32 && i < 40) frag_read(Vc, Uc, 2, i - 32);
+            if constexpr (i >= 50 && i < 58) frag_read(Vc, Uc, 3, i - 50);   // consumed at the top of the next iteration
             if constexpr (i >= 34 && i < 42) {
                 if ((DBG & 16) == 0) xf_col(i - 34);
             }
@@ -316,6 +321,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         body(IC<1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<16>([&](auto ic) { mfma(decltype(ic)::value); });   // group 3 of the last chunk
     __syncthreads();
 
     if ((DBG & 32) != 0) {  // ablation: no epilogue (every accumulator stays live)
