@@ -261,9 +261,11 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     //      weights of a (channel, tap) are read once (LDS broadcast) and used for both ----------
     {
         const int oy = tid / S2D_TW, ox = tid - oy * S2D_TW;
-        float acc0[S2D_MAXF], acc1[S2D_MAXF];
+        // packed fp32: accp[f] = (pixel 0, pixel 1) of filter f; one v_pk_fma_f32 per (channel, tap, filter)
+        // with the weight broadcast to both halves -- half the vector-ALU instructions of the scalar form.
+        f32x2 accp[S2D_MAXF];
 #pragma unroll
-        for (int f = 0; f < S2D_MAXF; ++f) acc0[f] = acc1[f] = 0.f;
+        for (int f = 0; f < S2D_MAXF; ++f) accp[f] = (f32x2){0.f, 0.f};
         for (int ch = 0; ch < ((p.dbg & 8) ? 0 : nch); ++ch) {
             const float* f0 = feat + ch * S2D_NF + oy * S2D_FW + ox;
             const float* f1 = f0 + 8 * S2D_FW;
@@ -271,18 +273,18 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int o = (t / 3) * S2D_FW + (t % 3);
-                const float v0 = f0[o], v1 = f1[o];
+                const f32x2 v = (f32x2){f0[o], f1[o]};
                 const f32x4 wa = w4[t * 2], wb = w4[t * 2 + 1];
-                acc0[0] = fmaf(wa[0], v0, acc0[0]); acc0[1] = fmaf(wa[1], v0, acc0[1]);
-                acc0[2] = fmaf(wa[2], v0, acc0[2]); acc0[3] = fmaf(wa[3], v0, acc0[3]);
-                acc0[4] = fmaf(wb[0], v0, acc0[4]); acc0[5] = fmaf(wb[1], v0, acc0[5]);
-                acc0[6] = fmaf(wb[2], v0, acc0[6]); acc0[7] = fmaf(wb[3], v0, acc0[7]);
-                acc1[0] = fmaf(wa[0], v1, acc1[0]); acc1[1] = fmaf(wa[1], v1, acc1[1]);
-                acc1[2] = fmaf(wa[2], v1, acc1[2]); acc1[3] = fmaf(wa[3], v1, acc1[3]);
-                acc1[4] = fmaf(wb[0], v1, acc1[4]); acc1[5] = fmaf(wb[1], v1, acc1[5]);
-                acc1[6] = fmaf(wb[2], v1, acc1[6]); acc1[7] = fmaf(wb[3], v1, acc1[7]);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    accp[f] = __builtin_elementwise_fma(v, (f32x2){wa[f], wa[f]}, accp[f]);
+                    accp[4 + f] = __builtin_elementwise_fma(v, (f32x2){wb[f], wb[f]}, accp[4 + f]);
+                }
             }
         }
+        float acc0[S2D_MAXF], acc1[S2D_MAXF];
+#pragma unroll
+        for (int f = 0; f < S2D_MAXF; ++f) { acc0[f] = accp[f].x; acc1[f] = accp[f].y; }
         const int X = ox0 + ox;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {

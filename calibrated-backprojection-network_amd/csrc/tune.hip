@@ -7,6 +7,10 @@
 // rewritten with identical values -- geometry never changes an accumulation order) and the winner is
 // cached for the process.  No tuning while the stream is being captured into a graph (the model's
 // choice is used and nothing is cached) or with KBN_AUTOTUNE=0.  The cache holds integers only.
+// KBN_TUNE_CACHE=<file> makes it persistent: entries are read at first use and appended as they are
+// found (one line of 11 integers each), so that e.g. a profiled run replays the choices of an earlier
+// run without any timing launches of its own.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <map>
@@ -18,6 +22,31 @@ namespace kbn {
 
 static std::map<TuneKey, int> g_cache;
 static std::mutex g_mutex;
+static bool g_loaded = false;
+
+static void load_file_locked() {   // g_mutex held
+    if (g_loaded) return;
+    g_loaded = true;
+    const char* path = getenv("KBN_TUNE_CACHE");
+    if (!path || !*path) return;
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    TuneKey k;
+    int cand;
+    while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8],
+                  &k[9], &cand) == 11)
+        g_cache[k] = cand;
+    fclose(f);
+}
+
+static void append_file_locked(const TuneKey& k, int cand) {
+    const char* path = getenv("KBN_TUNE_CACHE");
+    if (!path || !*path) return;
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], cand);
+    fclose(f);
+}
 
 bool tune_enabled() {
     static const bool on = !(getenv("KBN_AUTOTUNE") && atoi(getenv("KBN_AUTOTUNE")) == 0);
@@ -26,6 +55,7 @@ bool tune_enabled() {
 
 bool tune_lookup(const TuneKey& key, int* cand) {
     std::lock_guard<std::mutex> g(g_mutex);
+    load_file_locked();
     auto it = g_cache.find(key);
     if (it == g_cache.end()) return false;
     *cand = it->second;
@@ -62,6 +92,7 @@ int tune_pick(const TuneKey& key, int ncand, int model, const std::function<int(
     if (best_ms < 1e29f) {
         std::lock_guard<std::mutex> g(g_mutex);
         g_cache[key] = best;
+        append_file_locked(key, best);
     }
     return best;
 }

@@ -342,12 +342,15 @@ class KBNetEncoder(torch.nn.Module):
         sx, sy = w1 / w0, h1 / h0
         conv_fused = None
         skips = []
+        kinv1 = None   # the level-1 inverse serves every deeper level (Q1): computed once
         for level in range(4):
             oh, ow = (h + 1) // 2, (w + 1) // 2
             if level in self.resolutions_backprojection:
                 blk = getattr(self, f"calibrated_backprojection{level + 1}")
                 if level > 0:
-                    kinv = ops.intrinsics_inverse(intrinsics, sx, sy)
+                    if kinv1 is None:
+                        kinv1 = ops.intrinsics_inverse(intrinsics, sx, sy)
+                    kinv = kinv1
                 skip = torch.empty((n, ff[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
                 out_fused, out_depth = skip[:, :ff[level]], skip[:, ff[level]:]
                 conv_image, conv_depth, conv_fused = blk.run(conv_image, conv_depth, kinv, conv_fused,
