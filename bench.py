@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-void", action="store_true", help="skip the VOID 480x640 side measurement")
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of HIP-graph replay")
     args = ap.parse_args()
 
@@ -181,6 +182,25 @@ def main():
     torch.cuda.synchronize()
     refstyle_ms = 1e3 * (time.perf_counter() - t2) / args.steps
 
+    # Second shape north_star names (VOID 480 x 640, VOID preset, same batch): a short side measurement with
+    # its own weights and graph; `value` above stays the KITTI metric.
+    void_fps = None
+    if world == 1 and not args.no_void:
+        vcfg = kb.void_config()
+        vmodel = kb.modules.KBNetModel.from_config(vcfg, dev)
+        vmodel.load_state_dicts(*kb.synthetic.make_state_dicts(vcfg, seed=0, gain=1.45))
+        vframes = [f.to(dev) for f in kb.synthetic.make_frames(per, 480, 640, "void", seed=1)]
+        vreplay = vmodel.capture(*vframes)
+        for _ in range(3):
+            vreplay(*vframes)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(10):
+            vreplay(*vframes)
+        torch.cuda.synchronize()
+        void_fps = per * 10 / (time.perf_counter() - t3)
+        del vreplay, vmodel, vframes
+
     ms_per_step = 1e3 * elapsed / args.steps
     fps = per * world * args.steps / elapsed
     gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
@@ -228,7 +248,8 @@ def main():
                    "parallelism": f"frames sharded over {world} rank(s), RCCL all-gather of outputs",
                    "launch": "eager" if args.eager else "HIP graph replay",
                    "eager_ms_per_step_with_event_timing": round(eager_ms, 4),
-                   "reference_style_region_ms_per_step": round(refstyle_ms, 4)},
+                   "reference_style_region_ms_per_step": round(refstyle_ms, 4),
+                   "void_480x640_frames_per_s": None if void_fps is None else round(void_fps, 1)},
         "roofline": roofline, "kernels": breakdown,
     }
 
