@@ -109,30 +109,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
 
-    int bid = xcd_remap(blockIdx.x, p.nblocks);
-    const int nt = bid % p.nTilesN;
-    bid /= p.nTilesN;
-    const int rx = bid % p.regionsX;
-    bid /= p.regionsX;
-    const int ry = bid % p.regionsY;
-    const int n = bid / p.regionsY;
-    const int y0 = ry * 2 * p.RT, x0 = rx * 2 * p.CT;  // first output pixel of the region
-
-    // ---- this lane's raw granules (channel-plane byte offsets, -1 = out of image) ----
+    // Persistent workgroups: one per CU (the LDS footprint allows no more), each walks the tile list
+    // t = blockIdx.x, blockIdx.x + gridDim.x, ...  While tile t's outputs are being stored, the first DMAs
+    // of tile t + gridDim.x are already in flight -- with one workgroup per CU nothing else would cover
+    // the start-up latency of a tile.
+    int nt = 0, n = 0, y0 = 0, x0 = 0;           // current STAGING tile (wave-uniform)
+    unsigned gv0 = 0, gv1 = 0;                    // this lane's raw granules: byte offset inside a channel plane ...
+    unsigned long long gm0 = 0, gm1 = 0;          // ... and the lanes whose granule is inside the image
     const int cv4 = p.colsS >> 2, nf4 = p.rowsS * cv4;
-    int goff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int f = j * 64 + lane;
-        int g = -1;
-        if (f < nf4) {
-            const int r = f / cv4, cv = f - r * cv4;
-            const int Y = y0 - 1 + r, X = x0 - 4 + cv * 4;
-            if (Y >= 0 && Y < p.H && X >= 0 && X < p.W) g = (Y * p.W + X) * 4;
-        }
-        goff[j] = g;
-    }
-
     // ---- this lane's tile (input transform + epilogue) ----
     const int ntile = p.RT * p.CT;
     const int tl = lane < ntile ? lane : 0;
@@ -148,12 +132,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     const int b_off = 2 * wave * WCK * WNT + (lk >> 1) * 2 * WNT + li * 2 + (lk & 1);  // + x*512 + c4*256 + nb*32
 
     f32x4 acc[2][4][4];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[x][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int HW = p.H * p.W;
     const int nch = p.Cin / WCK;
@@ -163,13 +141,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const unsigned rdst0 = lds0 + 4u * (unsigned)(wave * p.plane), rdst1 = rdst0 + 4u * (unsigned)raw_floats;
     const unsigned udst0 = lds0 + 4u * (unsigned)(2 * raw_floats + wave * 256), udst1 = udst0 + 4u * U_CHUNK;
-    const float* usrc = uniform_ptr(p.up + (long long)nt * nch * U_CHUNK + wave * 256);  // U of the chunk to stage next
+    const float* usrc = nullptr;   // U of the chunk to stage next
     // Plane of channel (gch + wave) of the concatenated input (every source holds a multiple of 8
     // channels, so a chunk never straddles two); `advance_src` moves to the next chunk and stays on the
     // last one at the end (the surplus DMAs of the last iterations re-stage it into a dead buffer).
-    const float* s1w = uniform_ptr(p.src[1] + (long long)n * p.src_bstride[1] + (long long)wave * HW);
-    const float* s2w = uniform_ptr(p.src[2] + (long long)n * p.src_bstride[2] + (long long)wave * HW);
-    const float* gsrc = uniform_ptr(p.src[0] + (long long)n * p.src_bstride[0] + (long long)wave * HW);
+    const float* s1w = nullptr;
+    const float* s2w = nullptr;
+    const float* gsrc = nullptr;
     const int C0 = __builtin_amdgcn_readfirstlane(p.srcC[0]);
     const int C01 = __builtin_amdgcn_readfirstlane(p.srcC[0] + p.srcC[1]);
     const int Cin = __builtin_amdgcn_readfirstlane(p.Cin);
@@ -181,10 +159,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         gsrc = uniform_ptr(adv ? cand : gsrc);   // (pinned: the compiler does not always prove the select chain uniform)
         gch = adv ? nx : gch;
     };
-    // lanes whose granule j is inside the image (loop invariant)
-    const unsigned long long gm0 = __ballot(goff[0] >= 0), gm1 = (64 < nf4) ? __ballot(goff[1] >= 0) : 0ull;
-    const unsigned gv0 = goff[0] < 0 ? 0u : (unsigned)goff[0], gv1 = goff[1] < 0 ? 0u : (unsigned)goff[1];
     const unsigned uv = (unsigned)(lane * 16);
+    int uleft = 0;                                 // further advances before usrc reaches the last chunk
 
     // one DMA instruction of the raw tile (j = 0, 1) / of the U slice (j = 0..3) per call
     auto dma_raw = [&](unsigned dst, int j) {
@@ -247,24 +223,76 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         const int g = ((i >> 4) + 3) & 3, mb = (i >> 2) & 3, nb = i & 3;
         acc[g >> 1][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][mb], fb[g & 1][nb], acc[g >> 1][mb][nb], 0, 0, 0);
     };
+
+    // ---- per tile: decode, staging state, first DMAs ----
+    auto setup_tile = [&](int t) {
+        int bid = xcd_remap(t, p.nblocks);
+        nt = bid % p.nTilesN;
+        bid /= p.nTilesN;
+        const int rx = bid % p.regionsX;
+        bid /= p.regionsX;
+        const int ry = bid % p.regionsY;
+        n = bid / p.regionsY;
+        y0 = ry * 2 * p.RT; x0 = rx * 2 * p.CT;      // first output pixel of the region
+        int goff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f = j * 64 + lane;
+            int g = -1;
+            if (f < nf4) {
+                const int r = f / cv4, cv = f - r * cv4;
+                const int Y = y0 - 1 + r, X = x0 - 4 + cv * 4;
+                if (Y >= 0 && Y < p.H && X >= 0 && X < p.W) g = (Y * p.W + X) * 4;
+            }
+            goff[j] = g;
+        }
+        gm0 = __ballot(goff[0] >= 0); gm1 = (64 < nf4) ? __ballot(goff[1] >= 0) : 0ull;
+        gv0 = goff[0] < 0 ? 0u : (unsigned)goff[0]; gv1 = goff[1] < 0 ? 0u : (unsigned)goff[1];
+        usrc = uniform_ptr(p.up + (long long)nt * nch * U_CHUNK + wave * 256);
+        s1w = uniform_ptr(p.src[1] + (long long)n * p.src_bstride[1] + (long long)wave * HW);
+        s2w = uniform_ptr(p.src[2] + (long long)n * p.src_bstride[2] + (long long)wave * HW);
+        gsrc = uniform_ptr(p.src[0] + (long long)n * p.src_bstride[0] + (long long)wave * HW);
+        gch = 0;
+    };
+    // Wave w clears ITS two raw planes (out-of-image granules are never written by the DMAs and must read
+    // as zero padding; the previous tile may have had another mask), then issues raw(0), U(0), raw(1).
+    // Only the issuing wave ever touches these planes, U stage 0 was last read a whole chunk ago.
+    auto stage_first = [&]() {
+        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int e = lane * 4; e < p.plane; e += 256) {
+            *reinterpret_cast<f32x4*>(rawS + wave * p.plane + e) = zero;
+            *reinterpret_cast<f32x4*>(rawS + raw_floats + wave * p.plane + e) = zero;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_raw(rdst0, 0); dma_raw(rdst0, 1);                // raw(0)
+        advance_src();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_u(udst0, j);         // U(0)
+        usrc += U_CHUNK;                                     // -> U(1)
+        uleft = nch - 2;
+        dma_raw(rdst1, 0); dma_raw(rdst1, 1);                // raw(1)
+        advance_src();
+    };
+
+    int tile = blockIdx.x;
+    setup_tile(tile);
+    stage_first();
+  for (;;) {   // ---- tile loop ----
+    // output addressing of THIS tile (the staging state above moves on to the next tile before the epilogue)
+    const int o_nt = nt;
+    float* const outn = p.out + (long long)n * p.out_bstride;
+    const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
+    const bool in0 = lane < ntile && ox < p.W && oy < p.H, in1 = in0 && oy + 1 < p.H;
+    const unsigned o0 = (unsigned)(oy * p.W + ox), o1 = o0 + (unsigned)p.W;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[x][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q) fa[1][q] = fb[1][q] = 0.f;   // "group 3 of chunk -1": adds zeros
-
-    // ---- clear both raw stages once (out-of-image granules are never written afterwards) ----
-    {
-        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int e = tid * 4; e < 2 * raw_floats; e += 2048) *reinterpret_cast<f32x4*>(rawS + e) = zero;
-    }
-    __syncthreads();
-    dma_raw(rdst0, 0); dma_raw(rdst0, 1);                // raw(0)
-    advance_src();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dma_u(udst0, j);         // U(0)
-    usrc += U_CHUNK;                                     // -> U(1)
-    int uleft = nch - 2;                                 // further advances before usrc reaches the last chunk
-    dma_raw(rdst1, 0); dma_raw(rdst1, 1);                // raw(1)
-    advance_src();
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // all but raw(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first DMAs landed (and the previous tile's stores are out)
     transform(rawS, Vs);
 
     // ---- K loop.  One basic block per chunk with a fixed instruction interleave: all 8 waves run in
@@ -324,6 +352,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     static_for<16>([&](auto ic) { mfma(decltype(ic)::value); });   // group 3 of the last chunk
     __syncthreads();
 
+    // every wave is past its last LDS read of this tile: start the next tile's first DMAs (raw stages, U
+    // stage 0), then run this tile's epilogue in the rest of the LDS (U stage 1 | V stages)
+    const int next_tile = tile + (int)gridDim.x;
+    const bool more = next_tile < p.nblocks;
+    if (more) {
+        setup_tile(next_tile);
+        stage_first();
+    }
     if ((DBG & 32) != 0) {  // ablation: no epilogue (every accumulator stays live)
         f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -333,22 +369,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) sum += acc[x][mb][nb];
         if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.f) p.out[0] = 0.f;
-        return;
-    }
+    } else {
     // ---- output transform: 16 frequencies meet in LDS, one pass per 16 output channels ----
-    // The exchange buffer is double buffered (2 x 68 KiB) and the barriers are bare s_barrier behind an
-    // lgkmcnt wait: __syncthreads() would also drain vmcnt, i.e. wait for the previous pass's global
-    // stores to be acknowledged -- four exposed store latencies per workgroup.
-    // Addressing is hoisted: a lane's pixel offset is one 32-bit value, the channel plane a wave-uniform
-    // base (SGPR) -- the epilogue is instruction-issue bound, not bandwidth bound.
-    const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
-    const bool in0 = lane < ntile && ox < p.W && oy < p.H, in1 = in0 && oy + 1 < p.H;
-    const unsigned o0 = (unsigned)(oy * p.W + ox), o1 = o0 + (unsigned)p.W;
-    float* const outn = p.out + (long long)n * p.out_bstride;
+    // Bare s_barrier behind an lgkmcnt wait: __syncthreads() would also drain vmcnt, i.e. wait for the
+    // previous pass's global stores (and the next tile's DMAs) at every pass.  Addressing is hoisted: a
+    // lane's pixel offset is one 32-bit value, the channel plane a wave-uniform base.
+    float* const Ms = Us + U_CHUNK;              // [16 xi][16 n][M_NSTRIDE], 68 KiB of the 96 KiB U1 | V0 | V1
     const float slope = p.act ? p.slope : 1.f;   // act off == slope 1
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-        float* const Ms = smem + (nb & 1) * (16 * 16 * M_NSTRIDE);  // [16 xi][16 n][M_NSTRIDE]
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -358,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int nloc = wave + 8 * k;
-            const int oc = nt * WNT + nb * 16 + nloc;    // wave-uniform
+            const int oc = o_nt * WNT + nb * 16 + nloc;    // wave-uniform
             if (oc >= p.OC) continue;
             const float* m = Ms + nloc * M_NSTRIDE + lane;
             float s[2][4];
@@ -383,7 +412,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
                 }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Ms is rewritten by the next pass / the next tile's V
     }
+    }
+    if (!more) break;
+    tile = next_tile;
+  }   // tile loop
 }
 
 long long wino_packed_floats(int oc, int cin, int ks, int stride) {
@@ -431,7 +465,7 @@ static int wino_variant(const WinoParams& p, size_t lds, hipStream_t stream) {
             return KBN_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(p.nblocks), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(p.nblocks < 256 ? p.nblocks : 256), dim3(512), lds, stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
@@ -472,7 +506,7 @@ int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
         if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
         q.nblocks = (int)nb64;
         size_t lds = sizeof(float) * ((size_t)2 * WCK * q.plane + 2 * U_CHUNK + 2 * V_CHUNK);
-        const size_t lds_epi = 2 * sizeof(float) * (size_t)16 * 16 * M_NSTRIDE;
+        const size_t lds_epi = sizeof(float) * ((size_t)2 * WCK * q.plane + U_CHUNK + (size_t)16 * 16 * M_NSTRIDE);
         if (lds < lds_epi) lds = lds_epi;
         if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
         return wino_dispatch(q, lds, stream);
