@@ -264,9 +264,10 @@ def test_decoder_golden(dev, name):
     assert rel_err(out, g["logits"]) < TOL
 
 
-def test_depth_head_vs_oracle(dev):
+@pytest.mark.parametrize("shape", [(37, 70), (37, 72), (16, 64), (5, 200)])   # general kernel / LDS-DMA kernel (W % 4 == 0)
+def test_depth_head_vs_oracle(dev, shape):
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(2, 12, 37, 70, generator=g)
+    x = torch.randn(2, 12, *shape, generator=g)
     w = torch.randn(1, 12, 3, 3, generator=g) / 4
     logits = orc.conv2d(x, w, 1, None)
     ref = orc.depth_head(logits, 1.5, 100.0)
