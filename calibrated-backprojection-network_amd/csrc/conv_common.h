@@ -50,8 +50,10 @@ __host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks, int strid
     ConvPlan pl;
     // Channels per K chunk (the packed weight layout depends on it, hence on the stride the
     // weight is used with).  Stride-2 3x3 convs stage 4x the pixels per output pixel: CK = 4
-    // halves their LDS stage so that two workgroups stay resident per CU.
-    pl.CK = (ks == 1) ? 16 : ((cin <= 4 || stride == 2) ? 4 : 8);
+    // halves their LDS stage so that two workgroups stay resident per CU.  Narrow inputs (<= 16 channels:
+    // conv0_depth, deconv0's 12 -> 12) also take 4: no K padding (12 = 3 x 4) and staging of chunk c+1
+    // overlaps the MFMAs of chunk c even in a two- or three-chunk loop (-8 % / -20 % on those layers).
+    pl.CK = (ks == 1) ? 16 : ((cin <= 16 || stride == 2) ? 4 : 8);
     if (force_ck == 4 && ks == 3) pl.CK = 4;  // experiment hook (KBN_FORCE_CK)
     if (force_ck == 8 && ks == 3 && cin > 4) pl.CK = 8;
     int nblk = ceil_div(oc, 16);
