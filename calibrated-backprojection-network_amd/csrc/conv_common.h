@@ -182,6 +182,20 @@ __device__ __forceinline__ void lds_dma16_sm(const float* sbase_uniform, unsigne
         : "memory");
 }
 
+// 4-byte granules (lane l copies gsrc[voff] to LDS lds_base + 4*l): any alignment, e.g. maps whose
+// width is not a multiple of 4.
+__device__ __forceinline__ void lds_dma4_sm(const float* sbase_uniform, unsigned voff_bytes, unsigned lds_base_uniform,
+                                            unsigned long long lane_mask_uniform) {
+    unsigned keep;
+    unsigned long long keepx;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %5\n\ts_mov_b64 exec, %4\n\ts_nop 0\n\t"
+        "global_load_lds_dword %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(keepx)
+        : "v"(voff_bytes), "s"(sbase_uniform), "s"(lane_mask_uniform), "s"(lds_base_uniform)
+        : "memory");
+}
+
 // Pins a wave-uniform pointer into SGPRs (for the "s" operands above when the compiler's divergence
 // analysis cannot prove uniformity).
 __device__ __forceinline__ const float* uniform_ptr(const float* p) {

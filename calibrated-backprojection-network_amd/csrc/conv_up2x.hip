@@ -296,20 +296,23 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_kernel(cons
 // a loop-invariant register plus an immediate, and (c) the staging pointers live in SGPRs.  Vector-ALU
 // instructions between MFMAs cost matrix-pipe time (tools/probe/issue_probe.hip); the general kernel
 // above spends ~0.3 of them per MFMA on addresses and masks, this one none.
-template <int NB, int MW, int TWB>
+// GR = floats per DMA granule: 4 (16-byte granules, maps with W % 4 == 0) or 1 (dword granules, any map --
+// e.g. the 11 x 38 latent of a KITTI frame).
+template <int NB, int MW, int TWB, int GR>
 struct Up2xGeom {
     static constexpr int NT = NB * 16;
     static constexpr int TH = 4 * MW / TWB, TW = TWB * 16;
-    static constexpr int ROWS = TH + 1, COLS = TW + 8;          // staged rows / columns (x0-4 .. x0+TW+3)
+    static constexpr int XPAD = (GR == 4) ? 4 : 1;               // staged columns start at x0 - XPAD
+    static constexpr int ROWS = TH + 1, COLS = (GR == 4) ? TW + 8 : TW + 2;
     static constexpr int PLANE = ((ROWS * COLS + 15) / 32) * 32 + 16;
-    static constexpr int NF4 = ROWS * COLS / 4;                  // granules per channel
+    static constexpr int NF4 = ROWS * COLS / GR;                 // granules per channel
     static constexpr int MAXJ = (NF4 + 63) / 64;
     static constexpr int A_FLOATS = 8 * PLANE, B_FLOATS = 8 * 8 * NT, BUF = A_FLOATS + B_FLOATS;
 };
 
-template <int NB, int MW, int TWB>
+template <int NB, int MW, int TWB, int GR>
 __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(const Up2xParams p) {
-    using G = Up2xGeom<NB, MW, TWB>;
+    using G = Up2xGeom<NB, MW, TWB, GR>;
     constexpr int NT = G::NT, PLANE = G::PLANE, PITCH = G::COLS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -336,8 +339,8 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
         const int f = j * 64 + lane;
         int g = -1;
         if (f < G::NF4) {
-            const int r = f / (PITCH / 4), cv = f - r * (PITCH / 4);
-            const int Y = y0 - 1 + a + r, X = x0 - 4 + cv * 4;
+            const int r = f / (PITCH / GR), cv = f - r * (PITCH / GR);
+            const int Y = y0 - 1 + a + r, X = x0 - G::XPAD + cv * GR;
             if (Y >= 0 && Y < p.srcH && X >= 0 && X < p.srcW) g = (Y * p.srcW + X) * 4;
         }
         gv[j] = g < 0 ? 0u : (unsigned)g;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
     for (int mi = 0; mi < MW; ++mi) {
         const int mb = wave * MW + mi;
         const int oy = mb / TWB, seg = mb - oy * TWB;
-        mbase[mi] = oy * PITCH + seg * 16 + li + 3 + lk * PLANE;   // column x-1 of the lane's pixel
+        mbase[mi] = oy * PITCH + seg * 16 + li + (G::XPAD - 1) + lk * PLANE;   // column x-1 of the lane's pixel
     }
     const int boff = G::A_FLOATS + (lk >> 1) * 2 * NT + li * 2 + (lk & 1);
 
@@ -373,7 +376,10 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
         for (int t = 0; t < 2; ++t) {
             const unsigned dst = lds0 + 4u * (unsigned)(buf * G::BUF + (wave + 4 * t) * PLANE);
 #pragma unroll
-            for (int j = 0; j < G::MAXJ; ++j) lds_dma16_sm(aptr + (long long)(4 * t) * HW, gv[j], dst + j * 1024, gm[j]);
+            for (int j = 0; j < G::MAXJ; ++j) {
+                if constexpr (GR == 4) lds_dma16_sm(aptr + (long long)(4 * t) * HW, gv[j], dst + j * 1024, gm[j]);
+                else lds_dma4_sm(aptr + (long long)(4 * t) * HW, gv[j], dst + j * 256, gm[j]);
+            }
         }
         const unsigned bdst = lds0 + 4u * (unsigned)(buf * G::BUF + G::A_FLOATS + wave * 256);
 #pragma unroll
@@ -442,10 +448,10 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
     up2x_store<NB, MW>(p, acc, n, nt, a, y0, x0, TWB, wave, li, lk);
 }
 
-template <int NB, int MW, int TWB>
+template <int NB, int MW, int TWB, int GR = 4>
 static int up2x_dma_variant(Up2xParams& p, hipStream_t stream) {
-    using G = Up2xGeom<NB, MW, TWB>;
-    auto kern = conv_up2x_dma_kernel<NB, MW, TWB>;
+    using G = Up2xGeom<NB, MW, TWB, GR>;
+    auto kern = conv_up2x_dma_kernel<NB, MW, TWB, GR>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -554,6 +560,27 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
         };
         int cand = twb - 1;
         if (!ftw) cand = tune_pick(TuneKey{3, n, out_channels, in_channels, src_height, src_width, 0, 0, 0, 0}, 4, cand, launch, st);
+        return launch(cand);
+    }
+    // maps whose rows are not 16-byte aligned: the same kernel with dword DMA granules (wide outputs only)
+    if (!aligned && pl.NB >= 3 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad && !getenv("KBN_NO_UP2X_DMA") &&
+        !getenv("KBN_UP_MW")) {
+        auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
+            Up2xParams q = p;
+            switch ((pl.NB == 3 ? 300 : 400) + (cand >> 1) * 10 + (cand & 1) + 1) {
+                case 301: return up2x_dma_variant<3, 2, 1, 1>(q, st);
+                case 302: return up2x_dma_variant<3, 2, 2, 1>(q, st);
+                case 311: return up2x_dma_variant<3, 1, 1, 1>(q, st);
+                case 312: return up2x_dma_variant<3, 1, 2, 1>(q, st);
+                case 401: return up2x_dma_variant<4, 2, 1, 1>(q, st);
+                case 402: return up2x_dma_variant<4, 2, 2, 1>(q, st);
+                case 411: return up2x_dma_variant<4, 1, 1, 1>(q, st);
+                default: return up2x_dma_variant<4, 1, 2, 1>(q, st);
+            }
+        };
+        const long long tiles2 = (long long)ceil_div(src_width, 16) * ceil_div(src_height, 4 * pl.MW) * n * pl.nTilesN * 2;
+        const int model = tiles2 <= 512 ? 2 : 0;   // small maps: half-size tiles (see below)
+        const int cand = tune_pick(TuneKey{4, n, out_channels, in_channels, src_height, src_width, 0, 0, 0, 0}, 4, model, launch, st);
         return launch(cand);
     }
     // tile: 4*MW m-blocks of 16 low-res pixels, 16 or 32 wide; a lone workgroup round is avoided.

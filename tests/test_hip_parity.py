@@ -162,6 +162,22 @@ def test_upconv_nearest_resize_vs_oracle(dev, shapes):
     assert rel_err(up(x.to(dev), (oh, ow)), ref) < TIGHT
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(64, 64, (11, 38)), (32, 48, (5, 7)), (48, 40, (13, 18)), (64, 64, (12, 20))])
+def test_upconv2x_wide_outputs_any_alignment(dev, cin, cout, hw):
+    """Exact-2x up-convs with >= 48 output channels: LDS-DMA kernel with 16-byte granules when the rows are
+    aligned (W % 4 == 0), with dword granules otherwise (the 11 x 38 latent of a KITTI frame)."""
+    h, w = hw
+    g = torch.Generator().manual_seed(cin + w)
+    x = torch.randn(2, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    ref = orc.conv2d(torch.nn.functional.interpolate(x, size=(2 * h, 2 * w), mode="nearest"), wt, 1, 0.2)
+    up = kb.modules.UpConv2d(cin, cout, 3, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+    up.conv.conv.weight.data.copy_(wt)
+    first = up(x.to(dev), (2 * h, 2 * w)).clone()
+    assert rel_err(first, ref) < TIGHT
+    assert torch.equal(up(x.to(dev), (2 * h, 2 * w)), first)   # tuned geometry, same bits
+
+
 def test_decoder_block_concat_and_slice_output(dev):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 32, 9, 13, generator=g)
