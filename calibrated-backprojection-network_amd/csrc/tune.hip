@@ -71,22 +71,32 @@ int tune_pick(const TuneKey& key, int ncand, int model, const std::function<int(
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess) return model;
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return model; }
-    int best = model;
-    float best_ms = 1e30f;
+    // Two passes over the candidates; each sample is the average of 3 back-to-back launches (a single
+    // launch's time flatters geometries whose first wave of workgroups finds everything in cache), the
+    // score the better of the two samples.  The model's choice is kept unless something is >= 3 % faster.
+    float score[64];
+    bool valid[64];
+    if (ncand > 64) ncand = 64;
     for (int c = 0; c < ncand; ++c) {
-        if (launch(c) != KBN_OK) continue;  // warm (kernel attributes, caches); also filters invalid candidates
-        float ms = 1e30f;
-        for (int rep = 0; rep < 3; ++rep) {
+        score[c] = 1e30f;
+        valid[c] = launch(c) == KBN_OK;   // warm (kernel attributes, caches); also filters invalid candidates
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int c = 0; c < ncand; ++c) {
+            if (!valid[c]) continue;
             (void)hipEventRecord(e0, stream);
-            const int rc = launch(c);
+            int rc = KBN_OK;
+            for (int rep = 0; rep < 3 && rc == KBN_OK; ++rep) rc = launch(c);
             (void)hipEventRecord(e1, stream);
             float t = 1e30f;
             if (rc != KBN_OK || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) t = 1e30f;
-            ms = t < ms ? t : ms;
+            score[c] = t < score[c] ? t : score[c];
         }
-        const float score = ms * (c == model ? 0.98f : 1.0f);  // keep the model's choice unless something is clearly faster
-        if (score < best_ms) { best_ms = score; best = c; }
     }
+    int best = model;
+    float best_ms = (model >= 0 && model < ncand && valid[model]) ? score[model] * 0.97f : 1e30f;
+    for (int c = 0; c < ncand; ++c)
+        if (valid[c] && c != model && score[c] < best_ms) { best_ms = score[c]; best = c; }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (best_ms < 1e29f) {
