@@ -2,7 +2,7 @@
 """Throughput of the input pipeline (row f4) on the GPU box: KITTI-shaped PNG files (352 x 3648 RGB image
 triplets, 352 x 1216 16-bit sparse depth) -> InferenceFrameLoader -> preprocess -> graph-replayed forward.
 Prints decode-only, loader-only (decode + H2D + unpack) and end-to-end frames/s, next to the PIL loop the
-reference runs (one worker, one sample at a time).   usage: loader_bench.py [n_files] [workers]"""
+reference runs (one worker, one sample at a time).   usage: loader_bench.py [n_files] [workers] [prefetch]"""
 import os, sys, time, tempfile
 import numpy as np
 import torch
@@ -13,6 +13,7 @@ from PIL import Image
 
 n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+prefetch = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 H, W = 352, 1216
 d = tempfile.mkdtemp(prefix="kbn_loader_")
 g = np.random.Generator(np.random.Philox(5))
@@ -40,7 +41,7 @@ torch.cuda.synchronize()
 print(f"reference-style PIL loop, 1 worker : {min(n_files, 16) / (time.perf_counter() - t0):8.1f} frames/s")
 
 def run_loader(consume):
-    loader = kb.loader.InferenceFrameLoader(imgs, deps, ks, use_image_triplet=True, batch_size=8, device=dev, workers=workers)
+    loader = kb.loader.InferenceFrameLoader(imgs, deps, ks, use_image_triplet=True, batch_size=8, device=dev, workers=workers, prefetch=prefetch)
     for batch in loader:   # warm (pinned buffers, page cache)
         consume(*batch)
     torch.cuda.synchronize()
