@@ -19,11 +19,18 @@
 //     pre-transformed weights U of chunk c+1 into LDS.  Wave w stages channel w of the chunk, the
 //     same channel it transforms, so the raw tile needs no barrier of its own.
 //   * the input transform B^T d B of chunk c+1: thread = (channel = wave, tile = lane); 16 ds_read,
-//     32 adds, 16 ds_write into V[xi][c][tile] (tile index xor-swizzled by c&1 so that the MFMA A
-//     fragments of k and k+1 fall on disjoint banks without padding);
+//     16 packed-fp32 adds (v_pk_add_f32), 16 ds_write into V[xi][c][tile] (tile index xor-swizzled by
+//     c&1 so that the MFMA A fragments of k and k+1 fall on disjoint banks without padding);
 //   * the MFMAs of chunk c from V and U (both double buffered).
-// Epilogue: the accumulators of the 16 frequencies meet in LDS (one pass per 16 output channels),
-// each thread applies A^T . A to two (tile, channel) pairs, fuses LeakyReLU and stores 2 x float2.
+// The chunk body is ONE basic block with a fixed interleave (static_for + sched_barrier(0)): every MFMA
+// is followed by a slot holding a piece of the other two streams, because vector-ALU work that is not
+// interleaved costs matrix-pipe time (tools/probe/issue_probe.hip); the last MFMA group of a chunk is
+// issued after the NEXT chunk's barrier, where it covers the first fragment reads; DMA completion is
+// counted (vmcnt(2) / vmcnt(6)), not drained; everything wave-uniform lives in SGPRs.
+// Epilogue: the accumulators of the 16 frequencies meet in LDS (one pass per 16 output channels, bare
+// s_barrier), each thread applies A^T . A to two (tile, channel) pairs, fuses LeakyReLU and stores
+// 2 x float2.  Workgroups are persistent (one per CU -- the LDS footprint allows no more): the first
+// DMAs of a workgroup's next tile are issued before the current tile's epilogue.
 //
 // Weights: U = G g G^T is computed once (fp64, rounded to fp32) by wino_pack_kernel and lives behind
 // the direct-conv fragment-order weights in the caller's packed blob (kbn_conv2d_pack_weight), laid
