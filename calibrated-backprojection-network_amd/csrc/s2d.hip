@@ -5,11 +5,11 @@
 //   max-pools (:2183-2186), cat, n_convolution x [conv1x1 + LeakyReLU], cat with x,
 //   conv3x3 + LeakyReLU -- one launch, one read of x, one write of the n_filter maps.
 //
-// One workgroup (256 threads) produces a 16 x 32 output tile.  The sparse depth tile with
+// One workgroup (512 threads) produces a 32 x 32 output tile.  The sparse depth tile with
 // a halo of R+1 (R = largest pool radius) is staged in LDS twice: `zmin` with zeros
 // replaced by the 999 sentinel (+inf outside the image) and `zmax` (-inf outside).  Every
 // pool is evaluated separably -- a row pass into `hbuf`, then a column pass straight into
-// registers -- on the (16+2) x (32+2) "feature" region the 3x3 conv needs.  The 1x1 conv
+// registers -- on the (32+2) x (32+2) "feature" region the 3x3 conv needs.  The 1x1 conv
 // chain runs in registers, its outputs (plus the raw x channels) go to LDS as the 3x3
 // conv's input tile, zero outside the image exactly like the reference's zero padding.
 #include <math.h>
@@ -21,10 +21,10 @@
 
 namespace kbn {
 
-constexpr int S2D_TW = 32, S2D_TH = 16;
+constexpr int S2D_TW = 32, S2D_TH = 32, S2D_THREADS = 512;
 constexpr int S2D_FW = S2D_TW + 2, S2D_FH = S2D_TH + 2;
 constexpr int S2D_NF = S2D_FW * S2D_FH;                  // feature positions per tile (612)
-constexpr int S2D_NPOS = (S2D_NF + 255) / 256;           // feature positions per thread (3)
+constexpr int S2D_NPOS = (S2D_NF + S2D_THREADS - 1) / S2D_THREADS;           // feature positions per thread (3)
 constexpr int S2D_MAXPOOL = 8, S2D_MAXF = 8, S2D_MAXCONV = 4, S2D_MAXIN = 2;
 constexpr int S2D_MAXCH = S2D_MAXF + S2D_MAXIN;
 // LDS weight block (floats): 3x3 conv as [ch][tap][8 filters], 1x1 convs as [input][8 filters]
@@ -83,7 +83,7 @@ using VoidPools = StaticPools<2, 15, 17, 23, 27, 29>;         // bash/void/run_k
 using VoidTrainPools = StaticPools<3, 15, 17, 19, 23, 27>;    // bash/void/train_kbnet_void1500.sh:21-22
 
 template <typename CFG>
-__global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
+__global__ __launch_bounds__(S2D_THREADS) void s2d_kernel(const S2DParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int R = p.R;
     const int ZW = S2D_FW + 2 * R, ZH = S2D_FH + 2 * R;
@@ -105,11 +105,11 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
 
     // ---- weights -> LDS, transposed so that the 8 filters of one (input, tap) are contiguous --
     if (!p.pyramid) {
-        for (int e = tid; e < S2D_WC; e += 256) {
+        for (int e = tid; e < S2D_WC; e += S2D_THREADS) {
             const int f = e & 7, t = (e >> 3) % 9, ch = e / 72;
             wl[e] = (f < p.nf && ch < nch) ? p.wconv[((long long)f * nch + ch) * 9 + t] : 0.f;
         }
-        for (int e = tid; e < S2D_MAXCONV * S2D_WP; e += 256) {
+        for (int e = tid; e < S2D_MAXCONV * S2D_WP; e += S2D_THREADS) {
             const int f = e & 7, q = (e >> 3) & 7, i = e >> 6;
             const int cin = (i == 0) ? CFG::npool(p) : p.nf;
             wl[S2D_WC + e] = (i < p.nconv && f < p.nf && q < cin) ? p.wpool[i][f * cin + q] : 0.f;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     }
     // ---- stage the depth tile (+halo) -------------------------------------------------
     if (!(p.dbg & 16))
-    for (int e = tid; e < ZH * ZW; e += 256) {
+    for (int e = tid; e < ZH * ZW; e += S2D_THREADS) {
         int r = e / ZW, c = e - r * ZW;
         int Y = oy0 - 1 - R + r, X = ox0 - 1 - R + c;
         float vmin = INFINITY, vmax = -INFINITY;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     // ---- row pass, nested: one sweep outwards gives every min pool, another every max pool ----
     const int nmin = CFG::nmin(p), npool = CFG::npool(p);
     if (!(p.dbg & 1))
-    for (int e = tid; e < ZH * S2D_FW; e += 256) {
+    for (int e = tid; e < ZH * S2D_FW; e += S2D_THREADS) {
         const int r = e / S2D_FW, c = e - r * S2D_FW;
         {
             const float* s = zmin + r * ZW + c + R;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     float pooled[S2D_NPOS][S2D_MAXPOOL];
 #pragma unroll
     for (int u = 0; u < S2D_NPOS; ++u) {
-        const int e = tid + u * 256;
+        const int e = tid + u * S2D_THREADS;
 #pragma unroll
         for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
             float a = 0.f;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     // ---- 1x1 conv chain in registers; features + raw x channels to LDS ----------------
 #pragma unroll
     for (int u = 0; u < S2D_NPOS; ++u) {
-        const int e = tid + u * 256;
+        const int e = tid + u * S2D_THREADS;
         if (e >= S2D_NF) continue;
         const int fy = e / S2D_FW, fx = e - fy * S2D_FW;
         const int Y = oy0 - 1 + fy, X = ox0 - 1 + fx;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
     if (p.pyramid) return;
     __syncthreads();
 
-    // ---- 3x3 conv over [features | x] + LeakyReLU: each thread two pixels (rows oy, oy+8), the
+    // ---- 3x3 conv over [features | x] + LeakyReLU: each thread two pixels (rows oy, oy+16), the
     //      weights of a (channel, tap) are read once (LDS broadcast) and used for both ----------
     {
         const int oy = tid / S2D_TW, ox = tid - oy * S2D_TW;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
         for (int f = 0; f < S2D_MAXF; ++f) accp[f] = (f32x2){0.f, 0.f};
         for (int ch = 0; ch < ((p.dbg & 8) ? 0 : nch); ++ch) {
             const float* f0 = feat + ch * S2D_NF + oy * S2D_FW + ox;
-            const float* f1 = f0 + 8 * S2D_FW;
+            const float* f1 = f0 + (S2D_TH / 2) * S2D_FW;
             const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ch * 72);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const S2DParams p) {
         const int X = ox0 + ox;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int Y = oy0 + oy + half * 8;
+            const int Y = oy0 + oy + half * (S2D_TH / 2);
             if (Y < p.H && X < p.W) {
                 float* o = p.out + ((long long)n * p.nf) * p.H * p.W + (long long)Y * p.W + X;
 #pragma unroll
@@ -349,7 +349,7 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
                 return KBN_ERR_LAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S2D_THREADS), lds, stream, p);
         return KBN_OK;
     };
     static bool set_kitti = false, set_void = false, set_voidtrain = false, set_dyn = false;
