@@ -257,43 +257,57 @@ __global__ __launch_bounds__(S2D_THREADS) void s2d_kernel(const S2DParams p) {
     if (p.pyramid) return;
     __syncthreads();
 
-    // ---- 3x3 conv over [features | x] + LeakyReLU: each thread two pixels (rows oy, oy+16), the
-    //      weights of a (channel, tap) are read once (LDS broadcast) and used for both ----------
-    {
-        const int oy = tid / S2D_TW, ox = tid - oy * S2D_TW;
-        // packed fp32: accp[f] = (pixel 0, pixel 1) of filter f; one v_pk_fma_f32 per (channel, tap, filter)
-        // with the weight broadcast to both halves -- half the vector-ALU instructions of the scalar form.
-        f32x2 accp[S2D_MAXF];
+    // ---- 3x3 conv over [features | x] + LeakyReLU.  The phase is LDS-issue bound (one value per FMA pair
+    //      plus the broadcast weight reads), so half of the threads take 4 consecutive pixels of a row each:
+    //      a row of the window is 6 values = three 8-byte reads (+ two for the odd-aligned pairs the packed
+    //      FMAs of the middle tap need), and every weight read serves four pixels.  Packed fp32: one
+    //      v_pk_fma_f32 per (channel, tap, filter, pixel pair), weight broadcast to both halves. ----------
+    if (tid < S2D_TH * S2D_TW / 4) {
+        const int oy = tid / (S2D_TW / 4), oxq = (tid - oy * (S2D_TW / 4)) * 4;
+        f32x2 acc[2][S2D_MAXF];   // [pixel pair (0,1) / (2,3)][filter]
 #pragma unroll
-        for (int f = 0; f < S2D_MAXF; ++f) accp[f] = (f32x2){0.f, 0.f};
+        for (int f = 0; f < S2D_MAXF; ++f) acc[0][f] = acc[1][f] = (f32x2){0.f, 0.f};
         for (int ch = 0; ch < ((p.dbg & 8) ? 0 : nch); ++ch) {
-            const float* f0 = feat + ch * S2D_NF + oy * S2D_FW + ox;
-            const float* f1 = f0 + (S2D_TH / 2) * S2D_FW;
+            const float* fr = feat + ch * S2D_NF + oy * S2D_FW + oxq;   // column oxq <-> x - 1 of the first pixel
             const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ch * 72);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int o = (t / 3) * S2D_FW + (t % 3);
-                const f32x2 v = (f32x2){f0[o], f1[o]};
-                const f32x4 wa = w4[t * 2], wb = w4[t * 2 + 1];
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* r = fr + ky * S2D_FW;
+                const f32x2 e0 = *reinterpret_cast<const f32x2*>(r), e1 = *reinterpret_cast<const f32x2*>(r + 2),
+                            e2 = *reinterpret_cast<const f32x2*>(r + 4);
+                const f32x2 o0 = (f32x2){r[1], r[2]}, o1 = (f32x2){r[3], r[4]};
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    accp[f] = __builtin_elementwise_fma(v, (f32x2){wa[f], wa[f]}, accp[f]);
-                    accp[4 + f] = __builtin_elementwise_fma(v, (f32x2){wb[f], wb[f]}, accp[4 + f]);
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x2 va = kx == 0 ? e0 : (kx == 1 ? o0 : e1);   // pixels 0, 1 see columns kx, kx + 1
+                    const f32x2 vb = kx == 0 ? e1 : (kx == 1 ? o1 : e2);   // pixels 2, 3 see columns kx + 2, kx + 3
+                    const f32x4 wa = w4[(ky * 3 + kx) * 2], wb = w4[(ky * 3 + kx) * 2 + 1];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        acc[0][f] = __builtin_elementwise_fma(va, (f32x2){wa[f], wa[f]}, acc[0][f]);
+                        acc[1][f] = __builtin_elementwise_fma(vb, (f32x2){wa[f], wa[f]}, acc[1][f]);
+                        acc[0][4 + f] = __builtin_elementwise_fma(va, (f32x2){wb[f], wb[f]}, acc[0][4 + f]);
+                        acc[1][4 + f] = __builtin_elementwise_fma(vb, (f32x2){wb[f], wb[f]}, acc[1][4 + f]);
+                    }
                 }
             }
         }
-        float acc0[S2D_MAXF], acc1[S2D_MAXF];
+        const int Y = oy0 + oy, X = ox0 + oxq;
+        if (Y < p.H && X < p.W) {
+            const long long HW = (long long)p.H * p.W;
+            float* o = p.out + ((long long)n * p.nf) * HW + (long long)Y * p.W + X;
+            const bool vec = (X + 3 < p.W) && ((p.W & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
 #pragma unroll
-        for (int f = 0; f < S2D_MAXF; ++f) { acc0[f] = accp[f].x; acc1[f] = accp[f].y; }
-        const int X = ox0 + ox;
+            for (int f = 0; f < S2D_MAXF; ++f) {
+                if (f >= p.nf) continue;
+                const f32x4 v = (f32x4){leaky_relu(acc[0][f].x, p.slope), leaky_relu(acc[0][f].y, p.slope),
+                                        leaky_relu(acc[1][f].x, p.slope), leaky_relu(acc[1][f].y, p.slope)};
+                if (vec) {
+                    *reinterpret_cast<f32x4*>(o + f * HW) = v;
+                } else {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int Y = oy0 + oy + half * (S2D_TH / 2);
-            if (Y < p.H && X < p.W) {
-                float* o = p.out + ((long long)n * p.nf) * p.H * p.W + (long long)Y * p.W + X;
-#pragma unroll
-                for (int f = 0; f < S2D_MAXF; ++f)
-                    if (f < p.nf) o[(long long)f * p.H * p.W] = leaky_relu(half ? acc1[f] : acc0[f], p.slope);
+                    for (int i = 0; i < 4; ++i)
+                        if (X + i < p.W) o[f * HW + i] = v[i];
+                }
             }
         }
     }
