@@ -472,7 +472,14 @@ static int wino_variant(const WinoParams& p, size_t lds, hipStream_t stream) {
             return KBN_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(p.nblocks < 256 ? p.nblocks : 256), dim3(512), lds, stream, p);
+    static int n_cu = 0;   // persistent workgroups: one per CU of the current device
+    if (n_cu == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        n_cu = cus;
+    }
+    hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(p.nblocks < n_cu ? p.nblocks : n_cu), dim3(512), lds, stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
