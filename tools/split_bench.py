@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Experiment: does running the two halves of a batch as two concurrent branches (two streams, one captured
+graph) beat one batch-8 forward?  Kernel tails of one half could overlap the other half's kernels."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, kbnet_amd as kb
+dev = torch.device("cuda:0")
+cfg = kb.kitti_config()
+m = kb.modules.KBNetModel.from_config(cfg, dev)
+m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+fr = [f.to(dev) for f in kb.synthetic.make_frames(8, 352, 1216, "kitti", seed=1)]
+def branches(sizes):
+    nb = len(sizes)
+    offs = [sum(sizes[:i]) for i in range(nb + 1)]
+    parts = [[f[offs[i]:offs[i + 1]].contiguous() for f in fr] for i in range(nb)]
+    for h in parts:           # tune the smaller batch shapes outside any capture
+        for _ in range(2):
+            m.forward(*h)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(nb)]
+    g = torch.cuda.CUDAGraph()
+    outs = [None] * nb
+    with torch.cuda.graph(g):
+        cur = torch.cuda.current_stream()
+        for s in streams:
+            s.wait_stream(cur)
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                outs[i] = m.forward(*parts[i])
+        for s in streams:
+            cur.wait_stream(s)
+    return g, outs
+
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return 8 * reps / (time.perf_counter() - t)
+
+for _ in range(2):
+    m.forward(*fr)
+torch.cuda.synchronize()
+full = m.capture(*fr)
+print("one batch-8 graph        : %.1f frames/s" % timeit(lambda: full(*fr)))
+a = full(*fr).clone()
+for sizes in ([4, 4], [5, 3], [6, 2], [3, 3, 2], [4, 2, 2], [4, 4]):
+    g, outs = branches(sizes)
+    fps = timeit(g.replay)
+    g.replay(); torch.cuda.synchronize()
+    same = torch.equal(a, torch.cat(outs, 0))
+    print("concurrent branches %-10s: %.1f frames/s  same bits: %s" % (sizes, fps, same))
