@@ -479,7 +479,13 @@ static int wino_variant(const WinoParams& p, size_t lds, hipStream_t stream) {
             cus = 256;
         n_cu = cus;
     }
-    hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(p.nblocks < n_cu ? p.nblocks : n_cu), dim3(512), lds, stream, p);
+    int grid = p.nblocks < n_cu ? p.nblocks : n_cu;
+    if (const char* g = getenv("KBN_WINO_GRID")) {   // experiment hook: -1 = one workgroup per tile, N = N persistent workgroups
+        const int v = atoi(g);
+        if (v < 0) grid = p.nblocks;
+        else if (v > 0) grid = p.nblocks < v ? p.nblocks : v;
+    }
+    hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(grid), dim3(512), lds, stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
