@@ -78,3 +78,27 @@ with torch.cuda.graph(g):
         oB = dec(m, *enc(m, *parts[1]))
     cur.wait_stream(sA); cur.wait_stream(sB)
 print("skewed 2 x 4 (B starts after A's encoder): %.1f frames/s  same bits: %s" % (timeit(g.replay), torch.equal(a, torch.cat([oA, oB], 0))))
+
+# ---- small skews: branch B starts after branch A's S2D / after A's whole encoder level 0 ----
+def staged(model, image, sparse, valid, k, mark=None, stream=None):
+    x = torch.cat([sparse, valid], dim=1)
+    d = model.sparse_to_dense_pool(x)
+    ev = stream.record_event() if (mark == "s2d" and stream is not None) else None
+    latent, skips = model.encoder(image, d, k)
+    feats = model.decoder.features(latent, skips, d.shape[-2:])
+    out = kb.ops.depth_head(feats, model.decoder.output0.conv.weight, model.min_predict_depth, model.max_predict_depth)
+    return out, ev
+
+sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    cur = torch.cuda.current_stream()
+    sA.wait_stream(cur)
+    with torch.cuda.stream(sA):
+        oA, ev = staged(m, *parts[0], mark="s2d", stream=sA)
+    sB.wait_stream(cur)
+    sB.wait_event(ev)
+    with torch.cuda.stream(sB):
+        oB, _ = staged(m, *parts[1])
+    cur.wait_stream(sA); cur.wait_stream(sB)
+print("2 x 4, B starts after A's S2D            : %.1f frames/s  same bits: %s" % (timeit(g.replay), torch.equal(a, torch.cat([oA, oB], 0))))
