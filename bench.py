@@ -64,25 +64,30 @@ def conv_gflop_per_frame(cfg, h, w):
 
 
 def lookup_traffic(kernel, launches):
-    """HBM bytes per launch of `kernel` from the committed PMC collection (tools/collect_traffic.py:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled on gfx950), or None."""
+    """PMC evidence for `kernel` from the committed collection (tools/collect_pmc.py: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE / MFMA-busy in separate passes, FETCH_SIZE doubled on gfx950): (HBM bytes per launch, detail) or
+    (None, None)."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
     if not files:
-        return None
+        return None, None
     table = json.load(open(files[-1]))["kernels"]
     if kernel == "conv_wino":
         want = "conv_wino_kernel<0>"
     else:
         m = re.match(r"(conv_\w+)<([\d,]+)>", kernel)
         if not m:
-            return None
+            return None, None
         want = m.group(1) + "_kernel<" + m.group(2).replace(",", ", ")
     for name, e in table.items():
         if want in name:
-            return {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)}
-    return None
+            detail = {"source": os.path.relpath(files[-1], ROOT), "fetch_bytes": e.get("fetch_bytes"),
+                      "write_bytes": e.get("write_bytes"), "launches": e.get("launches")}
+            if "mfma_busy_frac" in e:   # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)
+                detail["mfma_busy_frac_pmc"] = round(e["mfma_busy_frac"], 4)
+            return e["hbm_bytes_per_launch"], detail
+    return None, None
 
 
 def cpu_baseline(cfg, sds, frames, budget_s=15.0, max_frames=6):
@@ -242,7 +247,7 @@ def main():
     roofline["measured_on"] = ("eager whole-batch launches, one kernel at a time, HIP events on the launch stream "
                                "(the timed graph may run the batch as concurrent sub-batch branches; "
                                "`rocprofv3 --stats -- bench.py --branches 1` shows the same launches)")
-    roofline["traffic"] = lookup_traffic(dom, dlaunch)
+    roofline["traffic"], roofline["pmc"] = lookup_traffic(dom, dlaunch)
     s2d = groups.get("s2d")
     if s2d:
         gbs = s2d[0] / s2d[1] / 1e9

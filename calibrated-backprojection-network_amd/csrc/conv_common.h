@@ -102,11 +102,18 @@ __device__ __forceinline__ ChanRef chan_lookup(const ConvParams& p, int n, int c
 }
 
 
-// Epilogue shared by both kernels: each lane holds 4 consecutive pixels (rows 4*(l>>4)+r of
+// Epilogue shared by the direct conv kernels: each lane holds 4 consecutive pixels (rows 4*(l>>4)+r of
 // the m-block) of output channel (l&15) of each n-block; fused LeakyReLU; float4 stores.
+struct StoreDst {
+    float* out;
+    long long out_bstride;
+    int outH, outW, OC, TWB, act;
+    float slope;
+};
+
 template <int NB, int MW>
-__device__ __forceinline__ void store_tile(const ConvParams& p, const f32x4 (&acc)[MW][NB], int n, int nt,
-                                           int oy0, int ox0, int wave, int li, int lk) {
+__device__ __forceinline__ void store_tile_dst(const StoreDst& p, const f32x4 (&acc)[MW][NB], int n, int nt,
+                                               int oy0, int ox0, int wave, int li, int lk) {
     constexpr int NT = NB * 16;
     const int HWo = p.outH * p.outW;
     float* outn = p.out + (long long)n * p.out_bstride;
@@ -139,6 +146,13 @@ __device__ __forceinline__ void store_tile(const ConvParams& p, const f32x4 (&ac
             }
         }
     }
+}
+
+template <int NB, int MW>
+__device__ __forceinline__ void store_tile(const ConvParams& p, const f32x4 (&acc)[MW][NB], int n, int nt,
+                                           int oy0, int ox0, int wave, int li, int lk) {
+    const StoreDst d{p.out, p.out_bstride, p.outH, p.outW, p.OC, p.TWB, p.act, p.slope};
+    store_tile_dst<NB, MW>(d, acc, n, nt, oy0, ox0, wave, li, lk);
 }
 
 // One 16-byte-per-lane LDS-DMA: lane l copies gsrc[0..3] to LDS byte address lds_base + 16*l.
@@ -241,5 +255,16 @@ int wino_query(int n, int oc, int cin, int H, int W, int* RT, int* CT);
 // Fills the staging geometry of `p` itself.  Returns KBN_ERR_UNSUPPORTED if not eligible.
 int conv_dma_launch(ConvParams& p, const ConvPlan& pl, TileChoice tc, int kernel_size, int stride,
                     hipStream_t stream);
+
+// kb_pair.hip: conv_image (3x3 s2) and conv_fused (1x1 s2) of a KB block in ONE launch -- they read the same
+// image tile.  Returns KBN_ERR_UNSUPPORTED when the shapes do not qualify (the caller then launches the two convs).
+struct KbPairArgs {
+    const float *image, *fused, *depth, *coords, *kinv, *proj, *wp_image, *wp_fused;
+    float *out_image, *out_fused;
+    long long image_bstride, fused_bstride, depth_bstride, coords_bstride, out_image_bstride, out_fused_bstride;
+    int n, height, width, channels_image, channels_depth, channels_fused, filters;
+    float slope;
+};
+int kb_pair_launch(const KbPairArgs& a, hipStream_t stream);
 
 }  // namespace kbn

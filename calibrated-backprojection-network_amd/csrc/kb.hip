@@ -10,7 +10,7 @@
 //                                                     (proj_depth dot product, xyz = coords*z)
 //                                                     happens while the tile is staged, and only
 //                                                     at the even pixels the stride-2 conv reads.
-#include "kbn_common.h"
+#include "conv_common.h"
 
 namespace kbn {
 
@@ -96,10 +96,27 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
     s_img.kind = KBN_SRC_TENSOR; s_img.channels = channels_image; s_img.data = image;
     s_img.batch_stride = image_batch_stride; s_img.src_height = height; s_img.src_width = width;
 
+    // Fast path: conv_image and conv_fused in one launch (kb_pair.hip) -- they read the same image tile.
+    bool paired = false;
+    if (filters_image == filters_fused) {
+        kbn::KbPairArgs a{};
+        a.image = image; a.fused = fused; a.depth = depth; a.coords = coordinates; a.kinv = kinv; a.proj = proj_weight;
+        a.wp_image = packed_w_image; a.wp_fused = packed_w_fused; a.out_image = out_image; a.out_fused = out_fused;
+        a.image_bstride = image_batch_stride; a.fused_bstride = fused_batch_stride; a.depth_bstride = depth_batch_stride;
+        a.coords_bstride = 3 * HW; a.out_image_bstride = out_image_batch_stride; a.out_fused_bstride = out_fused_batch_stride;
+        a.n = n; a.height = height; a.width = width; a.channels_image = channels_image; a.channels_depth = channels_depth;
+        a.channels_fused = channels_fused; a.filters = filters_image; a.slope = negative_slope;
+        rc = kbn::kb_pair_launch(a, st);
+        if (rc == KBN_OK) paired = true;
+        else if (rc != KBN_ERR_UNSUPPORTED) return rc;
+    }
+
     // conv_image = act(conv3x3 s2 (image))                      src/net_utils.py:1348
-    rc = kbn::conv2d_launch(&s_img, 1, packed_w_image, out_image, out_image_batch_stride, n, filters_image, 3, 2,
-                            height, width, KBN_RESIZE_NONE, 1, negative_slope, st);
-    if (rc != KBN_OK) return rc;
+    if (!paired) {
+        rc = kbn::conv2d_launch(&s_img, 1, packed_w_image, out_image, out_image_batch_stride, n, filters_image, 3, 2,
+                                height, width, KBN_RESIZE_NONE, 1, negative_slope, st);
+        if (rc != KBN_OK) return rc;
+    }
 
     // conv_depth = act(conv3x3 s2 (cat[depth, coordinates]))    src/net_utils.py:1351
     kbn_conv_src s_dep[2] = {};
@@ -114,6 +131,7 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
     rc = kbn::conv2d_launch(s_dep, 2, packed_w_depth, out_depth, out_depth_batch_stride, n, filters_depth, 3, 2,
                             height, width, KBN_RESIZE_NONE, 1, negative_slope, st);
     if (rc != KBN_OK) return rc;
+    if (paired) return KBN_OK;
 
     // conv_fused = act(conv1x1 s2 (cat[image, coordinates * act(proj_depth(depth)), fused]))
     //                                                            src/net_utils.py:1354-1369

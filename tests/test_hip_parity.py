@@ -266,6 +266,61 @@ def test_kb_block_golden(dev, name, mode):
     assert rel_err(cf, g["conv_fused"]) < TIGHT
 
 
+@pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [
+    (48, 16, 0, 48, 16, 36, 56),     # KB1: no fused input, 3 n-blocks
+    (48, 16, 48, 96, 32, 30, 44),    # KB2: two 48-filter tiles
+    (96, 32, 96, 192, 64, 21, 36),   # KB3: 4 n-blocks, odd height
+    (192, 64, 192, 384, 128, 11, 20),  # KB4: six 64-filter tiles
+])
+@pytest.mark.parametrize("mode", ["coordinates", "kinv"])
+def test_kb_block_paired_kernel(dev, monkeypatch, ci, cd, cf, fi, fd, h, w, mode):
+    """KBNet's own KB shapes take the one-launch conv_image + conv_fused kernel (csrc/kb_pair.hip): against the
+    oracle, and bit for bit against the two separate conv launches (KBN_NO_KB_PAIR=1) -- same accumulation order."""
+    g = torch.Generator().manual_seed(ci + cf + h)
+    n = 2
+    blk = kb.modules.CalibratedBackprojectionBlock(ci, cd, ci + cf, fi, fd, fi, 1, 1, 1, "xavier_normal",
+                                                   torch.nn.LeakyReLU(0.2)).to(dev)
+    image = torch.randn(n, ci, h, w, generator=g)
+    depth = torch.randn(n, cd, h, w, generator=g)
+    fused = torch.randn(n, cf, h, w, generator=g) if cf else None
+    k = torch.tensor([[[60.0, 0.0, w / 2.0], [0.0, 58.0, h / 2.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1)
+    k[1, 0, 0] = 71.0
+    coords = orc.camera_coordinates(k, h, w)
+    sd = {kk: v.detach().cpu() for kk, v in blk.state_dict().items()}
+    ref = orc.kb_block(image, depth, coords, fused, sd, 0.2)
+    arg = coords.to(dev) if mode == "coordinates" else kb.ops.intrinsics_inverse(k.to(dev))
+    run = lambda: [t.clone() for t in blk(image=image.to(dev), depth=depth.to(dev), coordinates=arg,
+                                          fused=None if fused is None else fused.to(dev))]
+    got = run()
+    again = run()                      # tuned tile shape: same bits
+    for a, b, r in zip(got, again, ref):
+        assert rel_err(a, r) < TIGHT
+        assert torch.equal(a, b)
+    monkeypatch.setenv("KBN_NO_KB_PAIR", "1")
+    sep = run()
+    for a, b in zip(got, sep):
+        assert torch.equal(a, b)
+
+
+def test_kb_block_paired_kernel_on_channel_slices(dev):
+    """The encoder hands the KB block channel slices of wider buffers and lets it write into slices
+    (skip = [conv_fused, conv_depth] without a concat): batch strides differ from C*H*W."""
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 2, 24, 40
+    blk = kb.modules.CalibratedBackprojectionBlock(48, 16, 48 + 48, 96, 32, 96, 1, 1, 1, "xavier_normal",
+                                                   torch.nn.LeakyReLU(0.2)).to(dev)
+    wide = torch.randn(n, 48 + 16 + 48 + 8, h, w, generator=g).to(dev)
+    image, depth, fused = wide[:, 0:48], wide[:, 48:64], wide[:, 64:112]
+    kinv = kb.ops.intrinsics_inverse(torch.tensor([[[50.0, 0.0, 20.0], [0.0, 50.0, 12.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1).to(dev))
+    ref = blk(image=image.contiguous(), depth=depth.contiguous(), coordinates=kinv, fused=fused.contiguous())
+    skip = torch.zeros(n, 96 + 32, 12, 20, device=dev)
+    out_image = torch.empty(n, 96, 12, 20, device=dev)
+    blk.run(image, depth, kinv, fused, out_image=out_image, out_depth=skip[:, 96:], out_fused=skip[:, :96])
+    assert torch.equal(out_image, ref[0])
+    assert torch.equal(skip[:, 96:], ref[1])
+    assert torch.equal(skip[:, :96], ref[2])
+
+
 # -------------------------------------------------------------------------- decoder
 @pytest.mark.parametrize("name", ["dec_even", "dec_odd"])
 def test_decoder_golden(dev, name):

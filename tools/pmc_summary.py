@@ -28,7 +28,7 @@ for k in sel:
     g = lambda n: e.get(n, float("nan"))
     dur = sum(e["_dur"]) / len(e["_dur"])
     mf = g("SQ_INSTS_MFMA") or float("nan")
-    print(f"{nm:34s} {k[1]:>8s} {dur:7.1f} {100*g('SQ_VALU_MFMA_BUSY_CYCLES')/(g('GRBM_GUI_ACTIVE')*4*256) if 'GRBM_GUI_ACTIVE' in e else 100*g('SQ_VALU_MFMA_BUSY_CYCLES')/busy/4:6.1f} "
+    print(f"{nm:34s} {k[1]:>8s} {dur:7.1f} {100*g('SQ_VALU_MFMA_BUSY_CYCLES')/(g('GRBM_GUI_ACTIVE')/8*1024) if 'GRBM_GUI_ACTIVE' in e else 100*g('SQ_VALU_MFMA_BUSY_CYCLES')/busy/4:6.1f} "
           f"{100*g('SQ_ACTIVE_INST_ANY')/wc:6.1f} {100*g('SQ_WAIT_ANY')/wc:6.1f} {100*g('SQ_WAIT_INST_ANY')/wc:6.1f} "
           f"{100*g('SQ_LDS_BANK_CONFLICT')/(g('SQ_LDS_IDX_ACTIVE') or 1):6.1f} {2*g('FETCH_SIZE')/1024:8.1f} {g('WRITE_SIZE')/1024:8.1f} "
           f"{g('SQ_INSTS_VALU')/mf:9.2f} {g('SQ_INSTS_LDS')/mf:8.2f}")
