@@ -33,7 +33,7 @@ for tag, counters in PASSES.items():
     for r in csv.DictReader(open(f)):
         if "kbn::" not in r["Kernel_Name"]:
             continue
-        name = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]
+        name = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0]
         res[name][r["Counter_Name"]] += float(r["Counter_Value"])
         if (name, r["Dispatch_Id"]) not in seen:
             seen.add((name, r["Dispatch_Id"]))
