@@ -19,7 +19,6 @@ drop-ins), but every `forward` is a sequence of HIP launches through the C ABI
 
 from __future__ import annotations
 
-import os
 from typing import List, Optional
 
 import torch
@@ -444,16 +443,16 @@ class GraphedForward:
                 self.static_out = model.forward(*self.static_in)
             else:
                 cur = torch.cuda.current_stream()
-                outs = [None] * branches
+                h, w = self.static_in[1].shape[-2:]
+                self.static_out = torch.empty((n, 1, h, w), device=self.static_in[0].device, dtype=torch.float32)
                 for s in self._streams:
                     s.wait_stream(cur)
-                for i, s in enumerate(self._streams):
+                for i, s in enumerate(self._streams):   # every branch writes its frames of the one output tensor
                     with torch.cuda.stream(s):
-                        outs[i + 1] = model.forward(*parts[i + 1])
-                outs[0] = model.forward(*parts[0])
+                        model.forward(*parts[i + 1], out=self.static_out[(i + 1) * per:(i + 2) * per])
+                model.forward(*parts[0], out=self.static_out[0:per])
                 for s in self._streams:
                     cur.wait_stream(s)
-                self.static_out = torch.cat(outs, dim=0)
 
     def __call__(self, image, sparse_depth, validity_map_depth, intrinsics):
         for dst, src in zip(self.static_in, (image, sparse_depth, validity_map_depth, intrinsics)):
@@ -508,90 +507,11 @@ class KBNetModel(object):
                    device)
 
     # -- forward ---------------------------------------------------------------
-    # Optional (KBN_OVERLAP=1): run the encoder's image / depth / fused chains on three HIP streams.
-    # Measured on MI355X at batch 8: -2 % eager, +-0 under graph replay (each kernel already fills
-    # the chip's LDS), so it is off by default.
-    overlap_streams = os.environ.get("KBN_OVERLAP", "0") not in ("", "0")
-
-    def _side_streams(self):
-        if getattr(self, "_streams", None) is None:
-            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
-        return self._streams
-
-    def _forward_overlapped(self, image, sparse_depth, validity_map_depth, intrinsics, return_logits):
-        """Same kernels as `forward`, but the encoder's three dependency chains run concurrently:
-        image chain (conv0_image -> conv_image 1..4, MFMA bound) on the caller's stream, depth
-        chain (S2D -> conv0_depth -> conv_depth 1..4 -> conv5_depth) and fused chain (conv_fused
-        1..4 -> conv5_image), both latency / staging bound, on two side streams, joined by events
-        before the decoder.  Every buffer is allocated on the caller's stream before the fork."""
-        enc = self.encoder
-        fi, fd, ff = enc._f
-        main = torch.cuda.current_stream()
-        s_dep, s_fus = self._side_streams()
-        n, _, h0, w0 = image.shape
-        dev = image.device
-        new = lambda c, h, w: torch.empty((n, c, h, w), device=dev, dtype=torch.float32)
-        image = image if _dense(image) else image.contiguous()
-        intrinsics = intrinsics.contiguous()
-        x = torch.cat([sparse_depth, validity_map_depth], dim=1)
-        sizes = [(h0, w0)]
-        for _ in range(5):
-            sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
-        s2d = new(self.sparse_to_dense_pool.conv.out_channels, h0, w0)
-        img = [new(fi[0], h0, w0)] + [new(fi[l], *sizes[l + 1]) for l in range(4)]
-        dep0 = new(fd[0], h0, w0)
-        skips = [new(ff[l] + fd[l], *sizes[l + 1]) for l in range(4)]
-        latent = new(fi[4] + fd[4], *sizes[5])
-        kinv0 = ops.intrinsics_inverse(intrinsics, 1.0, 1.0)
-        # Q1: every deeper KB level scales K by the level-1 ratio (reference src/networks.py:342-343)
-        kinv1 = ops.intrinsics_inverse(intrinsics, sizes[1][1] / w0, sizes[1][0] / h0)
-        fork = main.record_event()
-        s_dep.wait_event(fork)
-        s_fus.wait_event(fork)
-
-        s2dm = self.sparse_to_dense_pool
-        with torch.cuda.stream(s_dep):
-            ops.s2d_forward(x, [c.conv.weight for c in s2dm.pool_convs], s2dm.conv.conv.weight,
-                            s2dm.min_pool_sizes, s2dm.max_pool_sizes, s2dm._slope, out=s2d)
-            enc.conv0_depth.run([ops.tensor_src(s2d)], n, h0, w0, out=dep0)
-            e_dep = s_dep.record_event()
-        enc.conv0_image.run([ops.tensor_src(image)], n, h0, w0, out=img[0])
-        e_img = main.record_event()
-        dep_prev, fus_prev = dep0, None
-        for l in range(4):
-            blk = getattr(enc, f"calibrated_backprojection{l + 1}")
-            h, w = sizes[l]
-            kinv = kinv0 if l == 0 else kinv1
-            out_fused, out_depth = skips[l][:, :ff[l]], skips[l][:, ff[l]:]
-            with torch.cuda.stream(s_fus):  # conv_fused: needs image_{l-1}, depth_{l-1}, fused_{l-1}
-                s_fus.wait_event(e_img)
-                s_fus.wait_event(e_dep)
-                srcs = [ops.tensor_src(img[l]), ops.xyz_src(dep_prev, blk.proj_depth.conv.weight, kinv)]
-                if fus_prev is not None:
-                    srcs.append(ops.tensor_src(fus_prev))
-                blk.conv_fused.run(srcs, n, h, w, out=out_fused)
-            with torch.cuda.stream(s_dep):
-                blk.conv_depth.conv_block[0].run([ops.tensor_src(dep_prev), ops.coords_src(kinv)], n, h, w,
-                                                 out=out_depth)
-                e_dep = s_dep.record_event()
-            blk.conv_image.conv_block[0].run([ops.tensor_src(img[l])], n, h, w, out=img[l + 1])
-            e_img = main.record_event()
-            dep_prev, fus_prev = out_depth, out_fused
-        h, w = sizes[4]
-        with torch.cuda.stream(s_fus):
-            enc.conv5_image.conv_block[0].run([ops.tensor_src(fus_prev)], n, h, w, out=latent[:, :fi[4]])
-        with torch.cuda.stream(s_dep):
-            enc.conv5_depth.conv_block[0].run([ops.tensor_src(dep_prev)], n, h, w, out=latent[:, fi[4]:])
-        main.wait_stream(s_dep)
-        main.wait_stream(s_fus)
-        feats = self.decoder.features(latent, skips, (h0, w0))
-        return ops.depth_head(feats, self.decoder.output0.conv.weight, self.min_predict_depth,
-                              self.max_predict_depth, return_logits=return_logits)
-
     @torch.no_grad()
-    def forward(self, image, sparse_depth, validity_map_depth, intrinsics, return_logits=False):
-        if self.overlap_streams and self.encoder.resolutions_backprojection == [0, 1, 2, 3] and image.is_cuda:
-            return self._forward_overlapped(image, sparse_depth, validity_map_depth, intrinsics, return_logits)
+    def forward(self, image, sparse_depth, validity_map_depth, intrinsics, return_logits=False, out=None):
+        """`out` (extension): write the N x 1 x H x W depth map into this tensor instead of a new one."""
+        if out is not None and return_logits:
+            raise KbnError("out= and return_logits are mutually exclusive")
         input_depth = torch.cat([sparse_depth, validity_map_depth], dim=1)
         input_depth = self.sparse_to_dense_pool(input_depth)
         shape = input_depth.shape[-2:]
@@ -599,7 +519,7 @@ class KBNetModel(object):
         feats = self.decoder.features(latent, skips, shape)
         # output0 conv + sigmoid + d_min / (s + d_min/d_max), one kernel
         return ops.depth_head(feats, self.decoder.output0.conv.weight, self.min_predict_depth,
-                              self.max_predict_depth, return_logits=return_logits)
+                              self.max_predict_depth, return_logits=return_logits, out=out)
 
     def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None):
         """Captures one forward of this batch shape into a HIP graph and returns a callable

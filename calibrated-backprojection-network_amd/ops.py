@@ -308,7 +308,8 @@ def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_de
 
 
 # ---------------------------------------------------------------------- depth head
-def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, return_logits=False):
+def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, return_logits=False, out=None):
+    """`out`: optional contiguous N x 1 x H x W destination (e.g. a batch slice of a larger output buffer)."""
     lib = _lib.load()
     _require(x, "x", 4)
     x = x.contiguous()
@@ -317,7 +318,13 @@ def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, re
     n, c, h, wd = x.shape
     if tuple(w.shape) != (1, c, 3, 3):
         raise KbnError(f"depth head weight must be 1 x {c} x 3 x 3")
-    depth = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32)
+    if out is None:
+        depth = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32)
+    else:
+        _require(out, "out", 4)
+        if tuple(out.shape) != (n, 1, h, wd) or not out.is_contiguous():
+            raise KbnError(f"out must be a contiguous {(n, 1, h, wd)} tensor")
+        depth = out
     logits = torch.empty_like(depth) if return_logits else None
     check(_launch("depth_head", 4.0 * n * h * wd * (c + 1),
                   lambda: lib.kbn_depth_head_forward(x.data_ptr(), w.data_ptr(), depth.data_ptr(),

@@ -411,6 +411,12 @@ def test_graph_replay_with_concurrent_branches(dev):
         assert torch.equal(replay(*b), eager_b)
     with pytest.raises(kb._lib.KbnError):
         m.capture(*a, branches=3)
+    # forward(out=): the depth head writes straight into a batch slice of a caller's buffer (what the branches do)
+    buf = torch.zeros(6, 1, 64, 96, device=dev)
+    m.forward(*a, out=buf[1:5])
+    assert torch.equal(buf[1:5], eager_a) and buf[0].abs().max() == 0 and buf[5].abs().max() == 0
+    with pytest.raises(kb._lib.KbnError):
+        m.forward(*a, out=torch.zeros(4, 1, 64, 90, device=dev))
 
 
 def test_mixed_shape_stream_two_weight_sets(dev):
