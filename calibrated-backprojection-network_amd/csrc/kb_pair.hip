@@ -379,6 +379,10 @@ int kb_pair_launch(const KbPairArgs& a, hipStream_t stream) {
         const long long wgs = (long long)ceil_div(p.outW, tw) * ceil_div(p.outH, th) * a.n * p.nTilesN;
         if (wgs >= 1024) { model = c; break; }
     }
+    if (const char* f = getenv("KBN_PAIR_CAND")) {   // test hook: force a tile shape (tests/test_hip_parity.py)
+        const int c = atoi(f);
+        if (c >= 0 && c < kPairCands) return launch(c);
+    }
     const int cand = tune_pick(TuneKey{5, a.n, a.filters, a.channels_image, a.channels_fused, a.channels_depth, a.height,
                                        a.width, a.coords ? 1 : 0, 0},
                                kPairCands, model, launch, stream);

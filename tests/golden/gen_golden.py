@@ -20,7 +20,8 @@ Cases
   kb_*       net_utils.CalibratedBackprojectionBlock with / without `fused`, odd size.
   dec_*      networks.MultiScaleDecoder (n_resolution=1, 'up', linear output).
   fwd_*      KBNetModel.forward: KITTI preset, VOID preset (both narrow channels)
-             and an odd 70x100 frame.
+             and an odd 70x100 frame; fwd_kb012 / fwd_kb02: encoders with KB layers at levels
+             [0, 1, 2] / [0, 2] only (plain stride-2 blocks elsewhere).
   io/*       input pipeline: small PNG / .npy files written by this script's own PNG writer
              (every scanline filter type, split IDAT, gray / RGB / RGBA / palette / 16-bit gray) and what the
              reference's data_utils.load_image, datasets.load_image_triplet / load_depth and
@@ -224,11 +225,20 @@ def gen_decoder():
 
 
 # ----------------------------------------------------------------- full forward
-def gen_forward():
-    for name, preset, (h, w), n in (("kitti", "kitti", (64, 96), 2),
-                                    ("void", "void", (96, 128), 1),
-                                    ("odd", "void", (70, 100), 1)):
+def gen_forward(only=None):
+    import dataclasses
+    for name, preset, (h, w), n, kb_levels in (("kitti", "kitti", (64, 96), 2, None),
+                                               ("void", "void", (96, 128), 1, None),
+                                               ("odd", "void", (70, 100), 1, None),
+                                               # encoder topologies other than KBNet's [0, 1, 2, 3]: plain stride-2
+                                               # VGG blocks where a level has no KB layer (src/networks.py:150-299)
+                                               ("kb012", "kitti", (64, 96), 2, (0, 1, 2)),
+                                               ("kb02", "void", (48, 80), 1, (0, 2))):
+        if only and name not in only:
+            continue
         cfg = kb.PRESETS[preset]().narrow()
+        if kb_levels is not None:
+            cfg = dataclasses.replace(cfg, resolutions_backprojection=kb_levels)
         # gain > 1 keeps the logits O(1) (random xavier weights shrink the signal), so the
         # sigmoid head is exercised off its saturated ends
         sds = kb.synthetic.make_state_dicts(cfg, seed=5, gain=1.3 if preset == "kitti" else 1.45)
@@ -250,6 +260,7 @@ def gen_forward():
         out = model.forward(image, sparse, valid, k)
         save(f"fwd_{name}", image=image, sparse_depth=sparse, validity_map=valid, intrinsics=k,
              output_depth=out, preset=np.array(preset),
+             resolutions_backprojection=np.array(cfg.resolutions_backprojection),
              s2d=np_sd(sds[0]), encoder=np_sd(sds[1]), decoder=np_sd(sds[2]))
 
 
@@ -393,6 +404,9 @@ def gen_io():
 if __name__ == "__main__":
     if "--only-io" in sys.argv:
         gen_io()
+        sys.exit(0)
+    if "--only-topologies" in sys.argv:   # added later; leaves the other fixtures untouched
+        gen_forward(only=("kb012", "kb02"))
         sys.exit(0)
     gen_pre_eval()
     if "--only-pre-eval" in sys.argv:

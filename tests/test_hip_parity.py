@@ -302,6 +302,26 @@ def test_kb_block_paired_kernel(dev, monkeypatch, ci, cd, cf, fi, fd, h, w, mode
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [(48, 16, 48, 96, 32, 34, 72), (96, 32, 96, 192, 64, 19, 44)])
+def test_kb_block_paired_kernel_every_tile_shape(dev, monkeypatch, ci, cd, cf, fi, fd, h, w):
+    """All six (MW, TWB) tile shapes of kb_pair_kernel, for 3 and 4 n-blocks, forced through KBN_PAIR_CAND:
+    bit-identical to the two-launch path (tile geometry never changes an accumulation order)."""
+    g = torch.Generator().manual_seed(ci + h)
+    n = 2
+    blk = kb.modules.CalibratedBackprojectionBlock(ci, cd, ci + cf, fi, fd, fi, 1, 1, 1, "xavier_normal",
+                                                   torch.nn.LeakyReLU(0.2)).to(dev)
+    image, depth, fused = (torch.randn(n, c, h, w, generator=g).to(dev) for c in (ci, cd, cf))
+    kinv = kb.ops.intrinsics_inverse(torch.tensor([[[40.0, 0.0, w / 2.0], [0.0, 40.0, h / 2.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1).to(dev))
+    run = lambda: [t.clone() for t in blk(image=image, depth=depth, coordinates=kinv, fused=fused)]
+    monkeypatch.setenv("KBN_NO_KB_PAIR", "1")
+    ref = run()
+    monkeypatch.delenv("KBN_NO_KB_PAIR")
+    for cand in range(6):
+        monkeypatch.setenv("KBN_PAIR_CAND", str(cand))
+        for a, b in zip(run(), ref):
+            assert torch.equal(a, b), f"tile candidate {cand}"
+
+
 def test_kb_block_paired_kernel_on_channel_slices(dev):
     """The encoder hands the KB block channel slices of wider buffers and lets it write into slices
     (skip = [conv_fused, conv_depth] without a concat): batch strides differ from C*H*W."""
@@ -353,10 +373,14 @@ def _check_forward(out, ref):
     assert float(err) < TOL, f"max relative error {float(err):.3e}"
 
 
-@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd"])
+@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02"])
 def test_forward_golden(dev, name):
+    """fwd_kb012 / fwd_kb02: encoder topologies with plain stride-2 blocks where a level has no KB layer."""
+    import dataclasses
     g = load_golden(name)
     cfg = kb.PRESETS[str(g["preset"])]().narrow()
+    if "resolutions_backprojection" in g:
+        cfg = dataclasses.replace(cfg, resolutions_backprojection=tuple(int(v) for v in g["resolutions_backprojection"]))
     m = kb.modules.KBNetModel.from_config(cfg, dev)
     m.load_state_dicts(g["s2d"], g["encoder"], g["decoder"])
     out = m.forward(*to(dev, g["image"], g["sparse_depth"], g["validity_map"], g["intrinsics"]))

@@ -57,13 +57,16 @@ def test_decoder_matches_reference(name):
     assert torch.equal(out, g["logits"])
 
 
-@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd"])
+@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02"])
 def test_forward_matches_reference(name):
+    """fwd_kb012 / fwd_kb02: encoders with KB layers at levels [0, 1, 2] / [0, 2] only."""
     g = load_golden(name)
     cfg = kb.PRESETS[str(g["preset"])]().narrow()
+    levels = tuple(int(v) for v in g["resolutions_backprojection"]) if "resolutions_backprojection" in g else (0, 1, 2, 3)
     out = orc.kbnet_forward(g["image"], g["sparse_depth"], g["validity_map"], g["intrinsics"],
                             g["s2d"], g["encoder"], g["decoder"],
-                            cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+                            cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth,
+                            resolutions_backprojection=levels)
     assert torch.equal(out, g["output_depth"])
     assert out.min() >= cfg.min_predict_depth * 0.98 and out.max() <= cfg.max_predict_depth * 1.001
 
