@@ -443,8 +443,9 @@ int wino_pack(const float* weight, float* packed, int oc, int cin, hipStream_t s
 
 // Region shape: RT x CT tiles (CT even so that regions start on a 4-pixel boundary), chosen to
 // minimise the number of 256-workgroup rounds (one workgroup per CU), then the workgroup count.
-static const int kRegions[][2] = {{4, 16}, {8, 8}, {2, 32}, {6, 10}, {5, 12}, {3, 20}, {7, 8}, {10, 6}, {16, 4}};
-constexpr int kNumRegions = 9;
+// (every shape's staged tile, (2 RT + 2) x round_up(2 CT + 5, 4) floats per channel, fits the 512-float plane)
+static const int kRegions[][2] = {{4, 16}, {8, 8}, {2, 32}, {6, 10}, {5, 12}, {3, 20}, {7, 8}, {10, 6}};
+constexpr int kNumRegions = 8;
 
 static int choose_region(int H, int W, int n, int nTilesN) {   // index into kRegions
     const int th = ceil_div(H, 2), tw = ceil_div(W, 2);

@@ -237,6 +237,44 @@ def test_first_use_tuning_keeps_results_bitwise(dev):
         assert torch.equal(up(x, (24, 40)), first)
 
 
+def test_every_tile_and_region_shape_keeps_results_bitwise(dev, monkeypatch):
+    """The tuner may pick any tile shape of the direct kernels (MW x TWB), any Winograd region and either up-conv tile
+    width; force each one (KBN_FORCE_MW / KBN_FORCE_TWB / KBN_WINO_RT) and compare bit for bit with the default."""
+    g = torch.Generator().manual_seed(13)
+    act = torch.nn.LeakyReLU(0.2)
+    cases = [(48, 96, 3, 2, 38, 72), (12, 12, 3, 1, 40, 64), (99, 96, 1, 2, 30, 52), (64, 48, 3, 1, 26, 52)]
+    for cin, cout, k, stride, h, w in cases:
+        x = torch.randn(2, cin, h, w, generator=g).to(dev)
+        conv = kb.modules.Conv2d(cin, cout, k, stride, "xavier_normal", act).to(dev)
+        monkeypatch.setenv("KBN_NO_WINO", "1")            # the direct kernels, also for the wide 3x3 case
+        ref = conv(x).clone()
+        for mw in (1, 2, 4, 8):
+            for twb in (1, 2, 4):
+                monkeypatch.setenv("KBN_FORCE_MW", str(mw))
+                monkeypatch.setenv("KBN_FORCE_TWB", str(twb))
+                assert torch.equal(conv(x), ref), f"conv {cin}->{cout} k{k} s{stride}: MW={mw} TWB={twb}"
+        monkeypatch.delenv("KBN_FORCE_MW")
+        monkeypatch.delenv("KBN_FORCE_TWB")
+        monkeypatch.delenv("KBN_NO_WINO")
+    x = torch.randn(2, 64, 44, 72, generator=g).to(dev)
+    conv = kb.modules.Conv2d(64, 128, 3, 1, "xavier_normal", act).to(dev)
+    assert kb.ops.conv_plan(2, 128, 64, 3, 1, 44, 72)["kernel"] == "wino"
+    ref = conv(x).clone()
+    for rt in (4, 8, 2, 6, 5, 3, 7, 10):              # every entry of conv_wino.hip's kRegions
+        monkeypatch.setenv("KBN_WINO_RT", str(rt))
+        assert torch.equal(conv(x), ref), f"Winograd region with {rt} tile rows"
+    monkeypatch.delenv("KBN_WINO_RT")
+    for cin, cout, hw in ((32, 48, (12, 20)), (64, 12, (20, 36)), (64, 64, (11, 38))):
+        up = kb.modules.UpConv2d(cin, cout, 3, "xavier_normal", act).to(dev)
+        x = torch.randn(2, cin, *hw, generator=g).to(dev)
+        shape = (2 * hw[0], 2 * hw[1])
+        ref = up(x, shape).clone()
+        for twb in (1, 2):
+            monkeypatch.setenv("KBN_FORCE_TWB", str(twb))
+            assert torch.equal(up(x, shape), ref), f"up-conv {cin}->{cout}: TWB={twb}"
+        monkeypatch.delenv("KBN_FORCE_TWB")
+
+
 # ------------------------------------------------------------------------- KB block
 def _kb_module(g, dev):
     w = g["weights"]
