@@ -1,5 +1,7 @@
+"""CPU-baseline calibration: seconds per KITTI frame of the oracle (the CPU restatement of the reference) for a range of
+torch thread counts -- how bench.py's cpu_baseline chose 16 threads.  Lives under tests/ because it runs the oracle."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import kbnet_amd as kb
 from oracle import kbnet_oracle as orc
 cfg = kb.kitti_config(); sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)

@@ -6,7 +6,7 @@ usage: winograd_error.py [min_cin]"""
 import os, sys
 import torch
 import torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import kbnet_amd as kb
 from oracle import kbnet_oracle as orc
