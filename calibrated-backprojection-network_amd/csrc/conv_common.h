@@ -257,14 +257,16 @@ int conv_dma_launch(ConvParams& p, const ConvPlan& pl, TileChoice tc, int kernel
                     hipStream_t stream);
 
 // kb_pair.hip: conv_image (3x3 s2) and conv_fused (1x1 s2) of a KB block in ONE launch -- they read the same
-// image tile.  Returns KBN_ERR_UNSUPPORTED when the shapes do not qualify (the caller then launches the two convs).
+// image tile -- with conv_depth (3x3 s2 on cat[depth, coordinates]) riding along when its filters fit
+// (*depth_done).  Returns KBN_ERR_UNSUPPORTED when the shapes do not qualify (the caller then launches the convs).
 struct KbPairArgs {
-    const float *image, *fused, *depth, *coords, *kinv, *proj, *wp_image, *wp_fused;
-    float *out_image, *out_fused;
-    long long image_bstride, fused_bstride, depth_bstride, coords_bstride, out_image_bstride, out_fused_bstride;
-    int n, height, width, channels_image, channels_depth, channels_fused, filters;
+    const float *image, *fused, *depth, *coords, *kinv, *proj, *wp_image, *wp_fused, *wp_depth;
+    float *out_image, *out_fused, *out_depth;
+    long long image_bstride, fused_bstride, depth_bstride, coords_bstride, out_image_bstride, out_fused_bstride,
+        out_depth_bstride;
+    int n, height, width, channels_image, channels_depth, channels_fused, filters, filters_depth;
     float slope;
 };
-int kb_pair_launch(const KbPairArgs& a, hipStream_t stream);
+int kb_pair_launch(const KbPairArgs& a, hipStream_t stream, bool* depth_done);
 
 }  // namespace kbn

@@ -96,8 +96,9 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
     s_img.kind = KBN_SRC_TENSOR; s_img.channels = channels_image; s_img.data = image;
     s_img.batch_stride = image_batch_stride; s_img.src_height = height; s_img.src_width = width;
 
-    // Fast path: conv_image and conv_fused in one launch (kb_pair.hip) -- they read the same image tile.
-    bool paired = false;
+    // Fast path: conv_image and conv_fused in one launch (kb_pair.hip) -- they read the same image tile -- with
+    // conv_depth's MFMAs riding along in the same workgroups when its filter count fits.
+    bool paired = false, depth_done = false;
     if (filters_image == filters_fused) {
         kbn::KbPairArgs a{};
         a.image = image; a.fused = fused; a.depth = depth; a.coords = coordinates; a.kinv = kinv; a.proj = proj_weight;
@@ -106,7 +107,9 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
         a.coords_bstride = 3 * HW; a.out_image_bstride = out_image_batch_stride; a.out_fused_bstride = out_fused_batch_stride;
         a.n = n; a.height = height; a.width = width; a.channels_image = channels_image; a.channels_depth = channels_depth;
         a.channels_fused = channels_fused; a.filters = filters_image; a.slope = negative_slope;
-        rc = kbn::kb_pair_launch(a, st);
+        a.wp_depth = packed_w_depth; a.out_depth = out_depth; a.out_depth_bstride = out_depth_batch_stride;
+        a.filters_depth = filters_depth;
+        rc = kbn::kb_pair_launch(a, st, &depth_done);
         if (rc == KBN_OK) paired = true;
         else if (rc != KBN_ERR_UNSUPPORTED) return rc;
     }
@@ -128,9 +131,11 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
     } else {
         s_dep[1].kind = KBN_SRC_COORDS; s_dep[1].channels = 3; s_dep[1].kinv = kinv;
     }
-    rc = kbn::conv2d_launch(s_dep, 2, packed_w_depth, out_depth, out_depth_batch_stride, n, filters_depth, 3, 2,
-                            height, width, KBN_RESIZE_NONE, 1, negative_slope, st);
-    if (rc != KBN_OK) return rc;
+    if (!depth_done) {
+        rc = kbn::conv2d_launch(s_dep, 2, packed_w_depth, out_depth, out_depth_batch_stride, n, filters_depth, 3, 2,
+                                height, width, KBN_RESIZE_NONE, 1, negative_slope, st);
+        if (rc != KBN_OK) return rc;
+    }
     if (paired) return KBN_OK;
 
     // conv_fused = act(conv1x1 s2 (cat[image, coordinates * act(proj_depth(depth)), fused]))

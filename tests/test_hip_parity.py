@@ -312,8 +312,9 @@ def test_kb_block_golden(dev, name, mode):
 ])
 @pytest.mark.parametrize("mode", ["coordinates", "kinv"])
 def test_kb_block_paired_kernel(dev, monkeypatch, ci, cd, cf, fi, fd, h, w, mode):
-    """KBNet's own KB shapes take the one-launch conv_image + conv_fused kernel (csrc/kb_pair.hip): against the
-    oracle, and bit for bit against the two separate conv launches (KBN_NO_KB_PAIR=1) -- same accumulation order."""
+    """KBNet's own KB shapes take the one-launch KB block kernel (csrc/kb_pair.hip: conv_image + conv_fused on a
+    shared image tile, conv_depth riding along): against the oracle, and bit for bit against the three separate
+    conv launches (KBN_NO_KB_PAIR=1) -- same accumulation order."""
     g = torch.Generator().manual_seed(ci + cf + h)
     n = 2
     blk = kb.modules.CalibratedBackprojectionBlock(ci, cd, ci + cf, fi, fd, fi, 1, 1, 1, "xavier_normal",
@@ -338,17 +339,24 @@ def test_kb_block_paired_kernel(dev, monkeypatch, ci, cd, cf, fi, fd, h, w, mode
     sep = run()
     for a, b in zip(got, sep):
         assert torch.equal(a, b)
+    monkeypatch.delenv("KBN_NO_KB_PAIR")
+    monkeypatch.setenv("KBN_NO_KB_DEPTH_FUSION", "1")   # conv_image + conv_fused fused, conv_depth on its own
+    for a, b in zip(got, run()):
+        assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [(48, 16, 48, 96, 32, 34, 72), (96, 32, 96, 192, 64, 19, 44)])
+@pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [(48, 16, 0, 48, 16, 38, 68), (48, 16, 48, 96, 32, 34, 72),
+                                                (96, 32, 96, 192, 64, 19, 44)])
 def test_kb_block_paired_kernel_every_tile_shape(dev, monkeypatch, ci, cd, cf, fi, fd, h, w):
-    """All six (MW, TWB) tile shapes of kb_pair_kernel, for 3 and 4 n-blocks, forced through KBN_PAIR_CAND:
-    bit-identical to the two-launch path (tile geometry never changes an accumulation order)."""
+    """All six (MW, TWB) tile shapes of kb_pair_kernel -- 3 n-blocks with conv_depth riding along (KB1), 3 and 4
+    n-blocks without -- forced through KBN_PAIR_CAND: bit-identical to the three-launch path (tile geometry never
+    changes an accumulation order)."""
     g = torch.Generator().manual_seed(ci + h)
     n = 2
     blk = kb.modules.CalibratedBackprojectionBlock(ci, cd, ci + cf, fi, fd, fi, 1, 1, 1, "xavier_normal",
                                                    torch.nn.LeakyReLU(0.2)).to(dev)
-    image, depth, fused = (torch.randn(n, c, h, w, generator=g).to(dev) for c in (ci, cd, cf))
+    image, depth = (torch.randn(n, c, h, w, generator=g).to(dev) for c in (ci, cd))
+    fused = torch.randn(n, cf, h, w, generator=g).to(dev) if cf else None
     kinv = kb.ops.intrinsics_inverse(torch.tensor([[[40.0, 0.0, w / 2.0], [0.0, 40.0, h / 2.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1).to(dev))
     run = lambda: [t.clone() for t in blk(image=image, depth=depth, coordinates=kinv, fused=fused)]
     monkeypatch.setenv("KBN_NO_KB_PAIR", "1")
