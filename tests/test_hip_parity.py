@@ -309,6 +309,8 @@ def test_kb_block_golden(dev, name, mode):
     (48, 16, 48, 96, 32, 30, 44),    # KB2: two 48-filter tiles
     (96, 32, 96, 192, 64, 21, 36),   # KB3: 4 n-blocks, odd height
     (192, 64, 192, 384, 128, 11, 20),  # KB4: six 64-filter tiles
+    (48, 16, 0, 48, 16, 5, 8),       # a map smaller than any tile
+    (48, 16, 48, 96, 32, 3, 12),
 ])
 @pytest.mark.parametrize("mode", ["coordinates", "kinv"])
 def test_kb_block_paired_kernel(dev, monkeypatch, ci, cd, cf, fi, fd, h, w, mode):
