@@ -167,9 +167,12 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
 /* ----------------------------------------------------------- KB block ----------
  * net_utils.CalibratedBackprojectionBlock.forward(image, depth, coordinates, fused)
  *                                                  reference src/net_utils.py:1343-1371
- * Three kbn_conv2d_forward launches: conv_image (3x3 s2), conv_depth (3x3 s2 on
- * cat[depth, coordinates]) and conv_fused (1x1 s2 on cat[image, coordinates*z, fused])
- * with z = act(proj_depth(depth)) evaluated only where the stride-2 conv samples it.
+ * conv_image (3x3 s2), conv_depth (3x3 s2 on cat[depth, coordinates]) and conv_fused (1x1 s2 on
+ * cat[image, coordinates*z, fused]) with z = act(proj_depth(depth)) evaluated only where the
+ * stride-2 conv samples it.  KBNet's shapes (filters_image == filters_fused in {48, 96, 192, 384},
+ * aligned rows) run conv_image + conv_fused as ONE kernel over a shared image tile, with a
+ * 16-filter conv_depth in the same launch (csrc/kb_pair.hip); anything else takes three
+ * kbn_conv2d_forward-style launches.  Same results bit for bit either way.
  *   coordinates     N x 3 x H x W, or NULL to synthesize them from kinv (N x 3 x 3)
  *   fused           N x channels_fused x H x W or NULL (level 0)
  *   packed weights  from kbn_conv2d_pack_weight; proj_weight is the raw (1 x Cd x 1 x 1)
