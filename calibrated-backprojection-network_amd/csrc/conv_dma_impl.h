@@ -273,7 +273,12 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const
         cur ^= 1;
     }
 
-    store_tile<NB, MW>(p, acc, n, nt, oy0, ox0, wave, li, lk);
+    if (p.epi_lds) {   // launch-uniform
+        const StoreDst d{p.out, p.out_bstride, p.outH, p.outW, p.OC, p.TWB, p.act, p.slope};
+        store_tile_lds<NB, MW>(d, acc, n, nt, oy0, ox0, wave, li, lk, smem, tid);
+    } else {
+        store_tile<NB, MW>(p, acc, n, nt, oy0, ox0, wave, li, lk);
+    }
 }
 
 // ----------------------------------------------------------------- host dispatch (one tile width)
@@ -286,6 +291,7 @@ static int dma_variant(ConvParams& p, hipStream_t stream) {
         auto kern = conv_dma_kernel<KS, STRIDE, CK, NB, MW, TWB, SYN>;
         constexpr size_t lds = 2 * sizeof(float) * ((size_t)CK * G::PLANE + (size_t)CK * KS * KS * NB * 16);
         if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
+        if (lds < sizeof(float) * 16 * (64 * MW + 4)) p.epi_lds = 0;   // the LDS epilogue's scratch would not fit
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

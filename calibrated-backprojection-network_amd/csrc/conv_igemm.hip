@@ -450,6 +450,12 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     p.resize = resize; p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.nTilesN = pl.nTilesN;
     p.dbg = env_int("KBN_DEBUG");
+    {   // LDS-transposed epilogue for store-bound launches: few multiply-adds per output (conv0, deconv0's conv).
+        // KBN_EPI_LDS = 0 never / 2 always (A/B, tests); default: K = channels x taps <= 128
+        const char* e = getenv("KBN_EPI_LDS");
+        const int mode = e ? atoi(e) : 1;
+        p.epi_lds = mode == 2 || (mode == 1 && ctot * kernel_size * kernel_size <= 128);
+    }
 
     const bool s2 = (kernel_size == 3 && stride == 2);
     TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);

@@ -242,17 +242,21 @@ def test_every_tile_and_region_shape_keeps_results_bitwise(dev, monkeypatch):
     width; force each one (KBN_FORCE_MW / KBN_FORCE_TWB / KBN_WINO_RT) and compare bit for bit with the default."""
     g = torch.Generator().manual_seed(13)
     act = torch.nn.LeakyReLU(0.2)
-    cases = [(48, 96, 3, 2, 38, 72), (12, 12, 3, 1, 40, 64), (99, 96, 1, 2, 30, 52), (64, 48, 3, 1, 26, 52)]
+    cases = [(48, 96, 3, 2, 38, 72), (12, 12, 3, 1, 40, 64), (99, 96, 1, 2, 30, 52), (64, 48, 3, 1, 26, 52),
+             (3, 48, 3, 1, 37, 60), (8, 10, 3, 1, 21, 36)]    # conv0-like: odd height, 10 of 16 filters
     for cin, cout, k, stride, h, w in cases:
         x = torch.randn(2, cin, h, w, generator=g).to(dev)
         conv = kb.modules.Conv2d(cin, cout, k, stride, "xavier_normal", act).to(dev)
         monkeypatch.setenv("KBN_NO_WINO", "1")            # the direct kernels, also for the wide 3x3 case
         ref = conv(x).clone()
-        for mw in (1, 2, 4, 8):
-            for twb in (1, 2, 4):
-                monkeypatch.setenv("KBN_FORCE_MW", str(mw))
-                monkeypatch.setenv("KBN_FORCE_TWB", str(twb))
-                assert torch.equal(conv(x), ref), f"conv {cin}->{cout} k{k} s{stride}: MW={mw} TWB={twb}"
+        for epi in ("0", "2"):                            # plain epilogue / stores through LDS (store-bound layers)
+            monkeypatch.setenv("KBN_EPI_LDS", epi)
+            for mw in (1, 2, 4, 8):
+                for twb in (1, 2, 4):
+                    monkeypatch.setenv("KBN_FORCE_MW", str(mw))
+                    monkeypatch.setenv("KBN_FORCE_TWB", str(twb))
+                    assert torch.equal(conv(x), ref), f"conv {cin}->{cout} k{k} s{stride}: MW={mw} TWB={twb} epi={epi}"
+        monkeypatch.delenv("KBN_EPI_LDS")
         monkeypatch.delenv("KBN_FORCE_MW")
         monkeypatch.delenv("KBN_FORCE_TWB")
         monkeypatch.delenv("KBN_NO_WINO")
