@@ -199,7 +199,7 @@ def main():
     # Second shape north_star names (VOID 480 x 640, VOID preset, same batch): a short side measurement with
     # its own weights and graph; `value` above stays the KITTI metric.
     void_fps = None
-    if world == 1 and not args.no_void:
+    if not args.no_void:
         vcfg = kb.void_config()
         vmodel = kb.modules.KBNetModel.from_config(vcfg, dev)
         vmodel.load_state_dicts(*kb.synthetic.make_state_dicts(vcfg, seed=0, gain=1.45))
@@ -208,11 +208,14 @@ def main():
         for _ in range(3):
             vreplay(*vframes)
         torch.cuda.synchronize()
+        kb.dist.barrier()
         t3 = time.perf_counter()
         for _ in range(10):
             vreplay(*vframes)
         torch.cuda.synchronize()
-        void_fps = per * 10 / (time.perf_counter() - t3)
+        kb.dist.barrier()
+        # all ranks run their 8 frames at the same time: whole-job rate = frames of all ranks / slowest rank's time
+        void_fps = per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t3, dev)
         del vreplay, vmodel, vframes
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -267,6 +270,7 @@ def main():
                              f"HIP graph replay, {getattr(forward, 'branches', 1)} concurrent sub-batch branch(es)",
                    "eager_ms_per_step_with_event_timing": round(eager_ms, 4),
                    "reference_style_region_ms_per_step": round(refstyle_ms, 4),
+                   # side measurement: VOID preset, 480x640, same batch per GPU, forward only (no all-gather)
                    "void_480x640_frames_per_s": None if void_fps is None else round(void_fps, 1)},
         "roofline": roofline, "kernels": breakdown,
     }
