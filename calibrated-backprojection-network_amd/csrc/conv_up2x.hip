@@ -80,9 +80,49 @@ __global__ void pack_up2x_kernel(const float* __restrict__ w, float* __restrict_
     packed[e] = v;
 }
 
+// 3-product form of the two column phases (used by conv_up2x_dma_kernel<..., T3 = true>).  With the row-summed
+// column filter (g0, g1, g2) of a row phase / row tap, the two output columns of low-res pixel x are
+//     o0 = g0 in[x-1] + (g1 + g2) in[x]   =  (-g0) (in[x] - in[x-1]) + G in[x]
+//     o1 = (g0 + g1) in[x] + g2 in[x+1]   =    g2  (in[x+1] - in[x]) + G in[x],      G = g0 + g1 + g2:
+// three products (L = -g0 on the left difference, C = G on the pixel, R = g2 on the right difference) instead of
+// the four of the plain 4-phase form -- 3/4 of the MFMAs, the differences cost two VALU subtractions per fragment.
+// Layout per (row phase, n-tile): [chunk of 8 ch][dy][c4][L, C, R][4 x NT fragment block]; sums in fp64.
+__global__ void pack_up2x3_kernel(const float* __restrict__ w, float* __restrict__ packed, int OC, int Cin,
+                                  Up2xPlan pl, long long total) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int NT = pl.NT;
+    const long long per_nt = (long long)pl.Cpad * 6 * NT;
+    const long long per_a = per_nt * pl.nTilesN;
+    const int a = (int)(e / per_a);
+    long long rem = e - a * per_a;
+    const int nt = (int)(rem / per_nt);
+    int r = (int)(rem - nt * per_nt);
+    const int chunk = r / (48 * NT); r -= chunk * 48 * NT;
+    const int dy = r / (24 * NT); r -= dy * 24 * NT;
+    const int c4 = r / (12 * NT); r -= c4 * 12 * NT;
+    const int m = r / (4 * NT); r -= m * 4 * NT;
+    const int khalf = r / (2 * NT); r -= khalf * 2 * NT;
+    const int nn = r >> 1, klow = r & 1;
+    const int c = chunk * 8 + c4 * 4 + khalf * 2 + klow;
+    const int oc = nt * NT + nn;
+    float v = 0.f;
+    if (c < Cin && oc < OC) {
+        const float* wk = w + ((long long)oc * Cin + c) * 9;
+        const int ky0 = (a == 0) ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2);
+        const int ky1 = (a == 0) ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+        double g[3] = {0.0, 0.0, 0.0};
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = 0; kx < 3; ++kx) g[kx] += (double)wk[ky * 3 + kx];
+        v = (float)(m == 0 ? -g[0] : (m == 1 ? g[0] + g[1] + g[2] : g[2]));
+    }
+    packed[e] = v;
+}
+
 struct Up2xParams {
     const float* src;
     const float* wp;
+    const float* wp3;   // 3-product weights (behind the 4-phase ones in the packed blob)
     float* out;
     long long src_bstride, out_bstride;
     int N, Cin, Cpad, OC, srcH, srcW;
@@ -298,7 +338,7 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_kernel(cons
 // above spends ~0.3 of them per MFMA on addresses and masks, this one none.
 // GR = floats per DMA granule: 4 (16-byte granules, maps with W % 4 == 0) or 1 (dword granules, any map --
 // e.g. the 11 x 38 latent of a KITTI frame).
-template <int NB, int MW, int TWB, int GR>
+template <int NB, int MW, int TWB, int GR, bool T3 = false>
 struct Up2xGeom {
     static constexpr int NT = NB * 16;
     static constexpr int TH = 4 * MW / TWB, TW = TWB * 16;
@@ -307,12 +347,12 @@ struct Up2xGeom {
     static constexpr int PLANE = ((ROWS * COLS + 15) / 32) * 32 + 16;
     static constexpr int NF4 = ROWS * COLS / GR;                 // granules per channel
     static constexpr int MAXJ = (NF4 + 63) / 64;
-    static constexpr int A_FLOATS = 8 * PLANE, B_FLOATS = 8 * 8 * NT, BUF = A_FLOATS + B_FLOATS;
+    static constexpr int A_FLOATS = 8 * PLANE, B_FLOATS = 8 * (T3 ? 6 : 8) * NT, BUF = A_FLOATS + B_FLOATS;
 };
 
-template <int NB, int MW, int TWB, int GR>
+template <int NB, int MW, int TWB, int GR, bool T3>
 __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(const Up2xParams p) {
-    using G = Up2xGeom<NB, MW, TWB, GR>;
+    using G = Up2xGeom<NB, MW, TWB, GR, T3>;
     constexpr int NT = G::NT, PLANE = G::PLANE, PITCH = G::COLS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -356,9 +396,10 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
     }
     const int boff = G::A_FLOATS + (lk >> 1) * 2 * NT + li * 2 + (lk & 1);
 
-    f32x4 acc[2][MW][NB];
+    constexpr int NACC = T3 ? 3 : 2;   // T3: left-difference, centre and right-difference products
+    f32x4 acc[NACC][MW][NB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NACC; ++b)
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
@@ -367,7 +408,8 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
     const int HW = p.srcH * p.srcW;
     // wave-uniform staging state (SGPRs): plane of channel (c0 + wave) and this wave's weight granules
     const float* aptr = uniform_ptr(p.src + (long long)n * p.src_bstride + (long long)wave * HW);
-    const float* bptr = uniform_ptr(p.wp + ((long long)a * p.nTilesN + nt) * p.Cpad * 8 * NT + wave * 256);
+    const float* bptr = T3 ? uniform_ptr(p.wp3 + ((long long)a * p.nTilesN + nt) * p.Cpad * 6 * NT)
+                           : uniform_ptr(p.wp + ((long long)a * p.nTilesN + nt) * p.Cpad * 8 * NT + wave * 256);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const unsigned uv = (unsigned)(lane * 16);
 
@@ -381,9 +423,19 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
                 else lds_dma4_sm(aptr + (long long)(4 * t) * HW, gv[j], dst + j * 256, gm[j]);
             }
         }
-        const unsigned bdst = lds0 + 4u * (unsigned)(buf * G::BUF + G::A_FLOATS + wave * 256);
+        if constexpr (T3) {   // 48 * NT floats: not always a whole number of 1 KiB rounds -> masked tail
+            constexpr int n4 = G::B_FLOATS / 4;
+            const unsigned bdst = lds0 + 4u * (unsigned)(buf * G::BUF + G::A_FLOATS);
 #pragma unroll
-        for (int e = 0; e < G::B_FLOATS / 1024; ++e) lds_dma16_s(bptr + e * 1024, uv, bdst + e * 4096);
+            for (int e0 = 0; e0 < n4; e0 += 256) {
+                const int eb = e0 + wave * 64;
+                if (eb + lane < n4) lds_dma16_s(bptr + eb * 4, uv, bdst + eb * 16);
+            }
+        } else {
+            const unsigned bdst = lds0 + 4u * (unsigned)(buf * G::BUF + G::A_FLOATS + wave * 256);
+#pragma unroll
+            for (int e = 0; e < G::B_FLOATS / 1024; ++e) lds_dma16_s(bptr + e * 1024, uv, bdst + e * 4096);
+        }
         aptr += (long long)8 * HW;
         bptr += G::B_FLOATS;
     };
@@ -395,12 +447,32 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
 #pragma unroll
             for (int c4 = 0; c4 < 2; ++c4) {
                 const float* Ab = S + c4 * 4 * PLANE + dy * PITCH;
-                const float* Bb = S + (dy * 2 + c4) * 16 * NT + boff;
-                float av[MW][3], bv[2][2][NB];
+                float av[MW][3];
 #pragma unroll
                 for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) av[mi][j] = Ab[mbase[mi] + j];
+                if constexpr (T3) {
+                    const float* Bb = S + (dy * 2 + c4) * 12 * NT + boff;
+                    float b3[3][NB];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) b3[m][nb] = Bb[m * 4 * NT + nb * 32];
+#pragma unroll
+                    for (int mi = 0; mi < MW; ++mi) {
+                        const float dl = av[mi][1] - av[mi][0], dr = av[mi][2] - av[mi][1];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            acc[0][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dl, b3[0][nb], acc[0][mi][nb], 0, 0, 0);
+                            acc[1][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][1], b3[1][nb], acc[1][mi][nb], 0, 0, 0);
+                            acc[NACC - 1][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dr, b3[2][nb], acc[NACC - 1][mi][nb], 0, 0, 0);
+                        }
+                    }
+                    continue;
+                }
+                const float* Bb = S + (dy * 2 + c4) * 16 * NT + boff;
+                float bv[2][2][NB];
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
@@ -445,13 +517,25 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_up2x_dma_kernel(
         __syncthreads();
     }
 
-    up2x_store<NB, MW>(p, acc, n, nt, a, y0, x0, TWB, wave, li, lk);
+    if constexpr (T3) {   // o0 = L + C, o1 = R + C
+        f32x4 o[2][MW][NB];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                o[0][mi][nb] = acc[0][mi][nb] + acc[1][mi][nb];
+                o[1][mi][nb] = acc[NACC - 1][mi][nb] + acc[1][mi][nb];
+            }
+        up2x_store<NB, MW>(p, o, n, nt, a, y0, x0, TWB, wave, li, lk);
+    } else {
+        up2x_store<NB, MW>(p, acc, n, nt, a, y0, x0, TWB, wave, li, lk);
+    }
 }
 
-template <int NB, int MW, int TWB, int GR = 4>
+template <int NB, int MW, int TWB, int GR = 4, bool T3 = false>
 static int up2x_dma_variant(Up2xParams& p, hipStream_t stream) {
-    using G = Up2xGeom<NB, MW, TWB, GR>;
-    auto kern = conv_up2x_dma_kernel<NB, MW, TWB, GR>;
+    using G = Up2xGeom<NB, MW, TWB, GR, T3>;
+    auto kern = conv_up2x_dma_kernel<NB, MW, TWB, GR, T3>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -485,6 +569,31 @@ static int up2x_variant(const Up2xParams& p, size_t lds, hipStream_t stream) {
     return KBN_OK;
 }
 
+// (NB, half-size tile, TWB) -> instantiated LDS-DMA kernel, plain 4-phase (T3 = false) or 3-product form
+template <bool T3, int GR>
+static int up2x_dma_pick(Up2xParams& q, int NB, int half, int t, hipStream_t st) {
+    if constexpr (GR == 4) {
+        switch (NB * 100 + half * 10 + t) {
+            case 101: return up2x_dma_variant<1, 4, 1, 4, T3>(q, st);
+            case 102: return up2x_dma_variant<1, 4, 2, 4, T3>(q, st);
+            case 201: return up2x_dma_variant<2, 4, 1, 4, T3>(q, st);
+            case 202: return up2x_dma_variant<2, 4, 2, 4, T3>(q, st);
+            default: break;
+        }
+    }
+    if (NB < 3) return KBN_ERR_UNSUPPORTED;
+    switch ((NB == 3 ? 300 : 400) + half * 10 + t) {   // dword granules (GR = 1): wide outputs only
+        case 301: return up2x_dma_variant<3, 2, 1, GR, T3>(q, st);
+        case 302: return up2x_dma_variant<3, 2, 2, GR, T3>(q, st);
+        case 311: return up2x_dma_variant<3, 1, 1, GR, T3>(q, st);
+        case 312: return up2x_dma_variant<3, 1, 2, GR, T3>(q, st);
+        case 401: return up2x_dma_variant<4, 2, 1, GR, T3>(q, st);
+        case 402: return up2x_dma_variant<4, 2, 2, GR, T3>(q, st);
+        case 411: return up2x_dma_variant<4, 1, 1, GR, T3>(q, st);
+        default: return up2x_dma_variant<4, 1, 2, GR, T3>(q, st);
+    }
+}
+
 }  // namespace kbn
 
 extern "C" {
@@ -492,7 +601,7 @@ extern "C" {
 size_t kbn_upconv2x_packed_weight_bytes(int out_channels, int in_channels) {
     if (out_channels < 1 || in_channels < 1) return 0;
     kbn::Up2xPlan pl = kbn::make_up2x_plan(out_channels, in_channels);
-    return sizeof(float) * 2 * (size_t)pl.nTilesN * pl.Cpad * 8 * pl.NT;
+    return sizeof(float) * 2 * (size_t)pl.nTilesN * pl.Cpad * (8 + 6) * pl.NT;   // 4-phase weights + 3-product weights
 }
 
 int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
@@ -502,6 +611,10 @@ int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channel
     long long total = 2LL * pl.nTilesN * pl.Cpad * 8 * pl.NT;
     hipLaunchKernelGGL(kbn::pack_up2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, weight, packed, out_channels, in_channels, pl, total);
+    KBN_CHECK_LAUNCH();
+    const long long total3 = 2LL * pl.nTilesN * pl.Cpad * 6 * pl.NT;
+    hipLaunchKernelGGL(kbn::pack_up2x3_kernel, dim3((unsigned)((total3 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, weight, packed + total, out_channels, in_channels, pl, total3);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
@@ -517,6 +630,7 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
     const Up2xPlan pl = make_up2x_plan(out_channels, in_channels);
     Up2xParams p;
     p.src = src; p.wp = packed_weight; p.out = out;
+    p.wp3 = packed_weight + 2LL * pl.nTilesN * pl.Cpad * 8 * pl.NT;
     p.src_bstride = src_batch_stride; p.out_bstride = out_batch_stride;
     p.N = n; p.Cin = in_channels; p.Cpad = pl.Cpad; p.OC = out_channels;
     p.srcH = src_height; p.srcW = src_width;
@@ -539,48 +653,32 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
                 if (cost < best) { best = cost; twb = t; }
             }
         }
+        // The 3-product form (3/4 of the MFMAs, see pack_up2x3_kernel) is a property of the layer, not a tuning
+        // choice: it rounds differently from the 4-phase form, and results must not depend on the batch size or on
+        // what the tuner measured.  The tuner only picks the tile shape (bit-identical among themselves).
+        const int t3 = getenv("KBN_NO_UP2X3") ? 0 : 1;
         auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
             Up2xParams q = p;
-            const int t = (cand & 1) + 1, half = cand >> 1;
+            const int t = (cand & 1) + 1, half = (cand >> 1) & 1;
             if (half && pl.NB < 3) return (int)KBN_ERR_UNSUPPORTED;
-            switch (pl.NB * 100 + half * 10 + t) {
-                case 101: return up2x_dma_variant<1, 4, 1>(q, st);
-                case 102: return up2x_dma_variant<1, 4, 2>(q, st);
-                case 201: return up2x_dma_variant<2, 4, 1>(q, st);
-                case 202: return up2x_dma_variant<2, 4, 2>(q, st);
-                case 301: return up2x_dma_variant<3, 2, 1>(q, st);
-                case 302: return up2x_dma_variant<3, 2, 2>(q, st);
-                case 311: return up2x_dma_variant<3, 1, 1>(q, st);
-                case 312: return up2x_dma_variant<3, 1, 2>(q, st);
-                case 401: return up2x_dma_variant<4, 2, 1>(q, st);
-                case 402: return up2x_dma_variant<4, 2, 2>(q, st);
-                case 411: return up2x_dma_variant<4, 1, 1>(q, st);
-                default: return up2x_dma_variant<4, 1, 2>(q, st);
-            }
+            return t3 ? up2x_dma_pick<true, 4>(q, pl.NB, half, t, st) : up2x_dma_pick<false, 4>(q, pl.NB, half, t, st);
         };
         int cand = twb - 1;
-        if (!ftw) cand = tune_pick(TuneKey{3, n, out_channels, in_channels, src_height, src_width, 0, 0, 0, 0}, 4, cand, launch, st);
+        if (!ftw) cand = tune_pick(TuneKey{3, n, out_channels, in_channels, src_height, src_width, t3, 0, 0, 0}, 4, cand, launch, st);
         return launch(cand);
     }
     // maps whose rows are not 16-byte aligned: the same kernel with dword DMA granules (wide outputs only)
     if (!aligned && pl.NB >= 3 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad && !getenv("KBN_NO_UP2X_DMA") &&
         !getenv("KBN_UP_MW")) {
+        const int t3 = getenv("KBN_NO_UP2X3") ? 0 : 1;
         auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
             Up2xParams q = p;
-            switch ((pl.NB == 3 ? 300 : 400) + (cand >> 1) * 10 + (cand & 1) + 1) {
-                case 301: return up2x_dma_variant<3, 2, 1, 1>(q, st);
-                case 302: return up2x_dma_variant<3, 2, 2, 1>(q, st);
-                case 311: return up2x_dma_variant<3, 1, 1, 1>(q, st);
-                case 312: return up2x_dma_variant<3, 1, 2, 1>(q, st);
-                case 401: return up2x_dma_variant<4, 2, 1, 1>(q, st);
-                case 402: return up2x_dma_variant<4, 2, 2, 1>(q, st);
-                case 411: return up2x_dma_variant<4, 1, 1, 1>(q, st);
-                default: return up2x_dma_variant<4, 1, 2, 1>(q, st);
-            }
+            const int t = (cand & 1) + 1, half = (cand >> 1) & 1;
+            return t3 ? up2x_dma_pick<true, 1>(q, pl.NB, half, t, st) : up2x_dma_pick<false, 1>(q, pl.NB, half, t, st);
         };
         const long long tiles2 = (long long)ceil_div(src_width, 16) * ceil_div(src_height, 4 * pl.MW) * n * pl.nTilesN * 2;
         const int model = tiles2 <= 512 ? 2 : 0;   // small maps: half-size tiles (see below)
-        const int cand = tune_pick(TuneKey{4, n, out_channels, in_channels, src_height, src_width, 0, 0, 0, 0}, 4, model, launch, st);
+        const int cand = tune_pick(TuneKey{4, n, out_channels, in_channels, src_height, src_width, t3, 0, 0, 0}, 4, model, launch, st);
         return launch(cand);
     }
     // tile: 4*MW m-blocks of 16 low-res pixels, 16 or 32 wide; a lone workgroup round is avoided.
