@@ -279,7 +279,8 @@ def test_every_tile_and_region_shape_keeps_results_bitwise(dev, monkeypatch):
         monkeypatch.delenv("KBN_FORCE_TWB")
 
 
-@pytest.mark.parametrize("cin,cout,hw", [(64, 12, (20, 36)), (128, 64, (12, 24)), (256, 128, (11, 38)), (32, 48, (9, 20))])
+@pytest.mark.parametrize("cin,cout,hw", [(64, 12, (20, 36)), (128, 64, (12, 24)), (256, 128, (11, 38)), (32, 48, (9, 20)),
+                                         (48, 32, (7, 16)), (16, 20, (5, 12))])
 def test_upconv2x_three_product_form_vs_four_phase(dev, monkeypatch, cin, cout, hw):
     """The LDS-DMA up-conv kernels run the 3-product form of the column phases (3/4 of the MFMAs, two differences
     per fragment, csrc/conv_up2x.hip); KBN_NO_UP2X3=1 runs the plain 4-phase form.  Both against the oracle, and
