@@ -123,6 +123,7 @@ struct Up2xParams {
     const float* src;
     const float* wp;
     const float* wp3;   // 3-product weights (behind the 4-phase ones in the packed blob)
+    const float* wp9;   // 9-product weights (behind those)
     float* out;
     long long src_bstride, out_bstride;
     int N, Cin, Cpad, OC, srcH, srcW;
@@ -569,6 +570,240 @@ static int up2x_variant(const Up2xParams& p, size_t lds, hipStream_t stream) {
     return KBN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 9-product form: the 3-product identity (pack_up2x3_kernel) along the rows as well.  A workgroup covers BOTH row
+// phases of its low-res tile: per pixel and channel the 3x3 neighbourhood gives 9 values -- rows (in[y]-in[y-1],
+// in[y], in[y+1]-in[y]) x columns likewise -- and 9 channel-GEMMs with the weights T w T^t,
+// T = [[-1,0,0],[1,1,1],[0,0,1]], accumulate P[i][m]; the four outputs of the pixel are
+// o(a,b) = P[ia][jb] + P[ia][C] + P[C][jb] + P[C][C]  (ia = L for the upper output row, R for the lower; jb likewise).
+// 9 products per low-res pixel instead of the 12 of two 3-product row phases (16 of the plain 4-phase form); the
+// 12 subtractions per fragment run on the vector ALU.  9 accumulator sets limit the tile to 2 n-blocks x 2 m-blocks
+// (or 1 x 4 for <= 16 filters).
+struct Up2x9Plan { int NB, MW, NT, nTilesN; };
+__host__ __device__ inline bool up2x9_eligible(int oc) { return oc <= 16 || (oc % 32) == 0; }
+__host__ __device__ inline Up2x9Plan make_up2x9_plan(int oc) {
+    Up2x9Plan q;
+    if (oc <= 16) { q.NB = 1; q.MW = 4; } else { q.NB = 2; q.MW = 2; }
+    q.NT = q.NB * 16;
+    q.nTilesN = ceil_div(oc, q.NT);
+    return q;
+}
+
+// layout per n-tile: [chunk of 8 ch][c4][i*3+m][4 x NT fragment block]
+__global__ void pack_up2x9_kernel(const float* __restrict__ w, float* __restrict__ packed, int OC, int Cin, int Cpad,
+                                  Up2x9Plan q, long long total) {
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int NT = q.NT;
+    const long long per_nt = (long long)Cpad * 9 * NT;
+    const int nt = (int)(e / per_nt);
+    int r = (int)(e - nt * per_nt);
+    const int chunk = r / (72 * NT); r -= chunk * 72 * NT;
+    const int c4 = r / (36 * NT); r -= c4 * 36 * NT;
+    const int im = r / (4 * NT); r -= im * 4 * NT;
+    const int khalf = r / (2 * NT); r -= khalf * 2 * NT;
+    const int nn = r >> 1, klow = r & 1;
+    const int c = chunk * 8 + c4 * 4 + khalf * 2 + klow;
+    const int oc = nt * NT + nn;
+    float v = 0.f;
+    if (c < Cin && oc < OC) {
+        const float* wk = w + ((long long)oc * Cin + c) * 9;
+        const double T[3][3] = {{-1.0, 0.0, 0.0}, {1.0, 1.0, 1.0}, {0.0, 0.0, 1.0}};
+        const int i = im / 3, m = im - i * 3;
+        double acc = 0.0;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) acc += T[i][ky] * (double)wk[ky * 3 + kx] * T[m][kx];
+        v = (float)acc;
+    }
+    packed[e] = v;
+}
+
+template <int NB, int MW, int TWB>
+struct Up2x9Geom {
+    static constexpr int NT = NB * 16;
+    static constexpr int TH = 4 * MW / TWB, TW = TWB * 16;
+    static constexpr int ROWS = TH + 2, COLS = TW + 8;            // rows y0-1 .. y0+TH, columns x0-4 .. x0+TW+3
+    static constexpr int PLANE = ((ROWS * COLS + 15) / 32) * 32 + 16;
+    static constexpr int NF4 = ROWS * COLS / 4;
+    static constexpr int MAXJ = (NF4 + 63) / 64;
+    static constexpr int A_FLOATS = 8 * PLANE, B_FLOATS = 72 * NT, BUF = A_FLOATS + B_FLOATS;
+};
+
+template <int NB, int MW, int TWB>
+__global__ __launch_bounds__(256, 2) void conv_up2x9_kernel(const Up2xParams p) {
+    using G = Up2x9Geom<NB, MW, TWB>;
+    constexpr int NT = G::NT, PLANE = G::PLANE, PITCH = G::COLS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int y0 = ty * G::TH, x0 = tx * G::TW;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+
+    unsigned gv[G::MAXJ];
+    unsigned long long gm[G::MAXJ];
+#pragma unroll
+    for (int j = 0; j < G::MAXJ; ++j) {
+        const int f = j * 64 + lane;
+        int g = -1;
+        if (f < G::NF4) {
+            const int r = f / (PITCH / 4), cv = f - r * (PITCH / 4);
+            const int Y = y0 - 1 + r, X = x0 - 4 + cv * 4;
+            if (Y >= 0 && Y < p.srcH && X >= 0 && X < p.srcW) g = (Y * p.srcW + X) * 4;
+        }
+        gv[j] = g < 0 ? 0u : (unsigned)g;
+        gm[j] = __ballot(g >= 0);
+    }
+
+    int mbase[MW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int mb = wave * MW + mi;
+        const int oy = mb / TWB, seg = mb - oy * TWB;
+        mbase[mi] = oy * PITCH + seg * 16 + li + 3 + lk * PLANE;   // (row y-1, column x-1) of the lane's pixel
+    }
+    const int boff = G::A_FLOATS + (lk >> 1) * 2 * NT + li * 2 + (lk & 1);
+
+    f32x4 acc[9][MW][NB];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[q][mi][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int HW = p.srcH * p.srcW;
+    const float* aptr = uniform_ptr(p.src + (long long)n * p.src_bstride + (long long)wave * HW);
+    const float* bptr = uniform_ptr(p.wp9 + (long long)nt * p.Cpad * 9 * NT);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned uv = (unsigned)(lane * 16);
+
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned dst = lds0 + 4u * (unsigned)(buf * G::BUF + (wave + 4 * t) * PLANE);
+#pragma unroll
+            for (int j = 0; j < G::MAXJ; ++j) lds_dma16_sm(aptr + (long long)(4 * t) * HW, gv[j], dst + j * 1024, gm[j]);
+        }
+        constexpr int n4 = G::B_FLOATS / 4;
+        const unsigned bdst = lds0 + 4u * (unsigned)(buf * G::BUF + G::A_FLOATS);
+#pragma unroll
+        for (int e0 = 0; e0 < n4; e0 += 256) {
+            const int eb = e0 + wave * 64;
+            if (eb + lane < n4) lds_dma16_s(bptr + eb * 4, uv, bdst + eb * 16);
+        }
+        aptr += (long long)8 * HW;
+        bptr += G::B_FLOATS;
+    };
+    auto compute = [&](auto par) {
+        constexpr int PAR = decltype(par)::value;
+        const float* S = smem + PAR * G::BUF;
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+            const float* Ab = S + c4 * 4 * PLANE;
+            const float* Bb = S + c4 * 36 * NT + boff;
+            float d[MW][9], b9[9][NB];
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi) {
+                float r[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) r[i][j] = Ab[mbase[mi] + i * PITCH + j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {           // rows: upper difference, centre, lower difference
+                    const float u0 = r[1][j] - r[0][j], u2 = r[2][j] - r[1][j];
+                    r[0][j] = u0; r[2][j] = u2;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {           // columns likewise
+                    d[mi][i * 3 + 0] = r[i][1] - r[i][0];
+                    d[mi][i * 3 + 1] = r[i][1];
+                    d[mi][i * 3 + 2] = r[i][2] - r[i][1];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) b9[q][nb] = Bb[q * 4 * NT + nb * 32];
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[q][mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[mi][q], b9[q][nb], acc[q][mi][nb], 0, 0, 0);
+        }
+    };
+
+    {
+        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int e = tid * 4; e < G::A_FLOATS; e += 1024) {
+            *reinterpret_cast<f32x4*>(smem + e) = zero;
+            *reinterpret_cast<f32x4*>(smem + G::BUF + e) = zero;
+        }
+    }
+    __syncthreads();
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nch = p.Cpad / 8;   // even (launcher)
+    for (int c = 0; c < nch; c += 2) {
+        stage(1);
+        compute(IC2<0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 2 < nch) stage(0);
+        compute(IC2<1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {                       // upper / lower output row of every low-res row
+        const int ia = a == 0 ? 0 : 2;
+        f32x4 o[2][MW][NB];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f32x4 cc = acc[4][mi][nb];
+                o[0][mi][nb] = (acc[ia * 3 + 0][mi][nb] + acc[ia * 3 + 1][mi][nb]) + (acc[3][mi][nb] + cc);
+                o[1][mi][nb] = (acc[ia * 3 + 2][mi][nb] + acc[ia * 3 + 1][mi][nb]) + (acc[5][mi][nb] + cc);
+            }
+        up2x_store<NB, MW>(p, o, n, nt, a, y0, x0, TWB, wave, li, lk);
+    }
+}
+
+template <int NB, int MW, int TWB>
+static int up2x9_variant(Up2xParams& p, hipStream_t stream) {
+    using G = Up2x9Geom<NB, MW, TWB>;
+    auto kern = conv_up2x9_kernel<NB, MW, TWB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return KBN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    p.TWB = TWB; p.TH = G::TH;
+    p.tilesX = ceil_div(p.srcW, G::TW); p.tilesY = ceil_div(p.srcH, G::TH);
+    const long long nb64 = (long long)p.tilesX * p.tilesY * p.N * p.nTilesN;
+    if (nb64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.nblocks = (int)nb64;
+    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), 2 * sizeof(float) * G::BUF, stream, p);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
 // (NB, half-size tile, TWB) -> instantiated LDS-DMA kernel, plain 4-phase (T3 = false) or 3-product form
 template <bool T3, int GR>
 static int up2x_dma_pick(Up2xParams& q, int NB, int half, int t, hipStream_t st) {
@@ -601,7 +836,12 @@ extern "C" {
 size_t kbn_upconv2x_packed_weight_bytes(int out_channels, int in_channels) {
     if (out_channels < 1 || in_channels < 1) return 0;
     kbn::Up2xPlan pl = kbn::make_up2x_plan(out_channels, in_channels);
-    return sizeof(float) * 2 * (size_t)pl.nTilesN * pl.Cpad * (8 + 6) * pl.NT;   // 4-phase weights + 3-product weights
+    size_t floats = 2 * (size_t)pl.nTilesN * pl.Cpad * (8 + 6) * pl.NT;   // 4-phase weights + 3-product weights
+    if (kbn::up2x9_eligible(out_channels)) {                               // + 9-product weights
+        const kbn::Up2x9Plan q = kbn::make_up2x9_plan(out_channels);
+        floats += (size_t)q.nTilesN * pl.Cpad * 9 * q.NT;
+    }
+    return sizeof(float) * floats;
 }
 
 int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
@@ -616,6 +856,13 @@ int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channel
     hipLaunchKernelGGL(kbn::pack_up2x3_kernel, dim3((unsigned)((total3 + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, weight, packed + total, out_channels, in_channels, pl, total3);
     KBN_CHECK_LAUNCH();
+    if (kbn::up2x9_eligible(out_channels)) {
+        const kbn::Up2x9Plan q = kbn::make_up2x9_plan(out_channels);
+        const long long total9 = (long long)q.nTilesN * pl.Cpad * 9 * q.NT;
+        hipLaunchKernelGGL(kbn::pack_up2x9_kernel, dim3((unsigned)((total9 + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, weight, packed + total + total3, out_channels, in_channels, pl.Cpad, q, total9);
+        KBN_CHECK_LAUNCH();
+    }
     return KBN_OK;
 }
 
@@ -631,6 +878,7 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
     Up2xParams p;
     p.src = src; p.wp = packed_weight; p.out = out;
     p.wp3 = packed_weight + 2LL * pl.nTilesN * pl.Cpad * 8 * pl.NT;
+    p.wp9 = p.wp3 + 2LL * pl.nTilesN * pl.Cpad * 6 * pl.NT;
     p.src_bstride = src_batch_stride; p.out_bstride = out_batch_stride;
     p.N = n; p.Cin = in_channels; p.Cpad = pl.Cpad; p.OC = out_channels;
     p.srcH = src_height; p.srcW = src_width;
@@ -652,6 +900,20 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
                 const double cost = (double)((tiles + 511) / 512) * (4 * pl.MW * 16.0 + 0.1 * (th + 1) * (tw + 8));
                 if (cost < best) { best = cost; twb = t; }
             }
+        }
+        // 9-product form (both row phases in one workgroup) where the filter count allows; like the 3-product form a
+        // property of the layer (it rounds differently), never a tuner choice -- the tuner only picks the tile width.
+        if (up2x9_eligible(out_channels) && !getenv("KBN_NO_UP2X9") && !getenv("KBN_NO_UP2X3")) {
+            const Up2x9Plan q9 = make_up2x9_plan(out_channels);
+            auto launch9 = [&](int cand) -> int {   // candidate = TWB - 1
+                Up2xParams q = p;
+                q.nTilesN = q9.nTilesN;
+                if (q9.NB == 1) return cand ? up2x9_variant<1, 4, 2>(q, st) : up2x9_variant<1, 4, 1>(q, st);
+                return cand ? up2x9_variant<2, 2, 2>(q, st) : up2x9_variant<2, 2, 1>(q, st);
+            };
+            int c9 = twb - 1;
+            if (!ftw) c9 = tune_pick(TuneKey{7, n, out_channels, in_channels, src_height, src_width, 0, 0, 0, 0}, 2, c9, launch9, st);
+            return launch9(c9);
         }
         // The 3-product form (3/4 of the MFMAs, see pack_up2x3_kernel) is a property of the layer, not a tuning
         // choice: it rounds differently from the 4-phase form, and results must not depend on the batch size or on

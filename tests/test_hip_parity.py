@@ -282,20 +282,25 @@ def test_every_tile_and_region_shape_keeps_results_bitwise(dev, monkeypatch):
 @pytest.mark.parametrize("cin,cout,hw", [(64, 12, (20, 36)), (128, 64, (12, 24)), (256, 128, (11, 38)), (32, 48, (9, 20)),
                                          (48, 32, (7, 16)), (16, 20, (5, 12))])
 def test_upconv2x_three_product_form_vs_four_phase(dev, monkeypatch, cin, cout, hw):
-    """The LDS-DMA up-conv kernels run the 3-product form of the column phases (3/4 of the MFMAs, two differences
-    per fragment, csrc/conv_up2x.hip); KBN_NO_UP2X3=1 runs the plain 4-phase form.  Both against the oracle, and
-    within rounding of each other (they are different summations, not bit-identical)."""
+    """The LDS-DMA up-conv kernels use the 3-product identity o0 = -g0 (in[x]-in[x-1]) + G in[x], o1 = g2 (in[x+1]-in[x])
+    + G in[x] (csrc/conv_up2x.hip): along the columns (3/4 of the MFMAs; KBN_NO_UP2X9=1), or along rows and columns
+    (9 products per low-res pixel instead of 16; the default where the filter count allows); KBN_NO_UP2X3=1 runs the
+    plain 4-phase form.  All three against the oracle, and within rounding of each other (different summations)."""
     g = torch.Generator().manual_seed(cin + hw[0])
     act = torch.nn.LeakyReLU(0.2)
     up = kb.modules.UpConv2d(cin, cout, 3, "xavier_normal", act).to(dev)
     x = torch.randn(2, cin, *hw, generator=g)
     shape = (2 * hw[0], 2 * hw[1])
     ref = orc.conv2d(torch.nn.functional.interpolate(x, size=shape, mode="nearest"), up.conv.conv.weight.detach().cpu(), 1, 0.2)
-    a = up(x.to(dev), shape).clone()
+    default = up(x.to(dev), shape).clone()
+    monkeypatch.setenv("KBN_NO_UP2X9", "1")
+    three = up(x.to(dev), shape).clone()
     monkeypatch.setenv("KBN_NO_UP2X3", "1")
-    b = up(x.to(dev), shape).clone()
-    assert rel_err(a, ref) < TIGHT and rel_err(b, ref) < TIGHT
-    assert rel_err(a, b) < TIGHT and not torch.equal(a, b)
+    four = up(x.to(dev), shape).clone()
+    for y in (default, three, four):
+        assert rel_err(y, ref) < TIGHT
+    assert rel_err(three, four) < TIGHT and not torch.equal(three, four)
+    assert rel_err(default, four) < TIGHT
 
 
 # ------------------------------------------------------------------------- KB block
