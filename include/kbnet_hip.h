@@ -141,10 +141,14 @@ int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_
  * net_utils.UpConv2d.forward when the target size is exactly twice the input:
  * interpolate(nearest) + conv3x3 (+ activation)       reference src/net_utils.py:484-499
  * evaluated as four 2x2 convs on the low-resolution input (one per output phase) with
- * pre-summed weights: 4 instead of 9 MACs per output and input channel, no upsampled tensor.
+ * pre-summed weights: 4 instead of 9 MACs per output and input channel, no upsampled tensor;
+ * maps with 16-byte aligned rows go further: with differences of neighbouring input pixels the
+ * two phases of an axis share a product (o0 = -g0 (in[x]-in[x-1]) + G in[x], o1 = g2 (in[x+1]-in[x])
+ * + G in[x], G = g0+g1+g2): 3 or 2.25 MACs per output and input channel (csrc/conv_up2x.hip).
  *   src   N x in_channels x src_height x src_width (frames src_batch_stride apart)
  *   out   N x out_channels x 2*src_height x 2*src_width (frames out_batch_stride apart)
- *   packed_weight from kbn_upconv2x_pack_weight (OIHW 3x3 weight in, phase-summed blob out).
+ *   packed_weight from kbn_upconv2x_pack_weight (OIHW 3x3 weight in; the blob holds the 4-phase,
+ *   the 3-product and, for <= 16 or a multiple of 32 filters, the 9-product weights back to back).
  * Other target sizes go through kbn_conv2d_forward(..., KBN_RESIZE_NEAREST). */
 size_t kbn_upconv2x_packed_weight_bytes(int out_channels, int in_channels);
 int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
