@@ -50,6 +50,9 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 SIGNATURES = {
     "kbn_version": (_I, []),
     "kbn_status_string": (C.c_char_p, [_I]),
+    "kbn_reload_env": (None, []),
+    "kbn_set_autotune": (_I, [_I]),
+    "kbn_get_autotune": (_I, []),
     "kbn_s2d_forward": (_I, [_P, C.POINTER(_P), _P, _P, _I, _I, _I, _I, C.POINTER(_I), _I,
                              C.POINTER(_I), _I, _I, _I, _F, _P]),
     "kbn_s2d_pyramid": (_I, [_P, _L, _P, _I, _I, _I, C.POINTER(_I), _I, C.POINTER(_I), _I, _P]),
@@ -62,6 +65,7 @@ SIGNATURES = {
     "kbn_upconv2x_packed_weight_bytes": (C.c_size_t, [_I, _I]),
     "kbn_upconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
     "kbn_upconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_upconv2x_query": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_conv2d_query": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_kb_block_forward": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P,
                                   _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),

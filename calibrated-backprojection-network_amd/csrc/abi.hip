@@ -1,5 +1,48 @@
-// abi.hip -- version / status entry points of the C ABI (include/kbnet_hip.h).
+// abi.hip -- version / status entry points of the C ABI (include/kbnet_hip.h), the debug-knob table
+// (environment read once at load) and small per-device caches shared by the launch code.
+#include <stdlib.h>
+
 #include "kbn_common.h"
+
+namespace kbn {
+
+KnobValue g_knobs[KNOB_COUNT];
+
+static const char* const kKnobNames[KNOB_COUNT] = {
+    "KBN_DEBUG", "KBN_FORCE_MW", "KBN_FORCE_TWB", "KBN_FORCE_CK", "KBN_EPI_LDS", "KBN_NO_WINO", "KBN_NO_DMA",
+    "KBN_NO_UP2X_DMA", "KBN_NO_UP2X9", "KBN_NO_UP2X3", "KBN_UP_MW", "KBN_WINO_RT", "KBN_WINO_GRID", "KBN_NO_HEAD_DMA",
+    "KBN_NO_KB_PAIR", "KBN_NO_KB_DEPTH_FUSION", "KBN_PAIR_CAND", "KBN_S2D_DEBUG", "KBN_AUTOTUNE", "KBN_S2D_V1",
+    "KBN_NO_HEAD_FUSION", "KBN_NO_S2D_FUSION", "KBN_WINO_V1"};
+
+void tune_reload_env();   // tune.hip
+
+static void load_knobs() {
+    for (int k = 0; k < KNOB_COUNT; ++k) {
+        const char* v = getenv(kKnobNames[k]);
+        g_knobs[k].set = (v && *v) ? 1 : 0;
+        g_knobs[k].value = (v && *v) ? atoi(v) : 0;
+    }
+}
+
+namespace {
+struct KnobInit {
+    KnobInit() { load_knobs(); }
+} g_knob_init;   // runs when the shared library is loaded
+}  // namespace
+
+int device_cu_count() {
+    static std::atomic<int> cache[256];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::atomic<int>& slot = cache[dev & 255];
+    int v = slot.load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return -1;
+    slot.store(v, std::memory_order_relaxed);
+    return v;
+}
+
+}  // namespace kbn
 
 extern "C" {
 
@@ -14,6 +57,11 @@ const char* kbn_status_string(int status) {
         case KBN_ERR_LAUNCH: return "HIP launch error";
         default: return "unknown status";
     }
+}
+
+void kbn_reload_env(void) {
+    kbn::load_knobs();
+    kbn::tune_reload_env();
 }
 
 }  // extern "C"

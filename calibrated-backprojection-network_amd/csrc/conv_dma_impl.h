@@ -292,13 +292,8 @@ static int dma_variant(ConvParams& p, hipStream_t stream) {
         constexpr size_t lds = 2 * sizeof(float) * ((size_t)CK * G::PLANE + (size_t)CK * KS * KS * NB * 16);
         if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
         if (lds < sizeof(float) * 16 * (64 * MW + 4)) p.epi_lds = 0;   // the LDS epilogue's scratch would not fit
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return KBN_ERR_LAUNCH;
-            attr_set = true;
-        }
+        static DeviceOnce once;
+        if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
         p.TWB = TWB; p.TH = G::TH;
         p.tilesX = ceil_div(p.outW, G::TW);
         p.tilesY = ceil_div(p.outH, G::TH);

@@ -27,11 +27,6 @@
 
 namespace kbn {
 
-static int env_int(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : 0;
-}
-
 // ---------------------------------------------------------------- weight packing
 // packed[nt][chunk][tap][c4][k>>1][n][k&1]  (zero padded in both c and oc)
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int OC,
@@ -310,13 +305,8 @@ static int launch_variant(const ConvParams& p, size_t stage_bytes, hipStream_t s
     constexpr int MAXPOS = conv_maxpos(KS, STRIDE, MW);
     constexpr bool PIPE = (MAXPOS * CK <= 48);
     auto kern = conv_igemm_kernel<KS, STRIDE, CK, NB, MW, MAXPOS, PIPE>;
-    static bool attr_set = false;  // benign race: idempotent call
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
     if (p.rowsS * p.colsS > MAXPOS * 256) return KBN_ERR_UNSUPPORTED;
     size_t lds_bytes = stage_bytes * (PIPE ? 2 : 1);
     if (lds_bytes > 160 * 1024) return KBN_ERR_UNSUPPORTED;
@@ -359,7 +349,7 @@ static int launch_nb(const ConvParams& p, int NB, int MW, size_t lds, hipStream_
 static TileChoice choose_tile(int outH, int outW, int n, int nTilesN, int kernel_size, int stride, int max_mw,
                               int CK, int NT) {
     // experiment hooks (tools/conv_bench.py): KBN_FORCE_MW / KBN_FORCE_TWB pin the tile
-    const int force_mw = env_int("KBN_FORCE_MW"), force_twb = env_int("KBN_FORCE_TWB");
+    const int force_mw = knob(KNOB_FORCE_MW), force_twb = knob(KNOB_FORCE_TWB);
     const bool s2 = (kernel_size == 3 && stride == 2);
     double best_cost = 1e300;
     TileChoice best{max_mw, 2};
@@ -442,35 +432,34 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     }
     for (int s = n_src; s < KBN_MAX_SRC; ++s) p.src[s] = p.src[0];
 
-    const ConvPlan pl = make_plan(out_channels, ctot, kernel_size, stride, env_int("KBN_FORCE_CK"));
+    const ConvPlan pl = make_plan(out_channels, ctot, kernel_size, stride, knob(KNOB_FORCE_CK));
     p.nsrc = n_src; p.N = n; p.OC = out_channels; p.Ctot = ctot; p.Cpad = pl.Cpad;
     p.wp = packed_weight; p.out = out; p.out_bstride = out_batch_stride;
     p.inH = in_height; p.inW = in_width;
     p.outH = ceil_div(in_height, stride); p.outW = ceil_div(in_width, stride);
     p.resize = resize; p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.nTilesN = pl.nTilesN;
-    p.dbg = env_int("KBN_DEBUG");
+    p.dbg = knob(KNOB_DEBUG);
     {   // LDS-transposed epilogue for store-bound launches: few multiply-adds per output (conv0, deconv0's conv).
         // KBN_EPI_LDS = 0 never / 2 always (A/B, tests); default: K = channels x taps <= 128
-        const char* e = getenv("KBN_EPI_LDS");
-        const int mode = e ? atoi(e) : 1;
+        const int mode = knob_set(KNOB_EPI_LDS) ? knob(KNOB_EPI_LDS) : 1;
         p.epi_lds = mode == 2 || (mode == 1 && ctot * kernel_size * kernel_size <= 128);
     }
 
     const bool s2 = (kernel_size == 3 && stride == 2);
     TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
-    if (kernel_size == 3 && stride == 1 && !env_int("KBN_NO_WINO")) {  // wide 3x3: Winograd F(2x2,3x3)
+    if (kernel_size == 3 && stride == 1 && !knob(KNOB_NO_WINO)) {  // wide 3x3: Winograd F(2x2,3x3)
         int rc = conv_wino_launch(p, stream);
         if (rc != KBN_ERR_UNSUPPORTED) return rc;
     }
-    if (!env_int("KBN_NO_DMA")) {  // fast path: LDS-DMA staging (aligned tensor sources, no resize)
-        const bool forced = env_int("KBN_FORCE_MW") || env_int("KBN_FORCE_TWB");
+    if (!knob(KNOB_NO_DMA)) {  // fast path: LDS-DMA staging (aligned tensor sources, no resize)
+        const bool forced = knob(KNOB_FORCE_MW) || knob(KNOB_FORCE_TWB);
         int sig = n_src;
         for (int s = 0; s < n_src; ++s) sig = sig * 4 + srcs[s].kind;
         const TuneKey key{1, n, out_channels, ctot, kernel_size, stride, in_height, in_width, sig, 0};
-        const bool tuning = !forced && tune_enabled();
         int cand = cand_of_tile(tc);
-        if (tuning && tune_lookup(key, &cand)) tc = tile_of_cand(cand);     // tuned earlier
+        if (!forced && tune_lookup(key, &cand)) tc = tile_of_cand(cand);    // tuned earlier / preloaded cache
+        const bool tuning = !forced && tune_enabled();                      // opt-in (kbn_set_autotune)
         ConvParams q = p;
         int rc = conv_dma_launch(q, pl, tc, kernel_size, stride, stream);   // also the eligibility check
         if (rc == KBN_OK && tuning && !tune_lookup(key, &cand)) {           // first eligible launch of this shape
@@ -516,7 +505,7 @@ extern "C" {
 size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int kernel_size, int stride) {
     if (out_channels < 1 || in_channels < 1 || (kernel_size != 1 && kernel_size != 3)) return 0;
     if (stride != 1 && stride != 2) return 0;
-    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::env_int("KBN_FORCE_CK"));
+    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::knob(kbn::KNOB_FORCE_CK));
     return sizeof(float) * ((size_t)pl.nTilesN * pl.Cpad * kernel_size * kernel_size * pl.NT +
                             (size_t)kbn::wino_packed_floats(out_channels, in_channels, kernel_size, stride));
 }
@@ -525,7 +514,7 @@ int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels,
                            int kernel_size, int stride, kbn_stream_t stream) {
     if (!weight || !packed || out_channels < 1 || in_channels < 1) return KBN_ERR_INVALID_ARGUMENT;
     if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
-    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::env_int("KBN_FORCE_CK"));
+    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::knob(kbn::KNOB_FORCE_CK));
     int taps = kernel_size * kernel_size;
     long long total = (long long)pl.nTilesN * pl.Cpad * taps * pl.NT;
     int blocks = (int)((total + 255) / 256);
@@ -543,7 +532,7 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
     if (!info || n < 1 || out_channels < 1 || in_channels < 1 || in_height < 1 || in_width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
     if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
-    const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size, stride, env_int("KBN_FORCE_CK"));
+    const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size, stride, knob(KNOB_FORCE_CK));
     const int outH = ceil_div(in_height, stride), outW = ceil_div(in_width, stride);
     TileChoice tc = choose_tile(outH, outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
     {   // a tuned choice, if this shape has run already (tensor sources only: the common signatures)
@@ -562,8 +551,8 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
     info[5] = ceil_div(outW, tw) * ceil_div(outH, th) * n * pl.nTilesN;
     info[6] = maxpos;
     // 2: conv_dma_kernel (assuming 16-byte aligned planes), 1: conv_igemm_kernel pipelined, 0: not pipelined
-    info[7] = (!resize && (in_width & 3) == 0 && !env_int("KBN_NO_DMA")) ? 2 : ((maxpos * pl.CK <= 48) ? 1 : 0);
-    if (kernel_size == 3 && stride == 1 && !resize && !env_int("KBN_NO_WINO")) {
+    info[7] = (!resize && (in_width & 3) == 0 && !knob(KNOB_NO_DMA)) ? 2 : ((maxpos * pl.CK <= 48) ? 1 : 0);
+    if (kernel_size == 3 && stride == 1 && !resize && !knob(KNOB_NO_WINO)) {
         int rt = 0, ct = 0;
         const int wgs = wino_query(n, out_channels, in_channels, in_height, in_width, &rt, &ct);
         if (wgs > 0) { info[7] = 3; info[2] = rt; info[3] = ct; info[4] = 2 * rt; info[5] = wgs; }

@@ -537,13 +537,8 @@ template <int NB, int MW, int TWB, int GR = 4, bool T3 = false>
 static int up2x_dma_variant(Up2xParams& p, hipStream_t stream) {
     using G = Up2xGeom<NB, MW, TWB, GR, T3>;
     auto kern = conv_up2x_dma_kernel<NB, MW, TWB, GR, T3>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
     p.TWB = TWB; p.TH = G::TH;
     p.tilesX = ceil_div(p.srcW, G::TW); p.tilesY = ceil_div(p.srcH, G::TH);
     const long long nb64 = (long long)p.tilesX * p.tilesY * p.N * p.nTilesN * 2;
@@ -557,13 +552,8 @@ static int up2x_dma_variant(Up2xParams& p, hipStream_t stream) {
 template <int NB, int MW, int MAXPOS>
 static int up2x_variant(const Up2xParams& p, size_t lds, hipStream_t stream) {
     auto kern = conv_up2x_kernel<8, NB, MW, MAXPOS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
     if (p.rowsS * p.colsS > MAXPOS * 256) return KBN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, stream, p);
     KBN_CHECK_LAUNCH();
@@ -787,13 +777,8 @@ template <int NB, int MW, int TWB>
 static int up2x9_variant(Up2xParams& p, hipStream_t stream) {
     using G = Up2x9Geom<NB, MW, TWB>;
     auto kern = conv_up2x9_kernel<NB, MW, TWB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
     p.TWB = TWB; p.TH = G::TH;
     p.tilesX = ceil_div(p.srcW, G::TW); p.tilesY = ceil_div(p.srcH, G::TH);
     const long long nb64 = (long long)p.tilesX * p.tilesY * p.N * p.nTilesN;
@@ -888,13 +873,13 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
     // fast path: LDS-DMA staging, compile-time tile geometry
     const bool aligned = (src_width & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
                          (src_batch_stride & 3) == 0 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad;
-    if (aligned && !getenv("KBN_NO_UP2X_DMA")) {
-        const char* ftw = getenv("KBN_FORCE_TWB");
+    if (aligned && !knob(KNOB_NO_UP2X_DMA)) {
+        const int ftw = knob(KNOB_FORCE_TWB);
         int twb = 1;   // 16-wide tiles unless 32-wide ones waste fewer pixels / fill the rounds better
         {
             double best = 1e300;
             for (int t = 1; t <= 2; ++t) {
-                if (ftw && atoi(ftw) && atoi(ftw) != t) continue;
+                if (ftw && ftw != t) continue;
                 const int th = 4 * pl.MW / t, tw = t * 16;
                 const long long tiles = (long long)ceil_div(src_width, tw) * ceil_div(src_height, th) * n * pl.nTilesN * 2;
                 const double cost = (double)((tiles + 511) / 512) * (4 * pl.MW * 16.0 + 0.1 * (th + 1) * (tw + 8));
@@ -903,7 +888,7 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
         }
         // 9-product form (both row phases in one workgroup) where the filter count allows; like the 3-product form a
         // property of the layer (it rounds differently), never a tuner choice -- the tuner only picks the tile width.
-        if (up2x9_eligible(out_channels) && !getenv("KBN_NO_UP2X9") && !getenv("KBN_NO_UP2X3")) {
+        if (up2x9_eligible(out_channels) && !knob(KNOB_NO_UP2X9) && !knob(KNOB_NO_UP2X3)) {
             const Up2x9Plan q9 = make_up2x9_plan(out_channels);
             auto launch9 = [&](int cand) -> int {   // candidate = TWB - 1
                 Up2xParams q = p;
@@ -918,7 +903,7 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
         // The 3-product form (3/4 of the MFMAs, see pack_up2x3_kernel) is a property of the layer, not a tuning
         // choice: it rounds differently from the 4-phase form, and results must not depend on the batch size or on
         // what the tuner measured.  The tuner only picks the tile shape (bit-identical among themselves).
-        const int t3 = getenv("KBN_NO_UP2X3") ? 0 : 1;
+        const int t3 = knob(KNOB_NO_UP2X3) ? 0 : 1;
         auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
             Up2xParams q = p;
             const int t = (cand & 1) + 1, half = (cand >> 1) & 1;
@@ -930,9 +915,9 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
         return launch(cand);
     }
     // maps whose rows are not 16-byte aligned: the same kernel with dword DMA granules (wide outputs only)
-    if (!aligned && pl.NB >= 3 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad && !getenv("KBN_NO_UP2X_DMA") &&
-        !getenv("KBN_UP_MW")) {
-        const int t3 = getenv("KBN_NO_UP2X3") ? 0 : 1;
+    if (!aligned && pl.NB >= 3 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad && !knob(KNOB_NO_UP2X_DMA) &&
+        !knob(KNOB_UP_MW)) {
+        const int t3 = knob(KNOB_NO_UP2X3) ? 0 : 1;
         auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
             Up2xParams q = p;
             const int t = (cand & 1) + 1, half = (cand >> 1) & 1;
@@ -950,15 +935,15 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
     {
         const long long tiles2 = (long long)ceil_div(src_width, 16) * ceil_div(src_height, 4 * pl.MW) * n * pl.nTilesN * 2;
         if (pl.NB >= 3 && tiles2 <= 512) mw = 1;
-        const char* fm = getenv("KBN_UP_MW");
-        if (fm && atoi(fm) && pl.NB >= 3) mw = atoi(fm) == 1 ? 1 : pl.MW;
+        const int fm = knob(KNOB_UP_MW);
+        if (fm && pl.NB >= 3) mw = fm == 1 ? 1 : pl.MW;
     }
     const int mblocks = 4 * mw;
     double best_cost = 1e300;
     int best_twb = 1;
-    const char* ft = getenv("KBN_FORCE_TWB");
+    const int ft = knob(KNOB_FORCE_TWB);
     for (int twb = 1; twb <= 2; ++twb) {
-        if (ft && atoi(ft) && atoi(ft) != twb) continue;
+        if (ft && ft != twb) continue;
         const int th = mblocks / twb, tw = twb * 16;
         long long tiles = (long long)ceil_div(src_width, tw) * ceil_div(src_height, th) * n * pl.nTilesN * 2;
         double cost = (double)((tiles + 255) / 256) * (mblocks * 16.0 + 0.1 * (th + 1) * (tw + 2));
@@ -980,6 +965,32 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
         case 3: return mw == 1 ? up2x_variant<3, 1, 1>(p, lds, st) : up2x_variant<3, 2, 1>(p, lds, st);
         default: return mw == 1 ? up2x_variant<4, 1, 1>(p, lds, st) : up2x_variant<4, 2, 1>(p, lds, st);
     }
+}
+
+/* Which algebraic form kbn_upconv2x_forward runs for a problem and what it executes:
+ * info[4] = {channel products per low-resolution pixel (16 = four 2x2 phases, 12 = 3-product columns,
+ * 9 = 3-product rows and columns), padded output channels, padded input channels, 0}.
+ * Executed MFMA work = 2 * n * src_height * src_width * info[0] * info[1] * info[2] FLOP. */
+int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height, int src_width, int* info) {
+    using namespace kbn;
+    if (!info || n < 1 || in_channels < 1 || out_channels < 1 || src_height < 1 || src_width < 1)
+        return KBN_ERR_INVALID_ARGUMENT;
+    const Up2xPlan pl = make_up2x_plan(out_channels, in_channels);
+    const bool chunks_ok = (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad;
+    const bool aligned = (src_width & 3) == 0 && chunks_ok;   // plus 16-byte aligned planes, which torch tensors are
+    const int t3 = knob(KNOB_NO_UP2X3) ? 0 : 1;
+    info[0] = 16; info[1] = pl.nTilesN * pl.NT; info[2] = pl.Cpad; info[3] = 0;
+    if (aligned && !knob(KNOB_NO_UP2X_DMA)) {
+        if (up2x9_eligible(out_channels) && !knob(KNOB_NO_UP2X9) && t3) {
+            const Up2x9Plan q9 = make_up2x9_plan(out_channels);
+            info[0] = 9; info[1] = q9.nTilesN * q9.NT;
+        } else {
+            info[0] = t3 ? 12 : 16;
+        }
+    } else if (!aligned && pl.NB >= 3 && chunks_ok && !knob(KNOB_NO_UP2X_DMA) && !knob(KNOB_UP_MW)) {
+        info[0] = t3 ? 12 : 16;
+    }
+    return KBN_OK;
 }
 
 }  // extern "C"

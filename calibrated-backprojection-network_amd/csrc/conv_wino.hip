@@ -451,7 +451,7 @@ static int choose_region(int H, int W, int n, int nTilesN) {   // index into kRe
     const int th = ceil_div(H, 2), tw = ceil_div(W, 2);
     long long best_rounds = 1LL << 60, best_wgs = 1LL << 60;
     int best = 0;
-    const int force_rt = getenv("KBN_WINO_RT") ? atoi(getenv("KBN_WINO_RT")) : 0;
+    const int force_rt = knob(KNOB_WINO_RT);
     for (int i = 0; i < kNumRegions; ++i) {
         const int* c = kRegions[i];
         if (force_rt && c[0] != force_rt) continue;
@@ -466,25 +466,14 @@ static int choose_region(int H, int W, int n, int nTilesN) {   // index into kRe
 
 template <int DBG>
 static int wino_variant(const WinoParams& p, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<DBG>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
-        attr_set = true;
-    }
-    static int n_cu = 0;   // persistent workgroups: one per CU of the current device
-    if (n_cu == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            cus = 256;
-        n_cu = cus;
-    }
+    static DeviceOnce once;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv_wino_kernel<DBG>), 160 * 1024)) return rc;
+    int n_cu = device_cu_count();   // persistent workgroups: one per CU of the current device
+    if (n_cu < 1) n_cu = 256;
     int grid = p.nblocks < n_cu ? p.nblocks : n_cu;
-    if (const char* g = getenv("KBN_WINO_GRID")) {   // experiment hook: -1 = one workgroup per tile, N = N persistent workgroups
-        const int v = atoi(g);
+    if (const int v = knob(KNOB_WINO_GRID)) {   // experiment hook: -1 = one workgroup per tile, N = N persistent workgroups
         if (v < 0) grid = p.nblocks;
-        else if (v > 0) grid = p.nblocks < v ? p.nblocks : v;
+        else grid = p.nblocks < v ? p.nblocks : v;
     }
     hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(grid), dim3(512), lds, stream, p);
     KBN_CHECK_LAUNCH();
@@ -533,7 +522,7 @@ int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
         return wino_dispatch(q, lds, stream);
     };
     int cand = model;
-    if (!getenv("KBN_WINO_RT") && !p.dbg) {
+    if (!knob(KNOB_WINO_RT) && !p.dbg) {
         cand = tune_pick(TuneKey{2, p.N, p.OC, p.Cin, p.H, p.W, 0, 0, 0, 0}, kNumRegions, model, launch, stream);
     }
     return launch(cand);

@@ -160,18 +160,14 @@ extern "C" int kbn_depth_head_forward(const float* x, const float* weight, float
     float ratio = (float)((double)min_predict_depth / (double)max_predict_depth);
     const bool aligned = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(depth) & 15) == 0 && (!logits || (reinterpret_cast<uintptr_t>(logits) & 15) == 0);
-    if (aligned && !getenv("KBN_NO_HEAD_DMA")) {
+    if (aligned && !kbn::knob(kbn::KNOB_NO_HEAD_DMA)) {
         const int tilesX = ceil_div(width, HQ_TW), tilesY = ceil_div(height, HQ_TH);
         const long long blocks = (long long)tilesX * tilesY * n;
         if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
         const size_t lds = sizeof(float) * (size_t)channels * HQ_PLANE;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(depth_head_dma_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return KBN_ERR_LAUNCH;
-            attr_set = true;
-        }
+        static kbn::DeviceOnce once;
+        if (int rc = kbn::set_max_dynamic_lds(once, reinterpret_cast<const void*>(depth_head_dma_kernel), 160 * 1024))
+            return rc;
         hipLaunchKernelGGL(depth_head_dma_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, weight,
                            depth, logits, channels, height, width, tilesX, tilesY, min_predict_depth, ratio);
         KBN_CHECK_LAUNCH();

@@ -74,7 +74,11 @@ int kbn_png_info(const unsigned char* file, size_t file_bytes, int* width, int* 
     return KBN_OK;
 }
 
-int kbn_png_decode(const unsigned char* file, size_t file_bytes, void* pixels, size_t pixels_bytes) {
+}  // extern "C"
+
+namespace {
+
+int png_decode_impl(const unsigned char* file, size_t file_bytes, void* pixels, size_t pixels_bytes) {
     PngHeader h;
     int rc = parse_header(file, file_bytes, &h);
     if (rc != KBN_OK) return rc;
@@ -114,6 +118,7 @@ int kbn_png_decode(const unsigned char* file, size_t file_bytes, void* pixels, s
 
     // ---- inflate into [height][1 + stride] ----
     const size_t raw_bytes = (size_t)h.height * (stride + 1);
+    if (raw_bytes > 0xffffffffull) return KBN_ERR_UNSUPPORTED;         // zlib's avail_out is 32 bits wide
     std::vector<unsigned char> raw(raw_bytes);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
@@ -123,7 +128,7 @@ int kbn_png_decode(const unsigned char* file, size_t file_bytes, void* pixels, s
     int zrc = Z_OK;
     for (size_t i = 0; i < idat_ptr.size() && zrc == Z_OK; ++i) {
         zs.next_in = const_cast<unsigned char*>(idat_ptr[i]);
-        zs.avail_in = (uInt)idat_len[i];
+        zs.avail_in = (uInt)idat_len[i];                               // a chunk length is a 32-bit field
         zrc = inflate(&zs, Z_NO_FLUSH);
     }
     const bool complete = (zs.avail_out == 0) && (zrc == Z_OK || zrc == Z_STREAM_END);
@@ -172,6 +177,18 @@ int kbn_png_decode(const unsigned char* file, size_t file_bytes, void* pixels, s
     return KBN_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int kbn_png_decode(const unsigned char* file, size_t file_bytes, void* pixels, size_t pixels_bytes) {
+    try {   // nothing may throw across the ABI (or out of a worker thread): allocation failures become a status
+        return png_decode_impl(file, file_bytes, pixels, pixels_bytes);
+    } catch (...) {
+        return KBN_ERR_WORKSPACE;
+    }
+}
+
 // Decodes `n` files on `threads` host threads (work stealing over an atomic index; no Python, no GIL).
 // status[i] receives the per-file code; the return value is the first failure or KBN_OK.
 int kbn_png_decode_batch(const unsigned char* const* files, const size_t* file_bytes, void* const* pixels,
@@ -180,20 +197,27 @@ int kbn_png_decode_batch(const unsigned char* const* files, const size_t* file_b
     if (n == 0) return KBN_OK;
     if (threads < 1) threads = 1;
     if (threads > n) threads = n;
-    std::vector<int> local(status ? 0 : n);
-    int* st = status ? status : local.data();
-    std::atomic<int> next(0);
-    auto worker = [&]() {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1))
-            st[i] = kbn_png_decode(files[i], file_bytes[i], pixels[i], pixels_bytes[i]);
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
-    worker();
-    for (auto& t : pool) t.join();
-    for (int i = 0; i < n; ++i)
-        if (st[i] != KBN_OK) return st[i];
-    return KBN_OK;
+    try {
+        std::vector<int> local(status ? 0 : n);
+        int* st = status ? status : local.data();
+        std::atomic<int> next(0);
+        auto worker = [&]() noexcept {
+            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1))
+                st[i] = kbn_png_decode(files[i], file_bytes[i], pixels[i], pixels_bytes[i]);
+        };
+        std::vector<std::thread> pool;
+        try {
+            for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+        } catch (...) {   // the host refused another thread: the ones that started and this one share the work
+        }
+        worker();
+        for (auto& t : pool) t.join();
+        for (int i = 0; i < n; ++i)
+            if (st[i] != KBN_OK) return st[i];
+        return KBN_OK;
+    } catch (...) {
+        return KBN_ERR_WORKSPACE;
+    }
 }
 
 }  // extern "C"

@@ -36,12 +36,11 @@
 namespace kbn {
 namespace {
 inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
-inline bool env_on(const char* name) { const char* v = getenv(name); return v && atoi(v); }
 }  // namespace
 
 int kb_pair_launch(const KbPairArgs& a, hipStream_t stream, bool* depth_done) {
     *depth_done = false;
-    if (env_on("KBN_NO_KB_PAIR")) return KBN_ERR_UNSUPPORTED;
+    if (knob(KNOB_NO_KB_PAIR)) return KBN_ERR_UNSUPPORTED;
     // shapes: conv_image and conv_fused must pack with the same n-block count (3 or 4: 48 / 96 / 192 / 384 filters
     // and the like), image channels a whole number of 4-channel chunks, rows of every DMA source 16-byte aligned
     if (a.channels_image < 4 || (a.channels_image & 3) || (a.width & 3)) return KBN_ERR_UNSUPPORTED;
@@ -63,7 +62,7 @@ int kb_pair_launch(const KbPairArgs& a, hipStream_t stream, bool* depth_done) {
     // resolution, 92 -> 51 us).  Measured for the wider ones (32 / 64 / 128 filters at KB2-4, the kernel takes any
     // NBD <= NB): +5 / +12 / -5 us -- the extra accumulators cost occupancy -- so those keep their own launch.
     int nbd = 0;
-    if (a.wp_depth && a.out_depth && !env_on("KBN_NO_KB_DEPTH_FUSION")) {
+    if (a.wp_depth && a.out_depth && !knob(KNOB_NO_KB_DEPTH_FUSION)) {
         const ConvPlan plD = make_plan(a.filters_depth, a.channels_depth + 3, 3, 2);
         const bool fits = plI.NB == 3 && plD.NB == 1;
         if (plD.CK == 4 && fits && plD.nTilesN <= plI.nTilesN && aligned16(a.depth) && (a.depth_bstride & 3) == 0 &&
@@ -86,9 +85,9 @@ int kb_pair_launch(const KbPairArgs& a, hipStream_t stream, bool* depth_done) {
         if (wgs >= 1024) { model = c; break; }
     }
     int cand;
-    const char* forced = getenv("KBN_PAIR_CAND");   // test hook: force a tile shape (tests/test_hip_parity.py)
-    if (forced && atoi(forced) >= 0 && atoi(forced) < kPairCands) {
-        cand = atoi(forced);
+    const bool forced = knob_set(KNOB_PAIR_CAND) && knob(KNOB_PAIR_CAND) >= 0 && knob(KNOB_PAIR_CAND) < kPairCands;
+    if (forced) {   // test hook: force a tile shape (tests/test_hip_parity.py)
+        cand = knob(KNOB_PAIR_CAND);
     } else {
         cand = tune_pick(TuneKey{5, a.n, a.filters, a.channels_image, a.channels_fused, a.channels_depth, a.height,
                                  a.width, a.coords ? 1 : 0, nbd},

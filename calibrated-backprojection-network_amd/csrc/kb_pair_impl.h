@@ -375,13 +375,8 @@ int pair_variant(KbPairParams& p, hipStream_t stream) {
     else {
     auto kern = kb_pair_kernel<NB, MW, TWB, NBD>;
     if (PG::LDS_BYTES > 160 * 1024) return KBN_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return KBN_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
     p.tilesX = ceil_div(p.outW, PG::G3::TW);
     p.tilesY = ceil_div(p.outH, PG::G3::TH);
     const long long nb64 = (long long)p.tilesX * p.tilesY * p.a.n * p.nTilesN;

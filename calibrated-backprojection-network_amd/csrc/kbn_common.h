@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/kbnet_hip.h"
 
 #define KBN_CHECK_LAUNCH()                                   \
@@ -21,6 +23,40 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 __host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 __device__ __forceinline__ float leaky_relu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// ---- per-device one-time kernel setup -------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel, device): one bit per device
+// ordinal of the calling thread's current device, so that a process driving several GPUs (the reference
+// wraps its modules in torch.nn.DataParallel, src/kbnet_model.py:408-415) sets it on each of them.
+struct DeviceOnce {
+    std::atomic<unsigned long long> done[4] = {};   // 256 device ordinals
+};
+inline int set_max_dynamic_lds(DeviceOnce& once, const void* kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return KBN_ERR_LAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::atomic<unsigned long long>& word = once.done[(dev >> 6) & 3];
+    if (word.load(std::memory_order_relaxed) & bit) return KBN_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return KBN_ERR_LAUNCH;   // not a stream operation: legal while a stream is being captured
+    word.fetch_or(bit, std::memory_order_relaxed);
+    return KBN_OK;
+}
+int device_cu_count();   // abi.hip: compute units of the current device (cached per device), <= 0 on error
+
+// ---- debug / experiment knobs ------------------------------------------------------------------------
+// Read from the environment ONCE when the library is loaded (and again by kbn_reload_env(), which tests
+// and the ablation tools call after changing a variable): no getenv on any launch path.
+enum Knob {
+    KNOB_DEBUG, KNOB_FORCE_MW, KNOB_FORCE_TWB, KNOB_FORCE_CK, KNOB_EPI_LDS, KNOB_NO_WINO, KNOB_NO_DMA,
+    KNOB_NO_UP2X_DMA, KNOB_NO_UP2X9, KNOB_NO_UP2X3, KNOB_UP_MW, KNOB_WINO_RT, KNOB_WINO_GRID, KNOB_NO_HEAD_DMA,
+    KNOB_NO_KB_PAIR, KNOB_NO_KB_DEPTH_FUSION, KNOB_PAIR_CAND, KNOB_S2D_DEBUG, KNOB_AUTOTUNE, KNOB_S2D_V1,
+    KNOB_NO_HEAD_FUSION, KNOB_NO_S2D_FUSION, KNOB_WINO_V1, KNOB_COUNT
+};
+struct KnobValue { int set, value; };
+extern KnobValue g_knobs[KNOB_COUNT];
+inline int knob(Knob k) { return g_knobs[k].value; }        // 0 when unset
+inline bool knob_set(Knob k) { return g_knobs[k].set != 0; }
 
 // XCD-aware block remap (bijective for any grid size): the dispatcher places block b on
 // XCD b % 8; give every XCD one contiguous range of logical tiles so that neighbouring

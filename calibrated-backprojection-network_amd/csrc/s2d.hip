@@ -344,7 +344,7 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
     size_t pool_floats = (size_t)2 * ZH * ZW + (size_t)off;
     size_t feat_floats = (size_t)S2D_MAXCH * S2D_NF;
     p.pool_floats = (int)pool_floats;
-    { const char* v = getenv("KBN_S2D_DEBUG"); p.dbg = v ? atoi(v) : 0; }
+    p.dbg = knob(KNOB_S2D_DEBUG);
     size_t lds = sizeof(float) * (S2D_WFLOATS + (pool_floats > feat_floats ? pool_floats : feat_floats));
     if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
     long long blocks = (long long)p.tilesX * p.tilesY * p.N;
@@ -356,17 +356,12 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
             if (p.ksize[i++] != k) return false;
         return true;
     };
-    auto launch = [&](auto kern, bool& attr_set) -> int {
-        if (!attr_set) {  // once per kernel (not a stream operation: keep it out of graph captures)
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return KBN_ERR_LAUNCH;
-            attr_set = true;
-        }
+    auto launch = [&](auto kern, DeviceOnce& once) -> int {
+        if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S2D_THREADS), lds, stream, p);
         return KBN_OK;
     };
-    static bool set_kitti = false, set_void = false, set_voidtrain = false, set_dyn = false;
+    static DeviceOnce set_kitti, set_void, set_voidtrain, set_dyn;
     int rc;
     if (matches(5, {5, 7, 9, 11, 13, 15, 17})) rc = launch(s2d_kernel<KittiPools>, set_kitti);
     else if (matches(2, {15, 17, 23, 27, 29})) rc = launch(s2d_kernel<VoidPools>, set_void);

@@ -1,71 +1,97 @@
-// tune.hip -- first-use tuning of launch geometry (tile shape of the direct convs, region shape of the
-// Winograd kernel, tile shape of the up-convs).
+// tune.hip -- OPT-IN first-use tuning of launch geometry (tile shape of the direct convs, region shape of
+// the Winograd kernel, tile shape of the up-convs).
 //
-// The analytic cost models are within 10-15 % of the best geometry on some layers (workgroup-round
-// quantisation, HBM-bound stores; profiles/r01/v6_tile_sweep.txt).  The first launch of a problem
-// shape therefore times every candidate on the caller's stream (HIP events; the output is simply
-// rewritten with identical values -- geometry never changes an accumulation order) and the winner is
-// cached for the process.  No tuning while the stream is being captured into a graph (the model's
-// choice is used and nothing is cached) or with KBN_AUTOTUNE=0.  The cache holds integers only.
-// KBN_TUNE_CACHE=<file> makes it persistent: entries are read at first use and appended as they are
-// found (one line of 11 integers each), so that e.g. a profiled run replays the choices of an earlier
-// run without any timing launches of its own.
+// By default every ABI call launches the geometry its analytic cost model picks (or a choice cached by an
+// earlier tuning pass / a preloaded KBN_TUNE_CACHE file) and returns: nothing is timed and nothing
+// synchronises.  The cost models are within 10-15 % of the best geometry on some layers (workgroup-round
+// quantisation, HBM-bound stores; profiles/r01/v6_tile_sweep.txt), so a caller that wants the last few
+// percent switches tuning on around a warm-up pass:
+//
+//     kbn_set_autotune(1);  <one forward of every problem shape>;  kbn_set_autotune(0);
+//
+// While it is on, the first launch of a problem shape times every candidate on the caller's stream (HIP
+// events; the output is simply rewritten with identical values -- geometry never changes an accumulation
+// order) and the winner is cached per device for the process.  Never while the stream is being captured.
+// The cache holds integers only.  KBN_TUNE_CACHE=<file> (read when the library is loaded / kbn_reload_env)
+// preloads choices that apply to every device and receives the entries later tuning passes find, so that
+// e.g. a profiled run replays the choices of an earlier run without any timing launches of its own.
 #include <stdio.h>
 #include <stdlib.h>
 
 #include <map>
 #include <mutex>
+#include <string>
+#include <utility>
 
 #include "conv_common.h"
 
 namespace kbn {
 
-static std::map<TuneKey, int> g_cache;
+typedef std::pair<int, TuneKey> DevKey;          // device ordinal (-1 = any: entries from the cache file)
+static std::map<DevKey, int> g_cache;
 static std::mutex g_mutex;
-static bool g_loaded = false;
+static std::string g_path;
+static std::atomic<int> g_autotune{0};
 
 static void load_file_locked() {   // g_mutex held
-    if (g_loaded) return;
-    g_loaded = true;
-    const char* path = getenv("KBN_TUNE_CACHE");
-    if (!path || !*path) return;
-    FILE* f = fopen(path, "r");
+    if (g_path.empty()) return;
+    FILE* f = fopen(g_path.c_str(), "r");
     if (!f) return;
     TuneKey k;
     int cand;
     while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8],
                   &k[9], &cand) == 11)
-        g_cache[k] = cand;
+        g_cache[DevKey(-1, k)] = cand;
     fclose(f);
 }
 
 static void append_file_locked(const TuneKey& k, int cand) {
-    const char* path = getenv("KBN_TUNE_CACHE");
-    if (!path || !*path) return;
-    FILE* f = fopen(path, "a");
+    if (g_path.empty()) return;
+    FILE* f = fopen(g_path.c_str(), "a");
     if (!f) return;
     fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], cand);
     fclose(f);
 }
 
-bool tune_enabled() {
-    static const bool on = !(getenv("KBN_AUTOTUNE") && atoi(getenv("KBN_AUTOTUNE")) == 0);
-    return on;
+void tune_reload_env() {   // library load and kbn_reload_env(): the only places the environment is read
+    std::lock_guard<std::mutex> g(g_mutex);
+    const char* path = getenv("KBN_TUNE_CACHE");
+    const std::string p = (path && *path) ? path : "";
+    if (p != g_path) {
+        g_path = p;
+        load_file_locked();
+    }
+    const char* a = getenv("KBN_AUTOTUNE");
+    if (a && *a) g_autotune.store(atoi(a) != 0, std::memory_order_relaxed);
+}
+
+namespace {
+struct TuneInit {
+    TuneInit() { tune_reload_env(); }
+} g_tune_init;
+}  // namespace
+
+bool tune_enabled() { return g_autotune.load(std::memory_order_relaxed) != 0; }
+
+static int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : 0;
 }
 
 bool tune_lookup(const TuneKey& key, int* cand) {
+    const int dev = current_device();
     std::lock_guard<std::mutex> g(g_mutex);
-    load_file_locked();
-    auto it = g_cache.find(key);
+    auto it = g_cache.find(DevKey(dev, key));
+    if (it == g_cache.end()) it = g_cache.find(DevKey(-1, key));
     if (it == g_cache.end()) return false;
     *cand = it->second;
     return true;
 }
 
 int tune_pick(const TuneKey& key, int ncand, int model, const std::function<int(int)>& launch, hipStream_t stream) {
-    if (!tune_enabled()) return model;
     int cand = model;
     if (tune_lookup(key, &cand)) return cand;
+    if (!tune_enabled()) return model;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return model;
     hipEvent_t e0, e1;
@@ -100,11 +126,22 @@ int tune_pick(const TuneKey& key, int ncand, int model, const std::function<int(
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (best_ms < 1e29f) {
+        const int dev = current_device();
         std::lock_guard<std::mutex> g(g_mutex);
-        g_cache[key] = best;
+        g_cache[DevKey(dev, key)] = best;
         append_file_locked(key, best);
     }
     return best;
 }
 
 }  // namespace kbn
+
+extern "C" {
+
+int kbn_set_autotune(int enabled) {
+    return kbn::g_autotune.exchange(enabled ? 1 : 0, std::memory_order_relaxed);
+}
+
+int kbn_get_autotune(void) { return kbn::g_autotune.load(std::memory_order_relaxed); }
+
+}  // extern "C"

@@ -54,74 +54,138 @@ class ShardedRunner:
     """Runs `forward_fn` on this rank's frames and all-gathers the outputs.
 
     forward_fn(image, sparse_depth, validity, intrinsics) -> N_local x 1 x H x W.
-    The gather buffer is allocated once and re-used; ranks may hold different frame
-    counts (ragged tail) -- then the gather goes through padded slots."""
+    Gather buffers are allocated once per output shape and re-used; ranks may hold different
+    frame counts (ragged tail) -- then the gather goes through padded slots.
+
+    Lifetime of returned tensors: they are views of the runner's own buffers.  `step()` / `step_mixed()`
+    results are overwritten by the next call with the same output shape; `step_pipelined()` results by the
+    next-but-one call.  Clone what must live longer."""
 
     def __init__(self, forward_fn: Callable, rank: int, world: int):
         self.forward_fn = forward_fn
         self.rank, self.world = rank, world
-        self._buf = None
+        self._bufs = {}        # (per, shape[1:], device) -> gather buffer
         self._ring = None      # pipelined mode: [(staging, gathered, work)] x 2
         self._step = 0
 
+    # ---- fixed-shape stream, gather of step i overlapped with the forward of step i+1 -------------------
     def step_pipelined(self, local_inputs):
         """Forward of this step + an ASYNCHRONOUS all-gather of its outputs, overlapped with the
         next step's forward (RCCL runs on its own stream; xGMI traffic hides behind the MFMAs).
-        Equal shard sizes only.  Returns the gathered N_total x 1 x H x W tensor of the PREVIOUS
-        step (None on the first call); call `drain()` to get the last one."""
+        Every rank must hold the same number of frames (checked once).  Returns the gathered
+        N_total x 1 x H x W tensor of the PREVIOUS step (None on the first call); `drain()` returns the last."""
         out = self.forward_fn(*local_inputs)
-        if self.world == 1:
-            prev, self._last = getattr(self, "_last", None), out
-            return prev
         if self._ring is None:
-            mk = lambda: [torch.empty_like(out), torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]),
-                                                             device=out.device, dtype=out.dtype), None]
-            self._ring = [mk(), mk()]
+            if self.world > 1:   # a ragged shard would hang or fail inside the collective: check once
+                n = torch.tensor([out.shape[0], -out.shape[0]], device=out.device, dtype=torch.int64)
+                dist.all_reduce(n, op=dist.ReduceOp.MAX)
+                if int(n[0]) != -int(n[1]):
+                    raise ValueError(f"step_pipelined needs equal shards on every rank (min {-int(n[1])}, "
+                                     f"max {int(n[0])} frames); use step() / step_mixed() for ragged batches")
+            gathered = lambda: (torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]),
+                                            device=out.device, dtype=out.dtype) if self.world > 1 else None)
+            self._ring = [[torch.empty_like(out), gathered(), None] for _ in range(2)]
         slot = self._ring[self._step & 1]
         if slot[2] is not None:
             slot[2].wait()                      # the gather that used this slot two steps ago
         slot[0].copy_(out)                      # `out` may be a graph's static buffer: detach it
-        slot[2] = dist.all_gather_into_tensor(slot[1], slot[0], async_op=True)
+        if self.world > 1:
+            slot[2] = dist.all_gather_into_tensor(slot[1], slot[0], async_op=True)
         prev = self._ring[(self._step & 1) ^ 1]
         self._step += 1
-        if prev[2] is not None:
-            prev[2].wait()                      # orders the consumer after the previous gather
-            return prev[1]
-        return None
+        if self._step == 1:
+            return None
+        return self._finish(prev)
+
+    def _finish(self, slot):
+        if self.world == 1:
+            return slot[0]
+        if slot[2] is not None:
+            slot[2].wait()                      # orders the consumer after the gather
+        return slot[1]
 
     def drain(self):
-        if self.world == 1:
-            return getattr(self, "_last", None)
-        last = self._ring[(self._step - 1) & 1] if self._ring else None
-        if last is None:
+        if self._ring is None or self._step == 0:
             return None
-        if last[2] is not None:
-            last[2].wait()
-        return last[1]
+        return self._finish(self._ring[(self._step - 1) & 1])
+
+    # ---- one batch, any split ----------------------------------------------------------------------------
+    def _slots(self, out, per):
+        key = (per, tuple(out.shape[1:]), out.device, out.dtype)
+        buf = self._bufs.get(key)
+        if buf is None:
+            buf = self._bufs[key] = torch.empty((self.world * per,) + tuple(out.shape[1:]), device=out.device,
+                                                dtype=out.dtype)
+        return buf
+
+    def _gather_start(self, out, n_total):
+        """-> (buffer, work, per): `out` (N_local frames, N_local possibly 0 < per) into padded slots."""
+        per = -(-n_total // self.world)          # slot size (max frames on any rank)
+        buf = self._slots(out, per)
+        if out.shape[0] == per:
+            src = out.contiguous()
+        else:
+            src = torch.zeros((per,) + tuple(out.shape[1:]), device=out.device, dtype=out.dtype)
+            src[:out.shape[0]] = out
+        return buf, dist.all_gather_into_tensor(buf, src, async_op=True), per
+
+    def _gather_finish(self, buf, work, per, n_total):
+        work.wait()
+        if n_total == self.world * per:
+            return buf
+        parts = []
+        for r in range(self.world):
+            lo, hi = shard_bounds(n_total, r, self.world)
+            parts.append(buf[r * per:r * per + (hi - lo)])
+        return torch.cat(parts, dim=0)
 
     def step(self, local_inputs, n_total: Optional[int] = None, gather: bool = True):
         out = self.forward_fn(*local_inputs)
         if self.world == 1 or not gather:
             return out
-        n_local = out.shape[0]
-        n_total = n_total if n_total is not None else n_local * self.world
-        per = -(-n_total // self.world)  # slot size (max frames on any rank)
-        shape = (self.world * per,) + tuple(out.shape[1:])
-        if self._buf is None or tuple(self._buf.shape) != shape or self._buf.device != out.device:
-            self._buf = torch.empty(shape, device=out.device, dtype=out.dtype)
-        if n_local == per:
-            src = out.contiguous()
-        else:
-            src = torch.zeros((per,) + tuple(out.shape[1:]), device=out.device, dtype=out.dtype)
-            src[:n_local] = out
-        dist.all_gather_into_tensor(self._buf, src)
-        if n_total == self.world * per:
-            return self._buf
-        parts = []
-        for r in range(self.world):
-            lo, hi = shard_bounds(n_total, r, self.world)
-            parts.append(self._buf[r * per:r * per + (hi - lo)])
-        return torch.cat(parts, dim=0)
+        n_total = n_total if n_total is not None else out.shape[0] * self.world
+        lo, hi = shard_bounds(n_total, self.rank, self.world)
+        if out.shape[0] != hi - lo:
+            raise ValueError(f"rank {self.rank} holds {out.shape[0]} frames, shard_bounds gives {hi - lo} of {n_total}")
+        return self._gather_finish(*self._gather_start(out, n_total), n_total)
+
+    # ---- mixed-shape stream (BASELINE config 5) ----------------------------------------------------------
+    def step_mixed(self, buckets: Sequence[Tuple[Callable, Optional[Sequence[torch.Tensor]], int, Tuple[int, ...]]]):
+        """One step of a stream that mixes frame shapes (VOID 480x640 / NYUv2 416x576 / KITTI 352x1216, each
+        with its own weights and per-frame intrinsics).  `buckets`: one entry per shape, in the SAME order on
+        every rank: (forward_fn, this rank's inputs of that shape or None, n_total frames of that shape over all
+        ranks, output shape per frame e.g. (1, H, W)).  Frames of a bucket are split with `shard_bounds`, so a
+        rank may hold fewer frames than its neighbours or none (it then contributes an empty, padded slot).
+        One all-gather per shape bucket into that bucket's own buffer; the gather of bucket i is in flight
+        while bucket i+1 computes.  Returns the list of N_total x ... tensors, bucket order."""
+        pending = []
+        for forward_fn, inputs, n_total, frame_shape in buckets:
+            lo, hi = shard_bounds(n_total, self.rank, self.world)
+            out = None
+            if inputs is not None and hi > lo:
+                out = forward_fn(*inputs)
+                if out.shape[0] != hi - lo or tuple(out.shape[1:]) != tuple(frame_shape):
+                    raise ValueError(f"bucket {tuple(frame_shape)}: forward returned {tuple(out.shape)}, this rank's "
+                                     f"share is {hi - lo} frames")
+            elif hi > lo:
+                raise ValueError(f"rank {self.rank} owns {hi - lo} frames of bucket {tuple(frame_shape)} but got no inputs")
+            if self.world == 1:
+                pending.append((out, None, 0, n_total))
+                continue
+            if out is None:   # nothing of this shape here: still take part in the collective
+                ref = inputs[0] if inputs is not None else None
+                dev = ref.device if ref is not None else self._default_device()
+                out = torch.empty((0,) + tuple(frame_shape), device=dev, dtype=torch.float32)
+            pending.append(self._gather_start(out, n_total) + (n_total,))
+        results = []
+        for buf, work, per, n_total in pending:
+            results.append(buf if work is None else self._gather_finish(buf, work, per, n_total))
+        return results
+
+    def _default_device(self):
+        if dist.is_initialized() and dist.get_backend() == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
 
 
 def barrier():

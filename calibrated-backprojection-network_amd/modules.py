@@ -68,18 +68,28 @@ def _init_weight(weight, weight_initializer):
 
 class _PackedWeight:
     """Caches the MFMA-ordered copy of a conv weight; re-packs when the parameter is
-    modified in place (version bump), replaced or moved."""
+    modified in place (version bump), replaced or moved.  A re-pack of an unchanged shape on the
+    same device goes INTO the existing blob, so device pointers recorded in a captured HIP graph
+    stay valid (GraphedForward re-packs before replaying when it sees a parameter change)."""
 
     def __init__(self):
         self._key = None
         self._packed = None
+        self._args = None
 
     def get(self, weight: torch.Tensor, stride: int, up2x: bool = False) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, weight.device, stride, up2x)
         if key != self._key:
-            self._packed = ops.pack_upconv2x_weight(weight) if up2x else ops.pack_conv_weight(weight, stride)
+            self._packed = (ops.pack_upconv2x_weight(weight, out=self._packed) if up2x
+                            else ops.pack_conv_weight(weight, stride, out=self._packed))
             self._key = key
+            self._args = (stride, up2x)
         return self._packed
+
+    def refresh(self, weight: torch.Tensor):
+        """Re-packs if (and only if) this blob has been built before and the weight changed since."""
+        if self._packed is not None:
+            self.get(weight, *self._args)
 
 
 # ------------------------------------------------------------------------ layers
@@ -108,6 +118,9 @@ class Conv2d(torch.nn.Module):
         return self._packed.get(self.conv.weight, self.stride)
 
     def run(self, srcs, n, in_h, in_w, out=None, resize=False):
+        cin = sum(s.channels for s in srcs)
+        if cin != self.in_channels:   # the packed blob carries no size: a wrong count would read past the weight panel
+            raise KbnError(f"expected {self.in_channels} input channels in total, got {cin}")
         oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)
         if out is None:
             out = torch.empty((n, self.out_channels, oh, ow), device=self.conv.weight.device,
@@ -140,6 +153,8 @@ class UpConv2d(torch.nn.Module):
         self._packed_up2x = _PackedWeight()
 
     def forward(self, x, shape):
+        if x.shape[1] != self.conv.in_channels:
+            raise KbnError(f"expected {self.conv.in_channels} input channels, got {x.shape[1]}")
         x = x if _dense(x) else x.contiguous()
         n, _, h, w = x.shape
         oh, ow = int(shape[0]), int(shape[1])
@@ -198,7 +213,12 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             raise ValueError("the fused KB block needs a (leaky) ReLU activation")
 
     def run(self, image, depth, coordinates, fused, out_image=None, out_depth=None, out_fused=None):
-        n, _, h, w = image.shape
+        n, ci, h, w = image.shape
+        cd, cf = depth.shape[1], (0 if fused is None else fused.shape[1])
+        want = (self.conv_image.conv_block[0].in_channels, self.conv_depth.conv_block[0].in_channels - 3,
+                self.conv_fused.in_channels - 3 - self.conv_image.conv_block[0].in_channels)
+        if (ci, cd, cf) != want:   # the kernels trust these counts when they walk the packed weight panels
+            raise KbnError(f"KB block built for (image, depth, fused) channels {want}, got {(ci, cd, cf)}")
         oh, ow = (h + 1) // 2, (w + 1) // 2
         dev = image.device
         mk = lambda c: torch.empty((n, c, oh, ow), device=dev, dtype=torch.float32)
@@ -419,7 +439,7 @@ class GraphedForward:
     workgroups, the other branch's kernel already runs -- +4 % at 2 x 4 KITTI frames, bit-identical
     output.  Default: 2 branches for even batches of at least 4 frames, otherwise 1."""
 
-    def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics, branches=None):
+    def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True):
         self.static_in = [t.clone() for t in (image, sparse_depth, validity_map_depth, intrinsics)]
         n = self.static_in[0].shape[0]
         if branches is None:
@@ -428,13 +448,22 @@ class GraphedForward:
             raise KbnError(f"cannot split a batch of {n} frames into {branches} equal branches")
         per = n // branches
         parts = [[t[i * per:(i + 1) * per] for t in self.static_in] for i in range(branches)]
+        self.model = model
+        dev = self.static_in[0].device
+        with torch.cuda.device(dev):
+            self._capture(model, parts, branches, per, n, tune)
+
+    def _capture(self, model, parts, branches, per, n, tune):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up on a side stream: packs weights, sets kernel attributes, tunes
+        # warm-up on a side stream: packs weights, sets kernel attributes and -- the one place the host mirror
+        # opts in to it -- tunes launch geometry for this batch shape (ops.autotune; ABI calls never tune on their own)
+        with torch.cuda.stream(side), ops.autotune(bool(tune)):
             for _ in range(2):
                 model.forward(*parts[0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._weights = model.weight_state()
         self.branches = branches
         self._streams = [torch.cuda.Stream() for _ in range(branches - 1)]
         self.graph = torch.cuda.CUDAGraph()
@@ -455,6 +484,20 @@ class GraphedForward:
                     cur.wait_stream(s)
 
     def __call__(self, image, sparse_depth, validity_map_depth, intrinsics):
+        with torch.cuda.device(self.static_out.device):
+            return self._replay(image, sparse_depth, validity_map_depth, intrinsics)
+
+    def _replay(self, image, sparse_depth, validity_map_depth, intrinsics):
+        state = self.model.weight_state()
+        if state != self._weights:
+            # The graph holds raw device pointers: to the parameters (S2D, proj_depth and the head read them
+            # directly) and to the packed blobs.  In-place updates (load_state_dict, restore_model, copy_) keep
+            # the parameter storage; the blobs are re-packed in place here, ahead of the replay on this stream.
+            if [p for p, _ in state] != [p for p, _ in self._weights]:
+                raise KbnError("a parameter's storage moved after capture() (e.g. .to() or a re-assignment): "
+                               "call capture() again")
+            self.model.refresh_packed()
+            self._weights = state
         for dst, src in zip(self.static_in, (image, sparse_depth, validity_map_depth, intrinsics)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
@@ -521,12 +564,26 @@ class KBNetModel(object):
         return ops.depth_head(feats, self.decoder.output0.conv.weight, self.min_predict_depth,
                               self.max_predict_depth, return_logits=return_logits, out=out)
 
-    def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None):
+    def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True):
         """Captures one forward of this batch shape into a HIP graph and returns a callable
         `replay(image, sparse_depth, validity_map_depth, intrinsics) -> depth` (inputs are copied
         into the graph's static buffers unless they ARE those buffers; the output tensor is
-        re-used between replays).  Removes the ~35 per-launch host round trips of a forward."""
-        return GraphedForward(self, image, sparse_depth, validity_map_depth, intrinsics, branches)
+        re-used between replays).  Removes the ~35 per-launch host round trips of a forward.
+        `tune`: time candidate launch geometries during the warm-up (results are bit-identical either way)."""
+        return GraphedForward(self, image, sparse_depth, validity_map_depth, intrinsics, branches, tune)
+
+    def weight_state(self):
+        """(storage pointer, version) of every parameter: what a captured graph depends on."""
+        return [(p.data_ptr(), p._version) for p in self.parameters()]
+
+    def refresh_packed(self):
+        """Re-packs (in place) the MFMA-ordered blobs of weights that changed since they were packed."""
+        for m in self.modules():
+            for sub in m.modules():
+                if isinstance(sub, Conv2d):
+                    sub._packed.refresh(sub.conv.weight)
+                elif isinstance(sub, UpConv2d):
+                    sub._packed_up2x.refresh(sub.conv.conv.weight)
 
     # -- nn.Module-like plumbing the reference driver uses ------------------------
     def modules(self):

@@ -5,7 +5,9 @@ through libkbnet_hip.so.  CPU tensors are rejected (no fallback).
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import functools
 from typing import List, Optional, Sequence
 
 import torch
@@ -18,21 +20,80 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _on_tensor_device(fn):
+    """The C side launches on the calling thread's CURRENT device and on the stream it is handed, so every
+    wrapper below runs with the tensors' device current (reference modules accept any device:
+    `KBNetModel(..., device=cuda:1)` while cuda:0 is current, DataParallel replicas on per-device
+    threads) and takes torch's current stream of THAT device.  Tensors on different devices are an error."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        idx = None
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if idx is None:
+                    idx = a.device.index
+                elif a.device.index != idx:
+                    raise KbnError(f"{fn.__name__}: tensors live on different devices (cuda:{idx} and {a.device})")
+        if idx is None or idx == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(idx):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+def reload_env():
+    """Re-reads the KBN_* switches from the environment (the library reads them once at load time)."""
+    _lib.load().kbn_reload_env()
+
+
+@contextlib.contextmanager
+def autotune(enabled: bool = True):
+    """First-use tuning of launch geometry is OFF by default (ABI calls only enqueue work).  Inside this
+    context the first launch of every problem shape times its candidate geometries on the stream and
+    waits for its own events (kbn_set_autotune); the choices stay cached for the process."""
+    lib = _lib.load()
+    old = lib.kbn_set_autotune(1 if enabled else 0)
+    try:
+        yield
+    finally:
+        lib.kbn_set_autotune(old)
+
+
 # Optional per-launch timing (bench.py): when PROFILE is a list, every ABI call is
-# bracketed by HIP events recorded on the launch stream and (name, work, start, end)
-# is appended.  `work` is the launch's algorithmic FLOPs (convs) or bytes (S2D, head).
+# bracketed by HIP events recorded on the launch stream and (name, work, executed, start, end)
+# is appended.  `work` is the launch's ALGORITHMIC FLOPs (convs: the reference's direct
+# formulation) or bytes (S2D, head); `executed` the FLOPs the launch really issues on the matrix
+# cores (Winograd / phase-decomposed up-convs execute fewer; tile and channel padding execute more),
+# None for byte-bound launches.
 PROFILE = None
 
 
-def _launch(name: str, work: float, fn):
+def _launch(name: str, work: float, fn, executed=None):
     if PROFILE is None:
         return fn()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     status = fn()
     end.record()
-    PROFILE.append((name, work, start, end))
+    PROFILE.append((name, work, executed() if callable(executed) else executed, start, end))
     return status
+
+
+def conv_executed_flops(n, out_channels, in_channels, kernel_size, stride, in_height, in_width, resize=False):
+    """FLOPs kbn_conv2d_forward issues on the matrix cores for this problem, padding included, from the
+    launch plan (kbn_conv2d_query): Winograd F(2x2,3x3) regions of 64 tiles x 16 frequencies x 64-channel
+    output tiles; direct kernels 4*MW m-blocks of 16 pixels x NB n-blocks of 16 channels x padded K."""
+    pl = conv_plan(n, out_channels, in_channels, kernel_size, stride, in_height, in_width, resize)
+    if pl["kernel"] == "wino":
+        return 2.0 * pl["workgroups"] * 64 * 16 * in_channels * 64
+    cpad = -(-in_channels // pl["CK"]) * pl["CK"]
+    return 2.0 * pl["workgroups"] * (4 * pl["MW"] * 16) * (pl["NB"] * 16) * cpad * kernel_size * kernel_size
+
+
+def upconv2x_executed_flops(n, in_channels, out_channels, src_height, src_width):
+    info = (C.c_int * 4)()
+    check(_lib.load().kbn_upconv2x_query(n, in_channels, out_channels, src_height, src_width, info), "kbn_upconv2x_query")
+    return 2.0 * n * src_height * src_width * info[0] * info[1] * info[2]
 
 
 _PLAN_CACHE = {}
@@ -78,6 +139,7 @@ def _int_array(values: Sequence[int]):
 
 
 # ----------------------------------------------------------------------------- S2D
+@_on_tensor_device
 def s2d_forward(x, w_pool_convs: List[torch.Tensor], w_conv, min_pool_sizes, max_pool_sizes,
                 negative_slope: float = 0.2, out: Optional[torch.Tensor] = None):
     lib = _lib.load()
@@ -107,6 +169,7 @@ def s2d_forward(x, w_pool_convs: List[torch.Tensor], w_conv, min_pool_sizes, max
     return out
 
 
+@_on_tensor_device
 def s2d_pyramid(x, min_pool_sizes, max_pool_sizes):
     lib = _lib.load()
     _require(x, "x", 4)
@@ -121,6 +184,7 @@ def s2d_pyramid(x, min_pool_sizes, max_pool_sizes):
 
 
 # ---------------------------------------------------------------------- intrinsics
+@_on_tensor_device
 def intrinsics_inverse(intrinsics, scale_x: float = 1.0, scale_y: float = 1.0):
     lib = _lib.load()
     _require(intrinsics, "intrinsics", 3)
@@ -133,6 +197,7 @@ def intrinsics_inverse(intrinsics, scale_x: float = 1.0, scale_y: float = 1.0):
     return out
 
 
+@_on_tensor_device
 def camera_coordinates(kinv, height: int, width: int):
     lib = _lib.load()
     _require(kinv, "kinv", 3)
@@ -144,9 +209,16 @@ def camera_coordinates(kinv, height: int, width: int):
 
 
 # --------------------------------------------------------------------------- conv2d
-def pack_conv_weight(weight: torch.Tensor, stride: int = 1) -> torch.Tensor:
+def _reusable(blob, nfloats, like):
+    return (blob is not None and blob.numel() == nfloats and blob.device == like.device and
+            blob.dtype == torch.float32 and blob.is_contiguous())
+
+
+@_on_tensor_device
+def pack_conv_weight(weight: torch.Tensor, stride: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """OIHW -> MFMA fragment order for a conv of this stride (done once per weight; see
-    _PackedWeight in modules.py)."""
+    _PackedWeight in modules.py).  `out`: an existing blob of the right size to re-pack into (keeps
+    the device pointer a captured graph holds valid)."""
     lib = _lib.load()
     w = weight.detach().contiguous()
     _require(w, "weight", 4)
@@ -156,7 +228,7 @@ def pack_conv_weight(weight: torch.Tensor, stride: int = 1) -> torch.Tensor:
     nbytes = lib.kbn_conv2d_packed_weight_bytes(oc, cin, kh, stride)
     if nbytes == 0:
         raise KbnError(f"unsupported conv weight shape {tuple(w.shape)}")
-    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    packed = out if _reusable(out, nbytes // 4, w) else torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     check(lib.kbn_conv2d_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, kh, stride, _stream()),
           "kbn_conv2d_pack_weight")
     return packed
@@ -197,6 +269,7 @@ def xyz_src(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: torch.Tensor) 
     return s
 
 
+@_on_tensor_device
 def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int,
            kernel_size: int, stride: int, in_height: int, in_width: int, out: torch.Tensor,
            resize: bool = False, negative_slope: Optional[float] = 0.2):
@@ -223,12 +296,15 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
                                                  _lib.KBN_RESIZE_NEAREST if resize else _lib.KBN_RESIZE_NONE,
                                                  0 if negative_slope is None else 1,
                                                  0.0 if negative_slope is None else float(negative_slope),
-                                                 _stream())), "kbn_conv2d_forward")
+                                                 _stream()),
+                  executed=lambda: conv_executed_flops(n, out_channels, cin, kernel_size, stride, in_height, in_width,
+                                                       resize)), "kbn_conv2d_forward")
     return out
 
 
 # ---------------------------------------------------------------------- up-conv 2x
-def pack_upconv2x_weight(weight: torch.Tensor) -> torch.Tensor:
+@_on_tensor_device
+def pack_upconv2x_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """OIHW 3x3 weight -> phase-summed MFMA blob for `upconv2x` (once per weight)."""
     lib = _lib.load()
     w = weight.detach().contiguous()
@@ -236,12 +312,14 @@ def pack_upconv2x_weight(weight: torch.Tensor) -> torch.Tensor:
     oc, cin, kh, kw = w.shape
     if (kh, kw) != (3, 3):
         raise KbnError("upconv2x needs a 3x3 weight")
-    packed = torch.empty(lib.kbn_upconv2x_packed_weight_bytes(oc, cin) // 4, device=w.device, dtype=torch.float32)
+    nfloats = lib.kbn_upconv2x_packed_weight_bytes(oc, cin) // 4
+    packed = out if _reusable(out, nfloats, w) else torch.empty(nfloats, device=w.device, dtype=torch.float32)
     check(lib.kbn_upconv2x_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, _stream()),
           "kbn_upconv2x_pack_weight")
     return packed
 
 
+@_on_tensor_device
 def upconv2x(x: torch.Tensor, packed_weight: torch.Tensor, out_channels: int, out: torch.Tensor,
              negative_slope: Optional[float] = 0.2):
     """nearest 2x upsample + conv3x3 (+ LeakyReLU): x N x C x h x w -> out N x out_channels x 2h x 2w."""
@@ -256,11 +334,13 @@ def upconv2x(x: torch.Tensor, packed_weight: torch.Tensor, out_channels: int, ou
                   lambda: lib.kbn_upconv2x_forward(xptr, xbs, packed_weight.data_ptr(), optr, obs, n, cin,
                                                    out_channels, h, w, 0 if negative_slope is None else 1,
                                                    0.0 if negative_slope is None else float(negative_slope),
-                                                   _stream())), "kbn_upconv2x_forward")
+                                                   _stream()),
+                  executed=lambda: upconv2x_executed_flops(n, cin, out_channels, h, w)), "kbn_upconv2x_forward")
     return out
 
 
 # ------------------------------------------------------------------------ KB block
+@_on_tensor_device
 def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_depth, proj_weight,
              packed_w_fused, filters_image: int, filters_depth: int, filters_fused: int,
              out_image, out_depth, out_fused, negative_slope: float = 0.2):
@@ -302,12 +382,14 @@ def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_de
                                                    packed_w_image.data_ptr(), packed_w_depth.data_ptr(),
                                                    pw.data_ptr(), packed_w_fused.data_ptr(), oi, oibs, od, odbs,
                                                    of, ofbs, n, h, w, ci, cd, cf, filters_image, filters_depth,
-                                                   filters_fused, float(negative_slope), _stream())),
+                                                   filters_fused, float(negative_slope), _stream()),
+                  executed=flops),   # direct convs: executed = algorithmic (tile padding not counted)
           "kbn_kb_block_forward")
     return out_image, out_depth, out_fused
 
 
 # ---------------------------------------------------------------------- depth head
+@_on_tensor_device
 def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, return_logits=False, out=None):
     """`out`: optional contiguous N x 1 x H x W destination (e.g. a batch slice of a larger output buffer)."""
     lib = _lib.load()
@@ -335,6 +417,7 @@ def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, re
 
 
 # ------------------------------------------------------- pre-model stage / evaluation
+@_on_tensor_device
 def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5, normalize_image: bool = True):
     """Validity map + outlier removal (+ image / 255): what reference src/kbnet.py:899-912 does
     before calling the model.  Returns (image_normalized or None, filtered_validity, filtered_sparse)."""
@@ -359,6 +442,7 @@ def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5
     return out_img, validity, filtered
 
 
+@_on_tensor_device
 def unpack_frames(image_u8, depth_raw, width: Optional[int] = None, x_offset: int = 0):
     """Decoded PNG pixels on the device -> (image N x 3 x H x W float32 in 0..255, sparse depth
     N x 1 x H x W float32 = raw / 256): the tensors reference src/datasets.py:259-283 returns.
@@ -397,6 +481,7 @@ def unpack_frames(image_u8, depth_raw, width: Optional[int] = None, x_offset: in
     return image, depth
 
 
+@_on_tensor_device
 def eval_metrics(output_depth, ground_truth, ground_truth_validity, min_evaluate_depth: float,
                  max_evaluate_depth: float):
     """Per-frame (MAE [mm], RMSE [mm], iMAE [1/km], iRMSE [1/km]) as an N x 4 fp64 tensor, computed on

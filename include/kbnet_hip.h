@@ -9,10 +9,14 @@
  * Conventions
  *   - every tensor is fp32, NCHW, W-contiguous, device (HBM) memory owned by the
  *     caller; the library allocates nothing and keeps no pointer after return;
- *   - every call only enqueues work on `stream` (a hipStream_t) and returns;
+ *   - every call only enqueues work on `stream` (a hipStream_t of the calling thread's
+ *     current device) and returns: no synchronisation, no timing, no file I/O -- unless
+ *     the caller has switched first-use tuning on (kbn_set_autotune, OFF by default);
  *   - return value: KBN_OK (0) or a negative kbn_status; nothing throws across the ABI;
- *   - the library is re-entrant (no global mutable state besides one-time kernel
- *     attribute setup).
+ *   - the library is re-entrant and multi-device: its only process state is (a) one-time
+ *     kernel attribute setup, done per device, (b) the debug knobs, read from the
+ *     environment once at load time (kbn_reload_env re-reads them), (c) the launch-geometry
+ *     cache, per device, written only while tuning is on.
  */
 #ifndef KBNET_HIP_H
 #define KBNET_HIP_H
@@ -37,6 +41,20 @@ typedef enum kbn_status {
 
 int kbn_version(void);
 const char* kbn_status_string(int status);
+
+/* Re-reads the KBN_* debug / experiment variables and KBN_TUNE_CACHE from the environment
+ * (they are otherwise read once, when the library is loaded; no launch path calls getenv). */
+void kbn_reload_env(void);
+
+/* First-use tuning of launch geometry (tile / region shapes; csrc/tune.hip).  OFF by default:
+ * calls launch the analytic choice or a cached one.  While ON, the first call of a problem
+ * shape on a device times every candidate geometry on `stream` and waits for its own events --
+ * results are bit-identical whatever is picked -- so switch it on only around a warm-up pass:
+ *     kbn_set_autotune(1); <one forward per shape>; kbn_set_autotune(0);
+ * Never tunes while `stream` is being captured.  KBN_AUTOTUNE=1 in the environment at load time
+ * is the same switch; KBN_TUNE_CACHE=<file> preloads / records choices.  Returns the old state. */
+int kbn_set_autotune(int enabled);
+int kbn_get_autotune(void);
 
 /* ------------------------------------------------------------------ S2D -------
  * networks.SparseToDensePool.forward(x)            reference src/networks.py:2168-2196
@@ -157,6 +175,12 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
                          float* out, long long out_batch_stride, int n, int in_channels,
                          int out_channels, int src_height, int src_width, int apply_activation,
                          float negative_slope, kbn_stream_t stream);
+
+/* Which algebraic form kbn_upconv2x_forward runs for a problem (diagnostics, roofline accounting):
+ * info[4] = {channel products per low-resolution pixel: 16 four 2x2 phases / 12 three-product columns /
+ * 9 three-product rows and columns; padded output channels; padded input channels; 0}.  The launch
+ * executes 2 * n * src_height * src_width * info[0] * info[1] * info[2] FLOP on the matrix cores. */
+int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height, int src_width, int* info);
 
 /* Which kernel variant / tile geometry kbn_conv2d_forward picks for a problem (diagnostics,
  * profiling): info[8] = {CK, NB, MW, TWB, TH, workgroups, staged positions per thread, kernel};

@@ -41,3 +41,23 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture
+def kenv(monkeypatch):
+    """KBN_* switches for A/B tests: the library reads the environment once at load time, so every change
+    is followed by kbn_reload_env(); everything is restored (and re-read) when the test ends."""
+    import kbnet_amd as kb
+
+    class Env:
+        def setenv(self, name, value):
+            monkeypatch.setenv(name, value)
+            kb.ops.reload_env()
+
+        def delenv(self, name):
+            monkeypatch.delenv(name, raising=False)
+            kb.ops.reload_env()
+
+    yield Env()
+    monkeypatch.undo()
+    kb.ops.reload_env()

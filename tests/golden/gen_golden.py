@@ -22,6 +22,8 @@ Cases
   fwd_*      KBNetModel.forward: KITTI preset, VOID preset (both narrow channels)
              and an odd 70x100 frame; fwd_kb012 / fwd_kb02: encoders with KB layers at levels
              [0, 1, 2] / [0, 2] only (plain stride-2 blocks elsewhere).
+  ckpt_kitti_narrow.pth  written by the reference's KBNetModel.save_model (same weights as fwd_kitti): the
+             `.pth` layout restore_model must read (module.-prefixed keys, three state_dicts, optimizer state).
   io/*       input pipeline: small PNG / .npy files written by this script's own PNG writer
              (every scanline filter type, split IDAT, gray / RGB / RGBA / palette / 16-bit gray) and what the
              reference's data_utils.load_image, datasets.load_image_triplet / load_depth and
@@ -264,6 +266,28 @@ def gen_forward(only=None):
              s2d=np_sd(sds[0]), encoder=np_sd(sds[1]), decoder=np_sd(sds[2]))
 
 
+# ------------------------------------------------------- checkpoint layout (f3)
+def gen_checkpoint():
+    """A checkpoint written by the REFERENCE's own writer (KBNetModel.save_model, src/kbnet_model.py:353-376):
+    the narrow KITTI-preset model of fwd_kitti (same weights), an untouched Adam optimizer as the training loop
+    passes one (src/kbnet.py:507-518), train_step 1234.  The file is what restore_model (:378-406) reads."""
+    cfg = kb.PRESETS["kitti"]().narrow()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=5, gain=1.3)
+    model = build_reference_model(cfg)
+    load(model.sparse_to_dense_pool, sds[0])
+    load(model.encoder, sds[1])
+    load(model.decoder, sds[2])
+    optimizer = torch.optim.Adam([{"params": model.parameters(), "weight_decay": 0.0}], lr=1e-4)
+    path = os.path.join(HERE, "ckpt_kitti_narrow.pth")
+    model.save_model(path, 1234, optimizer)
+    ckpt = torch.load(path)
+    assert set(ckpt) == {"train_step", "optimizer_state_dict", "sparse_to_dense_pool_state_dict",
+                         "encoder_state_dict", "decoder_state_dict"}
+    assert all(k.startswith("module.") for k in ckpt["encoder_state_dict"])
+    print(f"ckpt_kitti_narrow.pth: {os.path.getsize(path) / 1024:.1f} KiB, "
+          f"{sum(v.numel() for d in list(ckpt.values())[2:] for v in d.values())} parameters")
+
+
 # ------------------------------------------- pre-model stage and evaluation (f1, f2)
 def gen_pre_eval():
     import eval_utils  # reference
@@ -405,6 +429,9 @@ if __name__ == "__main__":
     if "--only-io" in sys.argv:
         gen_io()
         sys.exit(0)
+    if "--only-checkpoint" in sys.argv:   # added in round 2; leaves the other fixtures untouched
+        gen_checkpoint()
+        sys.exit(0)
     if "--only-topologies" in sys.argv:   # added later; leaves the other fixtures untouched
         gen_forward(only=("kb012", "kb02"))
         sys.exit(0)
@@ -416,3 +443,4 @@ if __name__ == "__main__":
     gen_kb()
     gen_decoder()
     gen_forward()
+    gen_checkpoint()

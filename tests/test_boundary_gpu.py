@@ -1,0 +1,238 @@
+"""GPU tests of the drop-in boundary: the two north-star modules patched into a
+reference-shaped model the way INTEGRATION.md section 2 shows, non-default streams, several devices in one
+process, a checkpoint written by the reference's own `save_model`, and the RCCL path of dist.py.
+
+    python -m pytest tests -m gpu -q
+"""
+import os
+import socket
+import types
+
+import pytest
+import torch
+
+import kbnet_amd as kb
+from conftest import GOLDEN_DIR, load_golden
+from oracle import kbnet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north_star: "within 1e-4 relative fp32"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("GPU tests need a visible MI355X (run with -m gpu on a GPU box)")
+    kb._lib.load()
+    return torch.device("cuda:0")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# A stand-in with the SHAPE of the reference's model code (the reference itself cannot travel to the GPU box):
+# `networks` / `net_utils` namespaces whose two north-star symbols are replaced exactly as INTEGRATION.md
+# section 2 patches the reference's modules, an encoder that builds dense coordinates with torch ops like
+# reference src/networks.py:317-352 (incl. the level-1-ratio quirk) and calls the KB blocks BY KEYWORD
+# (:368-372, :401-405), and a model forward that calls S2D POSITIONALLY (src/kbnet_model.py:166-184).
+# Every other layer of the stand-in is a plain torch.nn.functional op, i.e. what the unpatched reference runs.
+# ----------------------------------------------------------------------------------------------------------
+def _patched_namespaces():
+    networks, net_utils = types.SimpleNamespace(), types.SimpleNamespace()
+    networks.SparseToDensePool = kb.modules.SparseToDensePool
+    net_utils.CalibratedBackprojectionBlock = kb.modules.CalibratedBackprojectionBlock
+    return networks, net_utils
+
+
+def _torch_conv(x, w, stride=1, slope=0.2):
+    y = torch.nn.functional.conv2d(x, w, stride=stride, padding=w.shape[-1] // 2)
+    return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
+
+
+class _ReferenceShapedModel:
+    def __init__(self, cfg, sds, device):
+        networks, net_utils = _patched_namespaces()
+        act = torch.nn.LeakyReLU(negative_slope=0.20, inplace=True)
+        fi, fd = cfg.n_filters_encoder_image, cfg.n_filters_encoder_depth
+        self.cfg = cfg
+        self.sd_enc = {k: v.to(device) for k, v in sds[1].items()}
+        self.sd_dec = {k: v.to(device) for k, v in sds[2].items()}
+        self.sparse_to_dense_pool = networks.SparseToDensePool(
+            input_channels=cfg.input_channels_depth, min_pool_sizes=list(cfg.min_pool_sizes_sparse_to_dense_pool),
+            max_pool_sizes=list(cfg.max_pool_sizes_sparse_to_dense_pool),
+            n_convolution=cfg.n_convolution_sparse_to_dense_pool, n_filter=cfg.n_filter_sparse_to_dense_pool,
+            weight_initializer=cfg.weight_initializer, activation_func=cfg.activation_func)
+        self.sparse_to_dense_pool.load_state_dict(sds[0])
+        self.sparse_to_dense_pool = torch.nn.DataParallel(self.sparse_to_dense_pool, device_ids=[device.index]).to(device)
+        self.kb = []
+        for n in range(4):
+            cf = fi[n - 1] + fi[n - 1] if n > 0 else fi[0]
+            blk = net_utils.CalibratedBackprojectionBlock(
+                in_channels_image=fi[max(n - 1, 0)], in_channels_depth=fd[max(n - 1, 0)], in_channels_fused=cf,
+                n_filter_image=fi[n], n_filter_depth=fd[n], n_filter_fused=fi[n], n_convolution_image=1,
+                n_convolution_depth=1, n_convolution_fused=1, weight_initializer=cfg.weight_initializer,
+                activation_func=act)
+            pref = f"calibrated_backprojection{n + 1}."
+            blk.load_state_dict({k[len(pref):]: v for k, v in sds[1].items() if k.startswith(pref)})
+            self.kb.append(blk.to(device))
+
+    @staticmethod
+    def _coordinates(k, n, h, w):       # reference src/networks.py:317-331 + src/net_utils.py:1601-1636
+        xs = torch.linspace(0, w - 1, w, device=k.device)
+        ys = torch.linspace(0, h - 1, h, device=k.device)
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        xy_h = torch.stack([xx, yy, torch.ones_like(xx)], 0).unsqueeze(0).repeat(n, 1, 1, 1)
+        return torch.matmul(torch.inverse(k), xy_h.view(n, 3, -1)).view(n, 3, h, w)
+
+    def forward(self, image, sparse_depth, validity_map_depth, intrinsics):
+        input_depth = torch.cat([sparse_depth, validity_map_depth], dim=1)
+        input_depth = self.sparse_to_dense_pool(input_depth)                      # positional, through DataParallel
+        n, _, h0, w0 = image.shape
+        e = self.sd_enc
+        conv_image = _torch_conv(image, e["conv0_image.conv.weight"])
+        conv_depth = _torch_conv(input_depth, e["conv0_depth.conv.weight"])
+        h1, w1 = (h0 + 1) // 2, (w0 + 1) // 2
+        scale = torch.tensor([[w1 / w0, 1.0, w1 / w0], [1.0, h1 / h0, h1 / h0], [1.0, 1.0, 1.0]], device=image.device)
+        fused, skips, h, w = None, [], h0, w0
+        for lvl in range(4):
+            k = intrinsics if lvl == 0 else intrinsics * scale               # Q1: level-1 ratio at every deeper level
+            coordinates = self._coordinates(k, n, h, w)
+            conv_image, conv_depth, fused = self.kb[lvl](image=conv_image, depth=conv_depth, coordinates=coordinates,
+                                                         fused=fused)       # by keyword, dense coordinates
+            skips.append(torch.cat([fused, conv_depth], 1))
+            h, w = (h + 1) // 2, (w + 1) // 2
+        c5i = _torch_conv(fused, e["conv5_image.conv_block.0.conv.weight"], 2)
+        c5d = _torch_conv(conv_depth, e["conv5_depth.conv_block.0.conv.weight"], 2)
+        x = torch.cat([c5i, c5d], 1)
+        d = self.sd_dec
+        for name, skip in (("deconv4", skips[3]), ("deconv3", skips[2]), ("deconv2", skips[1]), ("deconv1", skips[0]),
+                           ("deconv0", None)):
+            size = skip.shape[2:4] if skip is not None else (h0, w0)
+            x = _torch_conv(torch.nn.functional.interpolate(x, size=size, mode="nearest"),
+                            d[f"{name}.deconv.conv.conv.weight"])
+            x = _torch_conv(torch.cat([x, skip], 1) if skip is not None else x, d[f"{name}.conv.conv.weight"])
+        logits = _torch_conv(x, d["output0.conv.weight"], slope=None)
+        dmin, dmax = self.cfg.min_predict_depth, self.cfg.max_predict_depth
+        return dmin / (torch.sigmoid(logits) + dmin / dmax)
+
+
+def test_patched_reference_shaped_model_on_side_stream(dev):
+    """INTEGRATION.md section 2 end to end: the two HIP modules inside otherwise stock torch code (torch's own
+    convs for the rest, as in the unpatched reference), positional S2D call through DataParallel, keyword KB
+    calls with DENSE coordinates, everything on a non-default stream.  Checked against the oracle."""
+    cfg = kb.kitti_config().narrow()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=4, gain=1.3)
+    frames = kb.synthetic.make_frames(2, 96, 160, "kitti", seed=3, jitter_intrinsics=0.1)
+    ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth,
+                            cfg.max_predict_depth)
+    model = _ReferenceShapedModel(cfg, sds, dev)
+    dframes = [f.to(dev) for f in frames]
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side), torch.no_grad():
+        out = model.forward(*dframes)
+        # nothing ran on the default stream: the modules launch on torch's CURRENT stream
+    side.synchronize()
+    err = float(((out.cpu() - ref).abs() / ref.abs()).max())
+    assert err < TOL, err
+    # the all-HIP model on the same stream gives the same answer within the same bar
+    full = kb.modules.KBNetModel.from_config(cfg, dev)
+    full.load_state_dicts(*sds)
+    with torch.cuda.stream(side):
+        out2 = full.forward(*dframes)
+    side.synchronize()
+    assert float(((out2.cpu() - ref).abs() / ref.abs()).max()) < TOL
+
+
+def test_two_devices_in_one_process():
+    """Kernel attributes (dynamic LDS limit) are per device and the launches follow the tensors' device, not the
+    current one: a model on cuda:1 while cuda:0 is current (the reference accepts any `device`; DataParallel
+    replicas run on per-device threads, src/kbnet_model.py:408-415)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs GPUs")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    cfg = kb.kitti_config().narrow()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+    frames = kb.synthetic.make_frames(2, 64, 96, "kitti", seed=1)
+    outs = []
+    torch.cuda.set_device(0)
+    for index in (0, 1, 0):
+        d = torch.device("cuda", index)
+        m = kb.modules.KBNetModel.from_config(cfg, d)
+        m.load_state_dicts(*sds)
+        outs.append(m.forward(*[f.to(d) for f in frames]).cpu())   # current device stays 0 throughout
+        assert torch.cuda.current_device() == 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    dp = torch.nn.DataParallel(kb.modules.SparseToDensePool(2, [5, 7], [9], 8, 3, "xavier_normal", "leaky_relu"),
+                               device_ids=[0, 1]).to("cuda:0")
+    x = torch.cat(kb.synthetic.make_frames(4, 32, 64, "kitti", seed=2)[1:3], 1).to("cuda:0")
+    whole = dp.module(x)
+    assert torch.equal(dp(x), whole), "DataParallel scatter over two devices must reproduce the single-device result"
+
+
+def test_reference_written_checkpoint_restores_and_runs(dev):
+    """f3: tests/golden/ckpt_kitti_narrow.pth was written by the REFERENCE's KBNetModel.save_model
+    (src/kbnet_model.py:353-376; gen_golden.py gen_checkpoint) with the weights of golden fwd_kitti.
+    restore_model (the counterpart of :378-406) -> forward must reproduce the reference's own output."""
+    g = load_golden("fwd_kitti")
+    m = kb.modules.KBNetModel.from_config(kb.kitti_config().narrow(), dev)
+    step, _ = m.restore_model(os.path.join(GOLDEN_DIR, "ckpt_kitti_narrow.pth"))
+    assert step == 1234
+    out = m.forward(*[g[k].to(dev) for k in ("image", "sparse_depth", "validity_map", "intrinsics")])
+    err = float(((out.cpu() - g["output_depth"]).abs() / g["output_depth"].abs()).max())
+    assert err < TOL, err
+
+
+# ------------------------------------------------------------------------------------------------ RCCL
+def _rccl_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    r, local, w = kb.dist.init("nccl")
+    dev = torch.device("cuda", local)
+    cfg = kb.kitti_config().narrow()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    per = 4
+    frames = kb.synthetic.make_frames(per * world, 64, 96, "kitti", seed=1, jitter_intrinsics=0.1)
+    local_frames = [t.to(dev) for t in kb.dist.shard_frames(frames, rank, world)]
+    replay = m.capture(*local_frames)
+    runner = kb.dist.ShardedRunner(replay, rank, world)
+    assert runner.step_pipelined(replay.static_in) is None
+    first = runner.step_pipelined(replay.static_in).clone()
+    last = runner.drain().clone()
+    single = m.forward(*[t.to(dev) for t in frames])      # all frames on one rank, eager
+    ok = torch.equal(first, single) and torch.equal(last, single)
+    # ragged step(): 2 * world - 1 frames
+    n_total = per * world - 1
+    sub = [t[:n_total] for t in frames]
+    got = kb.dist.ShardedRunner(m.forward, rank, world).step(
+        [t.to(dev) for t in kb.dist.shard_frames(sub, rank, world)], n_total=n_total)
+    ok = ok and torch.equal(got, single[:n_total])
+    kb.dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_runner_rccl():
+    """dist.ShardedRunner over RCCL (backend 'nccl'): the real graphed forward on every rank, pipelined all-gather,
+    bitwise equal to one rank computing all frames.  Needs two devices (two RCCL ranks cannot share one GPU)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs GPUs")
+    world = min(2, torch.cuda.device_count())
+    if world < 2:
+        pytest.skip("needs two visible devices for two RCCL ranks")
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results)

@@ -21,8 +21,9 @@ TIGHT = 2e-5  # single-op checks: fp32 summation-order noise only
 
 @pytest.fixture(scope="module")
 def dev():
-    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
-    kb._lib.load()
+    if not torch.cuda.is_available():
+        pytest.skip("GPU tests need a visible MI355X (run with -m gpu on a GPU box)")
+    kb._lib.load()   # a missing extension is an error on a GPU box, never a skip
     return torch.device("cuda:0")
 
 
@@ -208,36 +209,46 @@ def test_decoder_block_winograd_concat(dev):
     assert kb.ops.conv_plan(2, 40, 96, 3, 1, 22, 36)["kernel"] == "wino"
 
 
-def test_winograd_matches_direct_kernel(dev, monkeypatch):
+def test_winograd_matches_direct_kernel(dev, kenv):
     """Same launch through the Winograd and the direct LDS-DMA kernel (KBN_NO_WINO=1)."""
     g = torch.Generator().manual_seed(11)
     x = torch.randn(2, 96, 30, 44, generator=g).to(dev)
     conv = kb.modules.Conv2d(96, 64, 3, 1, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
     a = conv(x).clone()
-    monkeypatch.setenv("KBN_NO_WINO", "1")
+    kenv.setenv("KBN_NO_WINO", "1")
     b = conv(x).clone()
     assert rel_err(a, b) < TIGHT
     assert not torch.equal(a, b)  # two different kernels did run
 
 
 def test_first_use_tuning_keeps_results_bitwise(dev):
-    """The first launch of a shape times every tile / region candidate (csrc/tune.hip); geometry never
-    changes an accumulation order, so the tuned launches must reproduce the first result bit for bit."""
+    """Tuning is opt-in (kbn_set_autotune / ops.autotune): plain ABI calls launch the analytic geometry and only
+    enqueue work.  Inside the context the first launch of a shape times every tile / region candidate
+    (csrc/tune.hip); geometry never changes an accumulation order, so untuned, tuning and tuned launches must
+    agree bit for bit."""
+    lib = kb._lib.load()
+    assert lib.kbn_get_autotune() == 0, "tuning must be off unless the caller switched it on"
     g = torch.Generator().manual_seed(12)
     for cin, cout, k, stride, h, w in ((48, 96, 3, 2, 46, 88), (64, 64, 3, 1, 26, 52), (51, 48, 1, 2, 30, 52)):
         x = torch.randn(2, cin, h, w, generator=g).to(dev)
         conv = kb.modules.Conv2d(cin, cout, k, stride, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
-        first = conv(x).clone()          # model's choice, then the candidates are timed
+        first = conv(x).clone()          # the cost model's choice, nothing timed
+        with kb.ops.autotune():
+            assert lib.kbn_get_autotune() == 1
+            assert torch.equal(conv(x), first)     # candidates are timed here
+        assert lib.kbn_get_autotune() == 0
         for _ in range(3):
-            assert torch.equal(conv(x), first)
+            assert torch.equal(conv(x), first)     # the cached winner
     up = kb.modules.UpConv2d(32, 48, 3, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
     x = torch.randn(2, 32, 12, 20, generator=g).to(dev)
     first = up(x, (24, 40)).clone()
+    with kb.ops.autotune():
+        assert torch.equal(up(x, (24, 40)), first)
     for _ in range(3):
         assert torch.equal(up(x, (24, 40)), first)
 
 
-def test_every_tile_and_region_shape_keeps_results_bitwise(dev, monkeypatch):
+def test_every_tile_and_region_shape_keeps_results_bitwise(dev, kenv):
     """The tuner may pick any tile shape of the direct kernels (MW x TWB), any Winograd region and either up-conv tile
     width; force each one (KBN_FORCE_MW / KBN_FORCE_TWB / KBN_WINO_RT) and compare bit for bit with the default."""
     g = torch.Generator().manual_seed(13)
@@ -247,41 +258,41 @@ def test_every_tile_and_region_shape_keeps_results_bitwise(dev, monkeypatch):
     for cin, cout, k, stride, h, w in cases:
         x = torch.randn(2, cin, h, w, generator=g).to(dev)
         conv = kb.modules.Conv2d(cin, cout, k, stride, "xavier_normal", act).to(dev)
-        monkeypatch.setenv("KBN_NO_WINO", "1")            # the direct kernels, also for the wide 3x3 case
+        kenv.setenv("KBN_NO_WINO", "1")            # the direct kernels, also for the wide 3x3 case
         ref = conv(x).clone()
         for epi in ("0", "2"):                            # plain epilogue / stores through LDS (store-bound layers)
-            monkeypatch.setenv("KBN_EPI_LDS", epi)
+            kenv.setenv("KBN_EPI_LDS", epi)
             for mw in (1, 2, 4, 8):
                 for twb in (1, 2, 4):
-                    monkeypatch.setenv("KBN_FORCE_MW", str(mw))
-                    monkeypatch.setenv("KBN_FORCE_TWB", str(twb))
+                    kenv.setenv("KBN_FORCE_MW", str(mw))
+                    kenv.setenv("KBN_FORCE_TWB", str(twb))
                     assert torch.equal(conv(x), ref), f"conv {cin}->{cout} k{k} s{stride}: MW={mw} TWB={twb} epi={epi}"
-        monkeypatch.delenv("KBN_EPI_LDS")
-        monkeypatch.delenv("KBN_FORCE_MW")
-        monkeypatch.delenv("KBN_FORCE_TWB")
-        monkeypatch.delenv("KBN_NO_WINO")
+        kenv.delenv("KBN_EPI_LDS")
+        kenv.delenv("KBN_FORCE_MW")
+        kenv.delenv("KBN_FORCE_TWB")
+        kenv.delenv("KBN_NO_WINO")
     x = torch.randn(2, 64, 44, 72, generator=g).to(dev)
     conv = kb.modules.Conv2d(64, 128, 3, 1, "xavier_normal", act).to(dev)
     assert kb.ops.conv_plan(2, 128, 64, 3, 1, 44, 72)["kernel"] == "wino"
     ref = conv(x).clone()
     for rt in (4, 8, 2, 6, 5, 3, 7, 10):              # every entry of conv_wino.hip's kRegions
-        monkeypatch.setenv("KBN_WINO_RT", str(rt))
+        kenv.setenv("KBN_WINO_RT", str(rt))
         assert torch.equal(conv(x), ref), f"Winograd region with {rt} tile rows"
-    monkeypatch.delenv("KBN_WINO_RT")
+    kenv.delenv("KBN_WINO_RT")
     for cin, cout, hw in ((32, 48, (12, 20)), (64, 12, (20, 36)), (64, 64, (11, 38))):
         up = kb.modules.UpConv2d(cin, cout, 3, "xavier_normal", act).to(dev)
         x = torch.randn(2, cin, *hw, generator=g).to(dev)
         shape = (2 * hw[0], 2 * hw[1])
         ref = up(x, shape).clone()
         for twb in (1, 2):
-            monkeypatch.setenv("KBN_FORCE_TWB", str(twb))
+            kenv.setenv("KBN_FORCE_TWB", str(twb))
             assert torch.equal(up(x, shape), ref), f"up-conv {cin}->{cout}: TWB={twb}"
-        monkeypatch.delenv("KBN_FORCE_TWB")
+        kenv.delenv("KBN_FORCE_TWB")
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(64, 12, (20, 36)), (128, 64, (12, 24)), (256, 128, (11, 38)), (32, 48, (9, 20)),
                                          (48, 32, (7, 16)), (16, 20, (5, 12))])
-def test_upconv2x_three_product_form_vs_four_phase(dev, monkeypatch, cin, cout, hw):
+def test_upconv2x_three_product_form_vs_four_phase(dev, kenv, cin, cout, hw):
     """The LDS-DMA up-conv kernels use the 3-product identity o0 = -g0 (in[x]-in[x-1]) + G in[x], o1 = g2 (in[x+1]-in[x])
     + G in[x] (csrc/conv_up2x.hip): along the columns (3/4 of the MFMAs; KBN_NO_UP2X9=1), or along rows and columns
     (9 products per low-res pixel instead of 16; the default where the filter count allows); KBN_NO_UP2X3=1 runs the
@@ -293,9 +304,9 @@ def test_upconv2x_three_product_form_vs_four_phase(dev, monkeypatch, cin, cout, 
     shape = (2 * hw[0], 2 * hw[1])
     ref = orc.conv2d(torch.nn.functional.interpolate(x, size=shape, mode="nearest"), up.conv.conv.weight.detach().cpu(), 1, 0.2)
     default = up(x.to(dev), shape).clone()
-    monkeypatch.setenv("KBN_NO_UP2X9", "1")
+    kenv.setenv("KBN_NO_UP2X9", "1")
     three = up(x.to(dev), shape).clone()
-    monkeypatch.setenv("KBN_NO_UP2X3", "1")
+    kenv.setenv("KBN_NO_UP2X3", "1")
     four = up(x.to(dev), shape).clone()
     for y in (default, three, four):
         assert rel_err(y, ref) < TIGHT
@@ -341,7 +352,7 @@ def test_kb_block_golden(dev, name, mode):
     (48, 16, 48, 96, 32, 3, 12),
 ])
 @pytest.mark.parametrize("mode", ["coordinates", "kinv"])
-def test_kb_block_paired_kernel(dev, monkeypatch, ci, cd, cf, fi, fd, h, w, mode):
+def test_kb_block_paired_kernel(dev, kenv, ci, cd, cf, fi, fd, h, w, mode):
     """KBNet's own KB shapes take the one-launch KB block kernel (csrc/kb_pair.hip: conv_image + conv_fused on a
     shared image tile, conv_depth riding along): against the oracle, and bit for bit against the three separate
     conv launches (KBN_NO_KB_PAIR=1) -- same accumulation order."""
@@ -365,19 +376,19 @@ def test_kb_block_paired_kernel(dev, monkeypatch, ci, cd, cf, fi, fd, h, w, mode
     for a, b, r in zip(got, again, ref):
         assert rel_err(a, r) < TIGHT
         assert torch.equal(a, b)
-    monkeypatch.setenv("KBN_NO_KB_PAIR", "1")
+    kenv.setenv("KBN_NO_KB_PAIR", "1")
     sep = run()
     for a, b in zip(got, sep):
         assert torch.equal(a, b)
-    monkeypatch.delenv("KBN_NO_KB_PAIR")
-    monkeypatch.setenv("KBN_NO_KB_DEPTH_FUSION", "1")   # conv_image + conv_fused fused, conv_depth on its own
+    kenv.delenv("KBN_NO_KB_PAIR")
+    kenv.setenv("KBN_NO_KB_DEPTH_FUSION", "1")   # conv_image + conv_fused fused, conv_depth on its own
     for a, b in zip(got, run()):
         assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [(48, 16, 0, 48, 16, 38, 68), (48, 16, 48, 96, 32, 34, 72),
                                                 (96, 32, 96, 192, 64, 19, 44)])
-def test_kb_block_paired_kernel_every_tile_shape(dev, monkeypatch, ci, cd, cf, fi, fd, h, w):
+def test_kb_block_paired_kernel_every_tile_shape(dev, kenv, ci, cd, cf, fi, fd, h, w):
     """All six (MW, TWB) tile shapes of kb_pair_kernel -- 3 n-blocks with conv_depth riding along (KB1), 3 and 4
     n-blocks without -- forced through KBN_PAIR_CAND: bit-identical to the three-launch path (tile geometry never
     changes an accumulation order)."""
@@ -389,11 +400,11 @@ def test_kb_block_paired_kernel_every_tile_shape(dev, monkeypatch, ci, cd, cf, f
     fused = torch.randn(n, cf, h, w, generator=g).to(dev) if cf else None
     kinv = kb.ops.intrinsics_inverse(torch.tensor([[[40.0, 0.0, w / 2.0], [0.0, 40.0, h / 2.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1).to(dev))
     run = lambda: [t.clone() for t in blk(image=image, depth=depth, coordinates=kinv, fused=fused)]
-    monkeypatch.setenv("KBN_NO_KB_PAIR", "1")
+    kenv.setenv("KBN_NO_KB_PAIR", "1")
     ref = run()
-    monkeypatch.delenv("KBN_NO_KB_PAIR")
+    kenv.delenv("KBN_NO_KB_PAIR")
     for cand in range(6):
-        monkeypatch.setenv("KBN_PAIR_CAND", str(cand))
+        kenv.setenv("KBN_PAIR_CAND", str(cand))
         for a, b in zip(run(), ref):
             assert torch.equal(a, b), f"tile candidate {cand}"
 
@@ -482,6 +493,79 @@ def test_forward_full_size_vs_oracle(dev, preset, shape):
     assert torch.equal(alone, out[1:2])
 
 
+def _worst_rel(out, ref):
+    return float(((out.cpu() - ref).abs() / ref.abs()).max())
+
+
+def test_forward_batch32_full_size_vs_oracle(dev):
+    """BASELINE configs[2] (fp32 leg) / configs[3]'s per-GPU share: KITTI 352x1216, 32 frames in one forward and in the
+    graph the bench replays (two 16-frame branches).  Three frames incl. the last one go through the oracle."""
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+    frames = kb.synthetic.make_frames(32, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    dframes = to(dev, *frames)
+    out = m.forward(*dframes).clone()
+    replay = m.capture(*dframes)
+    assert replay.branches == 2
+    assert torch.equal(replay(*dframes), out), "graph replay (2 x 16 frames) must reproduce the eager batch"
+    worst = 0.0
+    for i in (0, 17, 31):
+        ref = orc.kbnet_forward(*[f[i:i + 1] for f in frames], *sds, cfg.min_pools, cfg.max_pools,
+                                cfg.min_predict_depth, cfg.max_predict_depth)
+        worst = max(worst, _worst_rel(out[i:i + 1], ref))
+    print(f"batch 32 KITTI: worst element-wise relative error over frames 0/17/31 = {worst:.3e}")
+    assert worst < TOL, f"max relative error {worst:.3e}"
+
+
+@pytest.mark.parametrize("preset,shape", [("kitti", (352, 1216)), ("void", (480, 640)), ("nyu_v2", (416, 576))])
+def test_forward_full_size_seed_sweep(dev, preset, shape):
+    """Parity margin: five weight / input seeds per preset at BASELINE's sizes, the worst element-wise relative error
+    of the depth map asserted below north_star's 1e-4 and printed (pytest -s / the failure message)."""
+    cfg = kb.PRESETS[preset]()
+    worst, per_seed = 0.0, []
+    for seed in (0, 3, 7, 11, 19):
+        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3 if preset == "kitti" else 1.45)
+        frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
+        m = kb.modules.KBNetModel.from_config(cfg, dev)
+        m.load_state_dicts(*sds)
+        out = m.forward(*to(dev, *frames))
+        ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth,
+                                cfg.max_predict_depth)
+        per_seed.append(_worst_rel(out, ref))
+        worst = max(worst, per_seed[-1])
+    print(f"{preset} {shape}: max rel err per seed " + " ".join(f"{e:.2e}" for e in per_seed))
+    assert worst < TOL, f"{preset}: worst of 5 seeds {worst:.3e} (per seed: {per_seed})"
+
+
+def test_intermediate_tensors_elementwise_full_size(dev):
+    """Single-op tests use a max-norm metric (conftest.rel_err: max|a-b| / max|b|) because conv outputs cross zero.
+    This is the element-wise check of every intermediate tensor of ONE full-size KITTI forward: |a-b| <= 1e-4 |b| +
+    floor with floor = 1e-4 x the tensor's RMS (values near a zero crossing have no meaningful relative error)."""
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+    image, sparse, valid, k = kb.synthetic.make_frames(1, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
+    x = torch.cat([sparse, valid], 1)
+    s2d_ref = orc.sparse_to_dense_pool(x, sds[0], cfg.min_pools, cfg.max_pools)
+    latent_ref, skips_ref = orc.encoder(image, s2d_ref, k, sds[1], cfg.resolutions_backprojection)
+    logits_ref = orc.decoder(latent_ref, skips_ref, (352, 1216), sds[2])
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    s2d = m.sparse_to_dense_pool(x.to(dev))
+    latent, skips = m.encoder(image.to(dev), s2d, k.to(dev))
+    logits = m.decoder(latent, skips, (352, 1216))[-1]
+    report = []
+    for name, a, b in [("s2d", s2d, s2d_ref), ("latent", latent, latent_ref)] + \
+            [(f"skip{i + 1}", a, b) for i, (a, b) in enumerate(zip(skips, skips_ref))] + [("logits", logits, logits_ref)]:
+        a, b = a.double().cpu(), b.double()
+        floor = 1e-4 * float(b.pow(2).mean().sqrt())
+        excess = ((a - b).abs() - (1e-4 * b.abs() + floor)).max()
+        report.append((name, float(((a - b).abs() / (b.abs() + floor / 1e-4)).max())))
+        assert float(excess) <= 0.0, f"{name}: |a-b| exceeds 1e-4 |b| + {floor:.2e} by {float(excess):.3e}"
+    print("element-wise |a-b| / (|b| + rms): " + " ".join(f"{n} {e:.2e}" for n, e in report))
+
+
 def test_graph_replay_matches_eager(dev):
     cfg = kb.kitti_config().narrow()
     m = kb.modules.KBNetModel.from_config(cfg, dev)
@@ -493,6 +577,45 @@ def test_graph_replay_matches_eager(dev):
     assert torch.equal(replay(*a), eager_a)
     assert torch.equal(replay(*b), eager_b)   # new inputs are copied into the static buffers
     assert torch.equal(replay(*a), eager_a)
+
+
+def test_graph_replay_follows_weight_updates(dev):
+    """The graph holds raw pointers to parameters and packed blobs: an in-place weight update (load_state_dicts /
+    restore_model) after capture() must show up in the next replay (blobs are re-packed in place), and a parameter
+    whose storage moved must raise instead of replaying stale memory."""
+    cfg = kb.kitti_config().narrow()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    a = to(dev, *kb.synthetic.make_frames(2, 64, 96, "kitti", seed=1))
+    replay = m.capture(*a)
+    before = replay(*a).clone()
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=9, gain=1.3))
+    after = replay(*a).clone()
+    fresh = kb.modules.KBNetModel.from_config(cfg, dev)
+    fresh.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=9, gain=1.3))
+    assert not torch.equal(before, after)
+    assert torch.equal(after, fresh.forward(*a)), "replay after load_state_dicts must use the new weights everywhere"
+    w = m.decoder.deconv1.conv.conv.weight
+    w.data = w.data.clone()      # storage moved: the recorded pointer is stale
+    with pytest.raises(kb._lib.KbnError):
+        replay(*a)
+
+
+def test_channel_count_mismatch_raises(dev):
+    """Public entry points validate channel counts (the packed blobs carry no size)."""
+    act = torch.nn.LeakyReLU(0.2)
+    blk = kb.modules.DecoderBlock(32, 16, 16, "xavier_normal", act).to(dev)
+    x = torch.randn(1, 32, 6, 8, device=dev)
+    with pytest.raises(kb._lib.KbnError):
+        blk(x, torch.randn(1, 24, 12, 16, device=dev))        # skip with the wrong channel count
+    with pytest.raises(kb._lib.KbnError):
+        blk.deconv(torch.randn(1, 16, 6, 8, device=dev), (12, 16))
+    kbm = kb.modules.CalibratedBackprojectionBlock(48, 16, 96, 96, 32, 96, weight_initializer="xavier_normal",
+                                                   activation_func=act).to(dev)
+    kinv = torch.eye(3, device=dev).unsqueeze(0)
+    with pytest.raises(kb._lib.KbnError):
+        kbm(image=torch.randn(1, 48, 8, 16, device=dev), depth=torch.randn(1, 16, 8, 16, device=dev),
+            coordinates=kinv, fused=torch.randn(1, 40, 8, 16, device=dev))
 
 
 def test_graph_replay_with_concurrent_branches(dev):

@@ -55,6 +55,21 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(pa, pb)
 
 
+def test_reference_written_checkpoint_loads():
+    """f3: a .pth written by the reference's own KBNetModel.save_model (tests/golden/gen_golden.py gen_checkpoint,
+    reference src/kbnet_model.py:353-376): module.-prefixed keys, three state_dicts, optimizer state, train_step."""
+    from conftest import GOLDEN_DIR
+    g = load_golden("fwd_kitti")
+    m = _model(kb.kitti_config().narrow())
+    step, _ = m.restore_model(os.path.join(GOLDEN_DIR, "ckpt_kitti_narrow.pth"))
+    assert step == 1234
+    for mod, name in zip(m.modules(), ("s2d", "encoder", "decoder")):
+        sd = mod.state_dict()
+        assert set(sd) == set(g[name])
+        for k, v in sd.items():
+            assert torch.equal(v, g[name][k]), k
+
+
 def test_error_behaviour_mirrors_reference():
     with pytest.raises(ValueError):  # reference src/net_utils.py:45
         kb.modules.activation_func("swish")

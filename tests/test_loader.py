@@ -21,7 +21,8 @@ KS = [os.path.join(IO, f"k_{i}.npy") for i in range(3)]
 
 @pytest.fixture(scope="module")
 def dev():
-    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    if not torch.cuda.is_available():
+        pytest.skip("GPU tests need a visible MI355X (run with -m gpu on a GPU box)")
     kb._lib.load()
     return torch.device("cuda:0")
 

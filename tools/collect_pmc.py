@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel PMC evidence for bench.py's workload (KITTI 352x1216, batch 8, eager whole-batch launches):
+"""Per-kernel PMC evidence for bench.py's workload (KITTI 352x1216, batch 32 unless given, eager whole-batch launches):
   pass 1  --pmc FETCH_SIZE                      HBM read KiB  (gfx950: counts a 128-byte request as 64 B -> doubled)
   pass 2  --pmc WRITE_SIZE                      HBM write KiB
   pass 3  --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE
@@ -8,10 +8,11 @@
 Separate passes as MI355X_MICROARCH.md prescribes (TCC slots), no tracing flags next to --pmc.  First-use tuning is
 replayed from the newest profiles/r*/v*_tune_cache.txt (KBN_TUNE_CACHE) so that no timing launches are averaged in,
 and the VOID side measurement is skipped: every launch counted is one of the bench's whole-batch KITTI launches.
-usage (GPU box): python tools/collect_pmc.py <out.json>"""
+usage (GPU box): python tools/collect_pmc.py <out.json> [frames_per_gpu]"""
 import csv, glob, json, os, subprocess, sys, collections, re
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_json = sys.argv[1]
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 tmp = "/tmp/kbn_pmc"
 os.makedirs(tmp, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
@@ -26,7 +27,7 @@ res = collections.defaultdict(lambda: collections.defaultdict(float))
 for tag, counters in PASSES.items():
     subprocess.run(["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", tmp, "-o", tag, "--",
                     sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--eager",
-                    "--no-cpu-baseline", "--no-void"], cwd="/tmp", env=env, check=True,
+                    "--no-cpu-baseline", "--no-void", "--no-side-batch", "--frames-per-gpu", str(frames)], cwd="/tmp", env=env, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL)
     f = glob.glob(os.path.join(tmp, "**", tag + "_counter_collection.csv"), recursive=True)[0]
     seen = set()
@@ -55,7 +56,7 @@ for name, e in res.items():
     final[name] = row
 json.dump({"note": "rocprofv3 --pmc, three separate passes (FETCH_SIZE x2 on gfx950 | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES "
                    "SQ_INSTS_MFMA GRBM_GUI_ACTIVE), averaged over the whole-batch launches of "
-                   "bench.py --eager --steps 2 --warmup 1 --no-void with the tuner's choices replayed; "
+                   f"bench.py --eager --steps 2 --warmup 1 --no-void --frames-per-gpu {frames} with the tuner's choices replayed; "
                    "mfma_busy_frac = MFMA busy cycles / (GUI_ACTIVE per XCD x 1024 SIMDs)",
-           "kernels": final}, open(out_json, "w"), indent=1)
+           "frames_per_gpu": frames, "kernels": final}, open(out_json, "w"), indent=1)
 print(json.dumps({k: [round(v["hbm_bytes_per_launch"] / 1e6, 1), round(v.get("mfma_busy_frac", 0), 3)] for k, v in final.items()}, indent=1))
