@@ -5,15 +5,31 @@
 //   max-pools (:2183-2186), cat, n_convolution x [conv1x1 + LeakyReLU], cat with x,
 //   conv3x3 + LeakyReLU -- one launch, one read of x, one write of the n_filter maps.
 //
-// One workgroup (512 threads) produces a 32 x 32 output tile.  The sparse depth tile with
-// a halo of R+1 (R = largest pool radius) is staged in LDS twice: `zmin` with zeros
-// replaced by the 999 sentinel (+inf outside the image) and `zmax` (-inf outside).  Every
-// pool is evaluated separably -- a row pass into `hbuf`, then a column pass straight into
-// registers -- on the (32+2) x (32+2) "feature" region the 3x3 conv needs.  The 1x1 conv
-// chain runs in registers, its outputs (plus the raw x channels) go to LDS as the 3x3
-// conv's input tile, zero outside the image exactly like the reference's zero padding.
+// What bounds it.  Per pixel the layer moves 40 bytes (2 channels in, 8 out) but evaluates 904 multiply-adds
+// (1x1 chain 184, 3x3 conv 720): 45 FLOP/B, above the chip's fp32 balance (157 TFLOP/s : 8 TB/s = 20), so the
+// kernel is fp32-ARITHMETIC bound, not HBM bound -- and on gfx950 the fp32-input MFMAs and the vector ALU share
+// one multiply-add datapath (tools/probe/mfma4_probe.hip: a matrix-only wave and a v_fma-only wave on one SIMD
+// take the SUM of their times), so there is no second pipe to hide the convolutions behind.  The design
+// therefore minimises everything that is not a multiply-add and keeps two workgroups resident per CU so that
+// one's LDS / latency-bound phases overlap the other's arithmetic.
+//
+// One workgroup (256 threads) produces a 64 x 16 output tile:
+//   P1  the sparse depth tile with a halo of R+1 (R = largest pool radius) is staged in LDS twice: `zmin`
+//       (0 -> 999 sentinel, +inf outside the image) and `zmax` (-inf outside): coalesced row reads of x.
+//   P2  vertical pass, register blocked: a thread owns one column and 6 consecutive rows, reads the 6+2R
+//       values it needs ONCE and runs the nested sweep (one outward sweep yields every pool size) from
+//       registers; results go to per-pool planes V.
+//   P3  horizontal pass, register blocked: a thread owns 4 consecutive pixels of a row; per pool it reads the
+//       2r+4 values of V it needs as 16-byte words and forms the four windows from a shared core + prefix /
+//       suffix minima (2r+5 compares instead of 8r).  Exact 999-sentinel semantics, bit-exact pyramid.
+//   P4  the 1x1 conv chain on v_mfma_f32_4x4x1_16B_f32, used as "4 multiply-adds per lane": lane = pixel,
+//       B = the pixel's input value, A = 4 output-channel weights (lane&3 selects the channel), 2 instructions
+//       per input channel for the 8 filters; LeakyReLU on the vector ALU; features + the raw x channels go to
+//       LDS (overlaying V) as the 3x3 conv's input tile, zero outside the image like the reference's padding.
+//   P5  the 3x3 conv the same way: a wave owns 64 columns x 4 rows; per input channel it loads its 18 A
+//       operands (9 taps x 2 filter halves) and the 6 x 3 shifted B rows from LDS, then issues 72 MFMAs.
+//       Accumulation order = channels ascending, taps inside, one fp32 FMA chain per output (exact fp32).
 #include <math.h>
-#include <stdlib.h>
 
 #include <initializer_list>
 
@@ -21,15 +37,19 @@
 
 namespace kbn {
 
-constexpr int S2D_TW = 32, S2D_TH = 32, S2D_THREADS = 512;
-constexpr int S2D_FW = S2D_TW + 2, S2D_FH = S2D_TH + 2;
-constexpr int S2D_NF = S2D_FW * S2D_FH;                  // feature positions per tile (612)
-constexpr int S2D_NPOS = (S2D_NF + S2D_THREADS - 1) / S2D_THREADS;           // feature positions per thread (3)
-constexpr int S2D_MAXPOOL = 8, S2D_MAXF = 8, S2D_MAXCONV = 4, S2D_MAXIN = 2;
+constexpr int S2D_TW = 64, S2D_TH = 16, S2D_THREADS = 256;
+constexpr int S2D_FW = S2D_TW + 2, S2D_FH = S2D_TH + 2;      // feature region the 3x3 conv needs (66 x 18)
+constexpr int S2D_NQ = (S2D_FW + 3) / 4;                     // 4-pixel groups per feature row (17)
+constexpr int S2D_FWP = S2D_NQ * 4;                          // feature row pitch in LDS (68 floats, 16-byte rows)
+constexpr int S2D_GS = 6;                                    // rows per thread in the vertical pass (FH = 3 x 6)
+constexpr int S2D_MAXPOOL = 8, S2D_MAXF = 8, S2D_MAXCONV = 4, S2D_MAXIN = 2, S2D_MAXR = 15;
 constexpr int S2D_MAXCH = S2D_MAXF + S2D_MAXIN;
-// LDS weight block (floats): 3x3 conv as [ch][tap][8 filters], 1x1 convs as [input][8 filters]
-constexpr int S2D_WC = S2D_MAXCH * 9 * 8, S2D_WP = 8 * 8;
-constexpr int S2D_WFLOATS = S2D_WC + S2D_MAXCONV * S2D_WP;
+// LDS weight tables (floats), both in MFMA A-operand order [..][filter half][4 filters]:
+//   w3[(ch * 9 + tap) * 8 + half * 4 + j]    = conv.weight[4 half + j][ch][tap]
+//   w1[((layer * 8 + q) * 2 + half) * 4 + j] = pool_convs[layer].weight[4 half + j][q]   (0 beyond the fan-in)
+constexpr int S2D_W3 = S2D_MAXCH * 9 * 8, S2D_W1 = S2D_MAXCONV * 8 * 8;
+constexpr int S2D_WFLOATS = S2D_W3 + S2D_W1;
+static_assert(S2D_FH % S2D_GS == 0 && S2D_TH % 4 == 0, "tile geometry");
 
 struct S2DParams {
     const float* x;
@@ -41,17 +61,19 @@ struct S2DParams {
     int N, H, W, inC;
     int nmin, npool;
     int ksize[S2D_MAXPOOL];
-    int hoff[S2D_MAXPOOL];  // LDS offset (floats) of each pool's row-pass buffer
     int nconv, nf, R, Rmin, Rmax;
-    int tilesX, tilesY;
-    int pool_floats;        // zmin + zmax + row-pass buffers
-    int dbg;                // ablation (KBN_S2D_DEBUG): 1 no row pass, 2 no column pass, 4 no 1x1, 8 no 3x3, 16 no staging
+    int tilesX, tilesY, nblocks;
+    int dbg;   // phase ablation for tools/s2d_bench.py (KBN_S2D_DEBUG): 1 no vertical pass, 2 no horizontal pass, 4 no 1x1 chain, 8 no 3x3 conv, 16 no staging
     float slope;
 };
 
-// Pool configuration: compile-time lists for the reference's shipped presets (every pool loop
-// unrolls to straight-line code: all LDS reads of a window issue back to back with immediate
-// offsets), a run-time list for anything else.
+// staged depth tile (FW + 2R) x (FH + 2R); V rows hold FWP + 2R columns (pitch a multiple of 4 floats)
+__host__ __device__ constexpr int s2d_zw(int R) { return S2D_FW + 2 * R; }
+__host__ __device__ constexpr int s2d_zh(int R) { return S2D_FH + 2 * R; }
+__host__ __device__ constexpr int s2d_vp(int R) { return (S2D_FWP + 2 * R + 3) / 4 * 4; }
+
+// Pool configuration: compile-time lists for the reference's shipped presets (the register-blocked passes
+// unroll to straight-line code), a run-time list for anything else (same phases, plain loops).
 template <int NMIN, int... KS>
 struct StaticPools {
     static constexpr bool is_static = true;
@@ -62,245 +84,347 @@ struct StaticPools {
         for (int i = lo; i < hi; ++i) m = (K[i] / 2 > m) ? K[i] / 2 : m;
         return m;
     }
+    static constexpr int NMINP = NMIN;
     static constexpr int RMIN = cmax(0, NMIN), RMAX = cmax(NMIN, NP);
-    __device__ static constexpr int nmin(const S2DParams&) { return NMIN; }
-    __device__ static constexpr int npool(const S2DParams&) { return NP; }
-    __device__ static constexpr int ksize(const S2DParams&, int pi) { return pi < NP ? K[pi] : 1; }
-    __device__ static constexpr int rmin(const S2DParams&) { return RMIN; }
-    __device__ static constexpr int rmax(const S2DParams&) { return RMAX; }
+    static constexpr int RR = RMIN > RMAX ? RMIN : RMAX;
+    static constexpr int radius(int pi) { return K[pi] / 2; }
+    __device__ static constexpr int R(const S2DParams&) { return RR; }
 };
 struct DynamicPools {
     static constexpr bool is_static = false;
-    static constexpr int RMIN = 15, RMAX = 15;
-    __device__ static int nmin(const S2DParams& p) { return p.nmin; }
-    __device__ static int npool(const S2DParams& p) { return p.npool; }
-    __device__ static int ksize(const S2DParams& p, int pi) { return p.ksize[pi]; }
-    __device__ static int rmin(const S2DParams& p) { return p.Rmin; }
-    __device__ static int rmax(const S2DParams& p) { return p.Rmax; }
+    __device__ static int R(const S2DParams& p) { return p.R; }
 };
 using KittiPools = StaticPools<5, 5, 7, 9, 11, 13, 15, 17>;   // bash/kitti/run_kbnet_kitti_validation.sh:15-16
 using VoidPools = StaticPools<2, 15, 17, 23, 27, 29>;         // bash/void/run_kbnet_void1500.sh:15-16
 using VoidTrainPools = StaticPools<3, 15, 17, 19, 23, 27>;    // bash/void/train_kbnet_void1500.sh:21-22
 
+template <int N>
+struct IntC { static constexpr int value = N; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void s2d_for(F&& f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        s2d_for<I + 1, N>(static_cast<F&&>(f));
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);   // c[i] += A[4 * (lane / 4) + i] * B[lane]
+}
+
 template <typename CFG>
-__global__ __launch_bounds__(S2D_THREADS) void s2d_kernel(const S2DParams p) {
+__global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int R = p.R;
-    const int ZW = S2D_FW + 2 * R, ZH = S2D_FH + 2 * R;
-    float* wl = smem;                      // weights, live for the whole kernel
+    const int R = CFG::R(p);                       // compile-time for the static presets
+    const int ZW = s2d_zw(R), ZH = s2d_zh(R), VP = s2d_vp(R);
+    const int VPLANE = S2D_FH * VP;
+    float* w3 = smem;                      // weights, live for the whole kernel
+    float* w1 = smem + S2D_W3;
     float* zmin = smem + S2D_WFLOATS;
     float* zmax = zmin + ZH * ZW;
-    float* hb = zmax + ZH * ZW;            // row-pass buffers, one per pool
-    float* feat = smem + S2D_WFLOATS;      // [(nf + inC)][FH][FW]; overlays the pool buffers (dead by then)
+    float* vbuf = smem + S2D_WFLOATS + ((2 * ZH * ZW + 3) & ~3);   // [pool][FH][VP], 16-byte aligned rows
+    float* feat = vbuf;                    // [nf + inC][FH][FWP]: overlays V (dead once the pooled values are in registers)
 
-    const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
     const int tx = bid % p.tilesX;
     bid /= p.tilesX;
     const int ty = bid % p.tilesY;
     const int n = bid / p.tilesY;
     const int oy0 = ty * S2D_TH, ox0 = tx * S2D_TW;
+    const long long HW = (long long)p.H * p.W;
     const float* xz = p.x + (long long)n * p.x_bstride;  // channel 0 = sparse depth
     const int nch = p.nf + p.inC;
+    int npool = p.npool, nmin = p.nmin;
+    if constexpr (CFG::is_static) { npool = CFG::NP; nmin = CFG::NMINP; }
 
-    // ---- weights -> LDS, transposed so that the 8 filters of one (input, tap) are contiguous --
+    // ---- P0: weights -> LDS in A-operand order -------------------------------------------------
     if (!p.pyramid) {
-        for (int e = tid; e < S2D_WC; e += S2D_THREADS) {
+        for (int e = tid; e < S2D_W3; e += S2D_THREADS) {
             const int f = e & 7, t = (e >> 3) % 9, ch = e / 72;
-            wl[e] = (f < p.nf && ch < nch) ? p.wconv[((long long)f * nch + ch) * 9 + t] : 0.f;
+            w3[e] = (f < p.nf && ch < nch) ? p.wconv[((long long)f * nch + ch) * 9 + t] : 0.f;
         }
-        for (int e = tid; e < S2D_MAXCONV * S2D_WP; e += S2D_THREADS) {
+        for (int e = tid; e < S2D_W1; e += S2D_THREADS) {
             const int f = e & 7, q = (e >> 3) & 7, i = e >> 6;
-            const int cin = (i == 0) ? CFG::npool(p) : p.nf;
-            wl[S2D_WC + e] = (i < p.nconv && f < p.nf && q < cin) ? p.wpool[i][f * cin + q] : 0.f;
+            const int cin = (i == 0) ? npool : p.nf;
+            w1[e] = (i < p.nconv && f < p.nf && q < cin) ? p.wpool[i][f * cin + q] : 0.f;
         }
     }
-    // ---- stage the depth tile (+halo) -------------------------------------------------
-    if (!(p.dbg & 16))
-    for (int e = tid; e < ZH * ZW; e += S2D_THREADS) {
-        int r = e / ZW, c = e - r * ZW;
-        int Y = oy0 - 1 - R + r, X = ox0 - 1 - R + c;
-        float vmin = INFINITY, vmax = -INFINITY;
-        if (Y >= 0 && Y < p.H && X >= 0 && X < p.W) {
-            float v = xz[(long long)Y * p.W + X];
-            vmax = v;
-            vmin = (v == 0.f) ? 999.f : v;  // where(z == 0, -999, -z) in negated form
-        }
-        zmin[e] = vmin;
-        zmax[e] = vmax;
-    }
-    __syncthreads();
-
-    // ---- row pass, nested: one sweep outwards gives every min pool, another every max pool ----
-    const int nmin = CFG::nmin(p), npool = CFG::npool(p);
-    if (!(p.dbg & 1))
-    for (int e = tid; e < ZH * S2D_FW; e += S2D_THREADS) {
-        const int r = e / S2D_FW, c = e - r * S2D_FW;
-        {
-            const float* s = zmin + r * ZW + c + R;
-            float a = s[0];
+    // ---- P1: stage the depth tile (+halo): a batch of loads first, then the two LDS images ---------------
+    if (!(p.dbg & 16)) {
+        constexpr int MAXE = 12;
+        const int total = ZH * ZW;
+        for (int base = 0; base < total; base += MAXE * S2D_THREADS) {
+            float v[MAXE];
 #pragma unroll
-            for (int d = 1; d <= CFG::RMIN; ++d) {
-                if (d > CFG::rmin(p)) break;
-                a = fminf(a, fminf(s[-d], s[d]));
-#pragma unroll
-                for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
-                    if (pi < nmin && (CFG::ksize(p, pi) >> 1) == d) {
-                        const int rr = r - (R - d);
-                        if (rr >= 0 && rr < S2D_FH + 2 * d) hb[p.hoff[pi] + rr * S2D_FW + c] = a;
-                    }
-                }
+            for (int u = 0; u < MAXE; ++u) {
+                const int e = base + u * S2D_THREADS + tid;
+                const int r = e / ZW, c = e - r * ZW;
+                const int Y = oy0 - 1 - R + r, X = ox0 - 1 - R + c;
+                const bool inb = e < total && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+                v[u] = inb ? xz[(long long)Y * p.W + X] : -INFINITY;
             }
-        }
-        {
-            const float* s = zmax + r * ZW + c + R;
-            float a = s[0];
 #pragma unroll
-            for (int d = 1; d <= CFG::RMAX; ++d) {
-                if (d > CFG::rmax(p)) break;
-                a = fmaxf(a, fmaxf(s[-d], s[d]));
-#pragma unroll
-                for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
-                    if (pi >= nmin && pi < npool && (CFG::ksize(p, pi) >> 1) == d) {
-                        const int rr = r - (R - d);
-                        if (rr >= 0 && rr < S2D_FH + 2 * d) hb[p.hoff[pi] + rr * S2D_FW + c] = a;
-                    }
+            for (int u = 0; u < MAXE; ++u) {
+                const int e = base + u * S2D_THREADS + tid;
+                if (e < total) {
+                    zmax[e] = v[u];                                                              // -inf outside the image
+                    zmin[e] = (v[u] == 0.f) ? 999.f : ((v[u] == -INFINITY) ? INFINITY : v[u]);   // where(z == 0, 999, z)
                 }
             }
         }
     }
     __syncthreads();
 
-    // ---- column pass: pooled values of this thread's feature positions -> registers ------
-    float pooled[S2D_NPOS][S2D_MAXPOOL];
+    // ---- P2: vertical pass -> V[pool][feature row][z column] ------------------------------------------
+    if (p.dbg & 1) {
+    } else if constexpr (CFG::is_static) {
+        constexpr int NG = S2D_FH / S2D_GS;
+        for (int t = tid; t < ZW * NG; t += S2D_THREADS) {
+            const int g = t / ZW, c = t - g * ZW;
+            auto sweep = [&](auto is_min_c, const float* zsrc) {
+                constexpr bool IS_MIN = decltype(is_min_c)::value != 0;
+                constexpr int RS = IS_MIN ? CFG::RMIN : CFG::RMAX;
+                if constexpr (RS > 0) {
+                    float m[S2D_GS + 2 * RS];
+                    const float* s = zsrc + (g * S2D_GS + (CFG::RR - RS)) * ZW + c;
 #pragma unroll
-    for (int u = 0; u < S2D_NPOS; ++u) {
-        const int e = tid + u * S2D_THREADS;
+                    for (int i = 0; i < S2D_GS + 2 * RS; ++i) m[i] = s[i * ZW];
 #pragma unroll
-        for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
-            float a = 0.f;
-            if (pi < npool && e < S2D_NF && !(p.dbg & 2)) {
-                const int k = CFG::ksize(p, pi);
-                const float* s = hb + p.hoff[pi] + e;  // rows fy .. fy+k-1 of this pool's buffer
-                a = s[0];
-                if (pi < nmin) {
-                    if constexpr (CFG::is_static) {
-#pragma unroll
-                        for (int d = 1; d < 2 * CFG::RMIN + 1; ++d)
-                            if (d < k) a = fminf(a, s[d * S2D_FW]);
-                    } else {
-#pragma unroll 4
-                        for (int d = 1; d < k; ++d) a = fminf(a, s[d * S2D_FW]);
-                    }
-                    a = (a == 999.f) ? 0.f : a;  // where(pool == 999, 0, pool)
-                } else {
-                    if constexpr (CFG::is_static) {
-#pragma unroll
-                        for (int d = 1; d < 2 * CFG::RMAX + 1; ++d)
-                            if (d < k) a = fmaxf(a, s[d * S2D_FW]);
-                    } else {
-#pragma unroll 4
-                        for (int d = 1; d < k; ++d) a = fmaxf(a, s[d * S2D_FW]);
+                    for (int j = 0; j < S2D_GS; ++j) {
+                        float a = m[j + RS];
+                        s2d_for<1, RS + 1>([&](auto dc) {
+                            constexpr int d = decltype(dc)::value;
+                            a = IS_MIN ? fminf(a, fminf(m[j + RS - d], m[j + RS + d]))
+                                       : fmaxf(a, fmaxf(m[j + RS - d], m[j + RS + d]));
+                            s2d_for<0, CFG::NP>([&](auto pic) {
+                                constexpr int pi = decltype(pic)::value;
+                                if constexpr ((pi < CFG::NMINP) == IS_MIN && CFG::radius(pi) == d)
+                                    vbuf[pi * VPLANE + (g * S2D_GS + j) * VP + c] = a;
+                            });
+                        });
                     }
                 }
+            };
+            sweep(IntC<1>{}, zmin);
+            sweep(IntC<0>{}, zmax);
+        }
+    } else {
+        for (int t = tid; t < ZW * S2D_FH; t += S2D_THREADS) {
+            const int fr = t / ZW, c = t - fr * ZW;
+            const float* smin = zmin + (fr + R) * ZW + c;
+            const float* smax = zmax + (fr + R) * ZW + c;
+            float a = smin[0], b = smax[0];
+            for (int d = 1; d <= R; ++d) {
+                if (d <= p.Rmin) a = fminf(a, fminf(smin[-d * ZW], smin[d * ZW]));
+                if (d <= p.Rmax) b = fmaxf(b, fmaxf(smax[-d * ZW], smax[d * ZW]));
+                for (int pi = 0; pi < npool; ++pi)
+                    if ((p.ksize[pi] >> 1) == d) vbuf[pi * VPLANE + fr * VP + c] = pi < nmin ? a : b;
             }
-            pooled[u][pi] = a;
         }
     }
-    __syncthreads();  // the pool buffers are dead from here on: `feat` overlays them
+    __syncthreads();
 
-    // ---- 1x1 conv chain in registers; features + raw x channels to LDS ----------------
+    // ---- P3: horizontal pass: pooled values of 4 consecutive feature pixels per item -> registers ------
+    // item = (feature row fr, group q): feature columns 4q .. 4q+3 (columns >= FW are padding, never consumed)
+    constexpr int NITEM = S2D_FH * S2D_NQ, NROUND = (NITEM + S2D_THREADS - 1) / S2D_THREADS;
+    float pooled[NROUND][4][S2D_MAXPOOL];
+    float xin[NROUND][S2D_MAXIN][4];
 #pragma unroll
-    for (int u = 0; u < S2D_NPOS; ++u) {
-        const int e = tid + u * S2D_THREADS;
-        if (e >= S2D_NF) continue;
-        const int fy = e / S2D_FW, fx = e - fy * S2D_FW;
-        const int Y = oy0 - 1 + fy, X = ox0 - 1 + fx;
-        const bool inb = (Y >= 0 && Y < p.H && X >= 0 && X < p.W);
-        if (p.pyramid) {
-            if (inb && fy >= 1 && fy <= S2D_TH && fx >= 1 && fx <= S2D_TW) {
-                float* py = p.pyramid + ((long long)n * npool) * p.H * p.W + (long long)Y * p.W + X;
+    for (int rd = 0; rd < NROUND; ++rd) {
+        const int t = rd * S2D_THREADS + tid;
+        const int fr = t / S2D_NQ, q = t - fr * S2D_NQ;
+        const bool live = t < NITEM;
 #pragma unroll
-                for (int pi = 0; pi < S2D_MAXPOOL; ++pi)
-                    if (pi < npool) py[(long long)pi * p.H * p.W] = pooled[u][pi];
-            }
-            continue;
-        }
-        float h[S2D_MAXF], g[S2D_MAXF];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < S2D_MAXPOOL; ++q) h[q] = pooled[u][q];  // inputs of layer 0 (zero beyond npool)
-#pragma unroll
-        for (int i = 0; i < S2D_MAXCONV; ++i) {
-            if (i >= p.nconv || (p.dbg & 4)) break;
-            const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + S2D_WC + i * S2D_WP);
-#pragma unroll
-            for (int f = 0; f < S2D_MAXF; ++f) g[f] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {  // zero weights beyond the real fan-in
-                const f32x4 wa = w4[q * 2], wb = w4[q * 2 + 1];
-                g[0] = fmaf(wa[0], h[q], g[0]); g[1] = fmaf(wa[1], h[q], g[1]);
-                g[2] = fmaf(wa[2], h[q], g[2]); g[3] = fmaf(wa[3], h[q], g[3]);
-                g[4] = fmaf(wb[0], h[q], g[4]); g[5] = fmaf(wb[1], h[q], g[5]);
-                g[6] = fmaf(wb[2], h[q], g[6]); g[7] = fmaf(wb[3], h[q], g[7]);
-            }
-#pragma unroll
-            for (int f = 0; f < S2D_MAXF; ++f) h[f] = leaky_relu(g[f], p.slope);
-        }
-#pragma unroll
-        for (int f = 0; f < S2D_MAXF; ++f)
-            if (f < p.nf) feat[f * S2D_NF + e] = inb ? h[f] : 0.f;
+            for (int pi = 0; pi < S2D_MAXPOOL; ++pi) pooled[rd][j][pi] = 0.f;
+        // the raw x channels of these pixels (zero outside the image): issued now, consumed after the 1x1 chain
 #pragma unroll
         for (int ci = 0; ci < S2D_MAXIN; ++ci)
-            if (ci < p.inC)
-                feat[(p.nf + ci) * S2D_NF + e] = inb ? xz[(long long)ci * p.H * p.W + (long long)Y * p.W + X] : 0.f;
-    }
-    if (p.pyramid) return;
-    __syncthreads();
-
-    // ---- 3x3 conv over [features | x] + LeakyReLU.  The phase is LDS-issue bound (one value per FMA pair
-    //      plus the broadcast weight reads), so half of the threads take 4 consecutive pixels of a row each:
-    //      a row of the window is 6 values = three 8-byte reads (+ two for the odd-aligned pairs the packed
-    //      FMAs of the middle tap need), and every weight read serves four pixels.  Packed fp32: one
-    //      v_pk_fma_f32 per (channel, tap, filter, pixel pair), weight broadcast to both halves. ----------
-    if (tid < S2D_TH * S2D_TW / 4) {
-        const int oy = tid / (S2D_TW / 4), oxq = (tid - oy * (S2D_TW / 4)) * 4;
-        f32x2 acc[2][S2D_MAXF];   // [pixel pair (0,1) / (2,3)][filter]
 #pragma unroll
-        for (int f = 0; f < S2D_MAXF; ++f) acc[0][f] = acc[1][f] = (f32x2){0.f, 0.f};
-        for (int ch = 0; ch < ((p.dbg & 8) ? 0 : nch); ++ch) {
-            const float* fr = feat + ch * S2D_NF + oy * S2D_FW + oxq;   // column oxq <-> x - 1 of the first pixel
-            const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ch * 72);
+            for (int j = 0; j < 4; ++j) {
+                const int Y = oy0 - 1 + fr, X = ox0 - 1 + 4 * q + j;
+                const bool inb = live && ci < p.inC && !p.pyramid && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+                xin[rd][ci][j] = inb ? xz[(long long)ci * HW + (long long)Y * p.W + X] : 0.f;
+            }
+        if (!live || (p.dbg & 2)) continue;
+        if constexpr (CFG::is_static) {
+            s2d_for<0, CFG::NP>([&](auto pic) {
+                constexpr int pi = decltype(pic)::value;
+                constexpr int r = CFG::radius(pi);
+                constexpr bool IS_MIN = pi < CFG::NMINP;
+                constexpr int OFF = CFG::RR - r;              // z column of window element o of pixel j: 4q + j + OFF + o
+                constexpr int A0 = OFF & ~3, SH = OFF & 3;    // 16-byte aligned start, shift inside the first word
+                constexpr int NV = 2 * r + 4, NB = (SH + NV + 3) / 4;
+                static_assert(r >= 2, "the blocked window code needs pool sizes >= 5");
+                f32x4 w[NB];
+                const float* s = vbuf + pi * VPLANE + fr * VP + 4 * q + A0;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const float* r = fr + ky * S2D_FW;
-                const f32x2 e0 = *reinterpret_cast<const f32x2*>(r), e1 = *reinterpret_cast<const f32x2*>(r + 2),
-                            e2 = *reinterpret_cast<const f32x2*>(r + 4);
-                const f32x2 o0 = (f32x2){r[1], r[2]}, o1 = (f32x2){r[3], r[4]};
+                for (int m = 0; m < NB; ++m) w[m] = *reinterpret_cast<const f32x4*>(s + 4 * m);
+                auto v = [&](int o) { return w[(SH + o) >> 2][(SH + o) & 3]; };
+                auto mn = [&](float a, float b) { return IS_MIN ? fminf(a, b) : fmaxf(a, b); };
+                // windows v[j .. j + 2r], j = 0..3: shared core v[3 .. 2r] + prefix / suffix
+                float core = v(3);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const f32x2 va = kx == 0 ? e0 : (kx == 1 ? o0 : e1);   // pixels 0, 1 see columns kx, kx + 1
-                    const f32x2 vb = kx == 0 ? e1 : (kx == 1 ? o1 : e2);   // pixels 2, 3 see columns kx + 2, kx + 3
-                    const f32x4 wa = w4[(ky * 3 + kx) * 2], wb = w4[(ky * 3 + kx) * 2 + 1];
+                for (int o = 4; o <= 2 * r; ++o) core = mn(core, v(o));
+                const float l1 = mn(v(1), v(2)), l0 = mn(v(0), l1);
+                const float h2 = mn(v(2 * r + 1), v(2 * r + 2)), h3 = mn(h2, v(2 * r + 3));
+                float o0 = mn(core, l0), o1 = mn(core, mn(l1, v(2 * r + 1))), o2 = mn(core, mn(v(2), h2)), o3 = mn(core, h3);
+                if (IS_MIN) {   // where(pool == 999, 0, pool)
+                    o0 = (o0 == 999.f) ? 0.f : o0; o1 = (o1 == 999.f) ? 0.f : o1;
+                    o2 = (o2 == 999.f) ? 0.f : o2; o3 = (o3 == 999.f) ? 0.f : o3;
+                }
+                pooled[rd][0][pi] = o0; pooled[rd][1][pi] = o1; pooled[rd][2][pi] = o2; pooled[rd][3][pi] = o3;
+            });
+        } else {
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) {
-                        acc[0][f] = __builtin_elementwise_fma(va, (f32x2){wa[f], wa[f]}, acc[0][f]);
-                        acc[1][f] = __builtin_elementwise_fma(vb, (f32x2){wa[f], wa[f]}, acc[1][f]);
-                        acc[0][4 + f] = __builtin_elementwise_fma(va, (f32x2){wb[f], wb[f]}, acc[0][4 + f]);
-                        acc[1][4 + f] = __builtin_elementwise_fma(vb, (f32x2){wb[f], wb[f]}, acc[1][4 + f]);
-                    }
+            for (int pi = 0; pi < S2D_MAXPOOL; ++pi) {
+                if (pi >= npool) continue;
+                const int r = p.ksize[pi] >> 1;
+                const bool is_min = pi < nmin;
+                const float* s = vbuf + pi * VPLANE + fr * VP + 4 * q + R - r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = s[j];
+                    for (int o = 1; o <= 2 * r; ++o) a = is_min ? fminf(a, s[j + o]) : fmaxf(a, s[j + o]);
+                    pooled[rd][j][pi] = (is_min && a == 999.f) ? 0.f : a;
                 }
             }
         }
-        const int Y = oy0 + oy, X = ox0 + oxq;
-        if (Y < p.H && X < p.W) {
-            const long long HW = (long long)p.H * p.W;
+    }
+    if (p.pyramid) {
+#pragma unroll
+        for (int rd = 0; rd < NROUND; ++rd) {
+            const int t = rd * S2D_THREADS + tid;
+            const int fr = t / S2D_NQ, q = t - fr * S2D_NQ;
+            if (t >= NITEM || fr < 1 || fr > S2D_TH) continue;
+            const int Y = oy0 - 1 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int fx = 4 * q + j, X = ox0 - 1 + fx;
+                if (fx < 1 || fx > S2D_TW || Y >= p.H || X >= p.W) continue;
+                float* py = p.pyramid + ((long long)n * npool) * HW + (long long)Y * p.W + X;
+#pragma unroll
+                for (int pi = 0; pi < S2D_MAXPOOL; ++pi)
+                    if (pi < npool) py[(long long)pi * HW] = pooled[rd][j][pi];
+            }
+        }
+        return;
+    }
+    __syncthreads();  // every V read is done: `feat` overlays V from here on
+
+    // ---- P4: 1x1 conv chain on the matrix cores (lane = pixel), features + raw x channels -> LDS --------
+    {
+        float a1[S2D_MAXCONV][8][2];   // A operands: [layer][input][filter half], this lane's filter = lane & 3
+#pragma unroll
+        for (int i = 0; i < S2D_MAXCONV; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                a1[i][q][0] = w1[((i * 8 + q) * 2 + 0) * 4 + (lane & 3)];
+                a1[i][q][1] = w1[((i * 8 + q) * 2 + 1) * 4 + (lane & 3)];
+            }
+#pragma unroll
+        for (int rd = 0; rd < NROUND; ++rd) {
+            const int t = rd * S2D_THREADS + tid;
+            const int fr = t / S2D_NQ, q = t - fr * S2D_NQ;
+            if (rd * S2D_THREADS + wave * 64 >= NITEM) continue;   // whole wave idle (wave-uniform: no MFMA under a partial EXEC)
+            f32x4 h[4][2];                                         // [pixel][filter half]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j][0] = h[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < S2D_MAXCONV; ++i) {
+                if (i < p.nconv && !(p.dbg & 4)) {
+                    f32x4 g[4][2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j][0] = g[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {   // zero weights beyond the real fan-in
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float b = (i == 0) ? pooled[rd][j][qq] : h[j][qq >> 2][qq & 3];
+                            g[j][0] = mfma4(a1[i][qq][0], b, g[j][0]);
+                            g[j][1] = mfma4(a1[i][qq][1], b, g[j][1]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) h[j][hh][f] = leaky_relu(g[j][hh][f], p.slope);
+                }
+            }
+            if (t < NITEM) {
+                const int Y = oy0 - 1 + fr;
+                const bool rowin = Y >= 0 && Y < p.H;
+                bool inb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int X = ox0 - 1 + 4 * q + j;
+                    inb[j] = rowin && X >= 0 && X < p.W;
+                }
+                float* fo = feat + fr * S2D_FWP + 4 * q;
+#pragma unroll
+                for (int f = 0; f < S2D_MAXF; ++f)
+                    if (f < p.nf)
+                        *reinterpret_cast<f32x4*>(fo + f * (S2D_FH * S2D_FWP)) =
+                            (f32x4){inb[0] ? h[0][f >> 2][f & 3] : 0.f, inb[1] ? h[1][f >> 2][f & 3] : 0.f,
+                                    inb[2] ? h[2][f >> 2][f & 3] : 0.f, inb[3] ? h[3][f >> 2][f & 3] : 0.f};
+#pragma unroll
+                for (int ci = 0; ci < S2D_MAXIN; ++ci)
+                    if (ci < p.inC)
+                        *reinterpret_cast<f32x4*>(fo + (p.nf + ci) * (S2D_FH * S2D_FWP)) =
+                            (f32x4){xin[rd][ci][0], xin[rd][ci][1], xin[rd][ci][2], xin[rd][ci][3]};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- P5: 3x3 conv over [features | x] on the matrix cores + LeakyReLU.  Wave w: rows 4w .. 4w+3 of the
+    //      tile; lane = (row l >> 4, 4 consecutive columns 4 (l & 15) ..): the six feature values a row of the
+    //      window needs are one 16-byte + one 8-byte LDS read, and every filter leaves as one 16-byte store.
+    //      acc[pixel][half][j] = filter 4 half + j. ----------------------------------------------------------
+    {
+        constexpr int RW = S2D_TH / 4;     // rows per wave
+        static_assert(RW == 4, "lane mapping: 16 lanes x 4 columns per row, 4 rows per wave");
+        const int lr = lane >> 4, cg = lane & 15;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* fbase = feat + (wave * RW + lr) * S2D_FWP + 4 * cg;
+        for (int ch = 0; ch < ((p.dbg & 8) ? 0 : nch); ++ch) {
+            float a3[9][2], b[3][6];
+            const float* wsrc = w3 + ch * 72 + (lane & 3);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) { a3[tp][0] = wsrc[tp * 8]; a3[tp][1] = wsrc[tp * 8 + 4]; }
+            const float* fr = fbase + ch * (S2D_FH * S2D_FWP);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(fr + ky * S2D_FWP);
+                const f32x2 hi = *reinterpret_cast<const f32x2*>(fr + ky * S2D_FWP + 4);
+                b[ky][0] = lo[0]; b[ky][1] = lo[1]; b[ky][2] = lo[2]; b[ky][3] = lo[3]; b[ky][4] = hi[0]; b[ky][5] = hi[1];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j][0] = mfma4(a3[ky * 3 + kx][0], b[ky][j + kx], acc[j][0]);
+                        acc[j][1] = mfma4(a3[ky * 3 + kx][1], b[ky][j + kx], acc[j][1]);
+                    }
+        }
+        const int X = ox0 + 4 * cg, Y = oy0 + wave * RW + lr;
+        if (X < p.W && Y < p.H) {
             float* o = p.out + ((long long)n * p.nf) * HW + (long long)Y * p.W + X;
             const bool vec = (X + 3 < p.W) && ((p.W & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
 #pragma unroll
             for (int f = 0; f < S2D_MAXF; ++f) {
                 if (f >= p.nf) continue;
-                const f32x4 v = (f32x4){leaky_relu(acc[0][f].x, p.slope), leaky_relu(acc[0][f].y, p.slope),
-                                        leaky_relu(acc[1][f].x, p.slope), leaky_relu(acc[1][f].y, p.slope)};
+                const f32x4 v = (f32x4){leaky_relu(acc[0][f >> 2][f & 3], p.slope), leaky_relu(acc[1][f >> 2][f & 3], p.slope),
+                                        leaky_relu(acc[2][f >> 2][f & 3], p.slope), leaky_relu(acc[3][f >> 2][f & 3], p.slope)};
                 if (vec) {
                     *reinterpret_cast<f32x4*>(o + f * HW) = v;
                 } else {
@@ -319,36 +443,30 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
     if (n_min + n_max > S2D_MAXPOOL) return KBN_ERR_UNSUPPORTED;
     if ((n_min && !min_pool_sizes) || (n_max && !max_pool_sizes)) return KBN_ERR_INVALID_ARGUMENT;
     int R = 0;
+    p.Rmin = 0; p.Rmax = 0;
     for (int i = 0; i < n_min + n_max; ++i) {
         int k = i < n_min ? min_pool_sizes[i] : max_pool_sizes[i - n_min];
         if (k < 3 || (k & 1) == 0) return KBN_ERR_INVALID_ARGUMENT;  // the caller drops sizes <= 1
-        if (k > 31) return KBN_ERR_UNSUPPORTED;
+        if (k > 2 * S2D_MAXR + 1) return KBN_ERR_UNSUPPORTED;
         p.ksize[i] = k;
         if (k / 2 > R) R = k / 2;
+        if (i < n_min) { if (k / 2 > p.Rmin) p.Rmin = k / 2; } else { if (k / 2 > p.Rmax) p.Rmax = k / 2; }
     }
-    for (int i = n_min + n_max; i < S2D_MAXPOOL; ++i) { p.ksize[i] = 1; p.hoff[i] = 0; }
+    for (int i = n_min + n_max; i < S2D_MAXPOOL; ++i) p.ksize[i] = 1;
     p.nmin = n_min;
     p.npool = n_min + n_max;
     p.R = R;
-    p.Rmin = 0; p.Rmax = 0;
-    const int ZW = S2D_FW + 2 * R, ZH = S2D_FH + 2 * R;
-    int off = 0;
-    for (int i = 0; i < p.npool; ++i) {
-        const int rad = p.ksize[i] / 2;
-        if (i < n_min) { if (rad > p.Rmin) p.Rmin = rad; } else { if (rad > p.Rmax) p.Rmax = rad; }
-        p.hoff[i] = off;
-        off += (S2D_FH + 2 * rad) * S2D_FW;
-    }
     p.tilesX = ceil_div(p.W, S2D_TW);
     p.tilesY = ceil_div(p.H, S2D_TH);
-    size_t pool_floats = (size_t)2 * ZH * ZW + (size_t)off;
-    size_t feat_floats = (size_t)S2D_MAXCH * S2D_NF;
-    p.pool_floats = (int)pool_floats;
-    p.dbg = knob(KNOB_S2D_DEBUG);
-    size_t lds = sizeof(float) * (S2D_WFLOATS + (pool_floats > feat_floats ? pool_floats : feat_floats));
+    const size_t z_floats = ((size_t)2 * s2d_zh(R) * s2d_zw(R) + 3) & ~(size_t)3;
+    const size_t v_floats = (size_t)p.npool * S2D_FH * s2d_vp(R);
+    const size_t feat_floats = (size_t)S2D_MAXCH * S2D_FH * S2D_FWP;
+    const size_t lds = sizeof(float) * (S2D_WFLOATS + z_floats + (v_floats > feat_floats ? v_floats : feat_floats));
     if (lds > 160 * 1024) return KBN_ERR_UNSUPPORTED;
-    long long blocks = (long long)p.tilesX * p.tilesY * p.N;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.N;
     if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.nblocks = (int)blocks;
+    p.dbg = knob(KNOB_S2D_DEBUG);
     auto matches = [&](int nm, std::initializer_list<int> ks) {
         if (p.nmin != nm || p.npool != (int)ks.size()) return false;
         int i = 0;

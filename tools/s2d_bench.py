@@ -24,7 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     us = s.elapsed_time(e) * 100
     print(json.dumps({"us": round(us, 1), "GBps": round(8 * h * w * 40 / us / 1e3, 1)}))
     sys.exit(0)
-for dbg, tag in ((0, "full"), (16, "no z staging"), (1, "no row pass"), (2, "no column pass"), (4, "no 1x1 chain"), (8, "no 3x3 conv"), (31, "skeleton only"), (15, "staging+stores only")):
+for dbg, tag in ((0, "full"), (16, "no z staging"), (1, "no vertical pass"), (2, "no horizontal pass"), (4, "no 1x1 chain"), (8, "no 3x3 conv"), (12, "no convs"), (31, "skeleton only"), (15, "staging+stores only")):
     r = subprocess.run([sys.executable, __file__, "--one"], env=dict(os.environ, KBN_S2D_DEBUG=str(dbg)), capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     print(f"{tag:22s}", line[-1] if line else r.stderr[-300:], flush=True)
