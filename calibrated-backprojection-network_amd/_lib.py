@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkbnet_hip.so")
 
 KBN_OK = 0
+KBN_ERR_UNSUPPORTED = -2
 KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ = 0, 1, 2
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
 KBN_MAX_SRC = 3
@@ -72,6 +73,7 @@ SIGNATURES = {
     "kbn_preprocess_forward": (_I, [_P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _P]),
     "kbn_eval_accumulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "kbn_depth_head_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "kbn_conv_head_forward": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P]),
     "kbn_png_info": (_I, [_P, C.c_size_t, _P, _P, _P, _P]),
     "kbn_png_decode": (_I, [_P, C.c_size_t, _P, C.c_size_t]),
     "kbn_png_decode_batch": (_I, [_P, _P, _P, _P, _I, _I, _P]),

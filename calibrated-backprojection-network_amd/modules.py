@@ -418,11 +418,32 @@ class MultiScaleDecoder(torch.nn.Module):
 
     def features(self, x, skips, shape):
         """Everything up to (not including) output0."""
+        return self.deconv0(self.features_level1(x, skips), None, shape=tuple(shape)[-2:])
+
+    def features_level1(self, x, skips):
+        """deconv4 .. deconv1: the half-resolution features deconv0 starts from."""
         x = self.deconv4(x, skips[3])
         x = self.deconv3(x, skips[2])
         x = self.deconv2(x, skips[1])
-        x = self.deconv1(x, skips[0])
-        return self.deconv0(x, None, shape=tuple(shape)[-2:])
+        return self.deconv1(x, skips[0])
+
+    def depth(self, x, skips, shape, min_predict_depth, max_predict_depth, return_logits=False, out=None):
+        """The whole decoder + KBNetModel.forward's depth mapping (reference src/kbnet_model.py:179-184).  deconv0's
+        second conv, output0 and the sigmoid mapping run as ONE kernel when deconv0 has no skip and its width is a
+        multiple of 4 channels (KBNet: 12); otherwise conv, then the fused output0 + mapping head."""
+        x = self.features_level1(x, skips)
+        d0 = self.deconv0
+        if d0.skip_channels == 0:
+            up = d0.deconv(x, shape=tuple(shape)[-2:])
+            res = ops.conv_head(up, d0.conv.conv.weight, self.output0.conv.weight, min_predict_depth,
+                                max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
+            if res is not None:
+                return res
+            feats = d0.conv.run([ops.tensor_src(up, "deconv")], up.shape[0], up.shape[2], up.shape[3])
+        else:
+            feats = d0(x, None, shape=tuple(shape)[-2:])
+        return ops.depth_head(feats, self.output0.conv.weight, min_predict_depth, max_predict_depth,
+                              return_logits=return_logits, out=out)
 
     def forward(self, x, skips, shape=None):
         return [self.output0(self.features(x, skips, shape))]
@@ -559,10 +580,9 @@ class KBNetModel(object):
         input_depth = self.sparse_to_dense_pool(input_depth)
         shape = input_depth.shape[-2:]
         latent, skips = self.encoder(image, input_depth, intrinsics)
-        feats = self.decoder.features(latent, skips, shape)
-        # output0 conv + sigmoid + d_min / (s + d_min/d_max), one kernel
-        return ops.depth_head(feats, self.decoder.output0.conv.weight, self.min_predict_depth,
-                              self.max_predict_depth, return_logits=return_logits, out=out)
+        # decoder; its tail (deconv0's second conv + output0 + sigmoid + d_min / (s + d_min/d_max)) is one kernel
+        return self.decoder.depth(latent, skips, shape, self.min_predict_depth, self.max_predict_depth,
+                                  return_logits=return_logits, out=out)
 
     def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True):
         """Captures one forward of this batch shape into a HIP graph and returns a callable

@@ -416,6 +416,45 @@ def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, re
     return (depth, logits) if return_logits else depth
 
 
+@_on_tensor_device
+def conv_head(x, w_conv, w_out, min_predict_depth: float, max_predict_depth: float,
+              negative_slope: Optional[float] = 0.2, return_logits=False, out=None):
+    """deconv0's second conv + output0 + depth mapping in one launch (kbn_conv_head_forward).  Returns None when
+    the shape does not qualify (channels % 4, width % 4, alignment): the caller runs the two-launch path."""
+    lib = _lib.load()
+    xptr, xbs = _planes(x, "x")
+    n, c, h, wd = x.shape
+    wc = w_conv.detach().contiguous()
+    wo = w_out.detach().contiguous()
+    _require(wc, "w_conv", 4)
+    _require(wo, "w_out", 4)
+    if tuple(wc.shape) != (c, c, 3, 3) or tuple(wo.shape) != (1, c, 3, 3):
+        raise KbnError(f"conv_head weights must be {c} x {c} x 3 x 3 and 1 x {c} x 3 x 3")
+    if out is None:
+        depth = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32)
+    else:
+        _require(out, "out", 4)
+        if tuple(out.shape) != (n, 1, h, wd) or not out.is_contiguous():
+            raise KbnError(f"out must be a contiguous {(n, 1, h, wd)} tensor")
+        depth = out
+    logits = torch.empty_like(depth) if return_logits else None
+    flops = 2.0 * n * h * wd * c * 9 * c
+    status = _launch("conv_head", flops,
+                     lambda: lib.kbn_conv_head_forward(xptr, xbs, wc.data_ptr(), wo.data_ptr(), depth.data_ptr(),
+                                                       logits.data_ptr() if return_logits else None, n, c, h, wd,
+                                                       0 if negative_slope is None else 1,
+                                                       0.0 if negative_slope is None else float(negative_slope),
+                                                       float(min_predict_depth), float(max_predict_depth), _stream()),
+                     # 75 m-blocks of 16 positions per 64 x 16 tile, 16 filter columns, K = 9 c
+                     executed=2.0 * n * (-(-h // 16)) * (-(-wd // 64)) * 75 * 16 * 16 * 9 * c)
+    if status == _lib.KBN_ERR_UNSUPPORTED:
+        if PROFILE is not None:
+            PROFILE.pop()
+        return None
+    check(status, "kbn_conv_head_forward")
+    return (depth, logits) if return_logits else depth
+
+
 # ------------------------------------------------------- pre-model stage / evaluation
 @_on_tensor_device
 def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5, normalize_image: bool = True):

@@ -231,6 +231,18 @@ int kbn_depth_head_forward(const float* x, const float* weight, float* depth, fl
                            int channels, int height, int width, float min_predict_depth,
                            float max_predict_depth, kbn_stream_t stream);
 
+/* The decoder's tail in one launch: DecoderBlock deconv0's second conv (channels -> channels, 3x3,
+ * optional LeakyReLU; reference src/net_utils.py:1485-1487 with no skip, src/networks.py:1966-1983)
+ * + output0 + the depth mapping above; the channels-wide full-resolution tensor between the two convs
+ * stays on the CU.  x: N x channels x H x W (frames x_batch_stride elements apart), w_conv: channels x
+ * channels x 3 x 3 and w_out: 1 x channels x 3 x 3, both raw OIHW.  KBN_ERR_UNSUPPORTED unless channels is a
+ * multiple of 4 (<= 16), width a multiple of 4 and the planes 16-byte aligned: the caller then runs
+ * kbn_conv2d_forward + kbn_depth_head_forward (same results up to fp32 summation order). */
+int kbn_conv_head_forward(const float* x, long long x_batch_stride, const float* w_conv, const float* w_out,
+                          float* depth, float* logits, int n, int channels, int height, int width,
+                          int apply_activation, float negative_slope, float min_predict_depth,
+                          float max_predict_depth, kbn_stream_t stream);
+
 /* ------------------------------------------------- pre-model stage --
  * What the reference's run loop does between the host->device copy and the model call:
  *   validity = where(sparse > 0, 1, sparse)                        reference src/kbnet.py:899-902

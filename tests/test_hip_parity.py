@@ -454,6 +454,30 @@ def test_depth_head_vs_oracle(dev, shape):
     assert float(((d.cpu() - ref).abs() / ref).max()) < TOL
 
 
+@pytest.mark.parametrize("c,shape", [(12, (37, 72)), (4, (16, 64)), (16, (70, 100)), (12, (5, 200)), (8, (130, 68))])
+def test_conv_head_fused_vs_oracle(dev, kenv, c, shape):
+    """deconv0's second conv + output0 + depth mapping in one launch (kbn_conv_head_forward) against the oracle's
+    conv -> conv -> mapping and against the two-launch HIP path (KBN_NO_HEAD_FUSION=1)."""
+    h, wd = shape
+    g = torch.Generator().manual_seed(c * 1000 + h)
+    x = torch.randn(2, c, h, wd, generator=g)
+    wc = torch.randn(c, c, 3, 3, generator=g) * (1.3 / (c * 9) ** 0.5)
+    wo = torch.randn(1, c, 3, 3, generator=g) * 0.5
+    feats = orc.conv2d(x, wc, 1, 0.2)
+    logits = orc.conv2d(feats, wo, 1, None)
+    ref = orc.depth_head(logits, 1.5, 100.0)
+    res = kb.ops.conv_head(x.to(dev), wc.to(dev), wo.to(dev), 1.5, 100.0, 0.2, return_logits=True)
+    assert res is not None, "shape qualifies for the fused kernel"
+    d, lg = res
+    assert rel_err(lg, logits) < TIGHT
+    assert float(((d.cpu() - ref).abs() / ref).max()) < TOL
+    kenv.setenv("KBN_NO_HEAD_FUSION", "1")
+    assert kb.ops.conv_head(x.to(dev), wc.to(dev), wo.to(dev), 1.5, 100.0, 0.2) is None
+    kenv.delenv("KBN_NO_HEAD_FUSION")
+    # shapes the fused kernel does not take (channels % 4, width % 4) fall back inside MultiScaleDecoder.depth
+    assert kb.ops.conv_head(x[:, :, :, :wd - 2].contiguous().to(dev), wc.to(dev), wo.to(dev), 1.5, 100.0, 0.2) is None
+
+
 # --------------------------------------------------------------------- full forward
 def _check_forward(out, ref):
     err = ((out.cpu() - ref).abs() / ref.abs()).max()
