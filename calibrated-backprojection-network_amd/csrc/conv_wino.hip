@@ -57,6 +57,12 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+__device__ __forceinline__ float wino_max(float a, float b) {   // plain v_max_f32 (fmaxf adds a canonicalising v_max)
+    float o;
+    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+
 struct WinoParams {
     const float* src[KBN_MAX_SRC];
     long long src_bstride[KBN_MAX_SRC];
@@ -225,10 +231,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     // MFMA slot i of an iteration runs group (i/16 + 3) % 4: the LAST group of the previous chunk first --
     // its fragments are already in registers, so the matrix pipe has work while the first fragment reads
     // after the chunk's barrier are still in flight -- then groups 0..2 of this chunk.
-    auto mfma = [&](int i) {
+    // `first` (the first chunk of a tile): the 16 slots of "group 3 of the previous chunk" stay empty and groups 0 and 2 --
+    // the first products of their accumulators -- take a zero C operand, so that no accumulator is ever cleared
+    // by hand (128 v_mov per tile that would sit on the matrix pipe's issue port).
+    auto mfma = [&](int i, bool first = false) {
         if ((DBG & 4) != 0) return;
         const int g = ((i >> 4) + 3) & 3, mb = (i >> 2) & 3, nb = i & 3;
-        acc[g >> 1][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][mb], fb[g & 1][nb], acc[g >> 1][mb][nb], 0, 0, 0);
+        if (first && i < 16) return;
+        if (first && (g & 1) == 0)
+            acc[g >> 1][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][mb], fb[g & 1][nb], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else
+            acc[g >> 1][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g & 1][mb], fb[g & 1][nb], acc[g >> 1][mb][nb], 0, 0, 0);
     };
 
     // ---- per tile: decode, staging state, first DMAs ----
@@ -291,14 +304,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
     const bool in0 = lane < ntile && ox < p.W && oy < p.H, in1 = in0 && oy + 1 < p.H;
     const unsigned o0 = (unsigned)(oy * p.W + ox), o1 = o0 + (unsigned)p.W;
+    if ((DBG & 4) != 0) {   // ablation without MFMAs: defined accumulators for the epilogue
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[x][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) fa[1][q] = fb[1][q] = 0.f;   // "group 3 of chunk -1": adds zeros
+                for (int nb = 0; nb < 4; ++nb) acc[x][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first DMAs landed (and the previous tile's stores are out)
     transform(rawS, Vs);
 
@@ -311,8 +324,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     // at the top only U(c) must have landed (vmcnt(2): raw(c+1) may still fly), raw(c+1) is awaited
     // (vmcnt(6): U(c+1), raw(c+2) behind it) just before the transform reads it -- a full iteration
     // plus 24 MFMA slots after it was issued, which covers the loaded HBM latency.
-    auto body = [&](auto par) {
+    auto body = [&](auto par, auto first_c) {
         constexpr int PAR = decltype(par)::value;
+        constexpr bool FIRST = decltype(first_c)::value != 0;
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __syncthreads();
         const float* Vc = Vs + PAR * V_CHUNK;
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<64>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            mfma(i);
+            mfma(i, FIRST);
             if constexpr (i < 4) dma_u(udst, i);
             if constexpr (i == 4 || i == 5) dma_raw(rdst, i - 4);
             if constexpr (i >= 16 && i < 24) frag_read(Vc, Uc, 1, i - 16);   // (its registers were group 3's until slot 15)
@@ -351,9 +365,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
     };
     // nch is even (wino_plan): every chunk goes through `body`; the last one stages and transforms a
     // surplus copy of itself into dead buffers, which keeps the loop free of special cases.
-    for (int c = 0; c < nch; c += 2) {
-        body(IC<0>{});
-        body(IC<1>{});
+    body(IC<0>{}, IC<1>{});          // first chunk: zero-C products (nch >= 4, wino_plan)
+    body(IC<1>{}, IC<0>{});
+    for (int c = 2; c < nch; c += 2) {
+        body(IC<0>{}, IC<0>{});
+        body(IC<1>{}, IC<0>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     static_for<16>([&](auto ic) { mfma(decltype(ic)::value); });   // group 3 of the last chunk
@@ -410,8 +426,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoParams p) {
             for (int a = 0; a < 2; ++a) {
                 float v0 = s[a][0] + s[a][1] + s[a][2];
                 float v1 = s[a][1] - s[a][2] - s[a][3];
-                v0 = v0 > 0.f ? v0 : v0 * slope;
-                v1 = v1 > 0.f ? v1 : v1 * slope;
+                v0 = wino_max(v0, v0 * slope);   // LeakyReLU for 0 <= slope <= 1 (the launcher checks; 1 = no activation)
+                v1 = wino_max(v1, v1 * slope);
                 if ((DBG & 64) != 0) {   // ablation: epilogue without its global stores
                     if (v0 + v1 == 12345.f) oplane[0] = 0.f;
                 } else if (a ? in1 : in0) {
@@ -502,6 +518,7 @@ int conv_wino_launch(const ConvParams& cp, hipStream_t stream) {
     p.act = cp.act; p.slope = cp.slope; p.dbg = cp.dbg;
     p.vec_ok = ((reinterpret_cast<uintptr_t>(cp.out) & 7) == 0) && ((cp.out_bstride & 1) == 0) && ((p.W & 1) == 0);
     if (!p.vec_ok) return KBN_ERR_UNSUPPORTED;  // the epilogue stores float2
+    if (p.act && !(p.slope >= 0.f && p.slope <= 1.f)) return KBN_ERR_UNSUPPORTED;   // the epilogue's max(v, slope v) form
     const int model = choose_region(p.H, p.W, p.N, p.nTilesN);
     auto launch = [&](int cand) -> int {
         WinoParams q = p;
