@@ -87,11 +87,13 @@ struct StaticPools {
     static constexpr int NMINP = NMIN;
     static constexpr int RMIN = cmax(0, NMIN), RMAX = cmax(NMIN, NP);
     static constexpr int RR = RMIN > RMAX ? RMIN : RMAX;
+    static constexpr int RMAXZ = RR;          // radius the depth-tile register prefetch is sized for
     static constexpr int radius(int pi) { return K[pi] / 2; }
     __device__ static constexpr int R(const S2DParams&) { return RR; }
 };
 struct DynamicPools {
     static constexpr bool is_static = false;
+    static constexpr int RMAXZ = S2D_MAXR;
     __device__ static int R(const S2DParams& p) { return p.R; }
 };
 using KittiPools = StaticPools<5, 5, 7, 9, 11, 13, 15, 17>;   // bash/kitti/run_kbnet_kitti_validation.sh:15-16
@@ -106,6 +108,13 @@ __device__ __forceinline__ void s2d_for(F&& f) {
         f(IntC<I>{});
         s2d_for<I + 1, N>(static_cast<F&&>(f));
     }
+}
+
+// LeakyReLU as max(v, slope v): 2 vector instructions instead of 3 (0 <= slope <= 1, checked by the launcher)
+__device__ __forceinline__ float s2d_lrelu(float v, float slope) {
+    float t = v * slope, o;
+    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(v), "v"(t));
+    return o;
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -127,17 +136,48 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = xcd_remap(blockIdx.x, p.nblocks);
-    const int tx = bid % p.tilesX;
-    bid /= p.tilesX;
-    const int ty = bid % p.tilesY;
-    const int n = bid / p.tilesY;
-    const int oy0 = ty * S2D_TH, ox0 = tx * S2D_TW;
     const long long HW = (long long)p.H * p.W;
-    const float* xz = p.x + (long long)n * p.x_bstride;  // channel 0 = sparse depth
     const int nch = p.nf + p.inC;
     int npool = p.npool, nmin = p.nmin;
     if constexpr (CFG::is_static) { npool = CFG::NP; nmin = CFG::NMINP; }
+    const float slope = p.slope;
+
+    // Persistent workgroups (two per CU): tile t = blockIdx.x, blockIdx.x + gridDim.x, ...  The weight tables are
+    // staged once, and the next tile's depth values are fetched into registers while this tile's passes and
+    // convolutions run (the depth images in LDS are dead after the vertical pass).
+    struct Tile { int n, oy0, ox0; };
+    auto decode = [&](int t) {
+        int bid = xcd_remap(t, p.nblocks);
+        const int tx = bid % p.tilesX;
+        bid /= p.tilesX;
+        const int ty = bid % p.tilesY;
+        return Tile{bid / p.tilesY, ty * S2D_TH, tx * S2D_TW};
+    };
+    constexpr int MAXE = (s2d_zh(CFG::RMAXZ) * s2d_zw(CFG::RMAXZ) + S2D_THREADS - 1) / S2D_THREADS;
+    float vz[MAXE];
+    auto z_load = [&](const Tile& tl) {   // this thread's elements of the depth tile (+halo): -inf outside the image
+        const float* src = p.x + (long long)tl.n * p.x_bstride;
+        const int Yt = tl.oy0 - 1 - R, Xl = tl.ox0 - 1 - R;
+        const bool inside = Yt >= 0 && Yt + ZH <= p.H && Xl >= 0 && Xl + ZW <= p.W;   // block-uniform
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const int e = u * S2D_THREADS + tid;
+            const int r = e / ZW, c = e - r * ZW;
+            const int Y = Yt + r, X = Xl + c;
+            const bool ok = e < ZH * ZW && (inside || (Y >= 0 && Y < p.H && X >= 0 && X < p.W));
+            vz[u] = ok ? src[(long long)Y * p.W + X] : -INFINITY;
+        }
+    };
+    auto z_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const int e = u * S2D_THREADS + tid;
+            if (e < ZH * ZW) {
+                zmax[e] = vz[u];                                                              // -inf outside the image
+                zmin[e] = (vz[u] == 0.f) ? 999.f : ((vz[u] == -INFINITY) ? INFINITY : vz[u]);   // where(z == 0, 999, z)
+            }
+        }
+    };
 
     // ---- P0: weights -> LDS in A-operand order -------------------------------------------------
     if (!p.pyramid) {
@@ -151,31 +191,19 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
             w1[e] = (i < p.nconv && f < p.nf && q < cin) ? p.wpool[i][f * cin + q] : 0.f;
         }
     }
-    // ---- P1: stage the depth tile (+halo): a batch of loads first, then the two LDS images ---------------
-    if (!(p.dbg & 16)) {
-        constexpr int MAXE = 12;
-        const int total = ZH * ZW;
-        for (int base = 0; base < total; base += MAXE * S2D_THREADS) {
-            float v[MAXE];
-#pragma unroll
-            for (int u = 0; u < MAXE; ++u) {
-                const int e = base + u * S2D_THREADS + tid;
-                const int r = e / ZW, c = e - r * ZW;
-                const int Y = oy0 - 1 - R + r, X = ox0 - 1 - R + c;
-                const bool inb = e < total && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
-                v[u] = inb ? xz[(long long)Y * p.W + X] : -INFINITY;
-            }
-#pragma unroll
-            for (int u = 0; u < MAXE; ++u) {
-                const int e = base + u * S2D_THREADS + tid;
-                if (e < total) {
-                    zmax[e] = v[u];                                                              // -inf outside the image
-                    zmin[e] = (v[u] == 0.f) ? 999.f : ((v[u] == -INFINITY) ? INFINITY : v[u]);   // where(z == 0, 999, z)
-                }
-            }
-        }
-    }
+    // ---- P1 (first tile): stage the depth tile (+halo) ------------------------------------------------------
+    int tile_id = blockIdx.x;
+    Tile tl = decode(tile_id);
+    if (!(p.dbg & 16)) { z_load(tl); z_store(); }
     __syncthreads();
+
+  for (;;) {   // ---- tile loop ----
+    const int n = tl.n, oy0 = tl.oy0, ox0 = tl.ox0;
+    const float* xz = p.x + (long long)n * p.x_bstride;  // channel 0 = sparse depth
+    // the feature region (+1 halo, padded to 4-pixel groups) lies inside the image: no zero padding to apply
+    const bool interior = oy0 >= 1 && oy0 + S2D_TH < p.H && ox0 >= 1 && ox0 - 1 + S2D_FWP <= p.W;   // block-uniform
+    const int next_id = tile_id + (int)gridDim.x;
+    const bool more = next_id < p.nblocks;
 
     // ---- P2: vertical pass -> V[pool][feature row][z column] ------------------------------------------
     if (p.dbg & 1) {
@@ -225,6 +253,13 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
         }
     }
     __syncthreads();
+    Tile nxt = tl;
+    if (more) {   // next tile's depth values -> registers, in flight during P3 .. P5 (zmin / zmax are dead from here on)
+        nxt = decode(next_id);
+        if constexpr (CFG::is_static) {   // (the run-time pool path has no registers to spare: it loads at the loop tail)
+            if (!(p.dbg & 16)) z_load(nxt);
+        }
+    }
 
     // ---- P3: horizontal pass: pooled values of 4 consecutive feature pixels per item -> registers ------
     // item = (feature row fr, group q): feature columns 4q .. 4q+3 (columns >= FW are padding, never consumed)
@@ -246,7 +281,7 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int Y = oy0 - 1 + fr, X = ox0 - 1 + 4 * q + j;
-                const bool inb = live && ci < p.inC && !p.pyramid && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+                const bool inb = live && ci < p.inC && !p.pyramid && (interior || (Y >= 0 && Y < p.H && X >= 0 && X < p.W));
                 xin[rd][ci][j] = inb ? xz[(long long)ci * HW + (long long)Y * p.W + X] : 0.f;
             }
         if (!live || (p.dbg & 2)) continue;
@@ -311,20 +346,11 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
                     if (pi < npool) py[(long long)pi * HW] = pooled[rd][j][pi];
             }
         }
-        return;
     }
     __syncthreads();  // every V read is done: `feat` overlays V from here on
 
     // ---- P4: 1x1 conv chain on the matrix cores (lane = pixel), features + raw x channels -> LDS --------
-    {
-        float a1[S2D_MAXCONV][8][2];   // A operands: [layer][input][filter half], this lane's filter = lane & 3
-#pragma unroll
-        for (int i = 0; i < S2D_MAXCONV; ++i)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                a1[i][q][0] = w1[((i * 8 + q) * 2 + 0) * 4 + (lane & 3)];
-                a1[i][q][1] = w1[((i * 8 + q) * 2 + 1) * 4 + (lane & 3)];
-            }
+    if (!p.pyramid) {
 #pragma unroll
         for (int rd = 0; rd < NROUND; ++rd) {
             const int t = rd * S2D_THREADS + tid;
@@ -336,6 +362,12 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
 #pragma unroll
             for (int i = 0; i < S2D_MAXCONV; ++i) {
                 if (i < p.nconv && !(p.dbg & 4)) {
+                    float a1[8][2];   // A operands of this layer: [input][filter half], this lane's filter = lane & 3
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {
+                        a1[qq][0] = w1[((i * 8 + qq) * 2 + 0) * 4 + (lane & 3)];
+                        a1[qq][1] = w1[((i * 8 + qq) * 2 + 1) * 4 + (lane & 3)];
+                    }
                     f32x4 g[4][2];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j][0] = g[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -344,8 +376,8 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float b = (i == 0) ? pooled[rd][j][qq] : h[j][qq >> 2][qq & 3];
-                            g[j][0] = mfma4(a1[i][qq][0], b, g[j][0]);
-                            g[j][1] = mfma4(a1[i][qq][1], b, g[j][1]);
+                            g[j][0] = mfma4(a1[qq][0], b, g[j][0]);
+                            g[j][1] = mfma4(a1[qq][1], b, g[j][1]);
                         }
                     }
 #pragma unroll
@@ -353,25 +385,25 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                            for (int f = 0; f < 4; ++f) h[j][hh][f] = leaky_relu(g[j][hh][f], p.slope);
+                            for (int f = 0; f < 4; ++f) h[j][hh][f] = s2d_lrelu(g[j][hh][f], slope);
                 }
             }
             if (t < NITEM) {
-                const int Y = oy0 - 1 + fr;
-                const bool rowin = Y >= 0 && Y < p.H;
-                bool inb[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int X = ox0 - 1 + 4 * q + j;
-                    inb[j] = rowin && X >= 0 && X < p.W;
-                }
                 float* fo = feat + fr * S2D_FWP + 4 * q;
+                if (!interior) {   // zero padding of the feature map outside the image (block-uniform, border tiles only)
+                    const int Y = oy0 - 1 + fr;
+                    const bool rowin = Y >= 0 && Y < p.H;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int X = ox0 - 1 + 4 * q + j;
+                        if (!(rowin && X >= 0 && X < p.W)) h[j][0] = h[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
 #pragma unroll
                 for (int f = 0; f < S2D_MAXF; ++f)
                     if (f < p.nf)
                         *reinterpret_cast<f32x4*>(fo + f * (S2D_FH * S2D_FWP)) =
-                            (f32x4){inb[0] ? h[0][f >> 2][f & 3] : 0.f, inb[1] ? h[1][f >> 2][f & 3] : 0.f,
-                                    inb[2] ? h[2][f >> 2][f & 3] : 0.f, inb[3] ? h[3][f >> 2][f & 3] : 0.f};
+                            (f32x4){h[0][f >> 2][f & 3], h[1][f >> 2][f & 3], h[2][f >> 2][f & 3], h[3][f >> 2][f & 3]};
 #pragma unroll
                 for (int ci = 0; ci < S2D_MAXIN; ++ci)
                     if (ci < p.inC)
@@ -386,7 +418,7 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
     //      tile; lane = (row l >> 4, 4 consecutive columns 4 (l & 15) ..): the six feature values a row of the
     //      window needs are one 16-byte + one 8-byte LDS read, and every filter leaves as one 16-byte store.
     //      acc[pixel][half][j] = filter 4 half + j. ----------------------------------------------------------
-    {
+    if (!p.pyramid) {
         constexpr int RW = S2D_TH / 4;     // rows per wave
         static_assert(RW == 4, "lane mapping: 16 lanes x 4 columns per row, 4 rows per wave");
         const int lr = lane >> 4, cg = lane & 15;
@@ -423,8 +455,8 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
 #pragma unroll
             for (int f = 0; f < S2D_MAXF; ++f) {
                 if (f >= p.nf) continue;
-                const f32x4 v = (f32x4){leaky_relu(acc[0][f >> 2][f & 3], p.slope), leaky_relu(acc[1][f >> 2][f & 3], p.slope),
-                                        leaky_relu(acc[2][f >> 2][f & 3], p.slope), leaky_relu(acc[3][f >> 2][f & 3], p.slope)};
+                const f32x4 v = (f32x4){s2d_lrelu(acc[0][f >> 2][f & 3], slope), s2d_lrelu(acc[1][f >> 2][f & 3], slope),
+                                        s2d_lrelu(acc[2][f >> 2][f & 3], slope), s2d_lrelu(acc[3][f >> 2][f & 3], slope)};
                 if (vec) {
                     *reinterpret_cast<f32x4*>(o + f * HW) = v;
                 } else {
@@ -435,6 +467,15 @@ __global__ __launch_bounds__(S2D_THREADS, 2) void s2d_kernel(const S2DParams p) 
             }
         }
     }
+    if (!more) break;
+    tile_id = next_id;
+    tl = nxt;
+    if constexpr (!CFG::is_static) {
+        if (!(p.dbg & 16)) z_load(tl);
+    }
+    if (!(p.dbg & 16)) z_store();   // the prefetched depth tile -> LDS
+    __syncthreads();                // ... and every read of this tile's features is done (V is rewritten next)
+  }   // tile loop
 }
 
 static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const int* max_pool_sizes,
@@ -476,7 +517,11 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
     };
     auto launch = [&](auto kern, DeviceOnce& once) -> int {
         if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S2D_THREADS), lds, stream, p);
+        int cus = device_cu_count();
+        if (cus < 1) cus = 256;
+        const long long per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+        const long long grid = blocks < per_cu * cus ? blocks : per_cu * cus;   // persistent workgroups
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(S2D_THREADS), lds, stream, p);
         return KBN_OK;
     };
     static DeviceOnce set_kitti, set_void, set_voidtrain, set_dyn;
@@ -504,6 +549,7 @@ int kbn_s2d_forward(const float* x, const float* const* w_pool_convs, const floa
         return KBN_ERR_INVALID_ARGUMENT;
     if (n_filter > S2D_MAXF || input_channels > S2D_MAXIN || n_convolution > S2D_MAXCONV)
         return KBN_ERR_UNSUPPORTED;
+    if (!(negative_slope >= 0.f && negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;   // LeakyReLU / ReLU / identity
     S2DParams p{};
     p.x = x;
     p.x_bstride = (long long)input_channels * height * width;
