@@ -139,7 +139,7 @@ template <int I> struct IC2 { static constexpr int value = I; };
 // lane (two 16-byte stores), fused LeakyReLU.
 template <int NB, int MW>
 __device__ __forceinline__ void up2x_store(const Up2xParams& p, const f32x4 (&acc)[2][MW][NB], int n, int nt, int a,
-                                           int y0, int x0, int twb, int wave, int li, int lk) {
+                                           int y0, int x0, int twb, int wave, int li, int lk, bool vstack = false) {
     constexpr int NT = NB * 16;
     const int outH = 2 * p.srcH, outW = 2 * p.srcW;
     const long long HWo = (long long)outH * outW;
@@ -148,7 +148,8 @@ __device__ __forceinline__ void up2x_store(const Up2xParams& p, const f32x4 (&ac
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         const int mb = wave * MW + mi;
-        const int oyl = mb / twb, seg = mb - oyl * twb;
+        // vstack: a wave's m-blocks are MW vertically adjacent rows of one 16-pixel segment (9-product kernel)
+        const int oyl = vstack ? (wave / twb) * MW + mi : mb / twb, seg = vstack ? wave % twb : mb - oyl * twb;
         const int y = y0 + oyl;
         const int xl = x0 + seg * 16 + lk * 4;
         if (y >= p.srcH || xl >= p.srcW) continue;
@@ -656,8 +657,7 @@ __global__ __launch_bounds__(256, 2) void conv_up2x9_kernel(const Up2xParams p) 
     int mbase[MW];
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
-        const int mb = wave * MW + mi;
-        const int oy = mb / TWB, seg = mb - oy * TWB;
+        const int oy = (wave / TWB) * MW + mi, seg = wave % TWB;  // a wave owns MW vertically adjacent rows of one segment
         mbase[mi] = oy * PITCH + seg * 16 + li + 3 + lk * PLANE;   // (row y-1, column x-1) of the lane's pixel
     }
     const int boff = G::A_FLOATS + (lk >> 1) * 2 * NT + li * 2 + (lk & 1);
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void conv_up2x9_kernel(const Up2xParams p) 
             const float* Ab = S + c4 * 4 * PLANE;
             const float* Bb = S + c4 * 36 * NT + boff;
             float d[MW][9], b9[9][NB];
-            if constexpr (TWB == 1) {
+            {
                 // The wave's MW m-blocks are vertically adjacent rows of the tile: read the MW + 2 input rows once,
                 // take the column differences per input row, then the row differences between neighbouring rows --
                 // the lower difference of a row is the upper difference of the next one.  2 (MW + 2) + 3 (MW + 1)
@@ -722,26 +722,6 @@ __global__ __launch_bounds__(256, 2) void conv_up2x9_kernel(const Up2xParams p) 
                         d[mi][1 * 3 + j] = cv[mi + 1][j];    // centre row
                         d[mi][2 * 3 + j] = rd[mi + 1][j];    // lower difference: row y+1 - row y
                     }
-            } else {
-#pragma unroll
-                for (int mi = 0; mi < MW; ++mi) {
-                    float r[3][3];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) r[i][j] = Ab[mbase[mi] + i * PITCH + j];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {           // rows: upper difference, centre, lower difference
-                        const float u0 = r[1][j] - r[0][j], u2 = r[2][j] - r[1][j];
-                        r[0][j] = u0; r[2][j] = u2;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {           // columns likewise
-                        d[mi][i * 3 + 0] = r[i][1] - r[i][0];
-                        d[mi][i * 3 + 1] = r[i][1];
-                        d[mi][i * 3 + 2] = r[i][2] - r[i][1];
-                    }
-                }
             }
 #pragma unroll
             for (int q = 0; q < 9; ++q)
@@ -804,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void conv_up2x9_kernel(const Up2xParams p) 
                 o[0][mi][nb] = (acc[ia * 3 + 0][mi][nb] + acc[ia * 3 + 1][mi][nb]) + (acc[3][mi][nb] + cc);
                 o[1][mi][nb] = (acc[ia * 3 + 2][mi][nb] + acc[ia * 3 + 1][mi][nb]) + (acc[5][mi][nb] + cc);
             }
-        up2x_store<NB, MW>(p, o, n, nt, a, y0, x0, TWB, wave, li, lk);
+        up2x_store<NB, MW>(p, o, n, nt, a, y0, x0, TWB, wave, li, lk, true);
     }
 }
 
