@@ -561,9 +561,16 @@ def test_forward_full_size_seed_sweep(dev, preset, shape):
         worst = max(worst, per_seed[-1])
     print(f"{preset} {shape}: max rel err per seed " + " ".join(f"{e:.2e}" for e in per_seed))
     assert worst < TOL, f"{preset}: worst of 5 seeds {worst:.3e} (per seed: {per_seed})"
-    # How much of that is the ORACLE's own fp32 rounding?  The last seed again, against an fp64 evaluation of the same
+    # How much of that is the ORACLE's own fp32 rounding?  The WORST seed again, against an fp64 evaluation of the same
     # network (tests/analysis/oracle_fp64_distance.py): the HIP path must be about as close to the exact result as the
     # fp32 oracle is -- two fp32 evaluation orders cannot agree better with each other than with the truth.
+    seed = (0, 3, 7, 11, 19)[per_seed.index(worst)]
+    sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3 if preset == "kitti" else 1.45)
+    frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    out = m.forward(*to(dev, *frames))
+    ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
     torch.set_default_dtype(torch.float64)      # the oracle's pixel grid follows the default dtype (reference quirk Q8)
     try:
         ref64 = orc.kbnet_forward(*[f.double() for f in frames], *[{k: v.double() for k, v in sd.items()} for sd in sds],
@@ -572,7 +579,7 @@ def test_forward_full_size_seed_sweep(dev, preset, shape):
         torch.set_default_dtype(torch.float32)
     hip64 = float(((out.cpu().double() - ref64).abs() / ref64.abs()).max())
     orc64 = float(((ref.double() - ref64).abs() / ref64.abs()).max())
-    print(f"{preset} seed 19 vs fp64: HIP {hip64:.2e}, fp32 oracle {orc64:.2e}")
+    print(f"{preset} seed {seed} (worst) vs fp64: HIP {hip64:.2e}, fp32 oracle {orc64:.2e}")
     assert hip64 < TOL and hip64 < 3.0 * orc64 + 1e-5, (hip64, orc64)
 
 
