@@ -80,8 +80,11 @@ class _PackedWeight:
     def get(self, weight: torch.Tensor, stride: int, up2x: bool = False) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, weight.device, stride, up2x)
         if key != self._key:
-            self._packed = (ops.pack_upconv2x_weight(weight, out=self._packed) if up2x
-                            else ops.pack_conv_weight(weight, stride, out=self._packed))
+            if up2x == "bf16":      # throughput-only bf16 leg (ops.conv3x3_bf16)
+                self._packed = ops.pack_conv3x3_bf16_weight(weight, out=self._packed)
+            else:
+                self._packed = (ops.pack_upconv2x_weight(weight, out=self._packed) if up2x
+                                else ops.pack_conv_weight(weight, stride, out=self._packed))
             self._key = key
             self._args = (stride, up2x)
         return self._packed
@@ -113,15 +116,33 @@ class Conv2d(torch.nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self._slope = _slope(activation_func)
         self._packed = _PackedWeight()
+        self._packed_bf16 = _PackedWeight()
+        self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
 
     def packed(self):
         return self._packed.get(self.conv.weight, self.stride)
+
+    def _bf16_eligible(self, in_w):
+        return (self.bf16 and self.kernel_size == 3 and self.stride == 1 and self.in_channels % 16 == 0 and in_w % 4 == 0)
+
+    def run_bf16(self, srcs, n, h, w, out=None, up2x=False):
+        """3x3 stride-1 conv with bf16 MFMA operands (ops.conv3x3_bf16); None when the shape does not qualify."""
+        if not self._bf16_eligible(w) or len(srcs) > 2 or any(s.channels % 16 for s in srcs):
+            return None
+        if out is None:
+            out = torch.empty((n, self.out_channels, h, w), device=self.conv.weight.device, dtype=torch.float32)
+        return ops.conv3x3_bf16(srcs, self._packed_bf16.get(self.conv.weight, 1, up2x="bf16"), n, self.out_channels, h, w,
+                                out, up2x=up2x, negative_slope=self._slope)
 
     def run(self, srcs, n, in_h, in_w, out=None, resize=False):
         cin = sum(s.channels for s in srcs)
         if cin != self.in_channels:   # the packed blob carries no size: a wrong count would read past the weight panel
             raise KbnError(f"expected {self.in_channels} input channels in total, got {cin}")
         oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)
+        if self.bf16 and not resize:
+            res = self.run_bf16(srcs, n, in_h, in_w, out=out)
+            if res is not None:
+                return res
         if out is None:
             out = torch.empty((n, self.out_channels, oh, ow), device=self.conv.weight.device,
                               dtype=torch.float32)
@@ -159,6 +180,10 @@ class UpConv2d(torch.nn.Module):
         n, _, h, w = x.shape
         oh, ow = int(shape[0]), int(shape[1])
         if (oh, ow) == (2 * h, 2 * w) and self.conv.kernel_size == 3:
+            if self.conv.bf16:
+                res = self.conv.run_bf16([ops.tensor_src(x, "x")], n, oh, ow, up2x=True)
+                if res is not None:
+                    return res
             # exact 2x: four 2x2 phase convs on the low-res input (4/9 of the MACs)
             out = torch.empty((n, self.conv.out_channels, oh, ow), device=x.device, dtype=torch.float32)
             return ops.upconv2x(x, self._packed_up2x.get(self.conv.conv.weight, 1, up2x=True),
@@ -416,6 +441,15 @@ class MultiScaleDecoder(torch.nn.Module):
             cin = n_filters[i]
         self.output0 = Conv2d(n_filters[4], output_channels, 3, 1, weight_initializer, None)
 
+    def set_bf16(self, enabled: bool = True):
+        """THROUGHPUT-ONLY switch (BASELINE configs[2]'s bf16 figure): the decoder's 3x3 stride-1 convs with at least 16
+        input channels run with bf16 MFMA operands and fp32 accumulation (csrc/conv_bf16.hip).  Misses the 1e-4 parity
+        bar by construction; bench.py reports its rate and measured error under separate keys."""
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m.bf16 = bool(enabled)
+        return self
+
     def features(self, x, skips, shape):
         """Everything up to (not including) output0."""
         return self.deconv0(self.features_level1(x, skips), None, shape=tuple(shape)[-2:])
@@ -602,6 +636,7 @@ class KBNetModel(object):
             for sub in m.modules():
                 if isinstance(sub, Conv2d):
                     sub._packed.refresh(sub.conv.weight)
+                    sub._packed_bf16.refresh(sub.conv.weight)
                 elif isinstance(sub, UpConv2d):
                     sub._packed_up2x.refresh(sub.conv.conv.weight)
 

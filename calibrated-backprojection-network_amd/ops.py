@@ -455,6 +455,49 @@ def conv_head(x, w_conv, w_out, min_predict_depth: float, max_predict_depth: flo
     return (depth, logits) if return_logits else depth
 
 
+# ----------------------------------------------------- bf16 leg (throughput-only)
+@_on_tensor_device
+def pack_conv3x3_bf16_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """OIHW fp32 3x3 weight -> bf16 MFMA blob for `conv3x3_bf16` (in_channels % 16 == 0)."""
+    lib = _lib.load()
+    w = weight.detach().contiguous()
+    _require(w, "weight", 4)
+    oc, cin, kh, kw = w.shape
+    nbytes = lib.kbn_conv3x3_bf16_packed_weight_bytes(oc, cin) if (kh, kw) == (3, 3) else 0
+    if nbytes == 0:
+        raise KbnError(f"conv3x3_bf16 needs a 3x3 weight with in_channels % 16 == 0, got {tuple(w.shape)}")
+    packed = out if _reusable(out, nbytes // 4, w) else torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    check(lib.kbn_conv3x3_bf16_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, _stream()), "kbn_conv3x3_bf16_pack_weight")
+    return packed
+
+
+@_on_tensor_device
+def conv3x3_bf16(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
+                 out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2):
+    """THROUGHPUT-ONLY: 3x3 stride-1 conv (+ LeakyReLU) of up to two concatenated sources with bf16 MFMA operands and
+    fp32 accumulation (kbn_conv3x3_bf16_forward); `up2x`: the single source is nearest-upsampled by 2 first.  Returns
+    None when the shape does not qualify (the caller then stays on the fp32 kernels)."""
+    lib = _lib.load()
+    arr = (ConvSrc * len(srcs))(*srcs)
+    optr, obs = _planes(out, "out")
+    if tuple(out.shape) != (n, out_channels, height, width):
+        raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, height, width)}")
+    cin = sum(s.channels for s in srcs)
+    flops = 2.0 * n * height * width * cin * 9 * out_channels
+    status = _launch("conv_bf16", flops,
+                     lambda: lib.kbn_conv3x3_bf16_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
+                                                          out_channels, height, width, 1 if up2x else 0,
+                                                          0 if negative_slope is None else 1,
+                                                          0.0 if negative_slope is None else float(negative_slope),
+                                                          _stream()))
+    if status == _lib.KBN_ERR_UNSUPPORTED:
+        if PROFILE is not None:
+            PROFILE.pop()
+        return None
+    check(status, "kbn_conv3x3_bf16_forward")
+    return out
+
+
 # ------------------------------------------------------- pre-model stage / evaluation
 @_on_tensor_device
 def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5, normalize_image: bool = True):
