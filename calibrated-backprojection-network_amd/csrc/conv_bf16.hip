@@ -8,15 +8,15 @@
 // and weights are rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on their way into LDS, products accumulate
 // in fp32 on v_mfma_f32_32x32x16_bf16.  bench.py reports its rate and its measured error under separate keys.
 //
-// Workgroup = 256 threads = 8 x 32 output pixels x 64 filters.  K loop over chunks of 16 input channels (all 9 taps per
+// Workgroup = 256 threads = 16 x 32 output pixels x 64 filters.  K loop over chunks of 16 input channels (all 9 taps per
 // chunk), double buffered:
-//   A  the (8+2) x (32+2) input tile of the chunk: a thread loads the 8 channels of one pixel (8 coalesced dword loads,
-//      nearest-2x: source pixel (y >> 1, x >> 1)), converts and writes ONE 16-byte LDS word; layout [k-group][pixel][8
-//      channels] -> the MFMA A fragment of a lane (pixel = lane % 32, k-group = lane / 32) is one conflict-free
-//      ds_read_b128;
+//   A  the (16+2) x (32+2) input tile of the chunk (up-conv: the (8+2) x (16+2) low-resolution pixels it maps to; the
+//      fragment reads do the upsampling): a thread loads the 8 channels of one pixel (8 coalesced dword loads with a
+//      scalar plane base), converts and writes ONE 16-byte LDS word; layout [k-group][pixel][8 channels] -> the MFMA A
+//      fragment of a lane (pixel = lane % 32, k-group = lane / 32) is one ds_read_b128;
 //   B  the chunk's weights, pre-packed [tap][k-group][filter][8 channels] bf16: a straight LDS-DMA copy; B fragment =
 //      one ds_read_b128 (filter = lane % 32).
-// Wave w owns output rows 2w, 2w+1 (two 32-pixel m-blocks) x two 32-filter n-blocks: per tap 2 A + 2 B reads, 4 MFMAs.
+// Wave w owns output rows 4w .. 4w+3 (four 32-pixel m-blocks) x two 32-filter n-blocks: per tap 4 A + 2 B reads, 8 MFMAs.
 // With 16x the fp32 matrix rate the kernel is bound by its operand traffic (L2 -> LDS weights, HBM inputs), not by MFMAs.
 #include "conv_common.h"
 
@@ -26,13 +26,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BF_TH = 8, BF_TW = 32, BF_NT = 64, BF_CK = 16;
-constexpr int BF_ROWS = BF_TH + 2, BF_COLS = BF_TW + 2, BF_NPIX = BF_ROWS * BF_COLS;     // staged tile: 10 x 34 = 340 pixels
-constexpr int BF_A_BYTES = 2 * BF_NPIX * 16;                                             // [k-group][pixel][8 bf16]
-constexpr int BF_B_BYTES = 9 * 2 * BF_NT * 16;                                           // [tap][k-group][filter][8 bf16]
-constexpr int BF_STAGE = BF_A_BYTES + BF_B_BYTES;                                        // (NB = 1 kernels stage half of B)
-constexpr int BF_PR = (BF_NPIX + 255) / 256;          // pixel rounds per k-group (2): staging round u = k-group * BF_PR + pixel round
-constexpr int BF_ROUNDS = 2 * BF_PR;
+constexpr int BF_TH = 16, BF_TW = 32, BF_NT = 64, BF_CK = 16, BF_MB = 4;   // tile, filters per workgroup, chunk, m-blocks (rows) per wave
+// Staged input tile of a chunk.  Plain conv: the (16+2) x (32+2) pixels around the output tile.  Nearest-2x up-conv: the
+// (8+2) x (16+2) LOW-resolution pixels those map to -- the fragment reads do the upsampling ((y + ky + 1) >> 1,
+// (x + kx + 1) >> 1 in staged coordinates), so every source pixel is fetched once, not four times.
+template <bool UP>
+struct BfGeom {
+    static constexpr int ROWS = UP ? BF_TH / 2 + 2 : BF_TH + 2, COLS = UP ? BF_TW / 2 + 2 : BF_TW + 2, NPIX = ROWS * COLS;
+    static constexpr int A_BYTES = 2 * NPIX * 16;                 // [k-group][pixel][8 bf16]
+    static constexpr int PR = (NPIX + 255) / 256, ROUNDS = 2 * PR; // staging round u = k-group * PR + pixel round
+};
+template <bool UP, int NB>
+struct BfStage {
+    static constexpr int B_BYTES = 9 * 2 * NB * 32 * 16;          // [tap][k-group][filter][8 bf16]
+    static constexpr int BYTES = BfGeom<UP>::A_BYTES + B_BYTES;
+};
 
 struct Bf16ConvParams {
     const float* src[2];
@@ -70,9 +78,11 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
     packed[e] = bf16_bits(v);
 }
 
-template <int NB>   // 32-filter n-blocks per workgroup: 2 (64 filters), or 1 for layers with <= 32 filters
+template <int NB, bool UP>   // NB: 32-filter n-blocks per workgroup (2, or 1 for layers with <= 32 filters); UP: nearest-2x input
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvParams p) {
-    constexpr int NT = NB * 32, B_BYTES = 9 * 2 * NT * 16;
+    using G = BfGeom<UP>;
+    using ST = BfStage<UP, NB>;
+    constexpr int NT = NB * 32, B_BYTES = ST::B_BYTES, STAGE = ST::BYTES, NPIX = G::NPIX, PR = G::PR, ROUNDS = G::ROUNDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,38 +96,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
     const int n = bid / p.tilesY;
     const int oy0 = ty * BF_TH, ox0 = tx * BF_TW;
     const int H = p.H, W = p.W;
+    const int sH = UP ? H >> 1 : H, sW = UP ? W >> 1 : W;        // source planes
+    const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / BF_CK;
 
     // ---- this thread's staging pixels (the same for both k-groups): byte offset inside a source plane, or -1 ----
-    int goff[BF_PR], gsh[BF_PR];   // plain / nearest-2x source offsets
+    int goff[PR];
 #pragma unroll
-    for (int u = 0; u < BF_PR; ++u) {
+    for (int u = 0; u < PR; ++u) {
         const int pix = u * 256 + tid;
-        const int r = pix / BF_COLS, c = pix - r * BF_COLS;
-        const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
-        const bool ok = pix < BF_NPIX && Y >= 0 && Y < H && X >= 0 && X < W;
-        goff[u] = ok ? (Y * W + X) * 4 : -1;
-        gsh[u] = ok ? ((Y >> 1) * (W >> 1) + (X >> 1)) * 4 : -1;
+        const int r = pix / G::COLS, c = pix - r * G::COLS;
+        const int Y = (UP ? (oy0 >> 1) : oy0) - 1 + r, X = (UP ? (ox0 >> 1) : ox0) - 1 + c;
+        goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
     }
 
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
     const unsigned short* wp_nt = p.wp + (long long)nt * nchunks * (B_BYTES / 2);
 
-    float va[BF_ROUNDS][8];
+    float va[ROUNDS][8];
     // chunk -> (source, first channel inside it); every source holds a multiple of 16 channels (launcher).  The channel
     // plane goes into the scalar base of the load, the lane contributes its tile-invariant pixel offset: no vector
     // address arithmetic per load (vector instructions are paid for in matrix-pipe time).
     auto load_chunk = [&](int chunk) {
         int c = chunk * BF_CK, s = 0;
         if (p.nsrc > 1 && c >= p.srcC[0]) { c -= p.srcC[0]; s = 1; }
-        const bool up = p.up2x && s == 0;
-        const long long plane = up ? (long long)(H >> 1) * (W >> 1) : (long long)H * W;
         const float* base = p.src[s] + (long long)n * p.src_bstride[s] + (long long)c * plane;
 #pragma unroll
-        for (int u = 0; u < BF_ROUNDS; ++u) {
-            const int kg = u / BF_PR, pr = u - kg * BF_PR;
-            const int off = up ? gsh[pr] : goff[pr];
-            const unsigned voff = off < 0 ? 0u : (unsigned)off;   // masked lanes read element 0 of the plane (zeroed in store_chunk)
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int kg = u / PR, pr = u - kg * PR;
+            const unsigned voff = goff[pr] < 0 ? 0u : (unsigned)goff[pr];   // masked lanes read element 0 (zeroed in store_chunk)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 // scalar base + 32-bit lane offset, issued from asm (hipcc turns the C form into flat loads with 64-bit
@@ -127,26 +134,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
             }
         }
     };
-    auto store_chunk = [&](int buf, int chunk) {
-        unsigned char* A = smem + buf * BF_STAGE;
-        const bool up = p.up2x && !(p.nsrc > 1 && chunk * BF_CK >= p.srcC[0]);
+    auto store_chunk = [&](int buf) {
+        unsigned char* A = smem + buf * STAGE;
 #pragma unroll
-        for (int u = 0; u < BF_ROUNDS; ++u) {
-            const int kg = u / BF_PR, pr = u - kg * BF_PR, pix = pr * 256 + tid;
-            if (pix >= BF_NPIX) continue;
-            const bool ok = (up ? gsh[pr] : goff[pr]) >= 0;       // zero padding outside the image
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int kg = u / PR, pr = u - kg * PR, pix = pr * 256 + tid;
+            if (pix >= NPIX) continue;
+            const bool ok = goff[pr] >= 0;       // zero padding outside the image
             bf16x8 v;
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
                 const bf16x2 c = __builtin_convertvector((f32x2){ok ? va[u][k] : 0.f, ok ? va[u][k + 1] : 0.f}, bf16x2);
                 v[k] = c[0]; v[k + 1] = c[1];
             }
-            *reinterpret_cast<bf16x8*>(A + (kg * BF_NPIX + pix) * 16) = v;
+            *reinterpret_cast<bf16x8*>(A + (kg * NPIX + pix) * 16) = v;
         }
     };
     auto stage_b = [&](int buf, int chunk) {
         const float* src = reinterpret_cast<const float*>(wp_nt + (long long)chunk * (B_BYTES / 2));
-        const unsigned dst = lds0 + (unsigned)(buf * BF_STAGE + BF_A_BYTES);
+        const unsigned dst = lds0 + (unsigned)(buf * STAGE + G::A_BYTES);
         constexpr int n4 = B_BYTES / 16;                   // 1152 / 576 granules
 #pragma unroll
         for (int e0 = 0; e0 < n4; e0 += 256) {
@@ -155,29 +161,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
         }
     };
 
-    f32x16 acc[2][NB];
+    f32x16 acc[BF_MB][NB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < BF_MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
+    // A fragment of (row 4 wave + mb, pixel lm, tap (ky, kx)): staged pixel (4w + mb + ky, lm + kx), or for the up-conv
+    // the low-resolution pixel ((4w + mb + ky + 1) >> 1, (lm + kx + 1) >> 1) = (2w + ((mb + ky + 1) >> 1), ...)
+    int acol[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) acol[kx] = (g * NPIX + (UP ? ((lm + kx + 1) >> 1) : lm + kx)) * 16;
+    const int arow = (UP ? 2 * wave : 4 * wave) * G::COLS * 16;
+    const int bbase = (g * NT + lm) * 16;
     auto compute = [&](int buf) {
-        const unsigned char* A = smem + buf * BF_STAGE;
-        const unsigned char* B = A + BF_A_BYTES;
-        const int abase = (g * BF_NPIX + (2 * wave) * BF_COLS + lm) * 16;
-        const int bbase = (g * NT + lm) * 16;
+        const unsigned char* A = smem + buf * STAGE + arow;
+        const unsigned char* B = smem + buf * STAGE + G::A_BYTES + bbase;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
-            bf16x8 a[2], b[NB];
+            bf16x8 a[BF_MB], b[NB];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(A + abase + ((mb + ky) * BF_COLS + kx) * 16);
+            for (int mb = 0; mb < BF_MB; ++mb) {
+                const int r = UP ? ((mb + ky + 1) >> 1) : mb + ky;
+                a[mb] = *reinterpret_cast<const bf16x8*>(A + acol[kx] + r * G::COLS * 16);
+            }
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(B + bbase + (tap * 2 * NT + nb * 32) * 16);
+            for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(B + (tap * 2 * NT + nb * 32) * 16);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < BF_MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
     load_chunk(0);
     stage_b(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_chunk(0, 0);
+    store_chunk(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
@@ -198,17 +212,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
         }
         compute(cur);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the asm loads of load_chunk and the weight DMA have landed
-        if (more) store_chunk(cur ^ 1, c + 1);
+        if (more) store_chunk(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: acc[mb][nb][i]: pixel x = 8 (i / 4) + 4 (lane / 32) + (i % 4) of row 2 wave + mb, filter nb * 32 + lane % 32
+    // ---- epilogue: acc[mb][nb][i]: pixel x = 8 (i / 4) + 4 (lane / 32) + (i % 4) of row 4 wave + mb, filter nb * 32 + lane % 32
     const long long HW = (long long)H * W;
     float* outn = p.out + (long long)n * p.out_bstride;
     const float slope = p.act ? p.slope : 1.f;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int Y = oy0 + 2 * wave + mb;
+    for (int mb = 0; mb < BF_MB; ++mb) {
+        const int Y = oy0 + BF_MB * wave + mb;
         if (Y >= H) continue;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -280,20 +294,25 @@ int kbn_conv3x3_bf16_forward(const kbn_conv_src* srcs, int n_src, const void* pa
     p.wp = static_cast<const unsigned short*>(packed_weight);
     p.out = out; p.out_bstride = out_batch_stride;
     p.N = n; p.OC = out_channels; p.Cin = cin; p.H = height; p.W = width; p.up2x = upsample2x ? 1 : 0;
+    if (upsample2x && ((height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
     const int ntf = bf16_nt(out_channels);
     p.tilesX = ceil_div(width, BF_TW); p.tilesY = ceil_div(height, BF_TH); p.nTilesN = ceil_div(out_channels, ntf);
     const long long blocks = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
     if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
     p.nblocks = (int)blocks;
     p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
-    static DeviceOnce once1, once2;
-    if (ntf == 32) {
-        if (int rc = set_max_dynamic_lds(once1, reinterpret_cast<const void*>(conv3x3_bf16_kernel<1>), 160 * 1024)) return rc;
-        hipLaunchKernelGGL(conv3x3_bf16_kernel<1>, dim3(p.nblocks), dim3(256), 2 * BF_STAGE, (hipStream_t)stream, p);
-    } else {
-        if (int rc = set_max_dynamic_lds(once2, reinterpret_cast<const void*>(conv3x3_bf16_kernel<2>), 160 * 1024)) return rc;
-        hipLaunchKernelGGL(conv3x3_bf16_kernel<2>, dim3(p.nblocks), dim3(256), 2 * BF_STAGE, (hipStream_t)stream, p);
-    }
+    auto launch = [&](auto kern, size_t lds, DeviceOnce& once) -> int {
+        if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+        hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, (hipStream_t)stream, p);
+        return KBN_OK;
+    };
+    static DeviceOnce o10, o11, o20, o21;
+    int rc;
+    if (ntf == 32) rc = upsample2x ? launch(conv3x3_bf16_kernel<1, true>, 2 * BfStage<true, 1>::BYTES, o11)
+                                   : launch(conv3x3_bf16_kernel<1, false>, 2 * BfStage<false, 1>::BYTES, o10);
+    else rc = upsample2x ? launch(conv3x3_bf16_kernel<2, true>, 2 * BfStage<true, 2>::BYTES, o21)
+                         : launch(conv3x3_bf16_kernel<2, false>, 2 * BfStage<false, 2>::BYTES, o20);
+    if (rc != KBN_OK) return rc;
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
