@@ -18,6 +18,8 @@
 //      one ds_read_b128 (filter = lane % 32).
 // Wave w owns output rows 4w .. 4w+3 (four 32-pixel m-blocks) x two 32-filter n-blocks: per tap 4 A + 2 B reads, 8 MFMAs.
 // With 16x the fp32 matrix rate the kernel is bound by its operand traffic (L2 -> LDS weights, HBM inputs), not by MFMAs.
+// (Tried: x-aligned 40-column tiles with 16-byte staging loads -- slower, 465 -> 551 us on deconv1's conv at batch 16:
+// fewer staging items than threads, 18 % more bytes, 64 load registers.)
 #include "conv_common.h"
 
 namespace kbn {
