@@ -61,9 +61,12 @@ class ShardedRunner:
     results are overwritten by the next call with the same output shape; `step_pipelined()` results by the
     next-but-one call.  Clone what must live longer."""
 
-    def __init__(self, forward_fn: Callable, rank: int, world: int):
+    def __init__(self, forward_fn: Callable, rank: int, world: int, gather_single: bool = False):
+        """`gather_single`: run the collectives even with one rank (a one-rank RCCL group is legal): lets a single-GPU
+        box exercise the whole RCCL path -- stream ordering against graph replays included -- in tests."""
         self.forward_fn = forward_fn
         self.rank, self.world = rank, world
+        self.collective = world > 1 or (gather_single and dist.is_initialized())
         self._bufs = {}        # (per, shape[1:], device) -> gather buffer
         self._ring = None      # pipelined mode: [(staging, gathered, work)] x 2
         self._step = 0
@@ -76,20 +79,20 @@ class ShardedRunner:
         N_total x 1 x H x W tensor of the PREVIOUS step (None on the first call); `drain()` returns the last."""
         out = self.forward_fn(*local_inputs)
         if self._ring is None:
-            if self.world > 1:   # a ragged shard would hang or fail inside the collective: check once
+            if self.collective:   # a ragged shard would hang or fail inside the collective: check once
                 n = torch.tensor([out.shape[0], -out.shape[0]], device=out.device, dtype=torch.int64)
                 dist.all_reduce(n, op=dist.ReduceOp.MAX)
                 if int(n[0]) != -int(n[1]):
                     raise ValueError(f"step_pipelined needs equal shards on every rank (min {-int(n[1])}, "
                                      f"max {int(n[0])} frames); use step() / step_mixed() for ragged batches")
             gathered = lambda: (torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]),
-                                            device=out.device, dtype=out.dtype) if self.world > 1 else None)
+                                            device=out.device, dtype=out.dtype) if self.collective else None)
             self._ring = [[torch.empty_like(out), gathered(), None] for _ in range(2)]
         slot = self._ring[self._step & 1]
         if slot[2] is not None:
             slot[2].wait()                      # the gather that used this slot two steps ago
         slot[0].copy_(out)                      # `out` may be a graph's static buffer: detach it
-        if self.world > 1:
+        if self.collective:
             slot[2] = dist.all_gather_into_tensor(slot[1], slot[0], async_op=True)
         prev = self._ring[(self._step & 1) ^ 1]
         self._step += 1
@@ -98,7 +101,7 @@ class ShardedRunner:
         return self._finish(prev)
 
     def _finish(self, slot):
-        if self.world == 1:
+        if not self.collective:
             return slot[0]
         if slot[2] is not None:
             slot[2].wait()                      # orders the consumer after the gather
@@ -141,7 +144,7 @@ class ShardedRunner:
 
     def step(self, local_inputs, n_total: Optional[int] = None, gather: bool = True):
         out = self.forward_fn(*local_inputs)
-        if self.world == 1 or not gather:
+        if not self.collective or not gather:
             return out
         n_total = n_total if n_total is not None else out.shape[0] * self.world
         lo, hi = shard_bounds(n_total, self.rank, self.world)
@@ -169,7 +172,7 @@ class ShardedRunner:
                                      f"share is {hi - lo} frames")
             elif hi > lo:
                 raise ValueError(f"rank {self.rank} owns {hi - lo} frames of bucket {tuple(frame_shape)} but got no inputs")
-            if self.world == 1:
+            if not self.collective:
                 pending.append((out, None, 0, n_total))
                 continue
             if out is None:   # nothing of this shape here: still take part in the collective

@@ -184,6 +184,41 @@ def test_reference_written_checkpoint_restores_and_runs(dev):
 
 
 # ------------------------------------------------------------------------------------------------ RCCL
+def test_rccl_single_rank_group(dev):
+    """One-GPU boxes cannot host two RCCL ranks, but a ONE-rank group is legal: the whole RCCL path of dist.py --
+    group creation, the async all-gather on RCCL's stream ordered against HIP-graph replays, the pipelined ring of
+    buffers, ragged step(), the shape buckets of step_mixed -- runs on hardware (ShardedRunner(gather_single=True))."""
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        cfg = kb.kitti_config().narrow()
+        m = kb.modules.KBNetModel.from_config(cfg, dev)
+        m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+        a = [t.to(dev) for t in kb.synthetic.make_frames(4, 64, 96, "kitti", seed=1, jitter_intrinsics=0.1)]
+        b = [t.to(dev) for t in kb.synthetic.make_frames(4, 64, 96, "kitti", seed=2, jitter_intrinsics=0.1)]
+        ea, eb = m.forward(*a).clone(), m.forward(*b).clone()
+        replay = m.capture(*a)
+        runner = kb.dist.ShardedRunner(replay, 0, 1, gather_single=True)
+        assert runner.collective
+        assert runner.step_pipelined(a) is None
+        assert torch.equal(runner.step_pipelined(b), ea)      # result of step i arrives with step i+1
+        assert torch.equal(runner.step_pipelined(a), eb)
+        assert torch.equal(runner.drain(), ea)
+        eager = kb.dist.ShardedRunner(m.forward, 0, 1, gather_single=True)
+        assert torch.equal(eager.step(b, n_total=4), eb)
+        c = [t.to(dev) for t in kb.synthetic.make_frames(2, 32, 64, "kitti", seed=3)]
+        ec = m.forward(*c).clone()
+        outs = eager.step_mixed([(m.forward, a, 4, (1, 64, 96)), (m.forward, c, 2, (1, 32, 64))])
+        assert torch.equal(outs[0], ea) and torch.equal(outs[1], ec)
+        assert kb.dist.max_over_ranks(3.0, dev) == 3.0
+        kb.dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _rccl_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
