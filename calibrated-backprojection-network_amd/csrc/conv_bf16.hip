@@ -17,6 +17,8 @@
 //   B  the chunk's weights, pre-packed [tap][k-group][filter][8 channels] bf16: a straight LDS-DMA copy; B fragment =
 //      one ds_read_b128 (filter = lane % 32).
 // Wave w owns output rows 4w .. 4w+3 (four 32-pixel m-blocks) x two 32-filter n-blocks: per tap 4 A + 2 B reads, 8 MFMAs.
+// Stride-2 variant (the image convs of the KB blocks and conv5, reference src/net_utils.py:1348, src/networks.py:521-525):
+// 4 x 32 output pixels per workgroup, (8+1) x (64+1) staged pixels, fragment pixel (2 y + ky, 2 x + kx).
 // With 16x the fp32 matrix rate the kernel is bound by its operand traffic (L2 -> LDS weights, HBM inputs), not by MFMAs.
 // (Tried: x-aligned 40-column tiles with 16-byte staging loads -- slower, 465 -> 551 us on deconv1's conv at batch 16:
 // fewer staging items than threads, 18 % more bytes, 64 load registers.)
@@ -32,16 +34,20 @@ constexpr int BF_TH = 16, BF_TW = 32, BF_NT = 64, BF_CK = 16, BF_MB = 4;   // ti
 // Staged input tile of a chunk.  Plain conv: the (16+2) x (32+2) pixels around the output tile.  Nearest-2x up-conv: the
 // (8+2) x (16+2) LOW-resolution pixels those map to -- the fragment reads do the upsampling ((y + ky + 1) >> 1,
 // (x + kx + 1) >> 1 in staged coordinates), so every source pixel is fetched once, not four times.
-template <bool UP>
+template <int MODE>   // 0 plain 3x3, 1 nearest-2x up-conv, 2 stride-2 conv
 struct BfGeom {
-    static constexpr int ROWS = UP ? BF_TH / 2 + 2 : BF_TH + 2, COLS = UP ? BF_TW / 2 + 2 : BF_TW + 2, NPIX = ROWS * COLS;
+    static constexpr bool UP = MODE == 1, S2 = MODE == 2;
+    static constexpr int MB = S2 ? 1 : BF_MB;                     // 32-pixel rows per wave
+    static constexpr int TH = 4 * MB;                             // output rows per workgroup (16, stride 2: 4)
+    static constexpr int ROWS = UP ? TH / 2 + 2 : (S2 ? 2 * TH + 1 : TH + 2);
+    static constexpr int COLS = UP ? BF_TW / 2 + 2 : (S2 ? 2 * BF_TW + 1 : BF_TW + 2), NPIX = ROWS * COLS;
     static constexpr int A_BYTES = 2 * NPIX * 16;                 // [k-group][pixel][8 bf16]
     static constexpr int PR = (NPIX + 255) / 256, ROUNDS = 2 * PR; // staging round u = k-group * PR + pixel round
 };
-template <bool UP, int NB>
+template <int MODE, int NB>
 struct BfStage {
     static constexpr int B_BYTES = 9 * 2 * NB * 32 * 16;          // [tap][k-group][filter][8 bf16]
-    static constexpr int BYTES = BfGeom<UP>::A_BYTES + B_BYTES;
+    static constexpr int BYTES = BfGeom<MODE>::A_BYTES + B_BYTES;
 };
 
 struct Bf16ConvParams {
@@ -52,8 +58,9 @@ struct Bf16ConvParams {
     const unsigned short* wp;   // packed bf16 weights: [n-tile][chunk][tap][k-group][64 filters][8 channels]
     float* out;
     long long out_bstride;
-    int N, OC, Cin, H, W;       // output size = logical input size
-    int up2x;                   // source 0 holds (H/2) x (W/2) planes, nearest-upsampled on the fly
+    int N, OC, Cin, H, W;       // output size
+    int sH, sW;                 // source planes: H x W, (H/2) x (W/2) for the up-conv, the input size of a stride-2 conv
+    int up2x;
     int tilesX, tilesY, nTilesN, nblocks;
     int act;
     float slope;
@@ -80,10 +87,12 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __
     packed[e] = bf16_bits(v);
 }
 
-template <int NB, bool UP>   // NB: 32-filter n-blocks per workgroup (2, or 1 for layers with <= 32 filters); UP: nearest-2x input
+template <int NB, int MODE>   // NB: 32-filter n-blocks per workgroup (2, or 1 for layers with <= 32 filters); MODE: see BfGeom
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvParams p) {
-    using G = BfGeom<UP>;
-    using ST = BfStage<UP, NB>;
+    using G = BfGeom<MODE>;
+    using ST = BfStage<MODE, NB>;
+    constexpr bool UP = G::UP, S2 = G::S2;
+    constexpr int MB = G::MB;
     constexpr int NT = NB * 32, B_BYTES = ST::B_BYTES, STAGE = ST::BYTES, NPIX = G::NPIX, PR = G::PR, ROUNDS = G::ROUNDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
     bid /= p.tilesX;
     const int ty = bid % p.tilesY;
     const int n = bid / p.tilesY;
-    const int oy0 = ty * BF_TH, ox0 = tx * BF_TW;
+    const int oy0 = ty * G::TH, ox0 = tx * BF_TW;
     const int H = p.H, W = p.W;
-    const int sH = UP ? H >> 1 : H, sW = UP ? W >> 1 : W;        // source planes
+    const int sH = p.sH, sW = p.sW;                              // source planes
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / BF_CK;
 
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
     for (int u = 0; u < PR; ++u) {
         const int pix = u * 256 + tid;
         const int r = pix / G::COLS, c = pix - r * G::COLS;
-        const int Y = (UP ? (oy0 >> 1) : oy0) - 1 + r, X = (UP ? (ox0 >> 1) : ox0) - 1 + c;
+        const int Y = (UP ? (oy0 >> 1) : (S2 ? 2 * oy0 : oy0)) - 1 + r, X = (UP ? (ox0 >> 1) : (S2 ? 2 * ox0 : ox0)) - 1 + c;
         goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
     }
 
@@ -163,20 +172,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
         }
     };
 
-    f32x16 acc[BF_MB][NB];
+    f32x16 acc[MB][NB];
 #pragma unroll
-    for (int mb = 0; mb < BF_MB; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
-    // A fragment of (row 4 wave + mb, pixel lm, tap (ky, kx)): staged pixel (4w + mb + ky, lm + kx), or for the up-conv
-    // the low-resolution pixel ((4w + mb + ky + 1) >> 1, (lm + kx + 1) >> 1) = (2w + ((mb + ky + 1) >> 1), ...)
+    // A fragment of (row MB wave + mb, pixel lm, tap (ky, kx)): staged pixel (MB w + mb + ky, lm + kx); up-conv: the
+    // low-resolution pixel ((MB w + mb + ky + 1) >> 1, (lm + kx + 1) >> 1); stride 2: (2 (MB w + mb) + ky, 2 lm + kx)
     int acol[3];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) acol[kx] = (g * NPIX + (UP ? ((lm + kx + 1) >> 1) : lm + kx)) * 16;
-    const int arow = (UP ? 2 * wave : 4 * wave) * G::COLS * 16;
+    for (int kx = 0; kx < 3; ++kx) acol[kx] = (g * NPIX + (UP ? ((lm + kx + 1) >> 1) : (S2 ? 2 * lm + kx : lm + kx))) * 16;
+    const int arow = (UP ? MB / 2 : (S2 ? 2 * MB : MB)) * wave * G::COLS * 16;
     const int bbase = (g * NT + lm) * 16;
     auto compute = [&](int buf) {
         const unsigned char* A = smem + buf * STAGE + arow;
@@ -184,16 +193,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
-            bf16x8 a[BF_MB], b[NB];
+            bf16x8 a[MB], b[NB];
 #pragma unroll
-            for (int mb = 0; mb < BF_MB; ++mb) {
-                const int r = UP ? ((mb + ky + 1) >> 1) : mb + ky;
+            for (int mb = 0; mb < MB; ++mb) {
+                const int r = UP ? ((mb + ky + 1) >> 1) : (S2 ? 2 * mb + ky : mb + ky);
                 a[mb] = *reinterpret_cast<const bf16x8*>(A + acol[kx] + r * G::COLS * 16);
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(B + (tap * 2 * NT + nb * 32) * 16);
 #pragma unroll
-            for (int mb = 0; mb < BF_MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
@@ -223,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16ConvPara
     float* outn = p.out + (long long)n * p.out_bstride;
     const float slope = p.act ? p.slope : 1.f;
 #pragma unroll
-    for (int mb = 0; mb < BF_MB; ++mb) {
-        const int Y = oy0 + BF_MB * wave + mb;
+    for (int mb = 0; mb < MB; ++mb) {
+        const int Y = oy0 + MB * wave + mb;
         if (Y >= H) continue;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -273,32 +282,38 @@ int kbn_conv3x3_bf16_pack_weight(const float* weight, void* packed, int out_chan
 }
 
 int kbn_conv3x3_bf16_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
-                             long long out_batch_stride, int n, int out_channels, int height, int width, int upsample2x,
+                             long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
                              int apply_activation, float negative_slope, kbn_stream_t stream) {
     using namespace kbn;
     if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || !out || n < 1 || out_channels < 1 || height < 1 || width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
+    if (mode < 0 || mode > 2) return KBN_ERR_INVALID_ARGUMENT;
     if ((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3)) return KBN_ERR_UNSUPPORTED;
-    if (upsample2x && (n_src != 1 || (height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
-    if ((long long)height * width > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    if (mode == 1 && (n_src != 1 || (height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
     Bf16ConvParams p{};
     int cin = 0;
     for (int s = 0; s < n_src; ++s) {
         const kbn_conv_src& a = srcs[s];
         if (a.kind != KBN_SRC_TENSOR || !a.data || a.channels < 1 || (a.channels % BF_CK) != 0) return KBN_ERR_UNSUPPORTED;
-        const int sh = upsample2x ? height / 2 : height, sw = upsample2x ? width / 2 : width;
-        if (a.src_height != sh || a.src_width != sw) return KBN_ERR_INVALID_ARGUMENT;
+        if (s == 0) { p.sH = a.src_height; p.sW = a.src_width; }
+        if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
         p.src[s] = a.data; p.src_bstride[s] = a.batch_stride; p.srcC[s] = a.channels;
         cin += a.channels;
     }
+    // source planes vs output size: plain = same, up-conv = half, stride 2 = ceil(in / 2) = out
+    const bool dims_ok = mode == 0 ? (p.sH == height && p.sW == width)
+                       : mode == 1 ? (2 * p.sH == height && 2 * p.sW == width)
+                                   : (ceil_div(p.sH, 2) == height && ceil_div(p.sW, 2) == width);
+    if (!dims_ok) return KBN_ERR_INVALID_ARGUMENT;
+    if ((long long)p.sH * p.sW > 0x1fffffffLL || (long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
     if (n_src == 1) { p.src[1] = p.src[0]; p.src_bstride[1] = p.src_bstride[0]; p.srcC[1] = 0; }
     p.nsrc = n_src;
     p.wp = static_cast<const unsigned short*>(packed_weight);
     p.out = out; p.out_bstride = out_batch_stride;
-    p.N = n; p.OC = out_channels; p.Cin = cin; p.H = height; p.W = width; p.up2x = upsample2x ? 1 : 0;
-    if (upsample2x && ((height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
+    p.N = n; p.OC = out_channels; p.Cin = cin; p.H = height; p.W = width; p.up2x = mode == 1;
     const int ntf = bf16_nt(out_channels);
-    p.tilesX = ceil_div(width, BF_TW); p.tilesY = ceil_div(height, BF_TH); p.nTilesN = ceil_div(out_channels, ntf);
+    const int th = mode == 2 ? BfGeom<2>::TH : BfGeom<0>::TH;
+    p.tilesX = ceil_div(width, BF_TW); p.tilesY = ceil_div(height, th); p.nTilesN = ceil_div(out_channels, ntf);
     const long long blocks = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
     if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
     p.nblocks = (int)blocks;
@@ -308,12 +323,16 @@ int kbn_conv3x3_bf16_forward(const kbn_conv_src* srcs, int n_src, const void* pa
         hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, (hipStream_t)stream, p);
         return KBN_OK;
     };
-    static DeviceOnce o10, o11, o20, o21;
+    static DeviceOnce o[6];
     int rc;
-    if (ntf == 32) rc = upsample2x ? launch(conv3x3_bf16_kernel<1, true>, 2 * BfStage<true, 1>::BYTES, o11)
-                                   : launch(conv3x3_bf16_kernel<1, false>, 2 * BfStage<false, 1>::BYTES, o10);
-    else rc = upsample2x ? launch(conv3x3_bf16_kernel<2, true>, 2 * BfStage<true, 2>::BYTES, o21)
-                         : launch(conv3x3_bf16_kernel<2, false>, 2 * BfStage<false, 2>::BYTES, o20);
+    switch (mode * 2 + (ntf == 32 ? 0 : 1)) {
+        case 0: rc = launch(conv3x3_bf16_kernel<1, 0>, 2 * BfStage<0, 1>::BYTES, o[0]); break;
+        case 1: rc = launch(conv3x3_bf16_kernel<2, 0>, 2 * BfStage<0, 2>::BYTES, o[1]); break;
+        case 2: rc = launch(conv3x3_bf16_kernel<1, 1>, 2 * BfStage<1, 1>::BYTES, o[2]); break;
+        case 3: rc = launch(conv3x3_bf16_kernel<2, 1>, 2 * BfStage<1, 2>::BYTES, o[3]); break;
+        case 4: rc = launch(conv3x3_bf16_kernel<1, 2>, 2 * BfStage<2, 1>::BYTES, o[4]); break;
+        default: rc = launch(conv3x3_bf16_kernel<2, 2>, 2 * BfStage<2, 2>::BYTES, o[5]); break;
+    }
     if (rc != KBN_OK) return rc;
     KBN_CHECK_LAUNCH();
     return KBN_OK;

@@ -122,17 +122,16 @@ class Conv2d(torch.nn.Module):
     def packed(self):
         return self._packed.get(self.conv.weight, self.stride)
 
-    def _bf16_eligible(self, in_w):
-        return (self.bf16 and self.kernel_size == 3 and self.stride == 1 and self.in_channels % 16 == 0 and in_w % 4 == 0)
-
     def run_bf16(self, srcs, n, h, w, out=None, up2x=False):
-        """3x3 stride-1 conv with bf16 MFMA operands (ops.conv3x3_bf16); None when the shape does not qualify."""
-        if not self._bf16_eligible(w) or len(srcs) > 2 or any(s.channels % 16 for s in srcs):
+        """3x3 conv with bf16 MFMA operands (ops.conv3x3_bf16); `h` x `w` is the OUTPUT size.  None when the layer or
+        the shape does not qualify (kernel 3, input channels of every source % 16, output width % 4)."""
+        if (not self.bf16 or self.kernel_size != 3 or w % 4 or len(srcs) > 2 or any(s.channels % 16 for s in srcs)
+                or (up2x and self.stride != 1)):
             return None
         if out is None:
             out = torch.empty((n, self.out_channels, h, w), device=self.conv.weight.device, dtype=torch.float32)
         return ops.conv3x3_bf16(srcs, self._packed_bf16.get(self.conv.weight, 1, up2x="bf16"), n, self.out_channels, h, w,
-                                out, up2x=up2x, negative_slope=self._slope)
+                                out, up2x=up2x, negative_slope=self._slope, stride=self.stride)
 
     def run(self, srcs, n, in_h, in_w, out=None, resize=False):
         cin = sum(s.channels for s in srcs)
@@ -140,7 +139,7 @@ class Conv2d(torch.nn.Module):
             raise KbnError(f"expected {self.in_channels} input channels in total, got {cin}")
         oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)
         if self.bf16 and not resize:
-            res = self.run_bf16(srcs, n, in_h, in_w, out=out)
+            res = self.run_bf16(srcs, n, oh, ow, out=out)
             if res is not None:
                 return res
         if out is None:
@@ -255,6 +254,18 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             kinv = coordinates.contiguous()
         else:
             coords = coordinates.contiguous()
+        ci_conv = self.conv_image.conv_block[0]
+        if ci_conv.bf16 and kinv is not None:
+            # THROUGHPUT-ONLY bf16 leg: conv_image (most of the block's FLOPs) on bf16 MFMAs; conv_depth and conv_fused --
+            # their inputs are synthesized in-kernel (K^-1 [x y 1]^T, backprojection) -- stay on the fp32 conv kernels.
+            res = ci_conv.run_bf16([ops.tensor_src(image, "image")], n, oh, ow, out=out_image)
+            if res is not None:
+                self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth)
+                srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
+                if fused is not None:
+                    srcs.append(ops.tensor_src(fused, "fused"))
+                self.conv_fused.run(srcs, n, h, w, out=out_fused)
+                return out_image, out_depth, out_fused
         return ops.kb_block(image, depth, coords, kinv, fused,
                             self.conv_image.conv_block[0].packed(), self.conv_depth.conv_block[0].packed(),
                             self.proj_depth.conv.weight, self.conv_fused.packed(),
@@ -368,6 +379,15 @@ class KBNetEncoder(torch.nn.Module):
         self.conv5_image = VGGNetBlock(fi[3], fi[4], n_convolutions_image[4], 2, weight_initializer, act)
         self.conv5_depth = VGGNetBlock(fd[3], fd[4], n_convolutions_depth[4], 2, weight_initializer, act)
         self._f = (list(fi), list(fd), list(ff))
+
+    def set_bf16(self, enabled: bool = True):
+        """THROUGHPUT-ONLY switch (see MultiScaleDecoder.set_bf16): the stride-2 image convs of the KB blocks and both
+        convs of level 4 run with bf16 MFMA operands; conv0, conv_depth and conv_fused (narrow or synthesized inputs)
+        stay on the fp32 kernels."""
+        for name, m in self.named_modules():
+            if isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 2 and m.in_channels % 16 == 0:
+                m.bf16 = bool(enabled)
+        return self
 
     def forward(self, image, depth, intrinsics):
         fi, fd, ff = self._f
@@ -617,6 +637,14 @@ class KBNetModel(object):
         # decoder; its tail (deconv0's second conv + output0 + sigmoid + d_min / (s + d_min/d_max)) is one kernel
         return self.decoder.depth(latent, skips, shape, self.min_predict_depth, self.max_predict_depth,
                                   return_logits=return_logits, out=out)
+
+    def set_bf16(self, enabled: bool = True):
+        """THROUGHPUT-ONLY bf16 leg (BASELINE configs[2]): every 3x3 conv with at least 16 (a multiple of 16) input channels
+        per source -- the decoder's up-convs and concat convs, the stride-2 image convs of the encoder -- on bf16 MFMAs
+        with fp32 accumulation.  Misses the 1e-4 parity bar by construction; never the default."""
+        self.encoder.set_bf16(enabled)
+        self.decoder.set_bf16(enabled)
+        return self
 
     def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True):
         """Captures one forward of this batch shape into a HIP graph and returns a callable

@@ -473,10 +473,11 @@ def pack_conv3x3_bf16_weight(weight: torch.Tensor, out: Optional[torch.Tensor] =
 
 @_on_tensor_device
 def conv3x3_bf16(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
-                 out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2):
-    """THROUGHPUT-ONLY: 3x3 stride-1 conv (+ LeakyReLU) of up to two concatenated sources with bf16 MFMA operands and
-    fp32 accumulation (kbn_conv3x3_bf16_forward); `up2x`: the single source is nearest-upsampled by 2 first.  Returns
-    None when the shape does not qualify (the caller then stays on the fp32 kernels)."""
+                 out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1):
+    """THROUGHPUT-ONLY: 3x3 conv (+ LeakyReLU) of up to two concatenated sources with bf16 MFMA operands and fp32
+    accumulation (kbn_conv3x3_bf16_forward); `height` x `width` is the OUTPUT size; `up2x`: the single source is
+    nearest-upsampled by 2 first; `stride` 2: sources are the (2x larger) input planes.  Returns None when the shape does
+    not qualify (the caller then stays on the fp32 kernels)."""
     lib = _lib.load()
     arr = (ConvSrc * len(srcs))(*srcs)
     optr, obs = _planes(out, "out")
@@ -484,9 +485,11 @@ def conv3x3_bf16(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_c
         raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, height, width)}")
     cin = sum(s.channels for s in srcs)
     flops = 2.0 * n * height * width * cin * 9 * out_channels
+    if up2x and stride != 1:
+        raise KbnError("conv3x3_bf16: up2x and stride 2 are mutually exclusive")
     status = _launch("conv_bf16", flops,
                      lambda: lib.kbn_conv3x3_bf16_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
-                                                          out_channels, height, width, 1 if up2x else 0,
+                                                          out_channels, height, width, 1 if up2x else (2 if stride == 2 else 0),
                                                           0 if negative_slope is None else 1,
                                                           0.0 if negative_slope is None else float(negative_slope),
                                                           _stream()))

@@ -481,15 +481,18 @@ def test_conv_head_fused_vs_oracle(dev, kenv, c, shape):
 # ------------------------------------------------- bf16 leg (throughput-only, never parity-gated)
 @pytest.mark.parametrize("cins,cout,hw,up2x", [((32,), 48, (16, 64), False), ((64, 64), 64, (22, 76), False),
                                                ((128,), 64, (20, 36), True), ((16, 32), 12, (9, 40), False),
-                                               ((256, 512), 256, (22, 76), False), ((64,), 12, (36, 72), True)])
+                                               ((256, 512), 256, (22, 76), False), ((64,), 12, (36, 72), True),
+                                               ((48,), 96, (23, 44), "s2"), ((192,), 384, (22, 76), "s2"), ((16,), 16, (5, 8), "s2")])
 def test_conv3x3_bf16_kernel(dev, cins, cout, hw, up2x):
     """The bf16 MFMA conv of the throughput-only leg: against the oracle's conv on bf16-ROUNDED inputs and weights the
     only difference is fp32 summation order (2e-5, max norm) -- the kernel computes what it claims to; against the
     fp32 conv the error is bf16's (~1e-2), which is why this leg is never on the parity-gated path."""
-    h, w = hw
+    h, w = hw                                   # output size
     g = torch.Generator().manual_seed(sum(cins) + cout + h)
     n = 2
-    sh, sw = (h // 2, w // 2) if up2x else (h, w)
+    stride = 2 if up2x == "s2" else 1
+    up2x = up2x is True
+    sh, sw = (h // 2, w // 2) if up2x else ((2 * h - 1, 2 * w) if stride == 2 else (h, w))   # odd input height: ceil(in / 2) rows
     xs = [torch.randn(n, c, sh, sw, generator=g) for c in cins]
     cin = sum(cins)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
@@ -497,21 +500,22 @@ def test_conv3x3_bf16_kernel(dev, cins, cout, hw, up2x):
     if up2x:
         xcat = torch.nn.functional.interpolate(xcat, size=(h, w), mode="nearest")
     rb = lambda t: t.bfloat16().float()
-    ref_bf16 = orc.conv2d(rb(xcat), rb(wt), 1, 0.2)
-    ref_fp32 = orc.conv2d(xcat, wt, 1, 0.2)
+    ref_bf16 = orc.conv2d(rb(xcat), rb(wt), stride, 0.2)
+    ref_fp32 = orc.conv2d(xcat, wt, stride, 0.2)
+    assert tuple(ref_fp32.shape[-2:]) == (h, w)
     xd = [x.to(dev) for x in xs]
     out = torch.empty(n, cout, h, w, device=dev)
     res = kb.ops.conv3x3_bf16([kb.ops.tensor_src(x) for x in xd], kb.ops.pack_conv3x3_bf16_weight(wt.to(dev)), n, cout, h, w,
-                              out, up2x=up2x, negative_slope=0.2)
+                              out, up2x=up2x, negative_slope=0.2, stride=stride)
     assert res is not None
     assert rel_err(out, ref_bf16) < TIGHT
     assert 1e-4 < rel_err(out, ref_fp32) < 3e-2   # bf16 operands: two orders of magnitude off the fp32 bar
 
 
-def test_decoder_bf16_leg_error_is_reported_not_gated(dev):
-    """MultiScaleDecoder.set_bf16(): the whole forward with the decoder's wide 3x3 convs on bf16 MFMAs.  The result is
-    close to the fp32 forward in the bf16 sense (mean relative error < 2e-2) and NOT within the 1e-4 parity bar --
-    the reason bench.py reports this leg under its own keys."""
+def test_bf16_leg_error_is_reported_not_gated(dev):
+    """KBNetModel.set_bf16(): the whole forward with the decoder's wide 3x3 convs and the encoder's stride-2 image convs
+    on bf16 MFMAs.  The result is close to the fp32 forward in the bf16 sense (mean relative error < 2e-2) and NOT within
+    the 1e-4 parity bar -- the reason bench.py reports this leg under its own keys."""
     cfg = kb.kitti_config()
     sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
     frames = to(dev, *kb.synthetic.make_frames(2, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1))
@@ -519,11 +523,15 @@ def test_decoder_bf16_leg_error_is_reported_not_gated(dev):
     m.load_state_dicts(*sds)
     ref = m.forward(*frames).clone()
     m.decoder.set_bf16(True)
+    out_dec = m.forward(*frames).clone()
+    m.set_bf16(True)
     out = m.forward(*frames)
-    m.decoder.set_bf16(False)
+    m.set_bf16(False)
     assert torch.equal(m.forward(*frames), ref), "switching the leg off restores the fp32 path bit for bit"
+    err_dec = ((out_dec - ref).abs() / ref.abs())
     err = ((out - ref).abs() / ref.abs())
-    print(f"bf16 decoder leg vs fp32 path: max rel {float(err.max()):.3e}, mean rel {float(err.mean()):.3e}")
+    print(f"bf16 leg vs fp32 path: decoder only max rel {float(err_dec.max()):.3e}, mean rel {float(err_dec.mean()):.3e}; "
+          f"encoder image convs + decoder max rel {float(err.max()):.3e}, mean rel {float(err.mean()):.3e}")
     assert float(err.mean()) < 2e-2 and float(err.max()) > 1e-4
 
 
