@@ -12,7 +12,7 @@ static const char* const kKnobNames[KNOB_COUNT] = {
     "KBN_DEBUG", "KBN_FORCE_MW", "KBN_FORCE_TWB", "KBN_FORCE_CK", "KBN_EPI_LDS", "KBN_NO_WINO", "KBN_NO_DMA",
     "KBN_NO_UP2X_DMA", "KBN_NO_UP2X9", "KBN_NO_UP2X3", "KBN_UP_MW", "KBN_WINO_RT", "KBN_WINO_GRID", "KBN_NO_HEAD_DMA",
     "KBN_NO_KB_PAIR", "KBN_NO_KB_DEPTH_FUSION", "KBN_PAIR_CAND", "KBN_S2D_DEBUG", "KBN_AUTOTUNE",
-    "KBN_NO_HEAD_FUSION"};
+    "KBN_NO_HEAD_FUSION", "KBN_NO_SPLIT"};
 
 void tune_reload_env();   // tune.hip
 

@@ -1,0 +1,448 @@
+// conv_split.hip -- 3x3 convs with fp32-grade results on the 16-bit matrix core (operands split in two fp16 terms).
+//
+// gfx950 runs v_mfma_f32_*_f32 on the fp32 VECTOR datapath (157 TFLOP/s, issue shared with every other vector
+// instruction: tools/probe/valu_probe.hip); the matrix core proper takes 16-bit and narrower operands (2.5 PFLOP/s dense)
+// and runs beside the vector ALU (tools/probe/bf16x_probe.hip: an MFMA wave keeps 32 clk per MFMA with a v_fma wave on
+// the same SIMD).  This kernel feeds it fp32 operands as pairs of fp16 values:
+//     activation  a 2^-6   = h1 + 2^-11 h2,   h1 = fp16(a 2^-6),  h2 = fp16((a 2^-6 - h1) 2^11)      (22+ bits of a)
+//     weight      w 2^e    = w1 + w2,         w1 = fp16(w 2^e),   w2 = fp16(w 2^e - w1)              (22+ bits of w)
+//     a w 2^(e-6) = h1 w1 + h1 w2 + h2 (w1 2^-11)   (+ h2 w2 2^-11, below 2^-22 |a w|, dropped)
+// THREE fp16 MFMAs with fp32 accumulation per product, 3/16 of the fp32 MFMA's time.  The residual h2 is kept SCALED by
+// 2^11 so that it sits in fp16's normal range whenever h1 does (the matrix core flushes fp16 subnormals); e is chosen
+// per filter at pack time (largest |w 2^e| in [2^12, 2^13)), the 2^-6 keeps activations up to 4.2e6 finite in fp16, and
+// activations below 2^-8 = 0.0039 (h1 subnormal -> flushed, the mode register is set so) are carried by h2 alone with 11
+// bits.  Measured against an fp64 evaluation (profiles/r02/bf16x_probe.txt, K = 576 .. 6912): rms error 0.28e-6 .. 0.9e-6
+// of the output's rms, the fp32 MFMA chain (== fmaf chain) 0.44e-6 .. 1.7e-6 -- the accuracy class of the fp32 path, which
+// is why this kernel sits on the parity-gated path (tests/test_hip_parity.py holds it to the same 1e-4 bar).
+//
+// Direct 3x3 stride-1 conv (+ LeakyReLU) over one or two NCHW fp32 sources (MODE 0: the concat convs of the decoder,
+// reference src/net_utils.py:1483-1487; MODE 1: nearest-2x up-conv, :484-499), implicit GEMM with M = 32 output pixels of
+// a row, N = 32 filters, K = 16 channels per v_mfma_f32_32x32x16_f16.  Workgroup = 512 threads = 8 waves = 4 row groups x
+// 2 filter groups; tile 16 rows x 32 pixels x 64 NB filters; wave (rg, fg): rows 4 rg .. 4 rg + 3 (four m-blocks) x NB
+// n-blocks.  K loop over chunks of 16 channels, 9 taps each:
+//   A  the (16+2) x (32+2) input pixels of the chunk (up-conv: the (8+2) x (16+2) low-resolution pixels they map to; the
+//      fragment reads do the upsampling), split on the way into LDS: a thread loads 8 channels of a pixel (scalar plane
+//      base + lane offset), splits them (v_cvt_pk_f16_f32, v_cvt_f32_f16, v_pk_fma_f32) and writes two 16-byte words,
+//      layout [part][k-group][pixel][8 channels]: an MFMA A fragment is one ds_read_b128, fetched one m-block ahead of
+//      its MFMAs.  Double buffered: the global loads of chunk c+1 are in flight under the MFMAs of chunk c.
+//   B  weights pre-split at pack time, [chunk][tap][part][k-group][filter][8 channels] fp16; every wave loads its B
+//      fragments straight from global memory (one global_load_dwordx4 each; the four row-group waves of a filter group
+//      hit the same lines in L1), one tap ahead of the MFMAs; w1 2^-11 is formed in registers (v_pk_mul_f16).
+// No weight stage in LDS, ONE barrier per chunk.  Operand streams at the full MFMA rate: B 2731 / (pixels per tile) =
+// 5.3 B/clk/CU, A 1.4-2.8 B/clk/CU; the chip's power limit, not the streams, sets the rate (zero-filled operands run
+// 25 % faster through the same instruction stream).
+#include "conv_common.h"
+
+namespace kbn {
+
+typedef _Float16 sph8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sph2 __attribute__((ext_vector_type(2)));
+typedef float spf16 __attribute__((ext_vector_type(16)));
+
+constexpr int SP_TW = 32, SP_CK = 16, SP_MB = 4, SP_TH = 16, SP_THREADS = 512;
+constexpr float SP_PRESCALE = 0.015625f;   // 2^-6 on the activations
+constexpr int SP_WEXP = 13;                // largest |w 2^e| of a filter in [2^12, 2^13)
+
+template <int MODE>   // 0 plain 3x3, 1 nearest-2x up-conv, 2 stride-2 conv
+struct SpGeom {
+    static constexpr bool UP = MODE == 1, S2 = MODE == 2;
+    static constexpr int TH = S2 ? 8 : SP_TH;                            // output rows per workgroup
+    static constexpr int ROWS = UP ? TH / 2 + 2 : (S2 ? 2 * TH + 1 : TH + 2);
+    static constexpr int COLS = UP ? SP_TW / 2 + 2 : (S2 ? 2 * SP_TW + 1 : SP_TW + 2), NPIX = ROWS * COLS;
+    static constexpr int A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART;   // [part][k-group][pixel][8 fp16]
+    static constexpr int LDS = 2 * A_BYTES;
+    static constexpr int PR = (NPIX + 255) / 256;                        // staging rounds of a 256-thread half (one k-group each)
+    static constexpr int NLOADA = PR * 8;                                // vector-memory loads per chunk (inputs)
+};
+
+struct SplitConvParams {
+    const float* src[2];
+    long long src_bstride[2];
+    int srcC[2];
+    int nsrc;
+    const float* inv_scale;     // per filter: 2^(6 - e)
+    const _Float16* wp;         // [n-tile][chunk][tap][part][k-group][NT filters][8 channels] fp16
+    float* out;
+    long long out_bstride;
+    int N, OC, Cin, H, W;       // output size
+    int sH, sW;                 // source planes: H x W, (H/2) x (W/2) for the up-conv, the input size of a stride-2 conv
+    int tilesX, tilesY, nTilesN, nblocks;
+    int act;
+    float slope;
+};
+
+// two-term split of 8 floats: h1 = fp16(a 2^-6), h2 = fp16((a 2^-6 - h1) 2^11)
+__device__ __forceinline__ void sp_split8(const float (&v)[8], sph8& h1, sph8& h2) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const f32x2 a = {v[k], v[k + 1]};
+        const sph2 c1 = __builtin_convertvector(a * SP_PRESCALE, sph2);
+        const f32x2 f = {(float)c1[0], (float)c1[1]};
+        const f32x2 hi = a * (SP_PRESCALE * 2048.f);
+        const f32x2 r = {__builtin_fmaf(f[0], -2048.f, hi[0]), __builtin_fmaf(f[1], -2048.f, hi[1])};
+        const sph2 c2 = __builtin_convertvector(r, sph2);
+        h1[k] = c1[0]; h1[k + 1] = c1[1];
+        h2[k] = c2[0]; h2[k + 1] = c2[1];
+    }
+}
+
+// pass 1 of the pack: per-filter exponent; inv_scale[oc] = 2^(6 - e), 1 for padding filters
+__global__ void split_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int OC, int per_filter) {
+    const int oc = blockIdx.x;
+    __shared__ float red[256];
+    float m = 0.f;
+    if (oc < OC)
+        for (int i = threadIdx.x; i < per_filter; i += 256) m = fmaxf(m, fabsf(w[(long long)oc * per_filter + i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int ex = SP_WEXP;
+        if (red[0] > 0.f && red[0] < 3.0e38f) (void)frexpf(red[0], &ex);   // red[0] = m 2^ex, m in [0.5, 1)
+        int e = SP_WEXP - ex;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        inv_scale[oc] = ldexpf(1.f, 6 - e);
+    }
+}
+
+// pass 2: OIHW fp32 -> [n-tile][chunk][tap][part][k-group][n][8 k] fp16, zero padded
+__global__ void pack_split_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, _Float16* __restrict__ packed,
+                                  int OC, int Cin, int nchunks, int NT, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int per_chunk = 9 * 2 * 2 * NT * 8;
+    int r = (int)(e % per_chunk);
+    const long long q = e / per_chunk;
+    const int chunk = (int)(q % nchunks), nt = (int)(q / nchunks);
+    const int tap = r / (2 * 2 * NT * 8); r -= tap * 2 * 2 * NT * 8;
+    const int part = r / (2 * NT * 8); r -= part * 2 * NT * 8;
+    const int g = r / (NT * 8); r -= g * NT * 8;
+    const int n = r >> 3, k = r & 7;
+    const int c = chunk * SP_CK + g * 8 + k, oc = nt * NT + n;
+    _Float16 h = (_Float16)0.f;
+    if (c < Cin && oc < OC) {
+        const float ws = w[((long long)oc * Cin + c) * 9 + tap] * (64.f / inv_scale[oc]);   // w 2^e, exact
+        const _Float16 w1 = (_Float16)ws;
+        h = part == 0 ? w1 : (_Float16)(ws - (float)w1);
+    }
+    packed[e] = h;
+}
+
+template <int N>
+__device__ __forceinline__ void sp_wait_b(f32x4 (&b)[2][2]) {   // vmcnt(N), tied to the registers it guards
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+}
+
+// RG row groups x (8 / RG) filter groups of waves; a wave owns MB = TH / RG rows (m-blocks) x two 32-filter n-blocks.
+// APART: the two small terms (h1 w2, h2 w1 2^-11; 2^-11 of the sum) accumulate in their own registers, so that the main
+// accumulator is rounded once per k-step instead of three times (error vs fp64 / 1.7: the level of the Winograd kernel).
+template <int MODE, int RG, bool APART>
+__global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
+    using G = SpGeom<MODE>;
+    constexpr bool UP = G::UP, S2 = G::S2;
+    constexpr int NB = 2, FG = 8 / RG;
+    constexpr int NT = 64 * FG, NPIX = G::NPIX, PR = G::PR, COLS = G::COLS;
+    constexpr int MB = G::TH / RG;
+    static_assert(MB == 2 || MB == 4, "groups per chunk must be even (ping-pong A fragments)");
+    constexpr int B_TAP = 2 * 2 * NT * 16;                               // bytes: [part][k-group][filter][8 fp16]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // fp16 results of the vector ALU flush subnormals (MODE register bits 6-7 = 0): h1 of a tiny activation becomes 0 and
+    // its scaled residual carries the value; the matrix core would drop a subnormal h1 anyway
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave % RG, fg = wave / RG;
+    const int lm = lane & 31, g = lane >> 5;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int oy0 = ty * G::TH, ox0 = tx * SP_TW;
+    const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
+    const long long plane = (long long)sH * sW;
+    const int nchunks = p.Cin / SP_CK;
+
+    // ---- input staging: waves 0-3 take k-group 0 (channels 0-7 of the chunk), waves 4-7 k-group 1; a thread owns <= PR pixels
+    const int kg_st = wave >> 2, t256 = tid & 255;
+    // Stride 2: the columns of a staged row are stored de-interleaved (even columns, then odd ones), so that the 32
+    // lanes of a fragment read (columns 2 lm + kx) touch consecutive 16-byte words.
+    int goff[PR], slot[PR];
+#pragma unroll
+    for (int u = 0; u < PR; ++u) {
+        const int pix = u * 256 + t256;
+        const int r = pix / COLS, c = pix - r * COLS;
+        const int Y = (UP ? (oy0 >> 1) : (S2 ? 2 * oy0 : oy0)) - 1 + r, X = (UP ? (ox0 >> 1) : (S2 ? 2 * ox0 : ox0)) - 1 + c;
+        goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
+        slot[u] = S2 ? r * COLS + ((c & 1) ? (COLS + 1) / 2 + (c >> 1) : (c >> 1)) : pix;
+    }
+    const _Float16* wp_nt = p.wp + (long long)nt * nchunks * (9 * B_TAP / 2);
+
+    float va[PR][8];
+    auto load_chunk = [&](int chunk) {
+        int c = chunk * SP_CK, s = 0;
+        if (p.nsrc > 1 && c >= p.srcC[0]) { c -= p.srcC[0]; s = 1; }
+        const float* base = p.src[s] + (long long)n * p.src_bstride[s] + (long long)(c + kg_st * 8) * plane;
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const unsigned voff = goff[u] < 0 ? 0u : (unsigned)goff[u];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* sb = base + (long long)k * plane;   // wave-uniform
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(va[u][k]) : "v"(voff), "s"(sb) : "memory");
+            }
+        }
+    };
+    auto store_round = [&](int buf, int u) {   // split + write of one staging round (its loads have landed: caller)
+        unsigned char* A = smem + buf * G::A_BYTES + kg_st * NPIX * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));   // keeps the uses behind the caller's vmcnt wait
+        const int pix = u * 256 + t256;
+        if (pix < NPIX) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
+            sph8 h1, h2;
+            sp_split8(v, h1, h2);
+            *reinterpret_cast<sph8*>(A + slot[u] * 16) = h1;
+            *reinterpret_cast<sph8*>(A + G::A_PART + slot[u] * 16) = h2;
+        }
+    };
+    // weights: straight from L2 / L1 into the B fragments
+    const unsigned boff = (unsigned)((g * NT + fg * 32 * NB + lm) * 16);
+    auto load_b = [&](f32x4 (&b)[NB][2], int chunk, int tap) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(wp_nt + ((long long)chunk * 9 + tap) * (B_TAP / 2));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned char* sb = base + (t * 2 * NT + nb * 32) * 16;   // wave-uniform
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[nb][t]) : "v"(boff), "s"(sb) : "memory");
+            }
+    };
+
+    spf16 acc[MB][NB], lo[APART ? MB : 1][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[mb][nb][i] = 0.f;
+                if (APART) lo[mb][nb][i] = 0.f;
+            }
+
+    // A fragments are fetched one GROUP (GM m-blocks) ahead of the MFMAs that use them, ping-pong registers;
+    // sched_barriers pin that order.  Fragment of (row MB rg + mb, pixel lm, tap (ky, kx)): staged pixel
+    // (MB rg + mb + ky, lm + kx); up-conv: the low-resolution pixel ((MB rg + mb + ky + 1) >> 1, (lm + kx + 1) >> 1);
+    // stride 2: (2 (MB rg + mb) + ky, 2 lm + kx) = slot lm (kx 0), 33 + lm (kx 1), lm + 1 (kx 2) of the de-interleaved row.
+    constexpr int GM = 1, GPT = MB / GM, NGROUP = 9 * GPT;
+    const unsigned char* aptr[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+        aptr[kx] = smem + (g * NPIX + (UP ? MB / 2 : (S2 ? 2 * MB : MB)) * rg * COLS +
+                           (UP ? ((lm + kx + 1) >> 1) : (S2 ? (kx == 1 ? (COLS + 1) / 2 + lm : lm + (kx >> 1)) : lm + kx))) * 16;
+    auto load_a = [&](sph8 (&a)[GM][2], int abuf_off, int grp) {
+        const int tap = grp / GPT, mb0 = (grp % GPT) * GM;
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int m = 0; m < GM; ++m) {
+            const int r = UP ? ((mb0 + m + ky + 1) >> 1) : (S2 ? 2 * (mb0 + m) + ky : mb0 + m + ky);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                a[m][t] = *reinterpret_cast<const sph8*>(aptr[kx] + abuf_off + t * G::A_PART + r * COLS * 16);
+        }
+    };
+    auto mfma_group = [&](const sph8 (&a)[GM][2], const sph8 (&b)[NB][3], int grp) {
+        const int mb0 = (grp % GPT) * GM;
+        constexpr int TA[3] = {0, 0, 1}, TBP[3] = {0, 1, 2};   // h1 w1, h1 w2, h2 (w1 2^-11)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int m = 0; m < GM; ++m)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    spf16& c = (APART && t > 0) ? lo[mb0 + m][nb] : acc[mb0 + m][nb];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][TA[t]], b[nb][TBP[t]], c, 0, 0, 0);
+                }
+    };
+
+    f32x4 bq0[NB][2], bq1[NB][2];   // fetched weights (w1, w2) of the current / next tap
+    sph8 a0[GM][2], a1[GM][2];
+    // one chunk: nine taps, weights of tap t+1 in flight under the MFMAs of tap t; the next chunk's inputs are fetched
+    // during taps 0-1 and written (split) into the other A buffer during taps 3-4; ONE barrier per chunk
+    auto chunk_body = [&](int c, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        constexpr int NA = MORE ? G::NLOADA : 0, NBL = 2 * NB;
+        const int abuf = (c & 1) * G::A_BYTES;
+        load_a(a0, abuf, 0);
+        sph8 bw[NB][3];
+#pragma unroll
+        for (int grp = 0; grp < NGROUP; ++grp) {
+            const int tap = grp / GPT, gi = grp % GPT;
+            f32x4 (&bc)[NB][2] = (tap & 1) ? bq1 : bq0;
+            f32x4 (&bn)[NB][2] = (tap & 1) ? bq0 : bq1;
+            sph8 (&ac)[GM][2] = (grp & 1) ? a1 : a0;
+            sph8 (&an)[GM][2] = (grp & 1) ? a0 : a1;
+            if (grp + 1 < NGROUP) load_a(an, abuf, grp + 1);
+            if (gi == 0) {
+                if (tap < 8) load_b(bn, c, tap + 1);
+                else if (MORE) load_b(bn, c + 1, 0);
+                if (tap == 0 && MORE) load_chunk(c + 1);
+                // outstanding, oldest first: [b(tap)] b(tap+1) [inputs, taps 0-1]; b(tap) is what the MFMAs below need
+                if (tap <= 1) sp_wait_b<NBL + NA>(bc);
+                else if (tap < 8 || MORE) sp_wait_b<NBL>(bc);
+                else sp_wait_b<0>(bc);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    bw[nb][0] = __builtin_bit_cast(sph8, bc[nb][0]);
+                    bw[nb][1] = __builtin_bit_cast(sph8, bc[nb][1]);
+                    bw[nb][2] = bw[nb][0] * (_Float16)0.00048828125f;   // w1 2^-11
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(ac, bw, grp);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE && tap >= 3) {   // the wait of tap 2 covered the input loads; one staging round per group
+                const int u = (tap - 3) * GPT + gi;
+                if (u < PR) store_round((c & 1) ^ 1, u);
+            }
+        }
+        if (MORE) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bq0[nb][t] = bq1[nb][t];   // tap 8 used bq0 and fetched the next chunk's tap 0 into bq1
+        }
+        __syncthreads();
+    };
+
+    load_chunk(0);
+    load_b(bq0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < PR; ++u) store_round(0, u);
+    __syncthreads();
+    for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
+    chunk_body(nchunks - 1, std::false_type{});
+
+    // ---- epilogue: acc[mb][nb][i]: pixel x = 8 (i / 4) + 4 g + (i % 4) of row 4 rg + mb, filter fg * 32 NB + nb * 32 + lm
+    const long long oplane = (long long)H * W;
+    float* outn = p.out + (long long)n * p.out_bstride;
+    const float slope = p.act ? p.slope : 1.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int oc = nt * NT + fg * 32 * NB + nb * 32 + lm;
+        const float inv = p.inv_scale[oc];                           // padded to whole n-tiles
+        if (oc >= p.OC) continue;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int Y = oy0 + MB * rg + mb;
+            if (Y >= H) continue;
+            float* o = outn + (long long)oc * oplane + (long long)Y * W + ox0 + 4 * g;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int X = ox0 + 8 * q4 + 4 * g;
+                if (X >= W) continue;                                   // W % 4 == 0: a quad is in or out as a whole
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = (APART ? acc[mb][nb][q4 * 4 + j] + lo[mb][nb][q4 * 4 + j] : acc[mb][nb][q4 * 4 + j]) * inv;
+                    v[j] = t > 0.f ? t : t * slope;
+                }
+                *reinterpret_cast<f32x4*>(o + 8 * q4) = v;
+            }
+        }
+    }
+}
+
+}  // namespace kbn
+
+extern "C" {
+
+static int split_nt(int mode) { return mode == 2 ? 128 : 64; }   // filters per workgroup (stride 2: two filter groups of waves)
+
+size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, int mode) {
+    using namespace kbn;
+    if (out_channels < 1 || in_channels < 1 || (in_channels % SP_CK) != 0 || mode < 0 || mode > 2) return 0;
+    const int nt = split_nt(mode), tiles = ceil_div(out_channels, nt);
+    return (size_t)tiles * nt * 4 + (size_t)tiles * (in_channels / SP_CK) * (9 * 2 * 2 * nt * 16);
+}
+
+int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int mode,
+                                  kbn_stream_t stream) {
+    using namespace kbn;
+    const size_t bytes = kbn_conv3x3_split_packed_weight_bytes(out_channels, in_channels, mode);
+    if (!weight || !packed || bytes == 0) return KBN_ERR_INVALID_ARGUMENT;
+    const int nt = split_nt(mode), ocpad = ceil_div(out_channels, nt) * nt;
+    float* inv = static_cast<float*>(packed);
+    _Float16* wp = reinterpret_cast<_Float16*>(inv + ocpad);
+    const long long total = (long long)((bytes - (size_t)ocpad * 4) / 2);
+    hipLaunchKernelGGL(split_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels * 9);
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       inv, wp, out_channels, in_channels, in_channels / SP_CK, nt, total);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
+                              long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
+                              int apply_activation, float negative_slope, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || !out || n < 1 || out_channels < 1 || height < 1 || width < 1)
+        return KBN_ERR_INVALID_ARGUMENT;
+    if (mode < 0 || mode > 2) return KBN_ERR_INVALID_ARGUMENT;
+    if (knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
+    if ((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3)) return KBN_ERR_UNSUPPORTED;
+    if (mode == 1 && (n_src != 1 || (height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
+    SplitConvParams p{};
+    int cin = 0;
+    for (int s = 0; s < n_src; ++s) {
+        const kbn_conv_src& a = srcs[s];
+        if (a.kind != KBN_SRC_TENSOR || !a.data || a.channels < 1 || (a.channels % SP_CK) != 0) return KBN_ERR_UNSUPPORTED;
+        if (s == 0) { p.sH = a.src_height; p.sW = a.src_width; }
+        if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
+        p.src[s] = a.data; p.src_bstride[s] = a.batch_stride; p.srcC[s] = a.channels;
+        cin += a.channels;
+    }
+    const bool dims_ok = mode == 0 ? (p.sH == height && p.sW == width)
+                       : mode == 1 ? (2 * p.sH == height && 2 * p.sW == width)
+                                   : (ceil_div(p.sH, 2) == height && ceil_div(p.sW, 2) == width);
+    if (!dims_ok) return KBN_ERR_INVALID_ARGUMENT;
+    if ((long long)p.sH * p.sW > 0x1fffffffLL || (long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
+    if (n_src == 1) { p.src[1] = p.src[0]; p.src_bstride[1] = p.src_bstride[0]; p.srcC[1] = 0; }
+    p.nsrc = n_src;
+    const int ntf = split_nt(mode);
+    p.nTilesN = ceil_div(out_channels, ntf);
+    p.inv_scale = static_cast<const float*>(packed_weight);
+    p.wp = reinterpret_cast<const _Float16*>(p.inv_scale + p.nTilesN * ntf);
+    p.out = out; p.out_bstride = out_batch_stride;
+    p.N = n; p.OC = out_channels; p.Cin = cin; p.H = height; p.W = width;
+    p.tilesX = ceil_div(width, SP_TW); p.tilesY = ceil_div(height, mode == 2 ? SpGeom<2>::TH : SpGeom<0>::TH);
+    const long long blocks = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
+    if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.nblocks = (int)blocks;
+    p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
+    auto launch = [&](auto kern, size_t lds, DeviceOnce& once) -> int {
+        if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+        hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(SP_THREADS), lds, (hipStream_t)stream, p);
+        return KBN_OK;
+    };
+    static DeviceOnce o[3];
+    int rc;
+    switch (mode) {
+        case 0: rc = launch(conv3x3_split_kernel<0, 8, true>, SpGeom<0>::LDS, o[0]); break;
+        case 1: rc = launch(conv3x3_split_kernel<1, 8, true>, SpGeom<1>::LDS, o[1]); break;
+        default: rc = launch(conv3x3_split_kernel<2, 4, true>, SpGeom<2>::LDS, o[2]); break;
+    }
+    if (rc != KBN_OK) return rc;
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+}  // extern "C"

@@ -23,7 +23,7 @@ from typing import List, Optional
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import KbnError
 from .config import KBNetConfig
 
@@ -82,6 +82,8 @@ class _PackedWeight:
         if key != self._key:
             if up2x == "bf16":      # throughput-only bf16 leg (ops.conv3x3_bf16)
                 self._packed = ops.pack_conv3x3_bf16_weight(weight, out=self._packed)
+            elif up2x == "split":   # fp32 products on the bf16 matrix core (ops.conv3x3_split)
+                self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, stride=stride)
             else:
                 self._packed = (ops.pack_upconv2x_weight(weight, out=self._packed) if up2x
                                 else ops.pack_conv_weight(weight, stride, out=self._packed))
@@ -117,7 +119,20 @@ class Conv2d(torch.nn.Module):
         self._slope = _slope(activation_func)
         self._packed = _PackedWeight()
         self._packed_bf16 = _PackedWeight()
+        self._packed_split = _PackedWeight()
         self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
+        self.split = True   # fp32-grade 3x3 stride-1 convs on the bf16 matrix core where the shape qualifies
+
+    def run_split(self, srcs, n, h, w, out=None, up2x=False):
+        """3x3 stride-1 conv with two-term fp16 splits of both operands (ops.conv3x3_split, fp32-grade results); `h` x `w`
+        is the OUTPUT size.  None when the layer or the shape does not qualify."""
+        if (not self.split or self.kernel_size != 3 or w % 4 or len(srcs) > 2 or self.out_channels < 48
+                or (up2x and self.stride != 1) or any(s.kind != _lib.KBN_SRC_TENSOR or s.channels % 16 for s in srcs)):
+            return None
+        if out is None:
+            out = torch.empty((n, self.out_channels, h, w), device=self.conv.weight.device, dtype=torch.float32)
+        return ops.conv3x3_split(srcs, self._packed_split.get(self.conv.weight, self.stride, up2x="split"), n, self.out_channels, h, w,
+                                 out, up2x=up2x, negative_slope=self._slope, stride=self.stride)
 
     def packed(self):
         return self._packed.get(self.conv.weight, self.stride)
@@ -140,6 +155,10 @@ class Conv2d(torch.nn.Module):
         oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)
         if self.bf16 and not resize:
             res = self.run_bf16(srcs, n, oh, ow, out=out)
+            if res is not None:
+                return res
+        if not resize:
+            res = self.run_split(srcs, n, oh, ow, out=out)
             if res is not None:
                 return res
         if out is None:
@@ -171,6 +190,7 @@ class UpConv2d(torch.nn.Module):
                            weight_initializer=weight_initializer, activation_func=activation_func,
                            use_batch_norm=use_batch_norm, use_instance_norm=use_instance_norm)
         self._packed_up2x = _PackedWeight()
+        self.split_up = False   # the 9-product fp32 form is as fast as the split kernel's nine taps on most levels
 
     def forward(self, x, shape):
         if x.shape[1] != self.conv.in_channels:
@@ -181,6 +201,10 @@ class UpConv2d(torch.nn.Module):
         if (oh, ow) == (2 * h, 2 * w) and self.conv.kernel_size == 3:
             if self.conv.bf16:
                 res = self.conv.run_bf16([ops.tensor_src(x, "x")], n, oh, ow, up2x=True)
+                if res is not None:
+                    return res
+            if self.split_up:
+                res = self.conv.run_split([ops.tensor_src(x, "x")], n, oh, ow, up2x=True)
                 if res is not None:
                     return res
             # exact 2x: four 2x2 phase convs on the low-res input (4/9 of the MACs)
@@ -232,6 +256,7 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         self.conv_fused = Conv2d(in_channels_fused + 3, n_filter_fused, kernel_size=1, stride=2,
                                  weight_initializer=weight_initializer, activation_func=activation_func)
         self.n_filter_image, self.n_filter_depth, self.n_filter_fused = n_filter_image, n_filter_depth, n_filter_fused
+        self.split_image = n_filter_image >= 96   # conv_image on the split-operand kernel (KB1's 48 filters: the fused kernel wins)
         self._slope = _slope(activation_func)
         if self._slope is None:
             raise ValueError("the fused KB block needs a (leaky) ReLU activation")
@@ -259,6 +284,17 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             # THROUGHPUT-ONLY bf16 leg: conv_image (most of the block's FLOPs) on bf16 MFMAs; conv_depth and conv_fused --
             # their inputs are synthesized in-kernel (K^-1 [x y 1]^T, backprojection) -- stay on the fp32 conv kernels.
             res = ci_conv.run_bf16([ops.tensor_src(image, "image")], n, oh, ow, out=out_image)
+            if res is not None:
+                self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth)
+                srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
+                if fused is not None:
+                    srcs.append(ops.tensor_src(fused, "fused"))
+                self.conv_fused.run(srcs, n, h, w, out=out_fused)
+                return out_image, out_depth, out_fused
+        if ci_conv.split and self.split_image and kinv is not None:
+            # conv_image (most of the block's FLOPs) on the 16-bit matrix core (fp32-grade split operands); conv_depth and
+            # conv_fused -- their inputs are synthesized in-kernel (K^-1 [x y 1]^T, backprojection) -- on the fp32 kernels
+            res = ci_conv.run_split([ops.tensor_src(image, "image")], n, oh, ow, out=out_image)
             if res is not None:
                 self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth)
                 srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
@@ -665,6 +701,7 @@ class KBNetModel(object):
                 if isinstance(sub, Conv2d):
                     sub._packed.refresh(sub.conv.weight)
                     sub._packed_bf16.refresh(sub.conv.weight)
+                    sub._packed_split.refresh(sub.conv.weight)
                 elif isinstance(sub, UpConv2d):
                     sub._packed_up2x.refresh(sub.conv.conv.weight)
 

@@ -455,6 +455,64 @@ def conv_head(x, w_conv, w_out, min_predict_depth: float, max_predict_depth: flo
     return (depth, logits) if return_logits else depth
 
 
+# ----------------------------------------------------- fp32-grade convs on the 16-bit matrix core (split operands)
+@_on_tensor_device
+def pack_conv3x3_split_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None, stride: int = 1) -> torch.Tensor:
+    """OIHW fp32 3x3 weight -> per-filter scaled two-term fp16 split in MFMA order for `conv3x3_split` with the same
+    `stride` (in_channels % 16 == 0)."""
+    mode = 2 if stride == 2 else 0
+    lib = _lib.load()
+    w = weight.detach().contiguous()
+    _require(w, "weight", 4)
+    oc, cin, kh, kw = w.shape
+    nbytes = lib.kbn_conv3x3_split_packed_weight_bytes(oc, cin, mode) if (kh, kw) == (3, 3) else 0
+    if nbytes == 0:
+        raise KbnError(f"conv3x3_split needs a 3x3 weight with in_channels % 16 == 0, got {tuple(w.shape)}")
+    packed = out if _reusable(out, nbytes // 4, w) else torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    check(lib.kbn_conv3x3_split_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, mode, _stream()), "kbn_conv3x3_split_pack_weight")
+    return packed
+
+
+def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1):
+    """fp16 MFMA FLOPs the split kernel executes: three products per fp32 product, whole (16 | 8) x 32 x (64 | 128) tiles."""
+    nt = 128 if stride == 2 else 64
+    th = 8 if stride == 2 else 16
+    return 3 * 2.0 * n * (-(-height // th) * th) * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // nt) * nt)
+
+
+@_on_tensor_device
+def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
+                  out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1):
+    """3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
+    `stride` 2: sources are the 2x larger input planes), fp32 in / fp32 out, every product taken as three fp16 MFMAs
+    over two-term splits of both operands (kbn_conv3x3_split_forward): fp32-grade accuracy at 3/16 of the fp32 MFMA's
+    time.  `height` x `width` is the OUTPUT size.  Returns None when the shape does not qualify (the caller stays on the
+    fp32-MFMA kernels)."""
+    if up2x and stride != 1:
+        raise KbnError("conv3x3_split: up2x and stride 2 are mutually exclusive")
+    lib = _lib.load()
+    arr = (ConvSrc * len(srcs))(*srcs)
+    optr, obs = _planes(out, "out")
+    if tuple(out.shape) != (n, out_channels, height, width):
+        raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, height, width)}")
+    cin = sum(s.channels for s in srcs)
+    flops = 2.0 * n * height * width * cin * 9 * out_channels
+    status = _launch("conv_split", flops,
+                     lambda: lib.kbn_conv3x3_split_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
+                                                           out_channels, height, width,
+                                                           1 if up2x else (2 if stride == 2 else 0),
+                                                           0 if negative_slope is None else 1,
+                                                           0.0 if negative_slope is None else float(negative_slope),
+                                                           _stream()),
+                     executed=conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride))
+    if status == _lib.KBN_ERR_UNSUPPORTED:
+        if PROFILE is not None:
+            PROFILE.pop()
+        return None
+    check(status, "kbn_conv3x3_split_forward")
+    return out
+
+
 # ----------------------------------------------------- bf16 leg (throughput-only)
 @_on_tensor_device
 def pack_conv3x3_bf16_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

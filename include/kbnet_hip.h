@@ -182,6 +182,33 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
  * executes 2 * n * src_height * src_width * info[0] * info[1] * info[2] FLOP on the matrix cores. */
 int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height, int src_width, int* info);
 
+/* ------------------------------- fp32-grade 3x3 convs on the 16-bit matrix core --
+ * gfx950 executes fp32 MFMAs on the fp32 vector datapath (157 TFLOP/s); the matrix core proper takes
+ * 16-bit operands (2.5 PFLOP/s dense).  These entry points feed it fp32 operands as pairs of fp16 values:
+ * a 2^-6 = h1 + 2^-11 h2 (activations, split in the kernel), w 2^e = w1 + w2 (weights, split at pack time,
+ * e per filter), a w = 2^(6-e) (h1 w1 + h1 w2 + h2 (w1 2^-11)) up to 2^-22 |a w|: three fp16 MFMAs with fp32
+ * accumulation per product, 3/16 of the fp32 MFMA's time, errors measured against fp64 no larger than the
+ * fp32 MFMA chain's (profiles/r02/bf16x_probe.txt).  They ARE on the parity-gated path: the stride-1 3x3
+ * convs of the decoder (reference src/net_utils.py:484-499 nearest-2x + conv, :1483-1487 conv over
+ * cat[deconv, skip]) run through them when the shape qualifies.  Limits of the fp16 window: activations
+ * above 4.2e6 in magnitude overflow; activations below 0.0039 keep 11 bits.
+ *   mode      0: 3x3 stride 1 over height x width sources; 1: nearest-2x up-conv (ONE source with
+ *             (height/2) x (width/2) planes); 2: 3x3 stride 2 (source planes h x w with ceil(h/2) = height,
+ *             ceil(w/2) = width: the image convs of the KB blocks, reference src/net_utils.py:1348)
+ *   srcs      1 or 2 KBN_SRC_TENSOR sources, each a multiple of 16 channels
+ *   packed    from kbn_conv3x3_split_pack_weight (OIHW fp32 3x3 weight in) for the SAME mode (the
+ *             filter tiling of the blob depends on it)
+ *   out       N x out_channels x height x width fp32, frames out_batch_stride elements apart
+ * KBN_ERR_UNSUPPORTED unless width % 4 == 0 and `out` is 16-byte aligned (callers fall back to
+ * kbn_conv2d_forward / kbn_upconv2x_forward), or when KBN_NO_SPLIT is set. */
+size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, int mode);
+int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int mode,
+                                  kbn_stream_t stream);
+int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
+                              long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
+                              int apply_activation, float negative_slope, kbn_stream_t stream);
+
+
 /* ---------------------------------------------------- bf16 leg (THROUGHPUT-ONLY) ------
  * BASELINE.json configs[2] asks for a bf16 figure next to the fp32 one.  bf16 convolutions miss the
  * 1e-4 parity bar by two orders of magnitude, so nothing on the parity-gated path uses

@@ -479,6 +479,47 @@ def test_conv_head_fused_vs_oracle(dev, kenv, c, shape):
 
 
 # ------------------------------------------------- bf16 leg (throughput-only, never parity-gated)
+@pytest.mark.parametrize("cins,cout,hw,kind", [((32,), 48, (16, 64), "plain"), ((64, 64), 64, (22, 76), "plain"),
+                                               ((128,), 64, (20, 36), "up2x"), ((16, 32), 130, (9, 40), "plain"),
+                                               ((256, 512), 256, (22, 76), "plain"), ((64,), 96, (36, 72), "up2x"),
+                                               ((48,), 96, (23, 44), "s2"), ((192,), 384, (22, 76), "s2"), ((16,), 64, (5, 8), "s2")])
+@pytest.mark.parametrize("amag", [1.0, 300.0])
+def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
+    """kbn_conv3x3_split_forward: fp32 products as three fp16 MFMAs over two-term splits (csrc/conv_split.hip).  Held to
+    the accuracy class of the fp32 kernels: against an fp64 evaluation its error may not exceed 3.5x the error of the
+    oracle's own fp32 conv (a blocked CPU summation, itself 3-6x more accurate than an fp32 MFMA / fmaf chain of the same
+    length; both in units of the output's rms), and it stays below 1.5e-6 rms / 2e-5 max."""
+    h, w = hw                                   # output size
+    g = torch.Generator().manual_seed(sum(cins) + cout + h)
+    n = 2
+    stride = 2 if kind == "s2" else 1
+    up2x = kind == "up2x"
+    sh, sw = (h // 2, w // 2) if up2x else ((2 * h - 1, 2 * w) if stride == 2 else (h, w))
+    xs = [amag * torch.nn.functional.leaky_relu(torch.randn(n, c, sh, sw, generator=g), 0.2) for c in cins]
+    cin = sum(cins)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    wt[1] *= 1e-3                                # filters of very different magnitude: the per-filter exponent
+    wt[2] *= 50.0
+    xcat = torch.cat(xs, 1)
+    if up2x:
+        xcat = torch.nn.functional.interpolate(xcat, size=(h, w), mode="nearest")
+    ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xcat.double(), wt.double(), stride=stride, padding=1), 0.2)
+    ref32 = orc.conv2d(xcat, wt, stride, 0.2)
+    assert tuple(ref32.shape[-2:]) == (h, w)
+    xd = [x.to(dev) for x in xs]
+    out = torch.empty(n, cout, h, w, device=dev)
+    res = kb.ops.conv3x3_split([kb.ops.tensor_src(x) for x in xd], kb.ops.pack_conv3x3_split_weight(wt.to(dev), stride=stride), n, cout, h, w,
+                               out, up2x=up2x, negative_slope=0.2, stride=stride)
+    assert res is not None
+    rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()       # per filter: the filters differ by 5e4 in scale
+    e_hip = ((out.cpu().double() - ref64) / rms).abs()
+    e_orc = ((ref32.double() - ref64) / rms).abs()
+    print(f"split conv vs fp64: max {float(e_hip.max()):.2e} rms {float(e_hip.pow(2).mean().sqrt()):.2e}; "
+          f"oracle fp32 conv vs fp64: max {float(e_orc.max()):.2e} rms {float(e_orc.pow(2).mean().sqrt()):.2e}")
+    assert float(e_hip.pow(2).mean().sqrt()) < max(3.5 * float(e_orc.pow(2).mean().sqrt()), 6e-7)
+    assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5
+
+
 @pytest.mark.parametrize("cins,cout,hw,up2x", [((32,), 48, (16, 64), False), ((64, 64), 64, (22, 76), False),
                                                ((128,), 64, (20, 36), True), ((16, 32), 12, (9, 40), False),
                                                ((256, 512), 256, (22, 76), False), ((64,), 12, (36, 72), True),

@@ -1,150 +1,66 @@
 #!/usr/bin/env python3
-"""Experiment: does running the two halves of a batch as two concurrent branches (two streams, one captured
-graph) beat one batch-8 forward?  Kernel tails of one half could overlap the other half's kernels."""
-import os, sys, time
+"""Per-layer timing and fp64-referenced error of the split-operand convs (kbn_conv3x3_split_forward: fp32 products as three
+fp16 MFMAs) next to the fp32-MFMA kernels the same layers run otherwise (Winograd / 9-product up-conv), KITTI shapes (GPU box).
+usage: split_bench.py [batch]      SPLIT_ZERO=1: zero operands (DVFS check)   SPLIT_AMAG=x: activation magnitude"""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, kbnet_amd as kb
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device("cuda:0")
-cfg = kb.kitti_config()
-m = kb.modules.KBNetModel.from_config(cfg, dev)
-m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
-fr = [f.to(dev) for f in kb.synthetic.make_frames(8, 352, 1216, "kitti", seed=1)]
-def branches(sizes):
-    nb = len(sizes)
-    offs = [sum(sizes[:i]) for i in range(nb + 1)]
-    parts = [[f[offs[i]:offs[i + 1]].contiguous() for f in fr] for i in range(nb)]
-    for h in parts:           # tune the smaller batch shapes outside any capture
-        for _ in range(2):
-            m.forward(*h)
+AMAG = float(os.environ.get("SPLIT_AMAG", "1"))
+# name: (source channels, cout, H, W (output), up2x)
+LAYERS = [("deconv4_up", (512,), 256, 22, 76, True), ("deconv4_conv", (256, 512), 256, 22, 76, False),
+          ("deconv3_up", (256,), 128, 44, 152, True), ("deconv3_conv", (128, 256), 128, 44, 152, False),
+          ("deconv2_up", (128,), 128, 88, 304, True), ("deconv2_conv", (128, 128), 128, 88, 304, False),
+          ("deconv1_up", (128,), 64, 176, 608, True), ("deconv1_conv", (64, 64), 64, 176, 608, False),
+          ("kb2_image", (48,), 96, 88, 304, "s2"), ("kb3_image", (96,), 192, 44, 152, "s2"), ("kb4_image", (192,), 384, 22, 76, "s2")]
+g = torch.Generator().manual_seed(0)
+
+
+def timed(f):
+    for _ in range(3): f()
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream() for _ in range(nb)]
-    g = torch.cuda.CUDAGraph()
-    outs = [None] * nb
-    with torch.cuda.graph(g):
-        cur = torch.cuda.current_stream()
-        for s in streams:
-            s.wait_stream(cur)
-        for i, s in enumerate(streams):
-            with torch.cuda.stream(s):
-                outs[i] = m.forward(*parts[i])
-        for s in streams:
-            cur.wait_stream(s)
-    return g, outs
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10): f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) * 100
 
-def timeit(fn, reps=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(reps): fn()
-    torch.cuda.synchronize()
-    return 8 * reps / (time.perf_counter() - t)
 
-for _ in range(2):
-    m.forward(*fr)
-torch.cuda.synchronize()
-full = m.capture(*fr, branches=1)
-print("one batch-8 graph        : %.1f frames/s" % timeit(lambda: full(*fr)))
-a = full(*fr).clone()
-for sizes in ([4, 4], [5, 3], [6, 2], [3, 3, 2], [4, 2, 2], [4, 4]):
-    g, outs = branches(sizes)
-    fps = timeit(g.replay)
-    g.replay(); torch.cuda.synchronize()
-    same = torch.equal(a, torch.cat(outs, 0))
-    print("concurrent branches %-10s: %.1f frames/s  same bits: %s" % (sizes, fps, same))
-
-# ---- skewed branches: branch B starts when branch A's encoder is done (A decoder || B encoder) ----
-def enc(model, image, sparse, valid, k):
-    x = torch.cat([sparse, valid], dim=1)
-    d = model.sparse_to_dense_pool(x)
-    latent, skips = model.encoder(image, d, k)
-    return latent, skips, d.shape[-2:]
-
-def dec(model, latent, skips, shape):
-    feats = model.decoder.features(latent, skips, shape)
-    return kb.ops.depth_head(feats, model.decoder.output0.conv.weight, model.min_predict_depth, model.max_predict_depth)
-
-parts = [[f[i * 4:(i + 1) * 4].contiguous() for f in fr] for i in range(2)]
-sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    cur = torch.cuda.current_stream()
-    sA.wait_stream(cur)
-    with torch.cuda.stream(sA):
-        eA = enc(m, *parts[0])
-        mid = sA.record_event()
-        oA = dec(m, *eA)
-    sB.wait_event(mid)
-    with torch.cuda.stream(sB):
-        oB = dec(m, *enc(m, *parts[1]))
-    cur.wait_stream(sA); cur.wait_stream(sB)
-print("skewed 2 x 4 (B starts after A's encoder): %.1f frames/s  same bits: %s" % (timeit(g.replay), torch.equal(a, torch.cat([oA, oB], 0))))
-
-# ---- small skews: branch B starts after branch A's S2D / after A's whole encoder level 0 ----
-def staged(model, image, sparse, valid, k, mark=None, stream=None):
-    x = torch.cat([sparse, valid], dim=1)
-    d = model.sparse_to_dense_pool(x)
-    ev = stream.record_event() if (mark == "s2d" and stream is not None) else None
-    latent, skips = model.encoder(image, d, k)
-    feats = model.decoder.features(latent, skips, d.shape[-2:])
-    out = kb.ops.depth_head(feats, model.decoder.output0.conv.weight, model.min_predict_depth, model.max_predict_depth)
-    return out, ev
-
-sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    cur = torch.cuda.current_stream()
-    sA.wait_stream(cur)
-    with torch.cuda.stream(sA):
-        oA, ev = staged(m, *parts[0], mark="s2d", stream=sA)
-    sB.wait_stream(cur)
-    sB.wait_event(ev)
-    with torch.cuda.stream(sB):
-        oB, _ = staged(m, *parts[1])
-    cur.wait_stream(sA); cur.wait_stream(sB)
-print("2 x 4, B starts after A's S2D            : %.1f frames/s  same bits: %s" % (timeit(g.replay), torch.equal(a, torch.cat([oA, oB], 0))))
-
-# ---- free-running half-batch streams: no join per step, optional half-period phase offset --------------
-# Each half batch has its own encoder graph and decoder graph; stream A and stream B replay theirs back to back.
-# With `offset`, B starts when A's first encoder is done, so that A's decoder (MFMA-bound) overlaps B's encoder
-# (HBM-heavy) from then on -- unlike the in-graph skew above there is no tail per step, only one at the very end.
-def capture_pair(part, stream):
-    for _ in range(2):
-        dec(m, *enc(m, *part))
-    torch.cuda.synchronize()
-    ge, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(ge, stream=stream):
-        e = enc(m, *part)
-    with torch.cuda.graph(gd, stream=stream):
-        o = dec(m, *e)
-    return ge, gd, o
-
-sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
-geA, gdA, oA = capture_pair(parts[0], sA)
-geB, gdB, oB = capture_pair(parts[1], sB)
-torch.cuda.synchronize()
-
-def free_run(reps, offset):
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    ev = None
-    with torch.cuda.stream(sA):
-        geA.replay()
-        ev = sA.record_event()
-        gdA.replay()
-    if offset:
-        sB.wait_event(ev)
-    with torch.cuda.stream(sB):
-        geB.replay(); gdB.replay()
-    for _ in range(reps - 1):
-        with torch.cuda.stream(sA):
-            geA.replay(); gdA.replay()
-        with torch.cuda.stream(sB):
-            geB.replay(); gdB.replay()
-    torch.cuda.synchronize()
-    return 8 * reps / (time.perf_counter() - t)
-
-for offset in (False, True):
-    free_run(3, offset)
-    for reps in (20, 60):
-        print("free-running 2 x 4 streams, offset=%s, %d steps: %.1f frames/s  same bits: %s" %
-              (offset, reps, free_run(reps, offset), torch.equal(a, torch.cat([oA, oB], 0))))
+tot = [0.0, 0.0]
+for name, cins, cout, h, w, up in LAYERS:
+    stride = 2 if up == "s2" else 1
+    up = up is True
+    sh, sw = (h // 2, w // 2) if up else ((2 * h, 2 * w) if stride == 2 else (h, w))
+    xs = [(AMAG * torch.nn.functional.leaky_relu(torch.randn(B, c, sh, sw, generator=g), 0.2)).to(dev) for c in cins]
+    cin = sum(cins)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dev)
+    if os.environ.get("SPLIT_ZERO"):      # DVFS check: zero operands draw less power (same instruction stream)
+        xs = [torch.zeros_like(x) for x in xs]; wt = torch.zeros_like(wt)
+    srcs = [kb.ops.tensor_src(x) for x in xs]
+    out_s = torch.empty(B, cout, h, w, device=dev)
+    out_f = torch.empty(B, cout, h, w, device=dev)
+    ps = kb.ops.pack_conv3x3_split_weight(wt, stride=stride)
+    fs = lambda: kb.ops.conv3x3_split(srcs, ps, B, cout, h, w, out_s, up2x=up, negative_slope=0.2, stride=stride)
+    if up:
+        pf = kb.ops.pack_upconv2x_weight(wt)
+        ff = lambda: kb.ops.upconv2x(xs[0], pf, cout, out_f, 0.2)
+    else:
+        pf = kb.ops.pack_conv_weight(wt, stride)
+        ff = lambda: kb.ops.conv2d(srcs, pf, B, cout, 3, stride, sh, sw, out_f, negative_slope=0.2)
+    with kb.ops.autotune():
+        ff()
+    assert fs() is not None
+    us_s, us_f = timed(fs), timed(ff)
+    xin = torch.cat([x[:1] for x in xs], 1).double().cpu()
+    if up:
+        xin = torch.nn.functional.interpolate(xin, size=(h, w), mode="nearest")
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xin, wt.double().cpu(), stride=stride, padding=1), 0.2)
+    rms = float(ref.pow(2).mean().sqrt()) or 1.0
+    es, ef = (out_s[:1].cpu().double() - ref).abs(), (out_f[:1].cpu().double() - ref).abs()
+    flops = 2.0 * B * h * w * cin * 9 * cout
+    tot[0] += us_s; tot[1] += us_f
+    print(f"{name:13s} split {us_s:7.1f} us {flops / us_s / 1e6:6.1f} TFLOP/s (err vs fp64: max {float(es.max()) / rms:.2e} rms {float(es.pow(2).mean().sqrt()) / rms:.2e})"
+          f" | fp32 MFMA {us_f:7.1f} us {flops / us_f / 1e6:6.1f} TFLOP/s (max {float(ef.max()) / rms:.2e} rms {float(ef.pow(2).mean().sqrt()) / rms:.2e})", flush=True)
+print(f"sum: split {tot[0]:.1f} us, fp32 MFMA kernels {tot[1]:.1f} us per {B} frames")
