@@ -121,7 +121,8 @@ class Conv2d(torch.nn.Module):
         self._packed_bf16 = _PackedWeight()
         self._packed_split = _PackedWeight()
         self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
-        self.split = True   # fp32-grade 3x3 stride-1 convs on the bf16 matrix core where the shape qualifies
+        self.split = True   # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies
+        self._act_exp = None   # activation exponent of the split kernel's fp16 window, measured on the first call
 
     def run_split(self, srcs, n, h, w, out=None, up2x=False):
         """3x3 stride-1 conv with two-term fp16 splits of both operands (ops.conv3x3_split, fp32-grade results); `h` x `w`
@@ -129,10 +130,19 @@ class Conv2d(torch.nn.Module):
         if (not self.split or self.kernel_size != 3 or w % 4 or len(srcs) > 2 or self.out_channels < 48
                 or (up2x and self.stride != 1) or any(s.kind != _lib.KBN_SRC_TENSOR or s.channels % 16 for s in srcs)):
             return None
+        dev = self.conv.weight.device
         if out is None:
-            out = torch.empty((n, self.out_channels, h, w), device=self.conv.weight.device, dtype=torch.float32)
+            out = torch.empty((n, self.out_channels, h, w), device=dev, dtype=torch.float32)
+        k = self._act_exp
+        if k is None:
+            # first call of this layer: measure max |a| of its input and place the fp16 window on it (a host sync, once);
+            # while a graph is being captured the ABI default serves (GraphedForward warms up before it captures)
+            if torch.cuda.is_current_stream_capturing():
+                k = -6
+            else:
+                k = self._act_exp = ops.act_exponent_for(ops.absmax_srcs(srcs, n, dev))
         return ops.conv3x3_split(srcs, self._packed_split.get(self.conv.weight, self.stride, up2x="split"), n, self.out_channels, h, w,
-                                 out, up2x=up2x, negative_slope=self._slope, stride=self.stride)
+                                 out, up2x=up2x, negative_slope=self._slope, stride=self.stride, act_exponent=k)
 
     def packed(self):
         return self._packed.get(self.conv.weight, self.stride)
@@ -693,6 +703,14 @@ class KBNetModel(object):
     def weight_state(self):
         """(storage pointer, version) of every parameter: what a captured graph depends on."""
         return [(p.data_ptr(), p._version) for p in self.parameters()]
+
+    def recalibrate(self):
+        """Forgets the activation exponents of the split-operand convs: the next forward measures max |a| of every such
+        layer's input again (inputs whose activations left the 128x headroom of the previous calibration)."""
+        for m in self.modules():
+            for sub in m.modules():
+                if isinstance(sub, Conv2d):
+                    sub._act_exp = None
 
     def refresh_packed(self):
         """Re-packs (in place) the MFMA-ordered blobs of weights that changed since they were packed."""

@@ -473,6 +473,26 @@ def pack_conv3x3_split_weight(weight: torch.Tensor, out: Optional[torch.Tensor] 
     return packed
 
 
+def absmax_srcs(srcs: List[ConvSrc], n: int, device) -> float:
+    """max |x| over the tensor sources of a conv (kbn_absmax); synchronizes -- calibration only, never while capturing."""
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        amax = torch.zeros(1, device=device, dtype=torch.float32)
+        for s in srcs:
+            check(lib.kbn_absmax(s.data, s.batch_stride, n, s.channels * s.src_height * s.src_width, amax.data_ptr(), _stream()),
+                  "kbn_absmax")
+        return float(amax.item())
+
+
+def act_exponent_for(amax: float) -> int:
+    """Exponent k that puts max |a| of a layer input in (2^8, 2^9] of the split kernel's fp16 window: 128x of headroom
+    below fp16's 65504, full 22-bit precision down to 2^-23 of the maximum.  Degenerate maxima take the ABI default."""
+    import math
+    if not (amax > 0.0) or math.isinf(amax) or math.isnan(amax):
+        return -6
+    return max(-60, min(60, 9 - math.ceil(math.log2(amax))))
+
+
 def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1):
     """fp16 MFMA FLOPs the split kernel executes: three products per fp32 product, whole (16 | 8) x 32 x (64 | 128) tiles."""
     nt = 128 if stride == 2 else 64
@@ -482,12 +502,13 @@ def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1):
 
 @_on_tensor_device
 def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
-                  out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1):
+                  out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1,
+                  act_exponent: int = -6):
     """3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
     `stride` 2: sources are the 2x larger input planes), fp32 in / fp32 out, every product taken as three fp16 MFMAs
     over two-term splits of both operands (kbn_conv3x3_split_forward): fp32-grade accuracy at 3/16 of the fp32 MFMA's
-    time.  `height` x `width` is the OUTPUT size.  Returns None when the shape does not qualify (the caller stays on the
-    fp32-MFMA kernels)."""
+    time.  `height` x `width` is the OUTPUT size; `act_exponent` k places the fp16 window (|a| 2^k < 65504; full precision
+    for |a| 2^k >= 2^-14).  Returns None when the shape does not qualify (the caller stays on the fp32-MFMA kernels)."""
     if up2x and stride != 1:
         raise KbnError("conv3x3_split: up2x and stride 2 are mutually exclusive")
     lib = _lib.load()
@@ -500,7 +521,7 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     status = _launch("conv_split", flops,
                      lambda: lib.kbn_conv3x3_split_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
                                                            out_channels, height, width,
-                                                           1 if up2x else (2 if stride == 2 else 0),
+                                                           1 if up2x else (2 if stride == 2 else 0), int(act_exponent),
                                                            0 if negative_slope is None else 1,
                                                            0.0 if negative_slope is None else float(negative_slope),
                                                            _stream()),

@@ -185,13 +185,17 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
 /* ------------------------------- fp32-grade 3x3 convs on the 16-bit matrix core --
  * gfx950 executes fp32 MFMAs on the fp32 vector datapath (157 TFLOP/s); the matrix core proper takes
  * 16-bit operands (2.5 PFLOP/s dense).  These entry points feed it fp32 operands as pairs of fp16 values:
- * a 2^-6 = h1 + 2^-11 h2 (activations, split in the kernel), w 2^e = w1 + w2 (weights, split at pack time,
- * e per filter), a w = 2^(6-e) (h1 w1 + h1 w2 + h2 (w1 2^-11)) up to 2^-22 |a w|: three fp16 MFMAs with fp32
+ * a 2^k = h1 + 2^-11 h2 (activations, split in the kernel), w 2^e = w1 + w2 (weights, split at pack time,
+ * e per filter), a w = 2^-(e+k) (h1 w1 + h1 w2 + h2 (w1 2^-11)) up to 2^-22 |a w|: three fp16 MFMAs with fp32
  * accumulation per product, 3/16 of the fp32 MFMA's time, errors measured against fp64 no larger than the
  * fp32 MFMA chain's (profiles/r02/bf16x_probe.txt).  They ARE on the parity-gated path: the stride-1 3x3
  * convs of the decoder (reference src/net_utils.py:484-499 nearest-2x + conv, :1483-1487 conv over
- * cat[deconv, skip]) run through them when the shape qualifies.  Limits of the fp16 window: activations
- * above 4.2e6 in magnitude overflow; activations below 0.0039 keep 11 bits.
+ * cat[deconv, skip]) and the stride-2 image convs of the KB blocks run through them when the shape
+ * qualifies.
+ *   act_exponent  k: places the fp16 window on the activations: |a| 2^k must stay below 65504 (beyond: inf),
+ *             |a| 2^k >= 2^-14 keeps the full 22 bits, smaller activations keep 11.  -6 covers 0.0039 .. 4.2e6;
+ *             a caller that knows max |a| of the layer input puts it near 2^9 (the Python mirror measures it
+ *             once per layer, modules.Conv2d.run_split).  Range -60 .. 60.
  *   mode      0: 3x3 stride 1 over height x width sources; 1: nearest-2x up-conv (ONE source with
  *             (height/2) x (width/2) planes); 2: 3x3 stride 2 (source planes h x w with ceil(h/2) = height,
  *             ceil(w/2) = width: the image convs of the KB blocks, reference src/net_utils.py:1348)
@@ -201,12 +205,15 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
  *   out       N x out_channels x height x width fp32, frames out_batch_stride elements apart
  * KBN_ERR_UNSUPPORTED unless width % 4 == 0 and `out` is 16-byte aligned (callers fall back to
  * kbn_conv2d_forward / kbn_upconv2x_forward), or when KBN_NO_SPLIT is set. */
+/* Folds max |x| over n frames of per_frame contiguous floats (frames batch_stride elements apart) into *amax
+ * (device float, the caller zeroes it first): what a caller needs to pick act_exponent. */
+int kbn_absmax(const float* x, long long batch_stride, int n, long long per_frame, float* amax, kbn_stream_t stream);
 size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, int mode);
 int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int mode,
                                   kbn_stream_t stream);
 int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
                               long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
-                              int apply_activation, float negative_slope, kbn_stream_t stream);
+                              int act_exponent, int apply_activation, float negative_slope, kbn_stream_t stream);
 
 
 /* ---------------------------------------------------- bf16 leg (THROUGHPUT-ONLY) ------

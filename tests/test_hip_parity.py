@@ -483,12 +483,14 @@ def test_conv_head_fused_vs_oracle(dev, kenv, c, shape):
                                                ((128,), 64, (20, 36), "up2x"), ((16, 32), 130, (9, 40), "plain"),
                                                ((256, 512), 256, (22, 76), "plain"), ((64,), 96, (36, 72), "up2x"),
                                                ((48,), 96, (23, 44), "s2"), ((192,), 384, (22, 76), "s2"), ((16,), 64, (5, 8), "s2")])
-@pytest.mark.parametrize("amag", [1.0, 300.0])
+@pytest.mark.parametrize("amag", [1.0, 1e-4, 3e5])
 def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     """kbn_conv3x3_split_forward: fp32 products as three fp16 MFMAs over two-term splits (csrc/conv_split.hip).  Held to
     the accuracy class of the fp32 kernels: against an fp64 evaluation its error may not exceed 3.5x the error of the
     oracle's own fp32 conv (a blocked CPU summation, itself 3-6x more accurate than an fp32 MFMA / fmaf chain of the same
-    length; both in units of the output's rms), and it stays below 1.5e-6 rms / 2e-5 max."""
+    length; both in units of the output's rms), and it stays below 1.5e-6 rms / 2e-5 max.  Activation magnitudes of
+    1e-4 and 3e5 sit outside the default fp16 window: the exponent measured from max |a| (ops.act_exponent_for, what
+    modules.Conv2d does on a layer's first call) moves the window onto them."""
     h, w = hw                                   # output size
     g = torch.Generator().manual_seed(sum(cins) + cout + h)
     n = 2
@@ -508,8 +510,13 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     assert tuple(ref32.shape[-2:]) == (h, w)
     xd = [x.to(dev) for x in xs]
     out = torch.empty(n, cout, h, w, device=dev)
-    res = kb.ops.conv3x3_split([kb.ops.tensor_src(x) for x in xd], kb.ops.pack_conv3x3_split_weight(wt.to(dev), stride=stride), n, cout, h, w,
-                               out, up2x=up2x, negative_slope=0.2, stride=stride)
+    srcs = [kb.ops.tensor_src(x) for x in xd]
+    amax = kb.ops.absmax_srcs(srcs, n, dev)
+    assert amax == max(float(x.abs().max()) for x in xs)
+    k = kb.ops.act_exponent_for(amax)
+    assert 2.0 ** 8 < amax * 2.0 ** k <= 2.0 ** 9
+    res = kb.ops.conv3x3_split(srcs, kb.ops.pack_conv3x3_split_weight(wt.to(dev), stride=stride), n, cout, h, w,
+                               out, up2x=up2x, negative_slope=0.2, stride=stride, act_exponent=k if amag != 1.0 else -6)
     assert res is not None
     rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()       # per filter: the filters differ by 5e4 in scale
     e_hip = ((out.cpu().double() - ref64) / rms).abs()

@@ -15,6 +15,9 @@ LAYERS = [("deconv4_up", (512,), 256, 22, 76, True), ("deconv4_conv", (256, 512)
           ("deconv2_up", (128,), 128, 88, 304, True), ("deconv2_conv", (128, 128), 128, 88, 304, False),
           ("deconv1_up", (128,), 64, 176, 608, True), ("deconv1_conv", (64, 64), 64, 176, 608, False),
           ("kb2_image", (48,), 96, 88, 304, "s2"), ("kb3_image", (96,), 192, 44, 152, "s2"), ("kb4_image", (192,), 384, 22, 76, "s2")]
+ONLY = os.environ.get("SPLIT_ONLY")           # one layer, split kernel only (PMC runs)
+if ONLY:
+    LAYERS = [l for l in LAYERS if l[0] == ONLY]
 g = torch.Generator().manual_seed(0)
 
 
@@ -49,6 +52,10 @@ for name, cins, cout, h, w, up in LAYERS:
     else:
         pf = kb.ops.pack_conv_weight(wt, stride)
         ff = lambda: kb.ops.conv2d(srcs, pf, B, cout, 3, stride, sh, sw, out_f, negative_slope=0.2)
+    if ONLY:
+        for _ in range(5): fs()
+        torch.cuda.synchronize()
+        continue
     with kb.ops.autotune():
         ff()
     assert fs() is not None
