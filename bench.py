@@ -36,7 +36,16 @@ import kbnet_amd as kb  # noqa: E402
 HEIGHT, WIDTH = 352, 1216
 FRAMES_PER_GPU = 32      # configs[2] (fp32 leg) / configs[3] per-GPU share; --frames-per-gpu 8 = configs[1]
 SIDE_BATCH = 8           # configs[1]
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32, dense
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32, dense (the fp32 vector datapath)
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/fp16 MFMA (the matrix core proper)
+SPLIT_KERNELS = {"conv_split": "conv3x3_split_kernel<0, 8, true>", "conv_split_up": "conv3x3_split_kernel<1, 8, true>",
+                 "conv_split_s2": "conv3x3_split_kernel<2, 4, true>", "conv_split_upfold": "upconv2x_split_kernel"}
+
+
+def pipe_peak(name):
+    """Dense peak of the pipe a kernel group's MFMAs run on: the split-operand convs issue fp16 MFMAs (three per fp32
+    product), everything else v_mfma_f32_*_f32."""
+    return FP16_MFMA_PEAK_TFLOPS if name in SPLIT_KERNELS else FP32_MFMA_PEAK_TFLOPS
 HBM_PEAK_GBS = 8000.0
 WEIGHT_GAIN = 1.3  # keeps random-weight logits O(1) so the sigmoid head is off saturation
 
@@ -83,6 +92,8 @@ def lookup_traffic(kernel, launches, frames_per_gpu):
     table = doc["kernels"]
     if kernel == "conv_wino":
         want = "conv_wino_kernel<0>"
+    elif kernel in SPLIT_KERNELS:
+        want = SPLIT_KERNELS[kernel]
     else:
         m = re.match(r"(conv_\w+)<([\d,]+)>", kernel)
         if not m:
@@ -297,22 +308,30 @@ def main():
     # `frac` = achieved / peak is the matrix-pipe fraction and cannot exceed 1.  `algorithmic`: the same launches
     # priced at the reference's direct-conv FLOPs (2 * N * Hout * Wout * Cin * 9 * Cout), which may exceed the peak.
     achieved = dexec / dtime / 1e12
+    peak = pipe_peak(dom)
     mfma_flops = [v[3] for k, v in groups.items() if v[4] and v[3] > 0]
     mfma_time = [v[1] for k, v in groups.items() if v[4] and v[3] > 0]
-    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+    # seconds the executed FLOPs of every MFMA kernel would take at the dense peak of the pipe they run on
+    pipe_seconds = sum(v[3] / (pipe_peak(k) * 1e12) for k, v in groups.items() if v[4] and v[3] > 0)
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                 "launches": dlaunch, "avg_launch_us": round(dtime / dlaunch * 1e6, 2),
                 "flop_per_launch": dexec / dlaunch,
                 "algorithmic": {"flop_per_launch": dwork / dlaunch, "tflops": round(dwork / dtime / 1e12, 3),
                                 "multiple_of_peak": round(dwork / dtime / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                 "executed_over_algorithmic": round(dexec / dwork, 4)},
-                # whole forward: executed matrix-core FLOPs of every MFMA launch of a step / the timed step
-                "whole_forward_frac": round(sum(mfma_flops) / args.steps / (ms_per_step * 1e-3) / 1e12
-                                            / FP32_MFMA_PEAK_TFLOPS, 4),
+                # whole forward: time the executed FLOPs of every MFMA launch of a step need at the dense peak of their
+                # pipe (fp16 MFMA for the split-operand convs, fp32 MFMA for the rest) / the timed step
+                "whole_forward_frac": round(pipe_seconds / args.steps / (ms_per_step * 1e-3), 4),
                 "whole_forward_executed_gflop_per_frame": round(sum(mfma_flops) / args.steps / per / 1e9, 3),
                 "whole_forward_algorithmic_multiple_of_peak":
                     round(fps / world * gflop_frame / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
-                "mfma_kernels_eager_frac": round(sum(mfma_flops) / sum(mfma_time) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                "mfma_kernels_eager_frac": round(pipe_seconds / sum(mfma_time), 4)}
+    if dom in SPLIT_KERNELS:
+        roofline["pipe"] = ("fp16 MFMA (matrix core): every fp32 product is taken as three fp16 products over two-term "
+                            "splits of both operands, fp32 accumulation (csrc/conv_split.hip); `achieved` counts the "
+                            "fp16 MFMA FLOPs executed, 3x the fp32 products incl. tile padding; the kernel runs into the "
+                            "chip's power limit before the pipe's peak (zero-filled operands: +25 %)")
     if dom == "conv_wino":
         roofline["algorithm"] = "Winograd F(2x2,3x3) in fp32: 4/9 of the algorithmic multiply-adds reach the MFMAs"
     roofline["measured_on"] = ("eager whole-batch launches, one kernel at a time, HIP events on the launch stream "
@@ -330,7 +349,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"KITTI 352x1216, batch {per}/GPU (BASELINE configs[2] fp32 leg = configs[3] per-GPU share), "
-                               "fp32, full KBNet forward in HIP (S2D + KB layers + MFMA convs + head), "
+                               "fp32 tensors and accumulation, full KBNet forward in HIP (S2D + KB layers + MFMA convs + head; "
+                               "the wide 3x3 convs take their fp32 products as three fp16 MFMAs over split operands), "
                                "random xavier weights",
                    "frames_per_gpu": per, "global_batch": per * world, "height": HEIGHT, "width": WIDTH,
                    "gflop_per_frame": round(gflop_frame, 3),

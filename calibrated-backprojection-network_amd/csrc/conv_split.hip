@@ -288,11 +288,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 }
     };
 
-    f32x4 bq[3][NB][2];             // fetched weights (w1, w2): tap t lives in buffer t % 3, fetched TWO taps ahead
+    f32x4 bq0[NB][2], bq1[NB][2];   // fetched weights (w1, w2) of the current / next tap
     sph8 a0[GM][2], a1[GM][2];
-    // one chunk: nine taps, weights of tap t+2 in flight under the MFMAs of taps t, t+1 (9 % 3 == 0: the rotation carries
-    // over chunk boundaries); the next chunk's inputs are fetched during taps 0-2 and written (split) into the other A
-    // buffer from tap 4 on; ONE barrier per chunk
+    // one chunk: nine taps, weights of tap t+1 in flight under the MFMAs of tap t (fetching two taps ahead measured the
+    // same and costs 16 registers); the next chunk's inputs are fetched during taps 0-1 and written (split) into the
+    // other A buffer from tap 3 on; ONE barrier per chunk
     auto chunk_body = [&](int c, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         constexpr int NA = MORE ? G::NLOADA : 0, NBL = 2 * NB;
@@ -302,20 +302,18 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
 #pragma unroll
         for (int grp = 0; grp < NGROUP; ++grp) {
             const int tap = grp / GPT, gi = grp % GPT;
-            f32x4 (&bc)[NB][2] = bq[tap % 3];
-            f32x4 (&bn)[NB][2] = bq[(tap + 2) % 3];
+            f32x4 (&bc)[NB][2] = (tap & 1) ? bq1 : bq0;
+            f32x4 (&bn)[NB][2] = (tap & 1) ? bq0 : bq1;
             sph8 (&ac)[GM][2] = (grp & 1) ? a1 : a0;
             sph8 (&an)[GM][2] = (grp & 1) ? a0 : a1;
             if (grp + 1 < NGROUP) load_a(an, abuf, grp + 1);
             if (gi == 0) {
-                if (tap < 7) load_b(bn, c, tap + 2);
-                else if (MORE) load_b(bn, c + 1, tap - 7);
+                if (tap < 8) load_b(bn, c, tap + 1);
+                else if (MORE) load_b(bn, c + 1, 0);
                 if (tap == 0 && MORE) load_chunk(c + 1);
-                // outstanding, oldest first (loads retire in order): taps 0-2: b(tap) b(tap+1) [b(tap+2) | inputs in issue
-                // order]; tap 3 on: the inputs are older than everything still needed -> their wait is implied
-                if (tap <= 2) sp_wait_b<2 * NBL + NA>(bc);
-                else if (tap < 7 || MORE) sp_wait_b<2 * NBL>(bc);
-                else if (tap == 7) sp_wait_b<NBL>(bc);
+                // outstanding, oldest first: [b(tap)] b(tap+1) [inputs, taps 0-1]; b(tap) is what the MFMAs below need
+                if (tap <= 1) sp_wait_b<NBL + NA>(bc);
+                else if (tap < 8 || MORE) sp_wait_b<NBL>(bc);
                 else sp_wait_b<0>(bc);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -327,20 +325,25 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             __builtin_amdgcn_sched_barrier(0);
             mfma_group(ac, bw, grp);
             __builtin_amdgcn_sched_barrier(0);
-            if (MORE && tap >= 4) {   // the wait of tap 3 covered the input loads; one staging round per group
-                const int u = (tap - 4) * GPT + gi;
+            if (MORE && tap >= 3) {   // the wait of tap 2 covered the input loads; one staging round per group
+                const int u = (tap - 3) * GPT + gi;
                 if (u < PR) store_round((c & 1) ^ 1, u);
             }
+        }
+        if (MORE) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bq0[nb][t] = bq1[nb][t];   // tap 8 used bq0 and fetched the next chunk's tap 0 into bq1
         }
         __syncthreads();
     };
 
     load_chunk(0);
-    load_b(bq[0], 0, 0);
+    load_b(bq0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int u = 0; u < PR; ++u) store_round(0, u);
-    load_b(bq[1], 0, 1);
     __syncthreads();
     for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
     chunk_body(nchunks - 1, std::false_type{});
@@ -375,17 +378,277 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Nearest-2x up-conv in its FOLDED form on split operands (MODE 3 of the entry point).  An output pixel (2Y+py, 2X+px)
+// of conv3x3(upsample2x(x)) only sees the 2 x 2 low-resolution pixels (Y+py-1+dy, X+px-1+dx), dy, dx in {0, 1}, with
+// the 3 x 3 weights summed over the taps that land on the same source pixel (rows: py 0 -> {0}, {1,2}; py 1 -> {0,1},
+// {2}; columns alike): four 2 x 2 convs, one per output parity, 16 channel products per low-resolution pixel instead of
+// 36 -- 2.25x fewer MFMAs than MODE 1.  M = 32 low-resolution pixels of a row (one parity), N = 32 filters.
+// Workgroup = 8 waves = 8 row groups; tile 16 x 32 low-resolution pixels (32 x 64 outputs) x 32 filters; a wave owns two
+// low-resolution rows x four parities (eight accumulator blocks).  The 16 (parity, tap) weight sets of a chunk are
+// visited grouped by the source offset they read, (ox = px+dx, s = py+dy): the two rows of a wave then need the A
+// fragments of staged rows s and s+1 at column offset ox -- 12 fragment reads per chunk serve all 96 MFMAs; weights are
+// packed in that visiting order and fetched three sets ahead.  K per output = 4 Cin: a third of the roundings of the
+// unfolded form, so ONE accumulator per block keeps the accuracy of the APART kernels above.
+constexpr int UF_NT = 32, UF_ITEMS = 16;
+struct UfItem { int ox, s, py, dy, px, dx; };
+__host__ __device__ constexpr UfItem uf_item(int it) {
+    // ox 0: (px,dx) = (0,0); ox 1: (0,1), (1,0); ox 2: (1,1).  Same for s over (py,dy).  Order: ox, s, (py,dy), (px,dx).
+    int ox = it < 4 ? 0 : (it < 12 ? 1 : 2);
+    int r = it - (ox == 0 ? 0 : (ox == 1 ? 4 : 12));
+    const int ncol = ox == 1 ? 2 : 1;                 // (px,dx) combos of this ox
+    const int rowidx = r / ncol, colidx = r % ncol;   // rowidx 0..3 over (s, (py,dy)): s0:1, s1:2, s2:1
+    const int s = rowidx == 0 ? 0 : (rowidx < 3 ? 1 : 2);
+    const int py = s == 0 ? 0 : (s == 2 ? 1 : rowidx - 1);
+    const int px = ox == 0 ? 0 : (ox == 2 ? 1 : colidx);
+    return UfItem{ox, s, py, s - py, px, ox - px};
+}
+// folded weight of (py, dy) x (px, dx) from the nine taps of one (filter, channel)
+__device__ __forceinline__ float uf_fold(const float* w9, int py, int dy, int px, int dx) {
+    const int r0 = (py == 0) ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2), r1 = (py == 0) ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+    const int c0 = (px == 0) ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), c1 = (px == 0) ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int r = r0; r <= r1; ++r) {
+        float row = 0.f;
+        for (int c = c0; c <= c1; ++c) row += w9[r * 3 + c];
+        acc += row;
+    }
+    return acc;
+}
+
+__global__ void uf_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int OC, int Cin) {
+    const int oc = blockIdx.x;
+    __shared__ float red[256];
+    float m = 0.f;
+    if (oc < OC)
+        for (int i = threadIdx.x; i < Cin * UF_ITEMS; i += 256) {
+            const int c = i / UF_ITEMS;
+            const UfItem t = uf_item(i % UF_ITEMS);
+            m = fmaxf(m, fabsf(uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx)));
+        }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int ex = SP_WEXP;
+        if (red[0] > 0.f && red[0] < 3.0e38f) (void)frexpf(red[0], &ex);
+        int e = SP_WEXP - ex;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        inv_scale[oc] = ldexpf(1.f, -e);
+    }
+}
+
+// OIHW fp32 -> [n-tile][chunk][item][part][k-group][32 filters][8 channels] fp16 of the folded weights
+__global__ void uf_pack_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, _Float16* __restrict__ packed,
+                               int OC, int Cin, int nchunks, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    constexpr int per_item = 2 * 2 * UF_NT * 8, per_chunk = UF_ITEMS * per_item;
+    int r = (int)(e % per_chunk);
+    const long long q = e / per_chunk;
+    const int chunk = (int)(q % nchunks), nt = (int)(q / nchunks);
+    const int item = r / per_item; r -= item * per_item;
+    const int part = r / (2 * UF_NT * 8); r -= part * 2 * UF_NT * 8;
+    const int g = r / (UF_NT * 8); r -= g * UF_NT * 8;
+    const int n = r >> 3, k = r & 7;
+    const int c = chunk * SP_CK + g * 8 + k, oc = nt * UF_NT + n;
+    _Float16 h = (_Float16)0.f;
+    if (c < Cin && oc < OC) {
+        const UfItem t = uf_item(item);
+        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx) * (1.f / inv_scale[oc]);
+        const _Float16 w1 = (_Float16)ws;
+        h = part == 0 ? w1 : (_Float16)(ws - (float)w1);
+    }
+    packed[e] = h;
+}
+
+template <int N>
+__device__ __forceinline__ void uf_wait_b(f32x4 (&b)[2]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N));
+}
+
+__global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const SplitConvParams p) {
+    constexpr int ROWS = 18, COLS = 34, NPIX = ROWS * COLS, A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART, PR = 3, NA_ALL = PR * 8;
+    constexpr int B_ITEM = 2 * 2 * UF_NT * 16, NBL = 2, D = 3;       // bytes per weight set; loads per set; sets fetched ahead
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals (see conv3x3_split_kernel)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = row group: low-resolution rows 2 rg, 2 rg + 1
+    const int lm = lane & 31, g = lane >> 5;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int oy0 = ty * 16, ox0 = tx * 32;                            // low-resolution tile origin
+    const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
+    const long long plane = (long long)sH * sW;
+    const int nchunks = p.Cin / SP_CK;
+
+    const int kg_st = rg >> 2, t256 = tid & 255;
+    int goff[PR];
+#pragma unroll
+    for (int u = 0; u < PR; ++u) {
+        const int pix = u * 256 + t256;
+        const int r = pix / COLS, c = pix - r * COLS;
+        const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
+        goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
+    }
+    const _Float16* wp_nt = p.wp + (long long)nt * nchunks * (UF_ITEMS * B_ITEM / 2);
+
+    float va[PR][8];
+    auto load_chunk = [&](int chunk) {
+        const float* base = p.src[0] + (long long)n * p.src_bstride[0] + (long long)(chunk * SP_CK + kg_st * 8) * plane;
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const unsigned voff = goff[u] < 0 ? 0u : (unsigned)goff[u];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* sb = base + (long long)k * plane;
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(va[u][k]) : "v"(voff), "s"(sb) : "memory");
+            }
+        }
+    };
+    auto store_round = [&](int buf, int u) {
+        unsigned char* A = smem + buf * A_BYTES + kg_st * NPIX * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));
+        const int pix = u * 256 + t256;
+        if (pix < NPIX) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
+            sph8 h1, h2;
+            sp_split8(v, p.prescale, h1, h2);
+            *reinterpret_cast<sph8*>(A + pix * 16) = h1;
+            *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
+        }
+    };
+    const unsigned boff = (unsigned)((g * UF_NT + lm) * 16);
+    auto load_b = [&](f32x4 (&b)[2], int chunk, int item) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(wp_nt + ((long long)chunk * UF_ITEMS + item) * (B_ITEM / 2));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned char* sb = base + t * 2 * UF_NT * 16;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[t]) : "v"(boff), "s"(sb) : "memory");
+        }
+    };
+
+    spf16 acc[2][2][2];   // [low-resolution row of the wave][py][px]
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a >> 2][(a >> 1) & 1][a & 1][i] = 0.f;
+
+    const unsigned char* const aptr = smem + (g * NPIX + 2 * rg * COLS + lm) * 16;
+    sph8 af[4][2];        // A fragments of staged rows 2 rg + 0..3 at the current column offset (two split terms each)
+    auto load_arow = [&](int abuf, int ry, int ox) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            af[ry][t] = *reinterpret_cast<const sph8*>(aptr + abuf + t * A_PART + (ry * COLS + ox) * 16);
+    };
+
+    f32x4 bq[4][2];       // weight sets in flight: set `it` lives in bq[it % 4]
+    auto chunk_body = [&](int c, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        constexpr int NA = MORE ? NA_ALL : 0;
+        const int abuf = (c & 1) * A_BYTES;
+        load_arow(abuf, 0, 0);
+        load_arow(abuf, 1, 0);
+#pragma unroll
+        for (int it = 0; it < UF_ITEMS; ++it) {
+            const UfItem t = uf_item(it);
+            const bool first_of_group = it == 0 || uf_item(it - 1).s != t.s || uf_item(it - 1).ox != t.ox;
+            if (first_of_group) {   // fetch what the NEXT group reads and this one does not hold
+                if (t.s == 0) load_arow(abuf, 2, t.ox);
+                else if (t.s == 1) load_arow(abuf, 3, t.ox);
+                else if (t.ox < 2) { load_arow(abuf, 0, t.ox + 1); load_arow(abuf, 1, t.ox + 1); }
+            }
+            f32x4 (&bc)[2] = bq[it % 4];
+            if (it + D < UF_ITEMS) load_b(bq[(it + D) % 4], c, it + D);
+            else if (MORE) load_b(bq[(it + D) % 4], c + 1, it + D - UF_ITEMS);
+            if (it == 0 && MORE) load_chunk(c + 1);
+            // outstanding, oldest first: b(it) b(it+1) b(it+2) [b(it+3) | inputs in issue order]
+            if (it <= D) uf_wait_b<D * NBL + NA>(bc);
+            else if (MORE || it + D < UF_ITEMS) uf_wait_b<D * NBL>(bc);
+            else if (it == UF_ITEMS - 3) uf_wait_b<2 * NBL>(bc);
+            else if (it == UF_ITEMS - 2) uf_wait_b<NBL>(bc);
+            else uf_wait_b<0>(bc);
+            sph8 bw[3];
+            bw[0] = __builtin_bit_cast(sph8, bc[0]);
+            bw[1] = __builtin_bit_cast(sph8, bc[1]);
+            bw[2] = bw[0] * (_Float16)0.00048828125f;
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int TA[3] = {0, 0, 1};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[mb][t.py][t.px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mb + t.s][TA[k]], bw[k], acc[mb][t.py][t.px], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE && it > D + 1 && it - D - 2 < PR) store_round((c & 1) ^ 1, it - D - 2);   // the wait of set D+1 covered the inputs
+        }
+        __syncthreads();
+    };
+
+    load_chunk(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < PR; ++u) store_round(0, u);
+#pragma unroll
+    for (int it = 0; it < D; ++it) load_b(bq[it], 0, it);
+    __syncthreads();
+    for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
+    chunk_body(nchunks - 1, std::false_type{});
+
+    // ---- epilogue: acc[mb][py][px][i]: low-resolution x = 8 (i / 4) + 4 g + (i % 4), filter lm; outputs (2 Y + py, 2 x + px)
+    const long long oplane = (long long)H * W;
+    const int oc = nt * UF_NT + lm;
+    const float inv = p.inv_scale[oc] * p.unscale;
+    if (oc >= p.OC) return;
+    float* outc = p.out + (long long)n * p.out_bstride + (long long)oc * oplane;
+    const float slope = p.act ? p.slope : 1.f;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int Y = oy0 + 2 * rg + mb;
+        if (Y >= sH) continue;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            float* orow = outc + (long long)(2 * Y + py) * W;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int X = 2 * (ox0 + 8 * q4 + 4 * g);              // first output column of this lane's 8
+                f32x4 v0, v1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[mb][py][j & 1][q4 * 4 + (j >> 1)] * inv;
+                    const float b = acc[mb][py][j & 1][q4 * 4 + 2 + (j >> 1)] * inv;
+                    v0[j] = a > 0.f ? a : a * slope;
+                    v1[j] = b > 0.f ? b : b * slope;
+                }
+                if (X < W) *reinterpret_cast<f32x4*>(orow + X) = v0;
+                if (X + 4 < W) *reinterpret_cast<f32x4*>(orow + X + 4) = v1;
+            }
+        }
+    }
+}
+
 }  // namespace kbn
 
 extern "C" {
 
-static int split_nt(int mode) { return mode == 2 ? 128 : 64; }   // filters per workgroup (stride 2: two filter groups of waves)
+static int split_nt(int mode) { return mode == 2 ? 128 : (mode == 3 ? kbn::UF_NT : 64); }   // filters per workgroup
 
 size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, int mode) {
     using namespace kbn;
-    if (out_channels < 1 || in_channels < 1 || (in_channels % SP_CK) != 0 || mode < 0 || mode > 2) return 0;
+    if (out_channels < 1 || in_channels < 1 || (in_channels % SP_CK) != 0 || mode < 0 || mode > 3) return 0;
     const int nt = split_nt(mode), tiles = ceil_div(out_channels, nt);
-    return (size_t)tiles * nt * 4 + (size_t)tiles * (in_channels / SP_CK) * (9 * 2 * 2 * nt * 16);
+    return (size_t)tiles * nt * 4 + (size_t)tiles * (in_channels / SP_CK) * ((mode == 3 ? UF_ITEMS : 9) * 2 * 2 * nt * 16);
 }
 
 int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int mode,
@@ -397,6 +660,13 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
     float* inv = static_cast<float*>(packed);
     _Float16* wp = reinterpret_cast<_Float16*>(inv + ocpad);
     const long long total = (long long)((bytes - (size_t)ocpad * 4) / 2);
+    if (mode == 3) {
+        hipLaunchKernelGGL(uf_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels);
+        hipLaunchKernelGGL(uf_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv, wp,
+                           out_channels, in_channels, in_channels / SP_CK, total);
+        KBN_CHECK_LAUNCH();
+        return KBN_OK;
+    }
     hipLaunchKernelGGL(split_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels * 9);
     hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
                        inv, wp, out_channels, in_channels, in_channels / SP_CK, nt, total);
@@ -421,10 +691,10 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     if (act_exponent < -60 || act_exponent > 60) return KBN_ERR_INVALID_ARGUMENT;
     if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || !out || n < 1 || out_channels < 1 || height < 1 || width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
-    if (mode < 0 || mode > 2) return KBN_ERR_INVALID_ARGUMENT;
+    if (mode < 0 || mode > 3) return KBN_ERR_INVALID_ARGUMENT;
     if (knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
     if ((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3)) return KBN_ERR_UNSUPPORTED;
-    if (mode == 1 && (n_src != 1 || (height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
+    if ((mode == 1 || mode == 3) && (n_src != 1 || (height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
     SplitConvParams p{};
     int cin = 0;
     for (int s = 0; s < n_src; ++s) {
@@ -436,7 +706,7 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         cin += a.channels;
     }
     const bool dims_ok = mode == 0 ? (p.sH == height && p.sW == width)
-                       : mode == 1 ? (2 * p.sH == height && 2 * p.sW == width)
+                       : mode != 2 ? (2 * p.sH == height && 2 * p.sW == width)
                                    : (ceil_div(p.sH, 2) == height && ceil_div(p.sW, 2) == width);
     if (!dims_ok) return KBN_ERR_INVALID_ARGUMENT;
     if ((long long)p.sH * p.sW > 0x1fffffffLL || (long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
@@ -449,6 +719,7 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     p.out = out; p.out_bstride = out_batch_stride;
     p.N = n; p.OC = out_channels; p.Cin = cin; p.H = height; p.W = width;
     p.tilesX = ceil_div(width, SP_TW); p.tilesY = ceil_div(height, mode == 2 ? SpGeom<2>::TH : SpGeom<0>::TH);
+    if (mode == 3) { p.tilesX = ceil_div(p.sW, 32); p.tilesY = ceil_div(p.sH, 16); }   // tiles of 16 x 32 low-resolution pixels
     const long long blocks = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
     if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
     p.nblocks = (int)blocks;
@@ -459,12 +730,13 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(SP_THREADS), lds, (hipStream_t)stream, p);
         return KBN_OK;
     };
-    static DeviceOnce o[3];
+    static DeviceOnce o[4];
     int rc;
     switch (mode) {
         case 0: rc = launch(conv3x3_split_kernel<0, 8, true>, SpGeom<0>::LDS, o[0]); break;
         case 1: rc = launch(conv3x3_split_kernel<1, 8, true>, SpGeom<1>::LDS, o[1]); break;
-        default: rc = launch(conv3x3_split_kernel<2, 4, true>, SpGeom<2>::LDS, o[2]); break;
+        case 2: rc = launch(conv3x3_split_kernel<2, 4, true>, SpGeom<2>::LDS, o[2]); break;
+        default: rc = launch(upconv2x_split_kernel, 2 * 2 * 2 * 18 * 34 * 16 * 2, o[3]); break;
     }
     if (rc != KBN_OK) return rc;
     KBN_CHECK_LAUNCH();

@@ -82,8 +82,10 @@ class _PackedWeight:
         if key != self._key:
             if up2x == "bf16":      # throughput-only bf16 leg (ops.conv3x3_bf16)
                 self._packed = ops.pack_conv3x3_bf16_weight(weight, out=self._packed)
-            elif up2x == "split":   # fp32 products on the bf16 matrix core (ops.conv3x3_split)
+            elif up2x == "split":   # fp32-grade products on the 16-bit matrix core (ops.conv3x3_split)
                 self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, stride=stride)
+            elif up2x == "split_up":   # the same for the folded nearest-2x up-conv
+                self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, folded_up2x=True)
             else:
                 self._packed = (ops.pack_upconv2x_weight(weight, out=self._packed) if up2x
                                 else ops.pack_conv_weight(weight, stride, out=self._packed))
@@ -120,6 +122,7 @@ class Conv2d(torch.nn.Module):
         self._packed = _PackedWeight()
         self._packed_bf16 = _PackedWeight()
         self._packed_split = _PackedWeight()
+        self._packed_split_up = _PackedWeight()
         self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
         self.split = True   # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies
         self._act_exp = None   # activation exponent of the split kernel's fp16 window, measured on the first call
@@ -141,8 +144,10 @@ class Conv2d(torch.nn.Module):
                 k = -6
             else:
                 k = self._act_exp = ops.act_exponent_for(ops.absmax_srcs(srcs, n, dev))
-        return ops.conv3x3_split(srcs, self._packed_split.get(self.conv.weight, self.stride, up2x="split"), n, self.out_channels, h, w,
-                                 out, up2x=up2x, negative_slope=self._slope, stride=self.stride, act_exponent=k)
+        packed = (self._packed_split_up.get(self.conv.weight, 1, up2x="split_up") if up2x
+                  else self._packed_split.get(self.conv.weight, self.stride, up2x="split"))
+        return ops.conv3x3_split(srcs, packed, n, self.out_channels, h, w, out, up2x=up2x, negative_slope=self._slope,
+                                 stride=self.stride, act_exponent=k, folded_up2x=up2x)
 
     def packed(self):
         return self._packed.get(self.conv.weight, self.stride)
@@ -200,7 +205,7 @@ class UpConv2d(torch.nn.Module):
                            weight_initializer=weight_initializer, activation_func=activation_func,
                            use_batch_norm=use_batch_norm, use_instance_norm=use_instance_norm)
         self._packed_up2x = _PackedWeight()
-        self.split_up = False   # the 9-product fp32 form is as fast as the split kernel's nine taps on most levels
+        self.split_up = True    # folded 16-product form on split operands (ops.conv3x3_split(folded_up2x=True))
 
     def forward(self, x, shape):
         if x.shape[1] != self.conv.in_channels:
@@ -720,6 +725,7 @@ class KBNetModel(object):
                     sub._packed.refresh(sub.conv.weight)
                     sub._packed_bf16.refresh(sub.conv.weight)
                     sub._packed_split.refresh(sub.conv.weight)
+                    sub._packed_split_up.refresh(sub.conv.weight)
                 elif isinstance(sub, UpConv2d):
                     sub._packed_up2x.refresh(sub.conv.conv.weight)
 

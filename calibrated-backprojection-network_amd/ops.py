@@ -457,10 +457,12 @@ def conv_head(x, w_conv, w_out, min_predict_depth: float, max_predict_depth: flo
 
 # ----------------------------------------------------- fp32-grade convs on the 16-bit matrix core (split operands)
 @_on_tensor_device
-def pack_conv3x3_split_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None, stride: int = 1) -> torch.Tensor:
+def pack_conv3x3_split_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None, stride: int = 1,
+                              folded_up2x: bool = False) -> torch.Tensor:
     """OIHW fp32 3x3 weight -> per-filter scaled two-term fp16 split in MFMA order for `conv3x3_split` with the same
-    `stride` (in_channels % 16 == 0)."""
-    mode = 2 if stride == 2 else 0
+    `stride` / `folded_up2x` (in_channels % 16 == 0).  `folded_up2x`: the sixteen 2x2 parity weights of the nearest-2x
+    up-conv (sums of the 3x3 taps that read the same source pixel) instead of the nine taps."""
+    mode = 3 if folded_up2x else (2 if stride == 2 else 0)
     lib = _lib.load()
     w = weight.detach().contiguous()
     _require(w, "weight", 4)
@@ -493,8 +495,11 @@ def act_exponent_for(amax: float) -> int:
     return max(-60, min(60, 9 - math.ceil(math.log2(amax))))
 
 
-def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1):
-    """fp16 MFMA FLOPs the split kernel executes: three products per fp32 product, whole (16 | 8) x 32 x (64 | 128) tiles."""
+def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1, folded_up2x=False):
+    """fp16 MFMA FLOPs the split kernel executes: three products per fp32 product, whole (16 | 8) x 32 x (64 | 128) tiles
+    (folded up-conv: 16 products per low-resolution pixel, 16 x 32 low-resolution pixels x 32 filters)."""
+    if folded_up2x:
+        return 3 * 2.0 * n * (-(-(height // 2) // 16) * 16) * (-(-(width // 2) // 32) * 32) * cin * 16 * (-(-out_channels // 32) * 32)
     nt = 128 if stride == 2 else 64
     th = 8 if stride == 2 else 16
     return 3 * 2.0 * n * (-(-height // th) * th) * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // nt) * nt)
@@ -503,12 +508,14 @@ def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1):
 @_on_tensor_device
 def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
                   out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1,
-                  act_exponent: int = -6):
+                  act_exponent: int = -6, folded_up2x: bool = False):
     """3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
     `stride` 2: sources are the 2x larger input planes), fp32 in / fp32 out, every product taken as three fp16 MFMAs
     over two-term splits of both operands (kbn_conv3x3_split_forward): fp32-grade accuracy at 3/16 of the fp32 MFMA's
     time.  `height` x `width` is the OUTPUT size; `act_exponent` k places the fp16 window (|a| 2^k < 65504; full precision
-    for |a| 2^k >= 2^-14).  Returns None when the shape does not qualify (the caller stays on the fp32-MFMA kernels)."""
+    for |a| 2^k >= 2^-14); `folded_up2x` (with `up2x`): the folded 16-product form, weights from
+    pack_conv3x3_split_weight(folded_up2x=True).  Returns None when the shape does not qualify (the caller stays on the
+    fp32-MFMA kernels)."""
     if up2x and stride != 1:
         raise KbnError("conv3x3_split: up2x and stride 2 are mutually exclusive")
     lib = _lib.load()
@@ -518,14 +525,15 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
         raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, height, width)}")
     cin = sum(s.channels for s in srcs)
     flops = 2.0 * n * height * width * cin * 9 * out_channels
-    status = _launch("conv_split", flops,
+    mode = (3 if folded_up2x else 1) if up2x else (2 if stride == 2 else 0)
+    status = _launch(("conv_split", "conv_split_up", "conv_split_s2", "conv_split_upfold")[mode], flops,
                      lambda: lib.kbn_conv3x3_split_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
                                                            out_channels, height, width,
-                                                           1 if up2x else (2 if stride == 2 else 0), int(act_exponent),
+                                                           mode, int(act_exponent),
                                                            0 if negative_slope is None else 1,
                                                            0.0 if negative_slope is None else float(negative_slope),
                                                            _stream()),
-                     executed=conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride))
+                     executed=conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride, up2x and folded_up2x))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()

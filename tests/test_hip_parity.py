@@ -214,8 +214,22 @@ def test_winograd_matches_direct_kernel(dev, kenv):
     g = torch.Generator().manual_seed(11)
     x = torch.randn(2, 96, 30, 44, generator=g).to(dev)
     conv = kb.modules.Conv2d(96, 64, 3, 1, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+    conv.split = False               # the fp32-MFMA kernels (the split-operand kernel would take this shape first)
     a = conv(x).clone()
     kenv.setenv("KBN_NO_WINO", "1")
+    b = conv(x).clone()
+    assert rel_err(a, b) < TIGHT
+    assert not torch.equal(a, b)  # two different kernels did run
+
+
+def test_split_matches_fp32_kernels(dev, kenv):
+    """Same layer through the split-operand kernel (fp16 MFMAs) and, with KBN_NO_SPLIT=1, the fp32-MFMA kernel behind it."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 96, 30, 44, generator=g).to(dev)
+    conv = kb.modules.Conv2d(96, 64, 3, 1, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+    a = conv(x).clone()
+    assert conv._act_exp is not None  # the first call measured max |a| of the input
+    kenv.setenv("KBN_NO_SPLIT", "1")
     b = conv(x).clone()
     assert rel_err(a, b) < TIGHT
     assert not torch.equal(a, b)  # two different kernels did run
@@ -300,6 +314,7 @@ def test_upconv2x_three_product_form_vs_four_phase(dev, kenv, cin, cout, hw):
     g = torch.Generator().manual_seed(cin + hw[0])
     act = torch.nn.LeakyReLU(0.2)
     up = kb.modules.UpConv2d(cin, cout, 3, "xavier_normal", act).to(dev)
+    up.split_up = False              # the fp32-MFMA forms (the folded split-operand kernel takes the wide shapes first)
     x = torch.randn(2, cin, *hw, generator=g)
     shape = (2 * hw[0], 2 * hw[1])
     ref = orc.conv2d(torch.nn.functional.interpolate(x, size=shape, mode="nearest"), up.conv.conv.weight.detach().cpu(), 1, 0.2)
@@ -482,7 +497,9 @@ def test_conv_head_fused_vs_oracle(dev, kenv, c, shape):
 @pytest.mark.parametrize("cins,cout,hw,kind", [((32,), 48, (16, 64), "plain"), ((64, 64), 64, (22, 76), "plain"),
                                                ((128,), 64, (20, 36), "up2x"), ((16, 32), 130, (9, 40), "plain"),
                                                ((256, 512), 256, (22, 76), "plain"), ((64,), 96, (36, 72), "up2x"),
-                                               ((48,), 96, (23, 44), "s2"), ((192,), 384, (22, 76), "s2"), ((16,), 64, (5, 8), "s2")])
+                                               ((48,), 96, (23, 44), "s2"), ((192,), 384, (22, 76), "s2"), ((16,), 64, (5, 8), "s2"),
+                                               ((128,), 64, (20, 36), "up2x_folded"), ((64,), 96, (36, 76), "up2x_folded"),
+                                               ((512,), 40, (22, 76), "up2x_folded"), ((16,), 33, (70, 8), "up2x_folded")])
 @pytest.mark.parametrize("amag", [1.0, 1e-4, 3e5])
 def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     """kbn_conv3x3_split_forward: fp32 products as three fp16 MFMAs over two-term splits (csrc/conv_split.hip).  Held to
@@ -495,7 +512,7 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     g = torch.Generator().manual_seed(sum(cins) + cout + h)
     n = 2
     stride = 2 if kind == "s2" else 1
-    up2x = kind == "up2x"
+    up2x, folded = kind.startswith("up2x"), kind == "up2x_folded"
     sh, sw = (h // 2, w // 2) if up2x else ((2 * h - 1, 2 * w) if stride == 2 else (h, w))
     xs = [amag * torch.nn.functional.leaky_relu(torch.randn(n, c, sh, sw, generator=g), 0.2) for c in cins]
     cin = sum(cins)
@@ -515,8 +532,9 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     assert amax == max(float(x.abs().max()) for x in xs)
     k = kb.ops.act_exponent_for(amax)
     assert 2.0 ** 8 < amax * 2.0 ** k <= 2.0 ** 9
-    res = kb.ops.conv3x3_split(srcs, kb.ops.pack_conv3x3_split_weight(wt.to(dev), stride=stride), n, cout, h, w,
-                               out, up2x=up2x, negative_slope=0.2, stride=stride, act_exponent=k if amag != 1.0 else -6)
+    res = kb.ops.conv3x3_split(srcs, kb.ops.pack_conv3x3_split_weight(wt.to(dev), stride=stride, folded_up2x=folded), n, cout, h, w,
+                               out, up2x=up2x, negative_slope=0.2, stride=stride, act_exponent=k if amag != 1.0 else -6,
+                               folded_up2x=folded)
     assert res is not None
     rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()       # per filter: the filters differ by 5e4 in scale
     e_hip = ((out.cpu().double() - ref64) / rms).abs()

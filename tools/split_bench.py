@@ -44,8 +44,8 @@ for name, cins, cout, h, w, up in LAYERS:
     srcs = [kb.ops.tensor_src(x) for x in xs]
     out_s = torch.empty(B, cout, h, w, device=dev)
     out_f = torch.empty(B, cout, h, w, device=dev)
-    ps = kb.ops.pack_conv3x3_split_weight(wt, stride=stride)
-    fs = lambda: kb.ops.conv3x3_split(srcs, ps, B, cout, h, w, out_s, up2x=up, negative_slope=0.2, stride=stride)
+    ps = kb.ops.pack_conv3x3_split_weight(wt, stride=stride, folded_up2x=up)
+    fs = lambda: kb.ops.conv3x3_split(srcs, ps, B, cout, h, w, out_s, up2x=up, negative_slope=0.2, stride=stride, folded_up2x=up)
     if up:
         pf = kb.ops.pack_upconv2x_weight(wt)
         ff = lambda: kb.ops.upconv2x(xs[0], pf, cout, out_f, 0.2)
