@@ -155,7 +155,11 @@ __device__ __forceinline__ void sp_wait_b(f32x4 (&b)[2][2]) {   // vmcnt(N), tie
 // RG row groups x (8 / RG) filter groups of waves; a wave owns MB = TH / RG rows (m-blocks) x two 32-filter n-blocks.
 // APART: the two small terms (h1 w2, h2 w1 2^-11; 2^-11 of the sum) accumulate in their own registers, so that the main
 // accumulator is rounded once per k-step instead of three times (error vs fp64 / 1.7: the level of the Winograd kernel).
-template <int MODE, int RG, bool APART>
+// BLDS: the weights of a chunk (nine taps) are copied into LDS by LDS-DMA, double buffered like the inputs: every global
+// access of chunk c+1 is issued at the start of chunk c and awaited once, in front of the barrier that ends chunk c --
+// no vmcnt wait sits between MFMAs (waves retire their loads in order: with the weights fetched per tap into registers,
+// the tap-2 wait also had to wait for the next chunk's inputs, +28 % on the decoder's concat convs).
+template <int MODE, int RG, bool APART, bool BLDS>
 __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
     using G = SpGeom<MODE>;
     constexpr bool UP = G::UP, S2 = G::S2;
@@ -289,7 +293,66 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     };
 
     f32x4 bq0[NB][2], bq1[NB][2];   // fetched weights (w1, w2) of the current / next tap
-    sph8 a0[GM][2], a1[GM][2];
+    constexpr int AD = 1;           // A fragments fetched AD groups ahead (2 measured the same)
+    static_assert(NGROUP % (AD + 1) == 0, "the fragment rotation must close over a chunk");
+    sph8 aq[AD + 1][GM][2];
+    if constexpr (BLDS) {
+        constexpr int B_CHUNK = 9 * B_TAP;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+        auto stage_b = [&](int bbuf, int chunk) {
+            const float* src = reinterpret_cast<const float*>(wp_nt + (long long)chunk * (B_CHUNK / 2));
+            const unsigned dst = lds0 + (unsigned)(2 * G::A_BYTES + bbuf * B_CHUNK);
+            constexpr int n4 = B_CHUNK / 16;
+#pragma unroll
+            for (int e0 = 0; e0 < n4; e0 += SP_THREADS) {
+                const int eb = e0 + wave * 64;
+                if (eb + lane < n4) lds_dma16_s(src + eb * 4, (unsigned)(lane * 16), dst + eb * 16);
+            }
+        };
+        const unsigned char* const bptr = smem + 2 * G::A_BYTES + boff;
+        auto body = [&](int c, auto more_tag) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            const int abuf = (c & 1) * G::A_BYTES;
+            const unsigned char* B = bptr + (c & 1) * B_CHUNK;
+            if (MORE) {
+                stage_b((c & 1) ^ 1, c + 1);
+                load_chunk(c + 1);
+            }
+            load_a(aq[0], abuf, 0);
+            sph8 bw[NB][3];
+#pragma unroll
+            for (int grp = 0; grp < NGROUP; ++grp) {
+                const int tap = grp / GPT, gi = grp % GPT;
+                sph8 (&ac)[GM][2] = aq[grp % (AD + 1)];
+                if (grp + AD < NGROUP) load_a(aq[(grp + AD) % (AD + 1)], abuf, grp + AD);
+                if (gi == 0) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        bw[nb][0] = *reinterpret_cast<const sph8*>(B + tap * B_TAP + nb * 32 * 16);
+                        bw[nb][1] = *reinterpret_cast<const sph8*>(B + tap * B_TAP + (2 * NT + nb * 32) * 16);
+                        bw[nb][2] = bw[nb][0] * (_Float16)0.00048828125f;   // w1 2^-11
+                    }
+                }
+                if (MORE && grp == 5 * GPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's weights (DMA) and inputs: issued five taps ago
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(ac, bw, grp);
+                __builtin_amdgcn_sched_barrier(0);
+                if (MORE && tap >= 5) {   // split + write one staging round per group: the vector ALU works beside the MFMAs
+                    const int u = (tap - 5) * GPT + gi;   // (staggering the two waves of a SIMD -- taps 2-4 / 5-7 -- measured slower)
+                    if (u < PR) store_round((c & 1) ^ 1, u);
+                }
+            }
+            __syncthreads();
+        };
+        load_chunk(0);
+        stage_b(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < PR; ++u) store_round(0, u);
+        __syncthreads();
+        for (int c = 0; c + 1 < nchunks; ++c) body(c, std::true_type{});
+        body(nchunks - 1, std::false_type{});
+    } else {
     // one chunk: nine taps, weights of tap t+1 in flight under the MFMAs of tap t (fetching two taps ahead measured the
     // same and costs 16 registers); the next chunk's inputs are fetched during taps 0-1 and written (split) into the
     // other A buffer from tap 3 on; ONE barrier per chunk
@@ -297,16 +360,16 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
         constexpr bool MORE = decltype(more_tag)::value;
         constexpr int NA = MORE ? G::NLOADA : 0, NBL = 2 * NB;
         const int abuf = (c & 1) * G::A_BYTES;
-        load_a(a0, abuf, 0);
+#pragma unroll
+        for (int d = 0; d < AD; ++d) load_a(aq[d], abuf, d);
         sph8 bw[NB][3];
 #pragma unroll
         for (int grp = 0; grp < NGROUP; ++grp) {
             const int tap = grp / GPT, gi = grp % GPT;
             f32x4 (&bc)[NB][2] = (tap & 1) ? bq1 : bq0;
             f32x4 (&bn)[NB][2] = (tap & 1) ? bq0 : bq1;
-            sph8 (&ac)[GM][2] = (grp & 1) ? a1 : a0;
-            sph8 (&an)[GM][2] = (grp & 1) ? a0 : a1;
-            if (grp + 1 < NGROUP) load_a(an, abuf, grp + 1);
+            sph8 (&ac)[GM][2] = aq[grp % (AD + 1)];
+            if (grp + AD < NGROUP) load_a(aq[(grp + AD) % (AD + 1)], abuf, grp + AD);
             if (gi == 0) {
                 if (tap < 8) load_b(bn, c, tap + 1);
                 else if (MORE) load_b(bn, c + 1, 0);
@@ -347,6 +410,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     __syncthreads();
     for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
     chunk_body(nchunks - 1, std::false_type{});
+    }
 
     // ---- epilogue: acc[mb][nb][i]: pixel x = 8 (i / 4) + 4 g + (i % 4) of row 4 rg + mb, filter fg * 32 NB + nb * 32 + lm
     const long long oplane = (long long)H * W;
@@ -733,9 +797,9 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     static DeviceOnce o[4];
     int rc;
     switch (mode) {
-        case 0: rc = launch(conv3x3_split_kernel<0, 8, true>, SpGeom<0>::LDS, o[0]); break;
-        case 1: rc = launch(conv3x3_split_kernel<1, 8, true>, SpGeom<1>::LDS, o[1]); break;
-        case 2: rc = launch(conv3x3_split_kernel<2, 4, true>, SpGeom<2>::LDS, o[2]); break;
+        case 0: rc = launch(conv3x3_split_kernel<0, 8, true, true>, SpGeom<0>::LDS + 2 * 9 * 2 * 2 * 64 * 16, o[0]); break;
+        case 1: rc = launch(conv3x3_split_kernel<1, 8, true, false>, SpGeom<1>::LDS, o[1]); break;
+        case 2: rc = launch(conv3x3_split_kernel<2, 4, true, false>, SpGeom<2>::LDS, o[2]); break;
         default: rc = launch(upconv2x_split_kernel, 2 * 2 * 2 * 18 * 34 * 16 * 2, o[3]); break;
     }
     if (rc != KBN_OK) return rc;
