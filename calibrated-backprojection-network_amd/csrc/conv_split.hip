@@ -17,22 +17,28 @@
 // of the output's rms, the fp32 MFMA chain (== fmaf chain) 0.44e-6 .. 1.7e-6 -- the accuracy class of the fp32 path, which
 // is why this kernel sits on the parity-gated path (tests/test_hip_parity.py holds it to the same 1e-4 bar).
 //
-// Direct 3x3 stride-1 conv (+ LeakyReLU) over one or two NCHW fp32 sources (MODE 0: the concat convs of the decoder,
-// reference src/net_utils.py:1483-1487; MODE 1: nearest-2x up-conv, :484-499), implicit GEMM with M = 32 output pixels of
-// a row, N = 32 filters, K = 16 channels per v_mfma_f32_32x32x16_f16.  Workgroup = 512 threads = 8 waves = 4 row groups x
-// 2 filter groups; tile 16 rows x 32 pixels x 64 NB filters; wave (rg, fg): rows 4 rg .. 4 rg + 3 (four m-blocks) x NB
-// n-blocks.  K loop over chunks of 16 channels, 9 taps each:
-//   A  the (16+2) x (32+2) input pixels of the chunk (up-conv: the (8+2) x (16+2) low-resolution pixels they map to; the
-//      fragment reads do the upsampling), split on the way into LDS: a thread loads 8 channels of a pixel (scalar plane
-//      base + lane offset), splits them (v_cvt_pk_f16_f32, v_cvt_f32_f16, v_pk_fma_f32) and writes two 16-byte words,
-//      layout [part][k-group][pixel][8 channels]: an MFMA A fragment is one ds_read_b128, fetched one m-block ahead of
-//      its MFMAs.  Double buffered: the global loads of chunk c+1 are in flight under the MFMAs of chunk c.
-//   B  weights pre-split at pack time, [chunk][tap][part][k-group][filter][8 channels] fp16; every wave loads its B
-//      fragments straight from global memory (one global_load_dwordx4 each; the four row-group waves of a filter group
-//      hit the same lines in L1), one tap ahead of the MFMAs; w1 2^-11 is formed in registers (v_pk_mul_f16).
-// No weight stage in LDS, ONE barrier per chunk.  Operand streams at the full MFMA rate: B 2731 / (pixels per tile) =
-// 5.3 B/clk/CU, A 1.4-2.8 B/clk/CU; the chip's power limit, not the streams, sets the rate (zero-filled operands run
-// 25 % faster through the same instruction stream).
+// Direct 3x3 conv (+ LeakyReLU) over one or two NCHW fp32 sources -- MODE 0: the concat convs of the decoder, reference
+// src/net_utils.py:1483-1487; MODE 1: nearest-2x up-conv with nine taps, :484-499 (superseded by the folded form at the
+// end of this file); MODE 2: stride 2, the image convs of the KB blocks, :1348 -- as an implicit GEMM with M = 32 output
+// pixels of a row, N = 32 filters, K = 16 channels per v_mfma_f32_32x32x16_f16.  Workgroup = 512 threads = 8 waves = RG
+// row groups x 8/RG filter groups; a wave owns MB rows (m-blocks) x two 32-filter n-blocks and keeps TWO accumulators
+// per block: the main term h1 w1, and the two small terms (2^-11 of it) apart, so that the main accumulator is rounded
+// once per 16-channel step.  Stride 1: 8 x 1 waves, tile 16 rows x 32 pixels x 64 filters; stride 2: 4 x 2 waves, tile
+// 8 x 32 x 128.  K loop over chunks of 16 channels, 9 taps each:
+//   A  the (16+2) x (32+2) input pixels of the chunk (stride 2: 17 x 65, columns de-interleaved; up-conv: the
+//      (8+2) x (16+2) low-resolution pixels, the fragment reads do the upsampling), split on the way into LDS: a thread
+//      loads 8 channels of a pixel (scalar plane base + lane offset), splits them (v_cvt_pk_f16_f32, v_cvt_f32_f16,
+//      v_pk_fma_f32) and writes two 16-byte words, layout [part][k-group][pixel][8 channels]: an MFMA A fragment is one
+//      ds_read_b128, fetched one m-block ahead of its MFMAs.  Double buffered: the global loads of chunk c+1 are in
+//      flight under the MFMAs of chunk c, their split + LDS writes are spread over the MFMA groups of the later taps.
+//   B  weights pre-split at pack time, [chunk][tap][part][k-group][filter][8 channels] fp16.  MODE 0: the nine taps of
+//      a chunk are copied into LDS by LDS-DMA (double buffered): every global access of chunk c+1 is issued at the
+//      start of chunk c and awaited once, late in it -- no vmcnt wait between MFMAs.  MODE 2 (its input tile leaves no
+//      LDS for that): every wave loads its B fragments straight from global memory, one tap ahead (the row-group waves
+//      of a filter group hit the same lines in L1).  w1 2^-11 is formed in registers (v_pk_mul_f16).
+// ONE barrier per chunk.  What bounds it: the chip's power limit (the MFMAs alone: 77 % of the launch at 1.7-2.0 GHz;
+// zero-filled operands run 25 % faster through the same instruction stream), then the part of the skeleton that does
+// not hide under them (DESIGN.md section 4 has the ablation).
 #include "conv_common.h"
 
 namespace kbn {
