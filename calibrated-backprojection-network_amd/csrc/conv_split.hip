@@ -76,6 +76,7 @@ struct SplitConvParams {
     int tilesX, tilesY, nTilesN, nblocks;
     int act;
     float slope;
+    int vec4;                   // output rows are 16-byte aligned quads (width % 4 == 0, aligned base and strides)
     float prescale;             // 2^k on the activations (k = act_exponent of the launch)
     float unscale;              // 2^-k
 };
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     const long long oplane = (long long)H * W;
     float* outn = p.out + (long long)n * p.out_bstride;
     const float slope = p.act ? p.slope : 1.f;
+    const bool vec4 = p.vec4 != 0;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int oc = nt * NT + fg * 32 * NB + nb * 32 + lm;
@@ -435,14 +437,20 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int X = ox0 + 8 * q4 + 4 * g;
-                if (X >= W) continue;                                   // W % 4 == 0: a quad is in or out as a whole
+                if (X >= W) continue;
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float t = (APART ? acc[mb][nb][q4 * 4 + j] + lo[mb][nb][q4 * 4 + j] : acc[mb][nb][q4 * 4 + j]) * inv;
                     v[j] = t > 0.f ? t : t * slope;
                 }
-                *reinterpret_cast<f32x4*>(o + 8 * q4) = v;
+                if (vec4) {                                             // W % 4 == 0: a quad is in or out as a whole, rows 16-byte aligned
+                    *reinterpret_cast<f32x4*>(o + 8 * q4) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (X + j < W) o[8 * q4 + j] = v[j];
+                }
             }
         }
     }
@@ -763,7 +771,8 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         return KBN_ERR_INVALID_ARGUMENT;
     if (mode < 0 || mode > 3) return KBN_ERR_INVALID_ARGUMENT;
     if (knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
-    if ((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3)) return KBN_ERR_UNSUPPORTED;
+    const bool vec4 = !((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3));
+    if (!vec4 && (mode == 1 || mode == 3)) return KBN_ERR_UNSUPPORTED;   // the up-convs only store whole quads
     if ((mode == 1 || mode == 3) && (n_src != 1 || (height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
     SplitConvParams p{};
     int cin = 0;
@@ -795,6 +804,7 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     p.nblocks = (int)blocks;
     p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.prescale = ldexpf(1.f, act_exponent); p.unscale = ldexpf(1.f, -act_exponent);
+    p.vec4 = vec4 ? 1 : 0;
     auto launch = [&](auto kern, size_t lds, DeviceOnce& once) -> int {
         if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
         hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(SP_THREADS), lds, (hipStream_t)stream, p);

@@ -130,7 +130,7 @@ class Conv2d(torch.nn.Module):
     def run_split(self, srcs, n, h, w, out=None, up2x=False):
         """3x3 stride-1 conv with two-term fp16 splits of both operands (ops.conv3x3_split, fp32-grade results); `h` x `w`
         is the OUTPUT size.  None when the layer or the shape does not qualify."""
-        if (not self.split or self.kernel_size != 3 or w % 4 or len(srcs) > 2 or self.out_channels < 48
+        if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2 or self.out_channels < 48
                 or (up2x and self.stride != 1) or any(s.kind != _lib.KBN_SRC_TENSOR or s.channels % 16 for s in srcs)):
             return None
         dev = self.conv.weight.device

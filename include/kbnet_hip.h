@@ -203,8 +203,8 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
  *   packed    from kbn_conv3x3_split_pack_weight (OIHW fp32 3x3 weight in) for the SAME mode (the
  *             filter tiling of the blob depends on it)
  *   out       N x out_channels x height x width fp32, frames out_batch_stride elements apart
- * KBN_ERR_UNSUPPORTED unless width % 4 == 0 and `out` is 16-byte aligned (callers fall back to
- * kbn_conv2d_forward / kbn_upconv2x_forward), or when KBN_NO_SPLIT is set. */
+ * Modes 1 and 3 return KBN_ERR_UNSUPPORTED unless width % 4 == 0 and `out` is 16-byte aligned (callers fall back
+ * to kbn_upconv2x_forward); modes 0 and 2 store element-wise in that case.  KBN_NO_SPLIT=1: always unsupported. */
 /* Folds max |x| over n frames of per_frame contiguous floats (frames batch_stride elements apart) into *amax
  * (device float, the caller zeroes it first): what a caller needs to pick act_exponent. */
 int kbn_absmax(const float* x, long long batch_stride, int n, long long per_frame, float* amax, kbn_stream_t stream);
