@@ -1,0 +1,58 @@
+"""The arithmetic of csrc/conv_split.hip restated in numpy (no GPU): fp32 operands as pairs of fp16 values,
+a 2^k = h1 + 2^-11 h2, w 2^e = w1 + w2, a w = 2^-(e+k) (h1 w1 + h1 w2 + h2 (w1 2^-11)).  Checks the representation
+error of the scheme against fp64 and the exponent rule of the host mirror (ops.act_exponent_for)."""
+import math
+
+import numpy as np
+import pytest
+
+import kbnet_amd as kb
+
+
+def split_dot(a, w, k):
+    """sum_c a[c] w[c] the way the kernel forms it (products exact, accumulation here in fp64: the test isolates the
+    representation error; the GPU tests cover the fp32 accumulation)."""
+    wmax = np.abs(w).max()
+    e = 13 - math.frexp(float(wmax))[1] if wmax > 0 else 0
+    ap = (a * np.float32(2.0 ** k)).astype(np.float32)
+    h1 = ap.astype(np.float16)
+    h1 = np.where(np.abs(h1.astype(np.float32)) < 2.0 ** -14, np.float16(0), h1)      # subnormal results are flushed
+    h2 = ((ap - h1.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    ws = (w * np.float32(2.0 ** e)).astype(np.float32)
+    w1 = ws.astype(np.float16)
+    w2 = (ws - w1.astype(np.float32)).astype(np.float16)
+    w1s = (w1.astype(np.float32) * np.float32(2.0 ** -11)).astype(np.float16)
+    h1, h2, w1, w2, w1s = (x.astype(np.float64) for x in (h1, h2, w1, w2, w1s))
+    return float((h1 * w1 + h1 * w2 + h2 * w1s).sum() * 2.0 ** -(e + k))
+
+
+@pytest.mark.parametrize("amag", [1.0, 1e-4, 3e5])
+def test_split_product_representation_error(amag):
+    rng = np.random.default_rng(3)
+    K, trials = 2304, 64
+    errs, scale = [], []
+    for _ in range(trials):
+        a = rng.standard_normal(K).astype(np.float32)
+        a = (np.where(a < 0, 0.2 * a, a) * amag).astype(np.float32)
+        w = (rng.standard_normal(K) / math.sqrt(K)).astype(np.float32)
+        k = kb.ops.act_exponent_for(float(np.abs(a).max()))
+        ref = float((a.astype(np.float64) * w.astype(np.float64)).sum())
+        errs.append(split_dot(a, w, k) - ref)
+        scale.append(ref)
+    rms = math.sqrt(np.mean(np.square(errs))) / math.sqrt(np.mean(np.square(scale)))
+    assert rms < 4e-7, rms        # fp32 rounding of the operands alone would leave ~4e-8; an fmaf chain of this length ~8e-7
+
+
+def test_act_exponent_rule():
+    for amax in (1e-6, 0.0039, 1.0, 255.9, 256.0, 300.0, 65504.0, 4.0e6, 3.0e30):
+        k = kb.ops.act_exponent_for(amax)
+        assert 2.0 ** 8 < amax * 2.0 ** k <= 2.0 ** 9 or k in (-60, 60)
+    assert kb.ops.act_exponent_for(0.0) == -6 and kb.ops.act_exponent_for(float("inf")) == -6
+    assert kb.ops.act_exponent_for(float("nan")) == -6
+
+
+def test_default_window_limits():
+    """What the ABI default exponent (-6) covers: full precision from 2^-8 to fp16's maximum x 64."""
+    for a in (2.0 ** -8, 1.0, 4.0e6):
+        ap = np.float32(a) * np.float32(2.0 ** -6)
+        assert 2.0 ** -14 <= float(ap) <= 65504.0
