@@ -499,6 +499,7 @@ def test_conv_head_fused_vs_oracle(dev, kenv, c, shape):
                                                ((256, 512), 256, (22, 76), "plain"), ((64,), 96, (36, 72), "up2x"),
                                                ((48,), 96, (23, 44), "s2"), ((192,), 384, (22, 76), "s2"), ((16,), 64, (5, 8), "s2"),
                                                ((384,), 384, (11, 38), "s2"), ((32, 16), 64, (9, 37), "plain"),
+                                               ((16,), 48, (33, 20), "plain"), ((16,), 48, (6, 12), "up2x_folded"),
                                                ((128,), 64, (20, 36), "up2x_folded"), ((64,), 96, (36, 76), "up2x_folded"),
                                                ((512,), 40, (22, 76), "up2x_folded"), ((16,), 33, (70, 8), "up2x_folded")])
 @pytest.mark.parametrize("amag", [1.0, 1e-4, 3e5])
