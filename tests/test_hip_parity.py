@@ -668,6 +668,39 @@ def test_forward_batch32_full_size_vs_oracle(dev):
     assert worst < TOL, f"max relative error {worst:.3e}"
 
 
+def test_recalibrate_follows_input_scale(dev):
+    """The split-operand convs place their fp16 window on max |a| of each layer's input, measured on the first forward.
+    Weights rescaled so that the same frames produce activations 2^14 times the calibrated ones (conv0 x 2^14, output0
+    x 2^-14: the same network function, LeakyReLU being positively homogeneous) leave the window's 128x headroom: the
+    stale exponents must not pass silently (non-finite depths, or at least a worse result), and
+    KBNetModel.recalibrate() restores parity."""
+    cfg = kb.PRESETS["void"]()
+    h, w = 96, 160
+    frames = kb.synthetic.make_frames(1, h, w, "void", seed=5)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.45)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+    assert _worst_rel(m.forward(*to(dev, *frames)), ref) < TOL          # calibrated on these activations
+    exps = [sub._act_exp for mod in m.modules() for sub in mod.modules() if isinstance(sub, kb.modules.Conv2d) and sub._act_exp is not None]
+    assert len(exps) >= 6, "the wide convs of encoder and decoder run on the split kernel and hold a measured exponent"
+    # first encoder convs x 2^14, last decoder conv x 2^-14 (LeakyReLU is positively homogeneous: same network function
+    # up to rounding, every activation in between 2^14 times larger)
+    big = [dict(sd) for sd in sds]
+    enc, dec = big[1], big[2]
+    for kname in ("conv0_image.conv.weight", "conv0_depth.conv.weight"):
+        enc[kname] = enc[kname] * 2.0 ** 14
+    dec["output0.conv.weight"] = dec["output0.conv.weight"] * 2.0 ** -14
+    m.load_state_dicts(*big)
+    out_stale = m.forward(*to(dev, *frames))
+    m.recalibrate()
+    out_fresh = m.forward(*to(dev, *frames))
+    ref_big = orc.kbnet_forward(*frames, *big, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+    assert not torch.isfinite(out_stale).all() or _worst_rel(out_stale, ref_big) > _worst_rel(out_fresh, ref_big), \
+        "activations 2^14 above the calibrated window must not pass silently"
+    assert torch.isfinite(out_fresh).all() and _worst_rel(out_fresh, ref_big) < TOL
+
+
 @pytest.mark.parametrize("preset,shape", [("kitti", (352, 1216)), ("void", (480, 640)), ("nyu_v2", (416, 576))])
 def test_forward_full_size_seed_sweep(dev, preset, shape):
     """Parity margin: five weight / input seeds per preset at BASELINE's sizes, the worst element-wise relative error
