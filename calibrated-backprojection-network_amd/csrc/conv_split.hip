@@ -401,6 +401,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             }
         }
         if (MORE) {
+            sp_wait_b<0>(bq1);   // the fetch issued at tap 8 must have landed before its registers are copied
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
