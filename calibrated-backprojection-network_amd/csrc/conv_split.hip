@@ -286,6 +286,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
         }
     };
     auto mfma_group = [&](const sph8 (&a)[GM][2], const sph8 (&b)[NB][3], int grp) {
+        const bool nb0_live = nt * NT + fg * 32 * NB < p.OC, nb1_live = nt * NT + fg * 32 * NB + 32 < p.OC;   // wave-uniform
         const int mb0 = (grp % GPT) * GM;
         constexpr int TA[3] = {0, 0, 1}, TBP[3] = {0, 1, 2};   // h1 w1, h1 w2, h2 (w1 2^-11)
 #pragma unroll
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             for (int m = 0; m < GM; ++m)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
+                    if (!(nb == 0 ? nb0_live : nb1_live)) continue;   // n-block entirely past the last filter (96 or 192 of 128-wide tiles): no MFMAs for padding
                     spf16& c = (APART && t > 0) ? lo[mb0 + m][nb] : acc[mb0 + m][nb];
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][TA[t]], b[nb][TBP[t]], c, 0, 0, 0);
                 }
