@@ -295,6 +295,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             for (int m = 0; m < GM; ++m)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
+                    if (oy0 + MB * rg + mb0 + m >= H) continue;       // output row below the map (22 rows in 16-row tiles): no MFMAs
                     if (!(nb == 0 ? nb0_live : nb1_live)) continue;   // n-block entirely past the last filter (96 or 192 of 128-wide tiles): no MFMAs for padding
                     spf16& c = (APART && t > 0) ? lo[mb0 + m][nb] : acc[mb0 + m][nb];
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][TA[t]], b[nb][TBP[t]], c, 0, 0, 0);
@@ -669,8 +670,10 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const Spl
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
+                for (int mb = 0; mb < 2; ++mb) {
+                    if (oy0 + 2 * rg + mb >= sH) continue;            // low-resolution row below the map: no MFMAs (wave-uniform)
                     acc[mb][t.py][t.px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mb + t.s][TA[k]], bw[k], acc[mb][t.py][t.px], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
             if (MORE && it > D + 1 && it - D - 2 < PR) store_round((c & 1) ^ 1, it - D - 2);   // the wait of set D+1 covered the inputs
         }
