@@ -352,6 +352,11 @@ def main():
                                "fp32 tensors and accumulation, full KBNet forward in HIP (S2D + KB layers + MFMA convs + head; "
                                "the wide 3x3 convs take their fp32 products as three fp16 MFMAs over split operands), "
                                "random xavier weights",
+                   # what "f32" means on this path: tensors, accumulators and results are fp32; the wide 3x3 convs form every
+                   # fp32 product from two-term fp16 splits of both operands (three exact fp16 x fp16 MFMA products, 22+ bits of
+                   # each operand), measured error vs fp64 no larger than an fp32 MFMA chain's; same 1e-4 parity gate as before
+                   "arithmetic": "fp32 in / fp32 accumulate / fp32 out; 3x3 convs with >= 48 filters: fp32 products as 3 fp16 MFMAs "
+                                 "over split operands (csrc/conv_split.hip), everything else fp32 MFMA / VALU",
                    "frames_per_gpu": per, "global_batch": per * world, "height": HEIGHT, "width": WIDTH,
                    "gflop_per_frame": round(gflop_frame, 3),
                    "parallelism": f"frames sharded over {world} rank(s), RCCL all-gather of outputs",
