@@ -41,6 +41,13 @@
 // not hide under them (DESIGN.md section 4 has the ablation).
 #include "conv_common.h"
 
+// 1: tiles without padding (no output rows below the map, no 32-filter blocks past the last filter) run a K loop whose
+// MFMAs carry no tests at all; only the other tiles take the loop with a wave-uniform test in front of every MFMA (which
+// puts each MFMA in a basic block of its own).  0: every tile takes the tested loop (A/B builds).
+#ifndef KBN_SPLIT_STRAIGHT
+#define KBN_SPLIT_STRAIGHT 1
+#endif
+
 namespace kbn {
 
 typedef _Float16 sph8 __attribute__((ext_vector_type(8)));
@@ -285,7 +292,10 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 a[m][t] = *reinterpret_cast<const sph8*>(aptr[kx] + abuf_off + t * G::A_PART + r * COLS * 16);
         }
     };
-    auto mfma_group = [&](const sph8 (&a)[GM][2], const sph8 (&b)[NB][3], int grp) {
+    // CHK (a tag type): MFMAs of output rows below the map (22 rows in 16-row tiles) and of 32-filter blocks past the last
+    // filter (96 or 192 filters in 128-wide tiles) are skipped under wave-uniform branches
+    auto mfma_group = [&](auto chk_tag, const sph8 (&a)[GM][2], const sph8 (&b)[NB][3], int grp) {
+        constexpr bool CHK = decltype(chk_tag)::value;
         const bool nb0_live = nt * NT + fg * 32 * NB < p.OC, nb1_live = nt * NT + fg * 32 * NB + 32 < p.OC;   // wave-uniform
         const int mb0 = (grp % GPT) * GM;
         constexpr int TA[3] = {0, 0, 1}, TBP[3] = {0, 1, 2};   // h1 w1, h1 w2, h2 (w1 2^-11)
@@ -295,12 +305,14 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             for (int m = 0; m < GM; ++m)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    if (oy0 + MB * rg + mb0 + m >= H) continue;       // output row below the map (22 rows in 16-row tiles): no MFMAs
-                    if (!(nb == 0 ? nb0_live : nb1_live)) continue;   // n-block entirely past the last filter (96 or 192 of 128-wide tiles): no MFMAs for padding
+                    if (CHK && oy0 + MB * rg + mb0 + m >= H) continue;
+                    if (CHK && !(nb == 0 ? nb0_live : nb1_live)) continue;
                     spf16& c = (APART && t > 0) ? lo[mb0 + m][nb] : acc[mb0 + m][nb];
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][TA[t]], b[nb][TBP[t]], c, 0, 0, 0);
                 }
     };
+    // stride 2 keeps the tested loop for every tile: a second copy of its K loop does not fit the register file
+    const bool padded_tile = !KBN_SPLIT_STRAIGHT || S2 || oy0 + G::TH > H || (nt + 1) * NT - 32 >= p.OC;   // workgroup-uniform
 
     f32x4 bq0[NB][2], bq1[NB][2];   // fetched weights (w1, w2) of the current / next tap
     constexpr int AD = 1;           // A fragments fetched AD groups ahead (2 measured the same)
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             }
         };
         const unsigned char* const bptr = smem + 2 * G::A_BYTES + boff;
-        auto body = [&](int c, auto more_tag) {
+        auto body = [&](int c, auto more_tag, auto chk_tag) {
             constexpr bool MORE = decltype(more_tag)::value;
             const int abuf = (c & 1) * G::A_BYTES;
             const unsigned char* B = bptr + (c & 1) * B_CHUNK;
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 }
                 if (MORE && grp == 5 * GPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's weights (DMA) and inputs: issued five taps ago
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_group(ac, bw, grp);
+                mfma_group(chk_tag, ac, bw, grp);
                 __builtin_amdgcn_sched_barrier(0);
                 if (MORE && tap >= 5) {   // split + write one staging round per group: the vector ALU works beside the MFMAs
                     const int u = (tap - 5) * GPT + gi;   // (staggering the two waves of a SIMD -- taps 2-4 / 5-7 -- measured slower)
@@ -360,13 +372,17 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
 #pragma unroll
         for (int u = 0; u < PR; ++u) store_round(0, u);
         __syncthreads();
-        for (int c = 0; c + 1 < nchunks; ++c) body(c, std::true_type{});
-        body(nchunks - 1, std::false_type{});
+        auto k_loop = [&](auto chk_tag) {
+            for (int c = 0; c + 1 < nchunks; ++c) body(c, std::true_type{}, chk_tag);
+            body(nchunks - 1, std::false_type{}, chk_tag);
+        };
+        if (padded_tile) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
     } else {
     // one chunk: nine taps, weights of tap t+1 in flight under the MFMAs of tap t (fetching two taps ahead measured the
     // same and costs 16 registers); the next chunk's inputs are fetched during taps 0-1 and written (split) into the
     // other A buffer from tap 3 on; ONE barrier per chunk
-    auto chunk_body = [&](int c, auto more_tag) {
+    auto chunk_body = [&](int c, auto more_tag, auto chk_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         constexpr int NA = MORE ? G::NLOADA : 0, NBL = 2 * NB;
         const int abuf = (c & 1) * G::A_BYTES;
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma_group(ac, bw, grp);
+            mfma_group(chk_tag, ac, bw, grp);
             __builtin_amdgcn_sched_barrier(0);
             if (MORE && tap >= 3) {   // the wait of tap 2 covered the input loads; one staging round per group
                 const int u = (tap - 3) * GPT + gi;
@@ -419,8 +435,12 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
 #pragma unroll
     for (int u = 0; u < PR; ++u) store_round(0, u);
     __syncthreads();
-    for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
-    chunk_body(nchunks - 1, std::false_type{});
+    auto k_loop = [&](auto chk_tag) {
+        for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{}, chk_tag);
+        chunk_body(nchunks - 1, std::false_type{}, chk_tag);
+    };
+    if (S2 || padded_tile) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     }
 
     // ---- epilogue: acc[mb][nb][i]: pixel x = 8 (i / 4) + 4 g + (i % 4) of row 4 rg + mb, filter fg * 32 NB + nb * 32 + lm
@@ -552,6 +572,11 @@ __device__ __forceinline__ void uf_wait_b(f32x4 (&b)[2]) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N));
 }
 
+// BLDS: the sixteen weight sets of a chunk (32 KiB) are copied into LDS by LDS-DMA, double buffered, like the nine taps
+// of the concat convs: eight waves fetching every set straight from L1 move 256 KiB per chunk through the CU's vector
+// memory pipe (42 B/clk of its 64 beside the input loads); through LDS it is 32 KiB, every global access of chunk c+1
+// is issued at the start of chunk c and awaited once, late in it.
+template <bool BLDS>
 __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const SplitConvParams p) {
     constexpr int ROWS = 18, COLS = 34, NPIX = ROWS * COLS, A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART, PR = 3, NA_ALL = PR * 8;
     constexpr int B_ITEM = 2 * 2 * UF_NT * 16, NBL = 2, D = 3;       // bytes per weight set; loads per set; sets fetched ahead
@@ -635,6 +660,81 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const Spl
             af[ry][t] = *reinterpret_cast<const sph8*>(aptr + abuf + t * A_PART + (ry * COLS + ox) * 16);
     };
 
+    if constexpr (BLDS) {
+        constexpr int B_CHUNK = UF_ITEMS * B_ITEM;
+        constexpr int WAIT_IT = 9;   // the set whose MFMAs follow the wait for chunk c+1's accesses (issued ahead of set 0)
+        static_assert(WAIT_IT + PR < UF_ITEMS, "the staging rounds follow the wait inside the chunk");
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+        auto stage_b = [&](int bbuf, int chunk) {
+            const float* src = reinterpret_cast<const float*>(wp_nt + (long long)chunk * (B_CHUNK / 2));
+            const unsigned dst = lds0 + (unsigned)(2 * A_BYTES + bbuf * B_CHUNK);
+            constexpr int n4 = B_CHUNK / 16;
+            static_assert(n4 % SP_THREADS == 0, "whole rounds of the workgroup");
+#pragma unroll
+            for (int e0 = 0; e0 < n4; e0 += SP_THREADS) {
+                const int eb = e0 + rg * 64;
+                lds_dma16_s(src + eb * 4, (unsigned)(lane * 16), dst + eb * 16);
+            }
+        };
+        const unsigned char* const bptr = smem + 2 * A_BYTES + boff;
+        auto body = [&](int c, auto more_tag, auto chk_tag) {
+            constexpr bool MORE = decltype(more_tag)::value, CHK = decltype(chk_tag)::value;
+            const int abuf = (c & 1) * A_BYTES;
+            const unsigned char* B = bptr + (c & 1) * B_CHUNK;
+            if (MORE) {
+                stage_b((c & 1) ^ 1, c + 1);
+                load_chunk(c + 1);
+            }
+            load_arow(abuf, 0, 0);
+            load_arow(abuf, 1, 0);
+            sph8 bwq[2][2];   // (w1, w2) of the current / next set
+            bwq[0][0] = *reinterpret_cast<const sph8*>(B);
+            bwq[0][1] = *reinterpret_cast<const sph8*>(B + 2 * UF_NT * 16);
+#pragma unroll
+            for (int it = 0; it < UF_ITEMS; ++it) {
+                const UfItem t = uf_item(it);
+                const bool first_of_group = it == 0 || uf_item(it - 1).s != t.s || uf_item(it - 1).ox != t.ox;
+                if (first_of_group) {   // fetch what the NEXT group reads and this one does not hold
+                    if (t.s == 0) load_arow(abuf, 2, t.ox);
+                    else if (t.s == 1) load_arow(abuf, 3, t.ox);
+                    else if (t.ox < 2) { load_arow(abuf, 0, t.ox + 1); load_arow(abuf, 1, t.ox + 1); }
+                }
+                if (it + 1 < UF_ITEMS) {
+                    bwq[(it + 1) & 1][0] = *reinterpret_cast<const sph8*>(B + (it + 1) * B_ITEM);
+                    bwq[(it + 1) & 1][1] = *reinterpret_cast<const sph8*>(B + (it + 1) * B_ITEM + 2 * UF_NT * 16);
+                }
+                sph8 bw[3];
+                bw[0] = bwq[it & 1][0];
+                bw[1] = bwq[it & 1][1];
+                bw[2] = bw[0] * (_Float16)0.00048828125f;
+                if (MORE && it == WAIT_IT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's weights (DMA) and inputs
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int TA[3] = {0, 0, 1};
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        if (CHK && oy0 + 2 * rg + mb >= sH) continue;     // low-resolution row below the map: no MFMAs (wave-uniform)
+                        acc[mb][t.py][t.px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mb + t.s][TA[k]], bw[k], acc[mb][t.py][t.px], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (MORE && it >= WAIT_IT && it - WAIT_IT < PR) store_round((c & 1) ^ 1, it - WAIT_IT);
+            }
+            __syncthreads();
+        };
+        load_chunk(0);
+        stage_b(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < PR; ++u) store_round(0, u);
+        __syncthreads();
+        auto k_loop = [&](auto chk_tag) {
+            for (int c = 0; c + 1 < nchunks; ++c) body(c, std::true_type{}, chk_tag);
+            body(nchunks - 1, std::false_type{}, chk_tag);
+        };
+        if (!KBN_SPLIT_STRAIGHT || oy0 + 16 > sH) k_loop(std::true_type{});   // tile with rows below the map (workgroup-uniform)
+        else k_loop(std::false_type{});
+    } else {
     f32x4 bq[4][2];       // weight sets in flight: set `it` lives in bq[it % 4]
     auto chunk_body = [&](int c, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
@@ -689,6 +789,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const Spl
     __syncthreads();
     for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
     chunk_body(nchunks - 1, std::false_type{});
+    }
 
     // ---- epilogue: acc[mb][py][px][i]: low-resolution x = 8 (i / 4) + 4 g + (i % 4), filter lm; outputs (2 Y + py, 2 x + px)
     const long long oplane = (long long)H * W;
@@ -722,17 +823,247 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const Spl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The folded up-conv for NARROW layers (at most 16 filters, Cin % 32 == 0: deconv0's 64 -> 12 up-conv at full
+// resolution, reference src/net_utils.py:484-499 with n_filters_decoder[-1] = 12): 16-filter tiles on
+// v_mfma_f32_16x16x32_f16 instead of 32-filter tiles on 32x32x16 -- 12 of 16 columns live instead of 12 of 32.  Same
+// arithmetic as upconv2x_split_kernel (sixteen folded 2 x 2 weight sets, three fp16 products per fp32 product, one
+// accumulator per block).  M = 16 low-resolution pixels of a row, N = 16 filters, K = 32 channels per MFMA; chunk = 32
+// channels.  Workgroup = 8 waves = 4 row groups x 2 column halves; tile 16 x 32 low-resolution pixels; a wave owns four
+// low-resolution rows x 16 pixels x four parities (sixteen 16 x 16 accumulator blocks).  A in LDS as
+// [part][k-group (4)][pixel][8 fp16]; a group of weight sets (ox, s) reads the staged rows s .. s+3 at column offset
+// ox: rows stream through eight register slots (rows 2 and 3 have two: the last group of one column offset still
+// reads them while the first of the next is being fetched).  Weights: [chunk][set][part][k-group][16 filters][8
+// channels] fp16, one 1 KiB wave-wide load per (set, part), fetched three sets ahead.
+constexpr int U16_NT = 16, U16_CK = 32;
+typedef float spf4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr bool uf_narrow(int out_channels, int in_channels) {
+    return out_channels <= U16_NT && (in_channels % U16_CK) == 0;
+}
+
+// OIHW fp32 -> [n-tile][chunk][set][part][k-group (4)][16 filters][8 channels] fp16 of the folded weights
+__global__ void uf16_pack_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, _Float16* __restrict__ packed,
+                                 int OC, int Cin, int nchunks, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    constexpr int per_item = 2 * 4 * U16_NT * 8, per_chunk = UF_ITEMS * per_item;
+    int r = (int)(e % per_chunk);
+    const long long q = e / per_chunk;
+    const int chunk = (int)(q % nchunks), nt = (int)(q / nchunks);
+    const int item = r / per_item; r -= item * per_item;
+    const int part = r / (4 * U16_NT * 8); r -= part * 4 * U16_NT * 8;
+    const int g = r / (U16_NT * 8); r -= g * U16_NT * 8;
+    const int n = r >> 3, k = r & 7;
+    const int c = chunk * U16_CK + g * 8 + k, oc = nt * U16_NT + n;
+    _Float16 h = (_Float16)0.f;
+    if (c < Cin && oc < OC) {
+        const UfItem t = uf_item(item);
+        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx) * (1.f / inv_scale[oc]);
+        const _Float16 w1 = (_Float16)ws;
+        h = part == 0 ? w1 : (_Float16)(ws - (float)w1);
+    }
+    packed[e] = h;
+}
+
+__global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const SplitConvParams p) {
+    constexpr int COLS = 34, NPIX = 18 * COLS, KG = 4;
+    constexpr int A_PART = KG * NPIX * 16, A_BYTES = 2 * A_PART;      // [part][k-group][pixel][8 fp16]
+    constexpr int PR = (NPIX + 127) / 128, NA_ALL = PR * 8;           // staging rounds of a 128-thread quarter (one k-group each)
+    constexpr int B_ITEM = 2 * KG * U16_NT * 16, NBL = 2, D = 3;      // bytes per weight set; loads per set; sets fetched ahead
+    static_assert(D * NBL + NA_ALL < 64, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals (see conv3x3_split_kernel)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave >> 1, mblk = wave & 1;                         // low-resolution rows 4 rg .. 4 rg + 3, pixels 16 mblk .. + 15
+    const int lp = lane & 15, kq = lane >> 4;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int oy0 = ty * 16, ox0 = tx * 32;                            // low-resolution tile origin
+    const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
+    const long long plane = (long long)sH * sW;
+    const int nchunks = p.Cin / U16_CK;
+
+    const int kg_st = wave >> 1, t128 = tid & 127;                     // staging: two waves per k-group
+    int goff[PR];
+#pragma unroll
+    for (int u = 0; u < PR; ++u) {
+        const int pix = u * 128 + t128;
+        const int r = pix / COLS, c = pix - r * COLS;
+        const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
+        goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
+    }
+    const unsigned char* wp_nt = reinterpret_cast<const unsigned char*>(p.wp) + (long long)nt * nchunks * (UF_ITEMS * B_ITEM);
+
+    float va[PR][8];
+    auto load_chunk = [&](int chunk) {
+        const float* base = p.src[0] + (long long)n * p.src_bstride[0] + (long long)(chunk * U16_CK + kg_st * 8) * plane;
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const unsigned voff = goff[u] < 0 ? 0u : (unsigned)goff[u];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* sb = base + (long long)k * plane;         // wave-uniform
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(va[u][k]) : "v"(voff), "s"(sb) : "memory");
+            }
+        }
+    };
+    auto store_round = [&](int buf, int u) {
+        unsigned char* A = smem + buf * A_BYTES + kg_st * NPIX * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));
+        const int pix = u * 128 + t128;
+        if (pix < NPIX) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
+            sph8 h1, h2;
+            sp_split8(v, p.prescale, h1, h2);
+            *reinterpret_cast<sph8*>(A + pix * 16) = h1;
+            *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
+        }
+    };
+    const unsigned boff = (unsigned)(lane * 16);                       // [k-group kq][filter lp][8 channels]
+    auto load_b = [&](f32x4 (&b)[2], int chunk, int item) {
+        const unsigned char* base = wp_nt + ((long long)chunk * UF_ITEMS + item) * B_ITEM;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned char* sb = base + t * (B_ITEM / 2);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[t]) : "v"(boff), "s"(sb) : "memory");
+        }
+    };
+
+    spf4 acc[4][2][2];    // [low-resolution row of the wave][py][px]
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[a >> 2][(a >> 1) & 1][a & 1][i] = 0.f;
+
+    // staged row r (0..5 of the wave's six) at column offset ox lives in register slot r, rows 2 and 3 at odd ox in 6 and 7
+    const unsigned char* const aptr = smem + (kq * NPIX + 4 * rg * COLS + 16 * mblk + lp) * 16;
+    sph8 af[8][2];
+    auto slot = [](int r, int ox) constexpr { return (r == 2 || r == 3) && (ox & 1) ? r + 4 : r; };
+    auto load_arow = [&](int abuf, int r, int ox) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            af[slot(r, ox)][t] = *reinterpret_cast<const sph8*>(aptr + abuf + t * A_PART + (r * COLS + ox) * 16);
+    };
+
+    f32x4 bq[4][2];       // weight sets in flight: set `it` lives in bq[it % 4]
+    auto chunk_body = [&](int c, auto more_tag, auto chk_tag) {
+        constexpr bool MORE = decltype(more_tag)::value, CHK = decltype(chk_tag)::value;
+        constexpr int NA = MORE ? NA_ALL : 0;
+        const int abuf = (c & 1) * A_BYTES;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load_arow(abuf, r, 0);
+#pragma unroll
+        for (int it = 0; it < UF_ITEMS; ++it) {
+            const UfItem t = uf_item(it);
+            const bool first_of_group = it == 0 || uf_item(it - 1).s != t.s || uf_item(it - 1).ox != t.ox;
+            if (first_of_group) {   // fetch what the NEXT groups read and this one does not hold
+                if (t.s == 0) load_arow(abuf, 4, t.ox);
+                else if (t.s == 1) load_arow(abuf, 5, t.ox);
+                else if (t.ox < 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) load_arow(abuf, r, t.ox + 1);
+                }
+            }
+            f32x4 (&bc)[2] = bq[it % 4];
+            if (it + D < UF_ITEMS) load_b(bq[(it + D) % 4], c, it + D);
+            else if (MORE) load_b(bq[(it + D) % 4], c + 1, it + D - UF_ITEMS);
+            if (it == 0 && MORE) load_chunk(c + 1);
+            // outstanding, oldest first: b(it) b(it+1) b(it+2) [b(it+3) | inputs in issue order]
+            if (it <= D) uf_wait_b<D * NBL + NA>(bc);
+            else if (MORE || it + D < UF_ITEMS) uf_wait_b<D * NBL>(bc);
+            else if (it == UF_ITEMS - 3) uf_wait_b<2 * NBL>(bc);
+            else if (it == UF_ITEMS - 2) uf_wait_b<NBL>(bc);
+            else uf_wait_b<0>(bc);
+            sph8 bw[3];
+            bw[0] = __builtin_bit_cast(sph8, bc[0]);
+            bw[1] = __builtin_bit_cast(sph8, bc[1]);
+            bw[2] = bw[0] * (_Float16)0.00048828125f;
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int TA[3] = {0, 0, 1};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    if (CHK && oy0 + 4 * rg + mb >= sH) continue;      // low-resolution row below the map: no MFMAs (wave-uniform)
+                    acc[mb][t.py][t.px] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot(mb + t.s, t.ox)][TA[k]], bw[k],
+                                                                                  acc[mb][t.py][t.px], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE && it > D + 1 && it - D - 2 < PR) store_round((c & 1) ^ 1, it - D - 2);   // the wait of set D+1 covered the inputs
+        }
+        __syncthreads();
+    };
+
+    load_chunk(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < PR; ++u) store_round(0, u);
+    __syncthreads();
+    auto k_loop = [&](auto chk_tag) {
+        // the first weight fetches are issued INSIDE the variant that awaits them: a register copy at the branch between an
+        // asm load and its vmcnt wait would copy what the register held before the data arrived
+#pragma unroll
+        for (int it = 0; it < D; ++it) load_b(bq[it], 0, it);
+        for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{}, chk_tag);
+        chunk_body(nchunks - 1, std::false_type{}, chk_tag);
+    };
+    if (!KBN_SPLIT_STRAIGHT || oy0 + 16 > sH) k_loop(std::true_type{});   // tile with rows below the map (workgroup-uniform)
+    else k_loop(std::false_type{});
+
+    // ---- epilogue: acc[mb][py][px][i]: low-resolution x = 16 mblk + 4 kq + i, filter lp; outputs (2 Y + py, 2 x + px)
+    const long long oplane = (long long)H * W;
+    const int oc = nt * U16_NT + lp;
+    const float inv = p.inv_scale[oc] * p.unscale;                    // the table is padded to whole n-tiles
+    if (oc >= p.OC) return;
+    float* outc = p.out + (long long)n * p.out_bstride + (long long)oc * oplane;
+    const float slope = p.act ? p.slope : 1.f;
+    const int X = 2 * (ox0 + 16 * mblk + 4 * kq);                      // first of this lane's 8 output columns
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int Y = oy0 + 4 * rg + mb;
+        if (Y >= sH) continue;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            float* orow = outc + (long long)(2 * Y + py) * W;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = acc[mb][py][j & 1][j >> 1] * inv;
+                const float b = acc[mb][py][j & 1][2 + (j >> 1)] * inv;
+                v0[j] = a > 0.f ? a : a * slope;
+                v1[j] = b > 0.f ? b : b * slope;
+            }
+            if (X < W) *reinterpret_cast<f32x4*>(orow + X) = v0;
+            if (X + 4 < W) *reinterpret_cast<f32x4*>(orow + X + 4) = v1;
+        }
+    }
+}
+
 }  // namespace kbn
 
 extern "C" {
 
-static int split_nt(int mode) { return mode == 2 ? 128 : (mode == 3 ? kbn::UF_NT : 64); }   // filters per workgroup
+// filters per workgroup; the folded up-conv takes 16-filter tiles for narrow layers (upconv2x_split16_kernel)
+static int split_nt(int mode, int out_channels, int in_channels) {
+    return mode == 2 ? 128 : (mode == 3 ? (kbn::uf_narrow(out_channels, in_channels) ? kbn::U16_NT : kbn::UF_NT) : 64);
+}
 
 size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, int mode) {
     using namespace kbn;
     if (out_channels < 1 || in_channels < 1 || (in_channels % SP_CK) != 0 || mode < 0 || mode > 3) return 0;
-    const int nt = split_nt(mode), tiles = ceil_div(out_channels, nt);
-    return (size_t)tiles * nt * 4 + (size_t)tiles * (in_channels / SP_CK) * ((mode == 3 ? UF_ITEMS : 9) * 2 * 2 * nt * 16);
+    const int nt = split_nt(mode, out_channels, in_channels), tiles = ceil_div(out_channels, nt);
+    return (size_t)tiles * nt * 4 + (size_t)tiles * (in_channels / SP_CK) * ((mode == 3 ? UF_ITEMS : 9) * 2 * 2 * nt * 16);   // per 16 channels: [set][part][2 k-groups][nt][8] fp16
 }
 
 int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int mode,
@@ -740,12 +1071,18 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
     using namespace kbn;
     const size_t bytes = kbn_conv3x3_split_packed_weight_bytes(out_channels, in_channels, mode);
     if (!weight || !packed || bytes == 0) return KBN_ERR_INVALID_ARGUMENT;
-    const int nt = split_nt(mode), ocpad = ceil_div(out_channels, nt) * nt;
+    const int nt = split_nt(mode, out_channels, in_channels), ocpad = ceil_div(out_channels, nt) * nt;
     float* inv = static_cast<float*>(packed);
     _Float16* wp = reinterpret_cast<_Float16*>(inv + ocpad);
     const long long total = (long long)((bytes - (size_t)ocpad * 4) / 2);
     if (mode == 3) {
         hipLaunchKernelGGL(uf_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels);
+        if (uf_narrow(out_channels, in_channels)) {
+            hipLaunchKernelGGL(uf16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv,
+                               wp, out_channels, in_channels, in_channels / U16_CK, total);
+            KBN_CHECK_LAUNCH();
+            return KBN_OK;
+        }
         hipLaunchKernelGGL(uf_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv, wp,
                            out_channels, in_channels, in_channels / SP_CK, total);
         KBN_CHECK_LAUNCH();
@@ -797,7 +1134,7 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     if ((long long)p.sH * p.sW > 0x1fffffffLL || (long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
     if (n_src == 1) { p.src[1] = p.src[0]; p.src_bstride[1] = p.src_bstride[0]; p.srcC[1] = 0; }
     p.nsrc = n_src;
-    const int ntf = split_nt(mode);
+    const int ntf = split_nt(mode, out_channels, cin);
     p.nTilesN = ceil_div(out_channels, ntf);
     p.inv_scale = static_cast<const float*>(packed_weight);
     p.wp = reinterpret_cast<const _Float16*>(p.inv_scale + p.nTilesN * ntf);
@@ -816,13 +1153,26 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(SP_THREADS), lds, (hipStream_t)stream, p);
         return KBN_OK;
     };
-    static DeviceOnce o[4];
+    static DeviceOnce o[5];
     int rc;
+    if (mode == 3 && uf_narrow(out_channels, cin)) {
+        rc = launch(upconv2x_split16_kernel, 2 * 2 * 4 * 18 * 34 * 16, o[4]);
+        if (rc != KBN_OK) return rc;
+        KBN_CHECK_LAUNCH();
+        return KBN_OK;
+    }
     switch (mode) {
         case 0: rc = launch(conv3x3_split_kernel<0, 8, true, true>, SpGeom<0>::LDS + 2 * 9 * 2 * 2 * 64 * 16, o[0]); break;
         case 1: rc = launch(conv3x3_split_kernel<1, 8, true, false>, SpGeom<1>::LDS, o[1]); break;
         case 2: rc = launch(conv3x3_split_kernel<2, 4, true, false>, SpGeom<2>::LDS, o[2]); break;
-        default: rc = launch(upconv2x_split_kernel, 2 * 2 * 2 * 18 * 34 * 16 * 2, o[3]); break;
+        default:
+            if (knob(KNOB_DEBUG) & 16) {   // weights fetched per set into registers (the form before the LDS stage), for A/B runs
+                static DeviceOnce o3r;
+                rc = launch(upconv2x_split_kernel<false>, 2 * 2 * 2 * 18 * 34 * 16 * 2, o3r);
+            } else {   // two A buffers (18 x 34 pixels x 16 channels x two fp16 terms) + two buffers of sixteen weight sets
+                rc = launch(upconv2x_split_kernel<true>, 2 * (2 * 2 * 18 * 34 * 16) + 2 * UF_ITEMS * (2 * 2 * UF_NT * 16), o[3]);
+            }
+            break;
     }
     if (rc != KBN_OK) return rc;
     KBN_CHECK_LAUNCH();

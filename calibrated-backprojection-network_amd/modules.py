@@ -125,13 +125,21 @@ class Conv2d(torch.nn.Module):
         self._packed_split_up = _PackedWeight()
         self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
         self.split = True   # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies
+        # the folded up-conv of a layer with at most 16 filters has 16-filter tiles (upconv2x_split16_kernel); measured level
+        # with the fp32 9-product kernel on deconv0 (650 vs 640 us per 32 KITTI frames): off, the fp32 kernel stays
+        self.split_narrow_up = False
         self._act_exp = None   # activation exponent of the split kernel's fp16 window, measured on the first call
 
     def run_split(self, srcs, n, h, w, out=None, up2x=False):
         """3x3 stride-1 conv with two-term fp16 splits of both operands (ops.conv3x3_split, fp32-grade results); `h` x `w`
         is the OUTPUT size.  None when the layer or the shape does not qualify."""
-        if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2 or self.out_channels < 48
+        if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2
                 or (up2x and self.stride != 1) or any(s.kind != _lib.KBN_SRC_TENSOR or s.channels % 16 for s in srcs)):
+            return None
+        # narrow layers stay on the fp32 kernels (a 64-filter tile would be mostly padding) -- except the folded up-conv,
+        # which has 16-filter tiles for them (deconv0's 64 -> 12 at full resolution)
+        narrow_up = up2x and self.split_narrow_up and self.out_channels <= 16 and self.in_channels % 32 == 0
+        if self.out_channels < 48 and not narrow_up:
             return None
         dev = self.conv.weight.device
         if out is None:

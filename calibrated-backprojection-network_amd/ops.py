@@ -499,7 +499,8 @@ def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1, 
     """fp16 MFMA FLOPs the split kernel executes: three products per fp32 product, whole (16 | 8) x 32 x (64 | 128) tiles
     (folded up-conv: 16 products per low-resolution pixel, 16 x 32 low-resolution pixels x 32 filters)."""
     if folded_up2x:
-        return 3 * 2.0 * n * (-(-(height // 2) // 16) * 16) * (-(-(width // 2) // 32) * 32) * cin * 16 * (-(-out_channels // 32) * 32)
+        nt = 16 if (out_channels <= 16 and cin % 32 == 0) else 32   # narrow layers: 16-filter tiles (upconv2x_split16_kernel)
+        return 3 * 2.0 * n * (-(-(height // 2) // 16) * 16) * (-(-(width // 2) // 32) * 32) * cin * 16 * (-(-out_channels // nt) * nt)
     nt = 128 if stride == 2 else 64
     th = 8 if stride == 2 else 16
     return 3 * 2.0 * n * (-(-height // th) * th) * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // nt) * nt)

@@ -14,6 +14,7 @@ LAYERS = [("deconv4_up", (512,), 256, 22, 76, True), ("deconv4_conv", (256, 512)
           ("deconv3_up", (256,), 128, 44, 152, True), ("deconv3_conv", (128, 256), 128, 44, 152, False),
           ("deconv2_up", (128,), 128, 88, 304, True), ("deconv2_conv", (128, 128), 128, 88, 304, False),
           ("deconv1_up", (128,), 64, 176, 608, True), ("deconv1_conv", (64, 64), 64, 176, 608, False),
+          ("deconv0_up", (64,), 12, 352, 1216, True),
           ("kb2_image", (48,), 96, 88, 304, "s2"), ("kb3_image", (96,), 192, 44, 152, "s2"), ("kb4_image", (192,), 384, 22, 76, "s2")]
 ONLY = os.environ.get("SPLIT_ONLY")           # one layer, split kernel only (PMC runs)
 if ONLY:
