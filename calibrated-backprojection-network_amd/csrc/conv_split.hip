@@ -7,6 +7,9 @@
 //     activation  a 2^k    = h1 + 2^-11 h2,   h1 = fp16(a 2^k),   h2 = fp16((a 2^k - h1) 2^11)       (22+ bits of a)
 //     weight      w 2^e    = w1 + w2,         w1 = fp16(w 2^e),   w2 = fp16(w 2^e - w1)              (22+ bits of w)
 //     a w 2^(e+k) = h1 w1 + h1 w2 + h2 (w1 2^-11)   (+ h2 w2 2^-11, below 2^-22 |a w|, dropped)
+//                 = h1 w1 + 2^-11 (h1 (w2 2^11) + h2 w1): the 3x3 kernels keep w2 scaled by 2^11 as well (normal in fp16
+//                   down to |w2| = 2^-25) and sum the two small terms, both 2^11 times their share, in an accumulator of
+//                   their own that enters the result once, in the epilogue -- no per-tap scaling of w1 in the K loop
 // THREE fp16 MFMAs with fp32 accumulation per product, 3/16 of the fp32 MFMA's time.  The residual h2 is kept SCALED by
 // 2^11 so that it sits in fp16's normal range whenever h1 does (the matrix core flushes fp16 subnormals); e is chosen
 // per filter at pack time (largest |w 2^e| in [2^12, 2^13)); k (`act_exponent`) is the caller's: it places the fp16
@@ -35,7 +38,7 @@
 //      a chunk are copied into LDS by LDS-DMA (double buffered): every global access of chunk c+1 is issued at the
 //      start of chunk c and awaited once, late in it -- no vmcnt wait between MFMAs.  MODE 2 (its input tile leaves no
 //      LDS for that): every wave loads its B fragments straight from global memory, one tap ahead (the row-group waves
-//      of a filter group hit the same lines in L1).  w1 2^-11 is formed in registers (v_pk_mul_f16).
+//      of a filter group hit the same lines in L1).
 // ONE barrier per chunk.  What bounds it: the chip's power limit (the MFMAs alone: 77 % of the launch at 1.7-2.0 GHz;
 // zero-filled operands run 25 % faster through the same instruction stream), then the part of the skeleton that does
 // not hide under them (DESIGN.md section 4 has the ablation).
@@ -144,7 +147,8 @@ __global__ void pack_split_kernel(const float* __restrict__ w, const float* __re
     if (c < Cin && oc < OC) {
         const float ws = w[((long long)oc * Cin + c) * 9 + tap] * (1.f / inv_scale[oc]);   // w 2^e, exact
         const _Float16 w1 = (_Float16)ws;
-        h = part == 0 ? w1 : (_Float16)(ws - (float)w1);
+        h = part == 0 ? w1 : (_Float16)((ws - (float)w1) * 2048.f);   // the residual scaled by 2^11 (|.| <= 4096), like the activations'
+
     }
     packed[e] = h;
 }
@@ -175,6 +179,7 @@ __device__ __forceinline__ void sp_wait_b(f32x4 (&b)[2][2]) {   // vmcnt(N), tie
 // the tap-2 wait also had to wait for the next chunk's inputs, +28 % on the decoder's concat convs).
 template <int MODE, int RG, bool APART, bool BLDS>
 __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
+    static_assert(APART, "the two small terms share the scale 2^11 and an accumulator of their own");
     using G = SpGeom<MODE>;
     constexpr bool UP = G::UP, S2 = G::S2;
     constexpr int NB = 2, FG = 8 / RG;
@@ -294,11 +299,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     };
     // CHK (a tag type): MFMAs of output rows below the map (22 rows in 16-row tiles) and of 32-filter blocks past the last
     // filter (96 or 192 filters in 128-wide tiles) are skipped under wave-uniform branches
-    auto mfma_group = [&](auto chk_tag, const sph8 (&a)[GM][2], const sph8 (&b)[NB][3], int grp) {
+    auto mfma_group = [&](auto chk_tag, const sph8 (&a)[GM][2], const sph8 (&b)[NB][2], int grp) {
         constexpr bool CHK = decltype(chk_tag)::value;
         const bool nb0_live = nt * NT + fg * 32 * NB < p.OC, nb1_live = nt * NT + fg * 32 * NB + 32 < p.OC;   // wave-uniform
         const int mb0 = (grp % GPT) * GM;
-        constexpr int TA[3] = {0, 0, 1}, TBP[3] = {0, 1, 2};   // h1 w1, h1 w2, h2 (w1 2^-11)
+        constexpr int TA[3] = {0, 0, 1}, TBP[3] = {0, 1, 0};   // h1 w1 | h1 (w2 2^11), h2 w1: both 2^11 x their term of the product
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -311,8 +316,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][TA[t]], b[nb][TBP[t]], c, 0, 0, 0);
                 }
     };
-    // stride 2 keeps the tested loop for every tile: a second copy of its K loop does not fit the register file
-    const bool padded_tile = !KBN_SPLIT_STRAIGHT || S2 || oy0 + G::TH > H || (nt + 1) * NT - 32 >= p.OC;   // workgroup-uniform
+    const bool padded_tile = !KBN_SPLIT_STRAIGHT || oy0 + G::TH > H || (nt + 1) * NT - 32 >= p.OC;   // workgroup-uniform
 
     f32x4 bq0[NB][2], bq1[NB][2];   // fetched weights (w1, w2) of the current / next tap
     constexpr int AD = 1;           // A fragments fetched AD groups ahead (2 measured the same)
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 load_chunk(c + 1);
             }
             load_a(aq[0], abuf, 0);
-            sph8 bw[NB][3];
+            sph8 bw[NB][2];
 #pragma unroll
             for (int grp = 0; grp < NGROUP; ++grp) {
                 const int tap = grp / GPT, gi = grp % GPT;
@@ -352,7 +356,6 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                     for (int nb = 0; nb < NB; ++nb) {
                         bw[nb][0] = *reinterpret_cast<const sph8*>(B + tap * B_TAP + nb * 32 * 16);
                         bw[nb][1] = *reinterpret_cast<const sph8*>(B + tap * B_TAP + (2 * NT + nb * 32) * 16);
-                        bw[nb][2] = bw[nb][0] * (_Float16)0.00048828125f;   // w1 2^-11
                     }
                 }
                 if (MORE && grp == 5 * GPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's weights (DMA) and inputs: issued five taps ago
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
         const int abuf = (c & 1) * G::A_BYTES;
 #pragma unroll
         for (int d = 0; d < AD; ++d) load_a(aq[d], abuf, d);
-        sph8 bw[NB][3];
+        sph8 bw[NB][2];
 #pragma unroll
         for (int grp = 0; grp < NGROUP; ++grp) {
             const int tap = grp / GPT, gi = grp % GPT;
@@ -408,7 +411,6 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 for (int nb = 0; nb < NB; ++nb) {
                     bw[nb][0] = __builtin_bit_cast(sph8, bc[nb][0]);
                     bw[nb][1] = __builtin_bit_cast(sph8, bc[nb][1]);
-                    bw[nb][2] = bw[nb][0] * (_Float16)0.00048828125f;   // w1 2^-11
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
         for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{}, chk_tag);
         chunk_body(nchunks - 1, std::false_type{}, chk_tag);
     };
-    if (S2 || padded_tile) k_loop(std::true_type{});
+    if (padded_tile) k_loop(std::true_type{});
     else k_loop(std::false_type{});
     }
 
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float t = (APART ? acc[mb][nb][q4 * 4 + j] + lo[mb][nb][q4 * 4 + j] : acc[mb][nb][q4 * 4 + j]) * inv;
+                    const float t = __builtin_fmaf(lo[mb][nb][q4 * 4 + j], 0.00048828125f, acc[mb][nb][q4 * 4 + j]) * inv;   // main + 2^-11 small
                     v[j] = t > 0.f ? t : t * slope;
                 }
                 if (vec4) {                                             // W % 4 == 0: a quad is in or out as a whole, rows 16-byte aligned

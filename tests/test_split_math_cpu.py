@@ -1,5 +1,6 @@
 """The arithmetic of csrc/conv_split.hip restated in numpy (no GPU): fp32 operands as pairs of fp16 values,
-a 2^k = h1 + 2^-11 h2, w 2^e = w1 + w2, a w = 2^-(e+k) (h1 w1 + h1 w2 + h2 (w1 2^-11)).  Checks the representation
+a 2^k = h1 + 2^-11 h2, w 2^e = w1 + w2, a w = 2^-(e+k) (h1 w1 + h1 w2 + h2 (w1 2^-11)) -- the 3x3 kernels in the form
+h1 w1 + 2^-11 (h1 (w2 2^11) + h2 w1), the folded up-conv with w1 2^-11 formed per weight set.  Checks the representation
 error of the scheme against fp64 and the exponent rule of the host mirror (ops.act_exponent_for)."""
 import math
 
@@ -9,7 +10,7 @@ import pytest
 import kbnet_amd as kb
 
 
-def split_dot(a, w, k):
+def split_dot(a, w, k, folded=False):
     """sum_c a[c] w[c] the way the kernel forms it (products exact, accumulation here in fp64: the test isolates the
     representation error; the GPU tests cover the fp32 accumulation)."""
     wmax = np.abs(w).max()
@@ -20,14 +21,21 @@ def split_dot(a, w, k):
     h2 = ((ap - h1.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
     ws = (w * np.float32(2.0 ** e)).astype(np.float32)
     w1 = ws.astype(np.float16)
-    w2 = (ws - w1.astype(np.float32)).astype(np.float16)
-    w1s = (w1.astype(np.float32) * np.float32(2.0 ** -11)).astype(np.float16)
-    h1, h2, w1, w2, w1s = (x.astype(np.float64) for x in (h1, h2, w1, w2, w1s))
-    return float((h1 * w1 + h1 * w2 + h2 * w1s).sum() * 2.0 ** -(e + k))
+    flush = lambda x: np.where(np.abs(x.astype(np.float32)) < 2.0 ** -14, np.float16(0), x)   # the matrix core drops fp16 subnormals
+    if folded:   # the folded up-conv: one accumulator, w2 unscaled, w1 2^-11 formed in registers
+        w2 = flush((ws - w1.astype(np.float32)).astype(np.float16))
+        w1s = flush((w1.astype(np.float32) * np.float32(2.0 ** -11)).astype(np.float16))
+        h1, h2, w1, w2, w1s = (x.astype(np.float64) for x in (h1, h2, w1, w2, w1s))
+        return float((h1 * w1 + h1 * w2 + h2 * w1s).sum() * 2.0 ** -(e + k))
+    # the 3x3 kernels: the weight residual scaled by 2^11 like the activations', both small terms in one accumulator
+    w2 = flush(((ws - w1.astype(np.float32)) * np.float32(2048.0)).astype(np.float16))
+    h1, h2, w1, w2 = (x.astype(np.float64) for x in (h1, h2, w1, w2))
+    return float(((h1 * w1).sum() + (h1 * w2 + h2 * w1).sum() * 2.0 ** -11) * 2.0 ** -(e + k))
 
 
+@pytest.mark.parametrize("folded", [False, True])
 @pytest.mark.parametrize("amag", [1.0, 1e-4, 3e5])
-def test_split_product_representation_error(amag):
+def test_split_product_representation_error(amag, folded):
     rng = np.random.default_rng(3)
     K, trials = 2304, 64
     errs, scale = [], []
@@ -37,7 +45,7 @@ def test_split_product_representation_error(amag):
         w = (rng.standard_normal(K) / math.sqrt(K)).astype(np.float32)
         k = kb.ops.act_exponent_for(float(np.abs(a).max()))
         ref = float((a.astype(np.float64) * w.astype(np.float64)).sum())
-        errs.append(split_dot(a, w, k) - ref)
+        errs.append(split_dot(a, w, k, folded) - ref)
         scale.append(ref)
     rms = math.sqrt(np.mean(np.square(errs))) / math.sqrt(np.mean(np.square(scale)))
     assert rms < 4e-7, rms        # fp32 rounding of the operands alone would leave ~4e-8; an fmaf chain of this length ~8e-7
