@@ -89,6 +89,10 @@ struct SplitConvParams {
     int vec4;                   // output rows are 16-byte aligned quads (width % 4 == 0, aligned base and strides)
     float prescale;             // 2^k on the activations (k = act_exponent of the launch)
     float unscale;              // 2^-k
+    // conv1x1s2_split_kernel: three more input channels taken in fp32 in the epilogue (the KB block's backprojection)
+    const float* xyz;           // N x 3 x H x W (output size), or null
+    long long xyz_bstride;
+    const float* wxyz;          // out_channels x 3 fp32
 };
 
 // two-term split of 8 floats: h1 = fp16(a 2^k), h2 = fp16((a 2^k - h1) 2^11)
@@ -130,11 +134,13 @@ __global__ void split_scale_kernel(const float* __restrict__ w, float* __restric
 }
 
 // pass 2: OIHW fp32 -> [n-tile][chunk][tap][part][k-group][n][8 k] fp16, zero padded
+// `taps` = 9 (3x3) or 1 (1x1); channel c of the packed panel is channel c (c < skip_at) or c + skip of the weight: the
+// 1x1 conv of the KB block leaves its three backprojection channels out of the panel (they are taken in fp32)
 __global__ void pack_split_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, _Float16* __restrict__ packed,
-                                  int OC, int Cin, int nchunks, int NT, long long total) {
+                                  int OC, int Cin, int nchunks, int NT, long long total, int taps, int skip_at, int skip) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    const int per_chunk = 9 * 2 * 2 * NT * 8;
+    const int per_chunk = taps * 2 * 2 * NT * 8;
     int r = (int)(e % per_chunk);
     const long long q = e / per_chunk;
     const int chunk = (int)(q % nchunks), nt = (int)(q / nchunks);
@@ -145,7 +151,8 @@ __global__ void pack_split_kernel(const float* __restrict__ w, const float* __re
     const int c = chunk * SP_CK + g * 8 + k, oc = nt * NT + n;
     _Float16 h = (_Float16)0.f;
     if (c < Cin && oc < OC) {
-        const float ws = w[((long long)oc * Cin + c) * 9 + tap] * (1.f / inv_scale[oc]);   // w 2^e, exact
+        const int cw = c < skip_at ? c : c + skip;
+        const float ws = w[((long long)oc * (Cin + skip) + cw) * taps + tap] * (1.f / inv_scale[oc]);   // w 2^e, exact
         const _Float16 w1 = (_Float16)ws;
         h = part == 0 ? w1 : (_Float16)((ws - (float)w1) * 2048.f);   // the residual scaled by 2^11 (|.| <= 4096), like the activations'
 
@@ -1052,6 +1059,230 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 stride-2 conv (+ LeakyReLU) on split operands: conv_fused of the KB block, reference src/net_utils.py:1337-1343 and
+// :1366-1368 (cat[image, xyz, fused] -> Conv2d(kernel 1, stride 2)).  The tensor channels (image, fused: multiples of
+// 16) go through the matrix core like the 3x3 kernels' -- one "tap", M = 32 output pixels of a row (input pixels
+// (2y, 2x)), N = 32 filters, K = 16 channels -- the three backprojection channels K^-1 [x y 1]^T z, computed once per
+// block by kb_xyz_s2_kernel, enter in fp32 in the epilogue (three FMAs per output).  Workgroup = 8 waves = 4 row groups
+// x 2 filter groups, tile 8 rows x 32 pixels x 128 filters, main and small-term accumulators as in conv3x3_split_kernel.
+// A chunk is only twelve MFMAs per wave, so the K loop is a short software pipeline: weights of chunk c+1 and inputs of
+// chunk c+2 are issued at the top of chunk c (two register sets by chunk parity), the inputs of chunk c+1 are split and
+// written to the other A buffer after the MFMAs of chunk c; one barrier per chunk; vmcnt waits count the loads in
+// issue order (b(c) | inputs(c+1) | b(c+1) | inputs(c+2)).
+template <int N>
+__device__ __forceinline__ void c1_wait_b(f32x4 (&b)[2][2]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void c1_wait_a(float (&v)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "n"(N));
+}
+
+__global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const SplitConvParams p) {
+    constexpr int TH = 8, RG = 4, MB = 2, NB = 2, NT = 128, NPIX = TH * SP_TW;
+    constexpr int A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART;          // [part][k-group][pixel][8 fp16]
+    constexpr int B_CHUNK = 2 * 2 * NT * 16;                             // bytes: [part][k-group][filter][8 fp16]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");      // fp16 results flush subnormals (see conv3x3_split_kernel)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave % RG, fg = wave / RG;
+    const int lm = lane & 31, g = lane >> 5;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int oy0 = ty * TH, ox0 = tx * SP_TW;
+    const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
+    const long long plane = (long long)sH * sW;
+    const int nchunks = p.Cin / SP_CK;
+
+    // staging: waves 0-3 take k-group 0 of a chunk, waves 4-7 k-group 1; one pixel per thread: output (r, c) reads input (2 r, 2 c)
+    const int kg_st = wave >> 2, t256 = tid & 255;
+    const int sy = 2 * (oy0 + (t256 >> 5)), sx = 2 * (ox0 + (t256 & 31));
+    const int goff = (sy < sH && sx < sW) ? (sy * sW + sx) * 4 : -1;
+    const unsigned char* wp_nt = reinterpret_cast<const unsigned char*>(p.wp) + (long long)nt * nchunks * B_CHUNK;
+
+    float va[2][8];
+    auto load_chunk = [&](float (&v)[8], int chunk) {
+        int c = chunk * SP_CK, s = 0;
+        if (p.nsrc > 1 && c >= p.srcC[0]) { c -= p.srcC[0]; s = 1; }
+        const float* base = p.src[s] + (long long)n * p.src_bstride[s] + (long long)(c + kg_st * 8) * plane;
+        const unsigned voff = goff < 0 ? 0u : (unsigned)goff;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float* sb = base + (long long)k * plane;   // wave-uniform
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(v[k]) : "v"(voff), "s"(sb) : "memory");
+        }
+    };
+    auto store_chunk = [&](int buf, const float (&vin)[8]) {
+        unsigned char* A = smem + buf * A_BYTES + kg_st * NPIX * 16;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = goff >= 0 ? vin[k] : 0.f;
+        sph8 h1, h2;
+        sp_split8(v, p.prescale, h1, h2);
+        *reinterpret_cast<sph8*>(A + t256 * 16) = h1;
+        *reinterpret_cast<sph8*>(A + A_PART + t256 * 16) = h2;
+    };
+    const unsigned boff = (unsigned)((g * NT + fg * 32 * NB + lm) * 16);
+    auto load_b = [&](f32x4 (&b)[NB][2], int chunk) {
+        const unsigned char* base = wp_nt + (long long)chunk * B_CHUNK;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned char* sb = base + (t * 2 * NT + nb * 32) * 16;   // wave-uniform
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[nb][t]) : "v"(boff), "s"(sb) : "memory");
+            }
+    };
+
+    spf16 acc[MB][NB], lo[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[mb][nb][i] = 0.f; lo[mb][nb][i] = 0.f; }
+
+    const unsigned char* const aptr = smem + (g * NPIX + MB * rg * SP_TW + lm) * 16;
+    const bool nb0_live = nt * NT + fg * 32 * NB < p.OC, nb1_live = nt * NT + fg * 32 * NB + 32 < p.OC;   // wave-uniform
+    f32x4 bq[2][NB][2];
+    constexpr int NLB = 2 * NB, NLA = 8;   // loads per weight fetch / per input fetch
+    // PAR: parity of c (register sets).  ONE form of the body: past the last chunk the fetches repeat the last chunk (their
+    // data is never used) and the MFMAs are skipped, so that the vmcnt arithmetic is the same in every iteration and the
+    // kernel holds two copies of the body, not seven.
+    const int last = nchunks - 1;
+    auto body = [&](int c, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        load_b(bq[PAR ^ 1], min(c + 1, last));
+        load_chunk(va[PAR], min(c + 2, last));
+        // outstanding, oldest first: b(c) | inputs(c+1) | b(c+1) | inputs(c+2)
+        c1_wait_b<NLA + NLB + NLA>(bq[PAR]);
+        if (c <= last) {
+            sph8 bw[NB][2], a[MB][2];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bw[nb][0] = __builtin_bit_cast(sph8, bq[PAR][nb][0]);
+                bw[nb][1] = __builtin_bit_cast(sph8, bq[PAR][nb][1]);
+            }
+            const int abuf = PAR * A_BYTES;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a[mb][t] = *reinterpret_cast<const sph8*>(aptr + abuf + t * A_PART + mb * SP_TW * 16);
+            constexpr int TA[3] = {0, 0, 1}, TBP[3] = {0, 1, 0};   // h1 w1 | h1 (w2 2^11), h2 w1
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        spf16& d = t > 0 ? lo[mb][nb] : acc[mb][nb];
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][TA[t]], bw[nb][TBP[t]], d, 0, 0, 0);
+                    }
+        }
+        c1_wait_a<NLB + NLA>(va[PAR ^ 1]);   // inputs of chunk c+1 (fetched a chunk and a half ago)
+        store_chunk(PAR ^ 1, va[PAR ^ 1]);
+        __syncthreads();
+    };
+
+    load_chunk(va[0], 0);
+    c1_wait_a<0>(va[0]);
+    store_chunk(0, va[0]);
+    load_b(bq[0], 0);
+    load_chunk(va[1], min(1, last));
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        body(c, std::integral_constant<int, 0>{});
+        body(c + 1, std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated fetches of the last iterations land before their registers are reused
+
+    // ---- epilogue: acc[mb][nb][i]: pixel x = 8 (i / 4) + 4 g + (i % 4) of row MB rg + mb, filter fg * 64 + nb * 32 + lm
+    const long long oplane = (long long)H * W;
+    float* outn = p.out + (long long)n * p.out_bstride;
+    const float* xyzn = p.xyz ? p.xyz + (long long)n * p.xyz_bstride : nullptr;
+    const float slope = p.act ? p.slope : 1.f;
+    const bool vec4 = p.vec4 != 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int oc = nt * NT + fg * 32 * NB + nb * 32 + lm;
+        const float inv = p.inv_scale[oc] * p.unscale;               // 2^-e 2^-k; the table is padded to whole n-tiles
+        if (oc >= p.OC) continue;
+        float wx[3] = {0.f, 0.f, 0.f};
+        if (xyzn) { wx[0] = p.wxyz[oc * 3]; wx[1] = p.wxyz[oc * 3 + 1]; wx[2] = p.wxyz[oc * 3 + 2]; }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int Y = oy0 + MB * rg + mb;
+            if (Y >= H) continue;
+            float* o = outn + (long long)oc * oplane + (long long)Y * W + ox0 + 4 * g;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int X = ox0 + 8 * q4 + 4 * g;
+                if (X >= W) continue;
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = __builtin_fmaf(lo[mb][nb][q4 * 4 + j], 0.00048828125f, acc[mb][nb][q4 * 4 + j]) * inv;
+                    if (xyzn && X + j < W) {
+                        const float* xp = xyzn + (long long)Y * W + X + j;
+                        t += wx[0] * xp[0] + wx[1] * xp[oplane] + wx[2] * xp[2 * oplane];
+                    }
+                    v[j] = t > 0.f ? t : t * slope;
+                }
+                if (vec4) {
+                    *reinterpret_cast<f32x4*>(o + 8 * q4) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (X + j < W) o[8 * q4 + j] = v[j];
+                }
+            }
+        }
+    }
+}
+
+// the KB block's backprojection at the positions its stride-2 1x1 conv reads: xyz[:, j, y, x] = (K^-1 [2x 2y 1]^T)_j z,
+// z = act(proj_weight . depth[:, 2y, 2x]) (reference src/net_utils.py:1352-1359; the same expressions as the in-kernel
+// synthesis of the fp32 conv kernels, conv_dma_impl.h)
+__global__ void kb_xyz_s2_kernel(const float* __restrict__ depth, long long dbs, int Cd, int H, int W, const float* __restrict__ proj,
+                                 const float* __restrict__ kinv, int act, float slope, float* __restrict__ xyz, long long xbs,
+                                 int oh, int ow) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (idx >= oh * ow) return;
+    const int oy = idx / ow, ox = idx - oy * ow;
+    const int Y = 2 * oy, X = 2 * ox;
+    const long long HW = (long long)H * W;
+    const float* db = depth + (long long)n * dbs + (long long)Y * W + X;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = 0;
+    for (; c + 3 < Cd; c += 4) {
+        a0 = fmaf(proj[c], db[(long long)c * HW], a0);
+        a1 = fmaf(proj[c + 1], db[(long long)(c + 1) * HW], a1);
+        a2 = fmaf(proj[c + 2], db[(long long)(c + 2) * HW], a2);
+        a3 = fmaf(proj[c + 3], db[(long long)(c + 3) * HW], a3);
+    }
+    for (; c < Cd; ++c) a0 = fmaf(proj[c], db[(long long)c * HW], a0);
+    const float a = (a0 + a1) + (a2 + a3);
+    const float z = act ? leaky_relu(a, slope) : a;
+    const float* ki = kinv + (long long)n * 9;
+    float* o = xyz + (long long)n * xbs + idx;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        o[(long long)j * oh * ow] = (fmaf(ki[j * 3 + 1], (float)Y, ki[j * 3 + 0] * (float)X) + ki[j * 3 + 2]) * z;
+}
+
+__global__ void copy_wxyz_kernel(const float* __restrict__ w, float* __restrict__ wxyz, int OC, int cin_total, int xyz_offset) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < OC * 3) wxyz[e] = w[(long long)(e / 3) * cin_total + xyz_offset + e % 3];
+}
+
 }  // namespace kbn
 
 extern "C" {
@@ -1092,7 +1323,7 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
     }
     hipLaunchKernelGGL(split_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels * 9);
     hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
-                       inv, wp, out_channels, in_channels, in_channels / SP_CK, nt, total);
+                       inv, wp, out_channels, in_channels, in_channels / SP_CK, nt, total, 9, in_channels, 0);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
@@ -1177,6 +1408,97 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
             break;
     }
     if (rc != KBN_OK) return rc;
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+
+// ---- 1x1 stride-2 conv on split operands (conv_fused of the KB block) --------------------------------------------------
+// blob: [inv_scale: tiles x 128 floats][fp16 panel: tiles x (cin / 16) x 8 KiB][wxyz: out_channels x 3 floats, if any]
+static size_t c1_panel_bytes(int out_channels, int cin) {
+    return (size_t)kbn::ceil_div(out_channels, 128) * (128 * 4 + (size_t)(cin / kbn::SP_CK) * (2 * 2 * 128 * 16));
+}
+
+size_t kbn_conv1x1s2_split_packed_weight_bytes(int out_channels, int tensor_channels, int has_xyz) {
+    if (out_channels < 1 || tensor_channels < 1 || (tensor_channels % kbn::SP_CK) != 0) return 0;
+    return c1_panel_bytes(out_channels, tensor_channels) + (has_xyz ? (size_t)out_channels * 3 * 4 : 0);
+}
+
+int kbn_conv1x1s2_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int xyz_offset,
+                                    kbn_stream_t stream) {
+    using namespace kbn;
+    const bool has_xyz = xyz_offset >= 0;
+    const int cin = in_channels - (has_xyz ? 3 : 0);
+    if (!weight || !packed || (has_xyz && xyz_offset > cin) || kbn_conv1x1s2_split_packed_weight_bytes(out_channels, cin, has_xyz) == 0)
+        return KBN_ERR_INVALID_ARGUMENT;
+    const int ocpad = ceil_div(out_channels, 128) * 128;
+    float* inv = static_cast<float*>(packed);
+    _Float16* wp = reinterpret_cast<_Float16*>(inv + ocpad);
+    const long long total = (long long)((c1_panel_bytes(out_channels, cin) - (size_t)ocpad * 4) / 2);
+    // per-filter exponent over ALL input channels of the filter (the three fp32 ones can only make it more cautious)
+    hipLaunchKernelGGL(split_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels);
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv, wp,
+                       out_channels, cin, cin / SP_CK, 128, total, 1, has_xyz ? xyz_offset : cin, has_xyz ? 3 : 0);
+    if (has_xyz) {
+        float* wxyz = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + c1_panel_bytes(out_channels, cin));
+        hipLaunchKernelGGL(copy_wxyz_kernel, dim3(ceil_div(out_channels * 3, 256)), dim3(256), 0, (hipStream_t)stream, weight, wxyz,
+                           out_channels, in_channels, xyz_offset);
+    }
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_conv1x1s2_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, const float* xyz,
+                                long long xyz_batch_stride, float* out, long long out_batch_stride, int n, int out_channels,
+                                int height, int width, int act_exponent, int apply_activation, float negative_slope,
+                                kbn_stream_t stream) {
+    using namespace kbn;
+    if (act_exponent < -60 || act_exponent > 60) return KBN_ERR_INVALID_ARGUMENT;
+    if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || !out || n < 1 || out_channels < 1 || height < 1 || width < 1)
+        return KBN_ERR_INVALID_ARGUMENT;
+    if (knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
+    SplitConvParams p{};
+    int cin = 0;
+    for (int s = 0; s < n_src; ++s) {
+        const kbn_conv_src& a = srcs[s];
+        if (a.kind != KBN_SRC_TENSOR || !a.data || a.channels < 1 || (a.channels % SP_CK) != 0) return KBN_ERR_UNSUPPORTED;
+        if (s == 0) { p.sH = a.src_height; p.sW = a.src_width; }
+        if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
+        p.src[s] = a.data; p.src_bstride[s] = a.batch_stride; p.srcC[s] = a.channels;
+        cin += a.channels;
+    }
+    if (ceil_div(p.sH, 2) != height || ceil_div(p.sW, 2) != width) return KBN_ERR_INVALID_ARGUMENT;
+    if ((long long)p.sH * p.sW > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
+    if (n_src == 1) { p.src[1] = p.src[0]; p.src_bstride[1] = p.src_bstride[0]; p.srcC[1] = 0; }
+    p.nsrc = n_src;
+    p.nTilesN = ceil_div(out_channels, 128);
+    p.inv_scale = static_cast<const float*>(packed_weight);
+    p.wp = reinterpret_cast<const _Float16*>(p.inv_scale + p.nTilesN * 128);
+    p.xyz = xyz; p.xyz_bstride = xyz_batch_stride;
+    p.wxyz = xyz ? reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed_weight) + c1_panel_bytes(out_channels, cin)) : nullptr;
+    p.out = out; p.out_bstride = out_batch_stride;
+    p.N = n; p.OC = out_channels; p.Cin = cin; p.H = height; p.W = width;
+    p.tilesX = ceil_div(width, SP_TW); p.tilesY = ceil_div(height, 8);
+    const long long blocks = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
+    if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.nblocks = (int)blocks;
+    p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
+    p.prescale = ldexpf(1.f, act_exponent); p.unscale = ldexpf(1.f, -act_exponent);
+    p.vec4 = !((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3)) ? 1 : 0;
+    hipLaunchKernelGGL(conv1x1s2_split_kernel, dim3(p.nblocks), dim3(SP_THREADS), 2 * 2 * 2 * 256 * 16, (hipStream_t)stream, p);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_kb_xyz_s2_forward(const float* depth, long long depth_batch_stride, int depth_channels, int height, int width,
+                          const float* proj_weight, const float* kinv, int apply_activation, float negative_slope, float* xyz,
+                          long long xyz_batch_stride, int n, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!depth || !proj_weight || !kinv || !xyz || n < 1 || depth_channels < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    const int oh = ceil_div(height, 2), ow = ceil_div(width, 2);
+    hipLaunchKernelGGL(kb_xyz_s2_kernel, dim3(ceil_div(oh * ow, 256), n), dim3(256), 0, (hipStream_t)stream, depth, depth_batch_stride,
+                       depth_channels, height, width, proj_weight, kinv, apply_activation ? 1 : 0, negative_slope, xyz,
+                       xyz_batch_stride, oh, ow);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
