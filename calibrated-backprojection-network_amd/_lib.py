@@ -78,6 +78,10 @@ SIGNATURES = {
     "kbn_conv3x3_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_conv3x3_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "kbn_conv3x3_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_conv1x1s2_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
+    "kbn_conv1x1s2_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "kbn_conv1x1s2_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_kb_xyz_s2_forward": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _F, _P, _L, _I, _P]),
     "kbn_conv3x3_bf16_packed_weight_bytes": (C.c_size_t, [_I, _I]),
     "kbn_conv3x3_bf16_pack_weight": (_I, [_P, _P, _I, _I, _P]),
     "kbn_conv3x3_bf16_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P]),

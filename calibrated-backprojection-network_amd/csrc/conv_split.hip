@@ -1070,7 +1070,10 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
 // A chunk is only twelve MFMAs per wave, so the K loop is a short software pipeline: weights of chunk c+1 and inputs of
 // chunk c+2 are issued at the top of chunk c (two register sets by chunk parity), the inputs of chunk c+1 are split and
 // written to the other A buffer after the MFMAs of chunk c; one barrier per chunk; vmcnt waits count the loads in
-// issue order (b(c) | inputs(c+1) | b(c+1) | inputs(c+2)).
+// issue order (b(c) | inputs(c+1) | b(c+1) | inputs(c+2)).  Past the last chunk the fetches repeat the last chunk (never
+// used) and the MFMAs are skipped: the vmcnt arithmetic is the same in every iteration and the kernel holds two copies
+// of the body (seven tail variants spilled).  The loop is bound by memory latency, not by its MFMAs (a wave-private
+// variant without LDS and barriers, every lane fetching its own fragment, measured 15 % slower: twice the loads).
 template <int N>
 __device__ __forceinline__ void c1_wait_b(f32x4 (&b)[2][2]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
@@ -1100,7 +1103,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const Sp
     const int oy0 = ty * TH, ox0 = tx * SP_TW;
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
-    const int nchunks = p.Cin / SP_CK;
+    const int nchunks = p.Cin / SP_CK, last = nchunks - 1;
 
     // staging: waves 0-3 take k-group 0 of a chunk, waves 4-7 k-group 1; one pixel per thread: output (r, c) reads input (2 r, 2 c)
     const int kg_st = wave >> 2, t256 = tid & 255;
@@ -1151,14 +1154,9 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const Sp
             for (int i = 0; i < 16; ++i) { acc[mb][nb][i] = 0.f; lo[mb][nb][i] = 0.f; }
 
     const unsigned char* const aptr = smem + (g * NPIX + MB * rg * SP_TW + lm) * 16;
-    const bool nb0_live = nt * NT + fg * 32 * NB < p.OC, nb1_live = nt * NT + fg * 32 * NB + 32 < p.OC;   // wave-uniform
     f32x4 bq[2][NB][2];
     constexpr int NLB = 2 * NB, NLA = 8;   // loads per weight fetch / per input fetch
-    // PAR: parity of c (register sets).  ONE form of the body: past the last chunk the fetches repeat the last chunk (their
-    // data is never used) and the MFMAs are skipped, so that the vmcnt arithmetic is the same in every iteration and the
-    // kernel holds two copies of the body, not seven.
-    const int last = nchunks - 1;
-    auto body = [&](int c, auto par_tag) {
+    auto body = [&](int c, auto par_tag) {   // PAR: parity of c (register sets, A buffer)
         constexpr int PAR = decltype(par_tag)::value;
         load_b(bq[PAR ^ 1], min(c + 1, last));
         load_chunk(va[PAR], min(c + 2, last));

@@ -86,6 +86,8 @@ class _PackedWeight:
                 self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, stride=stride)
             elif up2x == "split_up":   # the same for the folded nearest-2x up-conv
                 self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, folded_up2x=True)
+            elif isinstance(up2x, tuple) and up2x[0] == "split_1x1s2":   # conv_fused of the KB block; up2x[1] = first xyz channel
+                self._packed = ops.pack_conv1x1s2_split_weight(weight, up2x[1], out=self._packed)
             else:
                 self._packed = (ops.pack_upconv2x_weight(weight, out=self._packed) if up2x
                                 else ops.pack_conv_weight(weight, stride, out=self._packed))
@@ -123,6 +125,10 @@ class Conv2d(torch.nn.Module):
         self._packed_bf16 = _PackedWeight()
         self._packed_split = _PackedWeight()
         self._packed_split_up = _PackedWeight()
+        self._packed_split_1x1 = _PackedWeight()
+        # conv_fused on split operands from this width on: KB3 / KB4 (192 / 384 filters: 239 vs 285 and 152 vs 253 us per 32
+        # KITTI frames); at KB2's 96 filters the layer is bound by its stride-2 HBM reads either way (365 vs 342 us)
+        self.split_fused_min_filters = 192
         self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
         self.split = True   # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies
         # the folded up-conv of a layer with at most 16 filters has 16-filter tiles (upconv2x_split16_kernel); measured level
@@ -156,6 +162,27 @@ class Conv2d(torch.nn.Module):
                   else self._packed_split.get(self.conv.weight, self.stride, up2x="split"))
         return ops.conv3x3_split(srcs, packed, n, self.out_channels, h, w, out, up2x=up2x, negative_slope=self._slope,
                                  stride=self.stride, act_exponent=k, folded_up2x=up2x)
+
+    def split_fused_qualifies(self, ci, cf):
+        return (self.split and self.kernel_size == 1 and self.stride == 2 and ci % 16 == 0 and cf % 16 == 0
+                and self.out_channels >= self.split_fused_min_filters and self.in_channels == ci + 3 + cf)
+
+    def run_split_fused(self, image, fused, xyz, n, h, w, out):
+        """conv_fused of a KB block -- this 1x1 stride-2 conv over cat[image, xyz, fused] -- with the tensor channels on
+        split operands and the three xyz channels (ops.kb_xyz_s2) in fp32 (ops.conv1x1s2_split); `h` x `w` is the OUTPUT
+        size.  None when the layer or the shapes do not qualify."""
+        ci, cf = image.shape[1], (0 if fused is None else fused.shape[1])
+        if not self.split_fused_qualifies(ci, cf):
+            return None
+        srcs = [ops.tensor_src(image, "image")] + ([] if fused is None else [ops.tensor_src(fused, "fused")])
+        k = self._act_exp
+        if k is None:
+            if torch.cuda.is_current_stream_capturing():
+                k = -6
+            else:
+                k = self._act_exp = ops.act_exponent_for(ops.absmax_srcs(srcs, n, image.device))
+        packed = self._packed_split_1x1.get(self.conv.weight, 2, up2x=("split_1x1s2", ci))
+        return ops.conv1x1s2_split(srcs, packed, xyz, n, self.out_channels, h, w, out, negative_slope=self._slope, act_exponent=k)
 
     def packed(self):
         return self._packed.get(self.conv.weight, self.stride)
@@ -280,6 +307,7 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
                                  weight_initializer=weight_initializer, activation_func=activation_func)
         self.n_filter_image, self.n_filter_depth, self.n_filter_fused = n_filter_image, n_filter_depth, n_filter_fused
         self.split_image = n_filter_image >= 96   # conv_image on the split-operand kernel (KB1's 48 filters: the fused kernel wins)
+        self.split_fused = True   # ... and with it conv_fused (1x1 stride 2) on split operands, xyz in fp32
         self._slope = _slope(activation_func)
         if self._slope is None:
             raise ValueError("the fused KB block needs a (leaky) ReLU activation")
@@ -320,6 +348,13 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             res = ci_conv.run_split([ops.tensor_src(image, "image")], n, oh, ow, out=out_image)
             if res is not None:
                 self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth)
+                if (self.split_fused and (fused is None or _dense(fused)) and self.proj_depth._slope is not None
+                        and self.conv_fused.split_fused_qualifies(ci, cf)):
+                    # conv_fused's tensor channels on the matrix core too; its backprojection channels, computed once at the
+                    # pixels a stride-2 1x1 conv reads, enter in fp32
+                    xyz = ops.kb_xyz_s2(depth, self.proj_depth.conv.weight, kinv, self.proj_depth._slope)
+                    if self.conv_fused.run_split_fused(image, fused, xyz, n, oh, ow, out_fused) is not None:
+                        return out_image, out_depth, out_fused
                 srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
                 if fused is not None:
                     srcs.append(ops.tensor_src(fused, "fused"))
@@ -734,6 +769,7 @@ class KBNetModel(object):
                     sub._packed_bf16.refresh(sub.conv.weight)
                     sub._packed_split.refresh(sub.conv.weight)
                     sub._packed_split_up.refresh(sub.conv.weight)
+                    sub._packed_split_1x1.refresh(sub.conv.weight)
                 elif isinstance(sub, UpConv2d):
                     sub._packed_up2x.refresh(sub.conv.conv.weight)
 

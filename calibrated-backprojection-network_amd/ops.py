@@ -543,6 +543,82 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     return out
 
 
+# ----------------------------------------------------- KB block: conv_fused on split operands
+@_on_tensor_device
+def pack_conv1x1s2_split_weight(weight: torch.Tensor, xyz_offset: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """OI11 fp32 weight of a 1x1 conv -> blob of `conv1x1s2_split`: per-filter scaled two-term fp16 split of the tensor
+    channels in MFMA order (+ the fp32 weights of the three xyz channels that start at input channel `xyz_offset`,
+    -1: the conv has none).  Tensor channels (in_channels, minus 3 with xyz) % 16 == 0."""
+    lib = _lib.load()
+    w = weight.detach().contiguous()
+    _require(w, "weight", 4)
+    oc, cin, kh, kw = w.shape
+    has_xyz = xyz_offset >= 0
+    nbytes = lib.kbn_conv1x1s2_split_packed_weight_bytes(oc, cin - (3 if has_xyz else 0), 1 if has_xyz else 0) if (kh, kw) == (1, 1) else 0
+    if nbytes == 0:
+        raise KbnError(f"conv1x1s2_split needs a 1x1 weight with tensor channels % 16 == 0, got {tuple(w.shape)}")
+    packed = out if _reusable(out, nbytes // 4, w) else torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    check(lib.kbn_conv1x1s2_split_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, int(xyz_offset), _stream()),
+          "kbn_conv1x1s2_split_pack_weight")
+    return packed
+
+
+@_on_tensor_device
+def kb_xyz_s2(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: torch.Tensor, negative_slope: Optional[float] = 0.2,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The KB block's backprojection K^-1 [x y 1]^T z, z = act(proj_weight . depth), at the input pixels (2y, 2x) its
+    stride-2 1x1 conv reads: N x 3 x ceil(H/2) x ceil(W/2) (kbn_kb_xyz_s2_forward)."""
+    lib = _lib.load()
+    dptr, dbs = _planes(depth, "depth")
+    n, cd, h, w = depth.shape
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    pw = proj_weight.detach().contiguous()
+    if pw.numel() != cd or tuple(kinv.shape) != (n, 3, 3) or not kinv.is_contiguous():
+        raise KbnError("kb_xyz_s2: proj_weight must hold one weight per depth channel, kinv must be a dense N x 3 x 3")
+    if out is None:
+        out = torch.empty((n, 3, oh, ow), device=depth.device, dtype=torch.float32)
+    optr, obs = _planes(out, "xyz")
+    check(_launch("kb_xyz", 2.0 * n * oh * ow * cd,
+                  lambda: lib.kbn_kb_xyz_s2_forward(dptr, dbs, cd, h, w, pw.data_ptr(), kinv.data_ptr(),
+                                                    0 if negative_slope is None else 1,
+                                                    0.0 if negative_slope is None else float(negative_slope),
+                                                    optr, obs, n, _stream())), "kbn_kb_xyz_s2_forward")
+    return out
+
+
+@_on_tensor_device
+def conv1x1s2_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, xyz: Optional[torch.Tensor], n: int, out_channels: int,
+                    height: int, width: int, out: torch.Tensor, negative_slope: Optional[float] = 0.2, act_exponent: int = -6):
+    """1x1 stride-2 conv (+ LeakyReLU) of one or two tensor sources (+ the three fp32 xyz channels of `xyz`, from
+    kb_xyz_s2) on split operands (kbn_conv1x1s2_split_forward); `height` x `width` is the OUTPUT size.  None when the
+    shape does not qualify."""
+    lib = _lib.load()
+    arr = (ConvSrc * len(srcs))(*srcs)
+    optr, obs = _planes(out, "out")
+    if tuple(out.shape) != (n, out_channels, height, width):
+        raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, height, width)}")
+    xptr, xbs = (None, 0)
+    if xyz is not None:
+        if tuple(xyz.shape) != (n, 3, height, width):
+            raise KbnError(f"xyz has shape {tuple(xyz.shape)}, expected {(n, 3, height, width)}")
+        xptr, xbs = _planes(xyz, "xyz")
+    cin = sum(s.channels for s in srcs)
+    flops = 2.0 * n * height * width * (cin + (3 if xyz is not None else 0)) * out_channels
+    executed = 3 * 2.0 * n * (-(-height // 8) * 8) * (-(-width // 32) * 32) * cin * (-(-out_channels // 128) * 128)
+    status = _launch("conv_split_1x1s2", flops,
+                     lambda: lib.kbn_conv1x1s2_split_forward(arr, len(srcs), packed_weight.data_ptr(), xptr, xbs, optr, obs, n,
+                                                             out_channels, height, width, int(act_exponent),
+                                                             0 if negative_slope is None else 1,
+                                                             0.0 if negative_slope is None else float(negative_slope),
+                                                             _stream()), executed=executed)
+    if status == _lib.KBN_ERR_UNSUPPORTED:
+        if PROFILE is not None:
+            PROFILE.pop()
+        return None
+    check(status, "kbn_conv1x1s2_split_forward")
+    return out
+
+
 # ----------------------------------------------------- bf16 leg (throughput-only)
 @_on_tensor_device
 def pack_conv3x3_bf16_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -215,6 +215,28 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
                               long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
                               int act_exponent, int apply_activation, float negative_slope, kbn_stream_t stream);
 
+/* conv_fused of the KB block on split operands -- reference src/net_utils.py:1337-1343 (Conv2d(in_channels_fused + 3,
+ * n_filter_fused, kernel_size=1, stride=2)) applied to cat[image, xyz, fused] (:1352-1368).  The tensor channels
+ * (image, fused: one or two KBN_SRC_TENSOR sources of H x W planes, channels % 16 == 0) are taken through the 16-bit
+ * matrix core like the 3x3 convs above; the three backprojection channels xyz = K^-1 [x y 1]^T z, z =
+ * act(proj_depth . depth) (:1352-1359), are computed once per block at the positions a stride-2 1x1 conv reads
+ * (kbn_kb_xyz_s2_forward: xyz[:, :, y, x] belongs to input pixel (2y, 2x)) and enter in fp32.
+ *   weight    out_channels x in_channels fp32 (the 1x1 OIHW weight), in_channels = tensor channels (+ 3);
+ *             xyz_offset = index of the first of the three xyz input channels (channels of `image`), -1: none
+ *   packed    kbn_conv1x1s2_split_packed_weight_bytes(out_channels, tensor_channels, has_xyz) bytes
+ *   xyz       N x 3 x height x width fp32 (output size), frames xyz_batch_stride apart; null iff packed without xyz
+ *   out       N x out_channels x height x width, height = ceil(H / 2), width = ceil(W / 2) */
+size_t kbn_conv1x1s2_split_packed_weight_bytes(int out_channels, int tensor_channels, int has_xyz);
+int kbn_conv1x1s2_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int xyz_offset,
+                                    kbn_stream_t stream);
+int kbn_conv1x1s2_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, const float* xyz,
+                                long long xyz_batch_stride, float* out, long long out_batch_stride, int n, int out_channels,
+                                int height, int width, int act_exponent, int apply_activation, float negative_slope,
+                                kbn_stream_t stream);
+int kbn_kb_xyz_s2_forward(const float* depth, long long depth_batch_stride, int depth_channels, int height, int width,
+                          const float* proj_weight, const float* kinv, int apply_activation, float negative_slope, float* xyz,
+                          long long xyz_batch_stride, int n, kbn_stream_t stream);
+
 
 /* ---------------------------------------------------- bf16 leg (THROUGHPUT-ONLY) ------
  * BASELINE.json configs[2] asks for a bf16 figure next to the fp32 one.  bf16 convolutions miss the

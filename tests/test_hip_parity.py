@@ -550,6 +550,101 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5
 
 
+@pytest.mark.parametrize("ci,cf,cd,cout,hw", [(48, 48, 16, 96, (35, 70)), (96, 96, 32, 192, (19, 44)), (192, 192, 64, 384, (11, 38)),
+                                               (48, 0, 16, 48, (38, 67)), (16, 32, 5, 130, (9, 131)), (64, 16, 8, 64, (16, 64))])
+@pytest.mark.parametrize("amag", [1.0, 1e-4, 3e5])
+def test_conv1x1s2_split_kernel(dev, ci, cf, cd, cout, hw, amag):
+    """conv_fused of the KB block on split operands (kbn_conv1x1s2_split_forward + kbn_kb_xyz_s2_forward): the tensor
+    channels of cat[image, xyz, fused] through the 16-bit matrix core, the three backprojection channels in fp32.  Same
+    bars as the 3x3 split kernels (fp64 reference), and within the suite's single-op tolerance of the fp32 kernels'
+    result (in-kernel xyz synthesis, fp32 MFMAs) for the same inputs."""
+    h, w = hw                                   # INPUT size; output ceil(h / 2) x ceil(w / 2)
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    g = torch.Generator().manual_seed(ci + cf + cout + h)
+    n = 2
+    lrelu = torch.nn.functional.leaky_relu
+    image = amag * lrelu(torch.randn(n, ci, h, w, generator=g), 0.2)
+    fused = amag * lrelu(torch.randn(n, cf, h, w, generator=g), 0.2) if cf else None
+    depth = lrelu(torch.randn(n, cd, h, w, generator=g), 0.2)
+    proj = torch.randn(1, cd, 1, 1, generator=g) / cd ** 0.5
+    kmat = torch.tensor([[[60.0, 0.0, w / 2.0], [0.0, 58.0, h / 2.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1)
+    kmat[1, 0, 0] = 71.0
+    cin = ci + 3 + cf
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    wt[1] *= 1e-3
+    wt[2] *= 50.0
+    wt[:, ci:ci + 3] *= amag                     # keeps the xyz term comparable to the tensor terms at every magnitude
+    coords = orc.camera_coordinates(kmat, h, w)
+    z64 = lrelu(torch.nn.functional.conv2d(depth.double(), proj.double()), 0.2)
+    xyz64 = coords.double() * z64
+    cat64 = torch.cat([image.double(), xyz64] + ([fused.double()] if cf else []), 1)
+    ref64 = lrelu(torch.nn.functional.conv2d(cat64, wt.double(), stride=2), 0.2)
+    cat32 = torch.cat([image, coords * lrelu(orc.conv2d(depth, proj, 1, None), 0.2)] + ([fused] if cf else []), 1)
+    ref32 = orc.conv2d(cat32, wt, 2, 0.2)
+    assert tuple(ref32.shape[-2:]) == (oh, ow)
+    kinv = kb.ops.intrinsics_inverse(kmat.to(dev))
+    imd, dd = image.to(dev), depth.to(dev)
+    fd = fused.to(dev) if cf else None
+    xyz = kb.ops.kb_xyz_s2(dd, proj.to(dev), kinv, 0.2)
+    assert rel_err(xyz, xyz64[:, :, ::2, ::2].float()) < TIGHT
+    srcs = [kb.ops.tensor_src(imd)] + ([kb.ops.tensor_src(fd)] if cf else [])
+    k = kb.ops.act_exponent_for(kb.ops.absmax_srcs(srcs, n, dev))
+    out = torch.empty(n, cout, oh, ow, device=dev)
+    res = kb.ops.conv1x1s2_split(srcs, kb.ops.pack_conv1x1s2_split_weight(wt.to(dev), ci), xyz, n, cout, oh, ow, out,
+                                 negative_slope=0.2, act_exponent=k if amag != 1.0 else -6)
+    assert res is not None
+    rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()
+    e_hip = ((out.cpu().double() - ref64) / rms).abs()
+    e_orc = ((ref32.double() - ref64) / rms).abs()
+    print(f"split 1x1 vs fp64: max {float(e_hip.max()):.2e} rms {float(e_hip.pow(2).mean().sqrt()):.2e}; "
+          f"oracle fp32 conv vs fp64: max {float(e_orc.max()):.2e} rms {float(e_orc.pow(2).mean().sqrt()):.2e}")
+    assert float(e_hip.pow(2).mean().sqrt()) < max(3.5 * float(e_orc.pow(2).mean().sqrt()), 6e-7)
+    assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5
+    # the fp32 kernels on the same inputs (xyz synthesized in-kernel)
+    out32 = torch.empty_like(out)
+    s32 = [kb.ops.tensor_src(imd), kb.ops.xyz_src(dd, proj.to(dev), kinv)] + ([kb.ops.tensor_src(fd)] if cf else [])
+    kb.ops.conv2d(s32, kb.ops.pack_conv_weight(wt.to(dev), 2), n, cout, 1, 2, h, w, out32, negative_slope=0.2)
+    assert rel_err(out, out32) < TIGHT
+    # without xyz channels: a plain 1x1 stride-2 conv of the tensor sources
+    wt_t = torch.cat([wt[:, :ci], wt[:, ci + 3:]], 1).contiguous()
+    res = kb.ops.conv1x1s2_split(srcs, kb.ops.pack_conv1x1s2_split_weight(wt_t.to(dev)), None, n, cout, oh, ow, out,
+                                 negative_slope=None, act_exponent=k if amag != 1.0 else -6)
+    ref = orc.conv2d(torch.cat([image] + ([fused] if cf else []), 1), wt_t, 2, None)
+    assert res is not None and rel_err(out, ref) < TIGHT
+
+
+@pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [(48, 16, 48, 96, 32, 34, 72), (96, 32, 96, 192, 64, 19, 44), (48, 16, 0, 96, 32, 21, 37)])
+def test_kb_block_split_fused(dev, ci, cd, cf, fi, fd, h, w):
+    """A KB block whose conv_image AND conv_fused run on split operands (KBNet's KB2-KB4 shapes) against the oracle, and
+    against the same block with conv_fused on the fp32 kernels."""
+    g = torch.Generator().manual_seed(ci + cf + h)
+    n = 2
+    blk = kb.modules.CalibratedBackprojectionBlock(ci, cd, ci + cf, fi, fd, fi, 1, 1, 1, "xavier_normal",
+                                                   torch.nn.LeakyReLU(0.2)).to(dev)
+    image = torch.randn(n, ci, h, w, generator=g)
+    depth = torch.randn(n, cd, h, w, generator=g)
+    fused = torch.randn(n, cf, h, w, generator=g) if cf else None
+    k = torch.tensor([[[60.0, 0.0, w / 2.0], [0.0, 58.0, h / 2.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1)
+    k[1, 0, 0] = 71.0
+    sd = {kk: v.detach().cpu() for kk, v in blk.state_dict().items()}
+    ref = orc.kb_block(image, depth, orc.camera_coordinates(k, h, w), fused, sd, 0.2)
+    kinv = kb.ops.intrinsics_inverse(k.to(dev))
+    run = lambda: [t.clone() for t in blk(image=image.to(dev), depth=depth.to(dev), coordinates=kinv,
+                                          fused=None if fused is None else fused.to(dev))]
+    assert blk.split_fused and blk.split_image
+    blk.conv_fused.split_fused_min_filters = 48   # KBNet routes KB3 / KB4 (>= 192 filters) this way; here every tested width
+    kb.ops.PROFILE = []
+    try:
+        got = run()
+    finally:
+        prof, kb.ops.PROFILE = kb.ops.PROFILE, None
+    assert "conv_split_1x1s2" in [r[0] for r in prof], "conv_fused took the split kernel"
+    blk.split_fused = False
+    fp32 = run()
+    for a, b, r in zip(got, fp32, ref):
+        assert rel_err(a, r) < TIGHT and rel_err(a, b) < TIGHT
+
+
 @pytest.mark.parametrize("cins,cout,hw,up2x", [((32,), 48, (16, 64), False), ((64, 64), 64, (22, 76), False),
                                                ((128,), 64, (20, 36), True), ((16, 32), 12, (9, 40), False),
                                                ((256, 512), 256, (22, 76), False), ((64,), 12, (36, 72), True),
