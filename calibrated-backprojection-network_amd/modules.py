@@ -598,6 +598,30 @@ class MultiScaleDecoder(torch.nn.Module):
 
 
 # ------------------------------------------------------------------------- model
+def paired_planes(first, second):
+    """The N x 2 x H x W tensor whose channel 0 is `first` and channel 1 is `second` when the two N x 1 x H x W fp32 tensors
+    ARE the two planes of one such buffer (`second`'s planes directly behind `first`'s, frame by frame) -- what
+    `new_depth_input_pair` hands out; None otherwise.  KBNetModel.forward uses it to skip the reference's
+    torch.cat([sparse_depth, validity_map_depth]) (a copy of both planes per call)."""
+    if (first.dim() != 4 or first.shape != second.shape or first.shape[1] != 1 or first.dtype != torch.float32
+            or second.dtype != torch.float32 or first.device != second.device):
+        return None
+    n, _, h, w = first.shape
+    hw = h * w
+    if (first.stride()[2:] != (w, 1) or second.stride()[2:] != (w, 1) or second.data_ptr() != first.data_ptr() + 4 * hw
+            or (n > 1 and (first.stride(0) != 2 * hw or second.stride(0) != 2 * hw))
+            or first.untyped_storage().data_ptr() != second.untyped_storage().data_ptr()):
+        return None
+    return torch.as_strided(first, (n, 2, h, w), (2 * hw, hw, w, 1))
+
+
+def new_depth_input_pair(n, height, width, device):
+    """(sparse_depth, validity_map_depth): N x 1 x H x W views of ONE N x 2 x H x W buffer, the layout S2D reads directly.
+    An input pipeline that writes its sparse depth and validity map here saves the concatenation of every forward."""
+    pair = torch.empty((n, 2, height, width), device=device, dtype=torch.float32)
+    return pair[:, 0:1], pair[:, 1:2]
+
+
 class GraphedForward:
     """HIP-graph replay of `KBNetModel.forward` for a fixed batch shape (torch.cuda.CUDAGraph is
     the plumbing: capture, private memory pool, replay; every node is one of our kernels or a
@@ -609,7 +633,11 @@ class GraphedForward:
     output.  Default: 2 branches for even batches of at least 4 frames, otherwise 1."""
 
     def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True):
-        self.static_in = [t.clone() for t in (image, sparse_depth, validity_map_depth, intrinsics)]
+        # the static sparse depth / validity inputs are the two planes of one buffer (paired_planes: no torch.cat in the graph)
+        sd, vm = new_depth_input_pair(sparse_depth.shape[0], sparse_depth.shape[2], sparse_depth.shape[3], sparse_depth.device)
+        sd.copy_(sparse_depth)
+        vm.copy_(validity_map_depth)
+        self.static_in = [image.clone(), sd, vm, intrinsics.clone()]
         n = self.static_in[0].shape[0]
         if branches is None:
             branches = 2 if (n >= 4 and n % 2 == 0) else 1
@@ -724,7 +752,9 @@ class KBNetModel(object):
         """`out` (extension): write the N x 1 x H x W depth map into this tensor instead of a new one."""
         if out is not None and return_logits:
             raise KbnError("out= and return_logits are mutually exclusive")
-        input_depth = torch.cat([sparse_depth, validity_map_depth], dim=1)
+        input_depth = paired_planes(sparse_depth, validity_map_depth)   # the two planes of one N x 2 x H x W buffer: no copy
+        if input_depth is None:
+            input_depth = torch.cat([sparse_depth, validity_map_depth], dim=1)   # reference src/kbnet_model.py:161
         input_depth = self.sparse_to_dense_pool(input_depth)
         shape = input_depth.shape[-2:]
         latent, skips = self.encoder(image, input_depth, intrinsics)

@@ -879,6 +879,23 @@ def test_graph_replay_matches_eager(dev):
     assert torch.equal(replay(*a), eager_a)
 
 
+def test_forward_reads_paired_depth_planes_without_concatenating(dev):
+    """Sparse depth and validity map as the two planes of one buffer (modules.new_depth_input_pair, what a captured graph
+    keeps as its static inputs): the forward skips torch.cat and returns the same bits."""
+    cfg = kb.PRESETS["void"]()
+    model = kb.modules.KBNetModel.from_config(cfg, dev)
+    model.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    image, sparse, valid, k = (t.to(dev) for t in kb.synthetic.make_frames(2, 64, 96, "void", seed=5))
+    ref = model.forward(image, sparse, valid, k)
+    sd, vm = kb.modules.new_depth_input_pair(2, 64, 96, dev)
+    sd.copy_(sparse); vm.copy_(valid)
+    assert kb.modules.paired_planes(sd, vm) is not None and kb.modules.paired_planes(sparse, valid) is None
+    assert torch.equal(model.forward(image, sd, vm, k), ref)
+    replay = model.capture(image, sparse, valid, k)            # the graph's static inputs are such a pair
+    assert kb.modules.paired_planes(replay.static_in[1], replay.static_in[2]) is not None
+    assert torch.equal(replay(image, sparse, valid, k), ref)
+
+
 def test_graph_replay_follows_weight_updates(dev):
     """The graph holds raw pointers to parameters and packed blobs: an in-place weight update (load_state_dicts /
     restore_model) after capture() must show up in the next replay (blobs are re-packed in place), and a parameter

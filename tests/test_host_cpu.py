@@ -133,3 +133,27 @@ def test_synthetic_frames_are_deterministic_and_well_formed():
     assert torch.equal(valid, (sparse > 0).float())
     assert torch.equal(sparse * 256, torch.round(sparse * 256))  # 16-bit PNG / 256 quantisation
     assert k[0, 2, 2] == 1 and k[0, 0, 0] > 0
+
+
+def test_paired_planes_recognises_only_the_two_planes_of_one_buffer():
+    """modules.paired_planes: the N x 2 x H x W view KBNetModel.forward hands to S2D instead of torch.cat([sparse, validity])."""
+    import torch
+    from kbnet_amd import modules
+    sd, vm = modules.new_depth_input_pair(3, 5, 7, "cpu")
+    sd.copy_(torch.arange(3 * 35, dtype=torch.float32).view(3, 1, 5, 7))
+    vm.copy_(-torch.arange(3 * 35, dtype=torch.float32).view(3, 1, 5, 7))
+    pair = modules.paired_planes(sd, vm)
+    assert pair is not None and pair.is_contiguous() and torch.equal(pair, torch.cat([sd, vm], 1))
+    assert pair.data_ptr() == sd.data_ptr()
+    sub = modules.paired_planes(sd[1:3], vm[1:3])              # a sub-batch (the branches of a captured graph)
+    assert sub is not None and torch.equal(sub, torch.cat([sd[1:3], vm[1:3]], 1))
+    assert modules.paired_planes(vm, sd) is None               # wrong order
+    assert modules.paired_planes(sd.clone(), vm) is None       # different buffers
+    assert modules.paired_planes(sd, vm.clone()) is None
+    flat = torch.zeros(2 * 35)                                 # adjacent in memory but not interleaved frame by frame
+    a, b = flat[:35].view(1, 1, 5, 7), flat[35:].view(1, 1, 5, 7)
+    assert torch.equal(modules.paired_planes(a, b), torch.cat([a, b], 1))   # one frame: adjacency is all it takes
+    two = torch.zeros(4 * 35)
+    a2, b2 = two[:70].view(2, 1, 5, 7), two[70:].view(2, 1, 5, 7)
+    assert modules.paired_planes(a2, b2) is None               # two frames each, back to back: not the paired layout
+    assert modules.paired_planes(sd.double(), vm.double()) is None
