@@ -330,8 +330,9 @@ def main():
     if dom in SPLIT_KERNELS:
         roofline["pipe"] = ("fp16 MFMA (matrix core): every fp32 product is taken as three fp16 products over two-term "
                             "splits of both operands, fp32 accumulation (csrc/conv_split.hip); `achieved` counts the "
-                            "fp16 MFMA FLOPs executed, 3x the fp32 products incl. tile padding; the kernel runs into the "
-                            "chip's power limit before the pipe's peak (zero-filled operands: +25 %)")
+                            "fp16 MFMA FLOPs executed, 3x the fp32 products incl. tile padding; a whole-chip stream of "
+                            "nothing but its instruction, v_mfma_f32_32x32x16_f16, sustains 1.66 PFLOP/s on zeros and 1.22 on "
+                            "random operands (profiles/r02/mfma_power_probe.txt): the kernel executes them at that rate")
     if dom == "conv_wino":
         roofline["algorithm"] = "Winograd F(2x2,3x3) in fp32: 4/9 of the algorithmic multiply-adds reach the MFMAs"
     roofline["measured_on"] = ("eager whole-batch launches, one kernel at a time, HIP events on the launch stream "

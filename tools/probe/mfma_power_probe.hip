@@ -62,7 +62,7 @@ template <int MIX>
 __global__ __launch_bounds__(512, 1) void stream_lds(const _Float16* src, float* out, int iters) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[32 * 1024];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 32 * 1024; i += 512) lds[i] = src[i & 4095];
+    for (int i = threadIdx.x; i < 32 * 1024; i += 512) lds[i] = src[i];   // 32 Ki independent values: no two fragments alike
     __syncthreads();
     const h8* base = reinterpret_cast<const h8*>(lds) + lane + (threadIdx.x >> 6) * 64;
     float s = 0.f;
@@ -135,14 +135,14 @@ __global__ __launch_bounds__(512, 1) void stream_lds(const _Float16* src, float*
 
 int main() {
     _Float16* src; float* out;
-    hipMalloc(&src, 4096 * sizeof(_Float16)); hipMalloc(&out, 64);
-    std::vector<_Float16> h(4096);
+    hipMalloc(&src, 32768 * sizeof(_Float16)); hipMalloc(&out, 64);
+    std::vector<_Float16> h(32768);
     int cus = 0; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int zero = 0; zero < 2; ++zero) {
         srand(1);
         for (auto& v : h) v = zero ? (_Float16)0.f : (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 8.f);
-        hipMemcpy(src, h.data(), 4096 * sizeof(_Float16), hipMemcpyHostToDevice);
+        hipMemcpy(src, h.data(), 32768 * sizeof(_Float16), hipMemcpyHostToDevice);
         for (int shape = 0; shape < 2; ++shape) {
             const int iters = 200000;                      // x 16 (32 for 16x16x32) MFMAs per wave
             const double flop_per_wave = shape == 0 ? iters * 16.0 * 32768.0 : iters * 32.0 * 16384.0;
@@ -163,7 +163,7 @@ int main() {
     // operands through LDS (random data)
     srand(1);
     for (auto& v : h) v = (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 8.f);
-    hipMemcpy(src, h.data(), 4096 * sizeof(_Float16), hipMemcpyHostToDevice);
+    hipMemcpy(src, h.data(), 32768 * sizeof(_Float16), hipMemcpyHostToDevice);
     for (int mix = 0; mix < 3; ++mix) {
         const int iters = mix == 0 ? 300000 : mix == 1 ? 600000 : 400000;   // >= 150 ms each: the power management needs tens of ms to settle
         // FLOPs per wave and iteration: MIX 0: 16 x 32768; MIX 1: 16 x 16384; MIX 2: 4 x 32768 + 16 x 16384
