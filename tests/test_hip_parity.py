@@ -550,6 +550,36 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5
 
 
+@pytest.mark.parametrize("cins,cout,hw", [((64, 64), 64, (22, 76)), ((32,), 48, (16, 64)), ((16, 32), 130, (9, 40)), ((128, 128), 128, (37, 52))])
+def test_conv3x3_split_k32_form(dev, kenv, cins, cout, hw):
+    """The 16x16x32 form of the concat-conv kernel (conv3x3_split_k32_kernel, KBN_DEBUG=64; off by default: slower on the
+    network's activations): same packed blob, same bars against fp64, and the 32x32x16 kernel's result within the suite's
+    single-op tolerance (the two sum in different orders)."""
+    h, w = hw
+    g = torch.Generator().manual_seed(sum(cins) + cout + h)
+    n = 2
+    xs = [torch.nn.functional.leaky_relu(torch.randn(n, c, h, w, generator=g), 0.2) for c in cins]
+    cin = sum(cins)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    wt[1] *= 1e-3
+    ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.cat(xs, 1).double(), wt.double(), padding=1), 0.2)
+    srcs_t = [x.to(dev) for x in xs]
+    srcs = [kb.ops.tensor_src(x) for x in srcs_t]
+    packed = kb.ops.pack_conv3x3_split_weight(wt.to(dev))
+    k = kb.ops.act_exponent_for(kb.ops.absmax_srcs(srcs, n, dev))
+    base = torch.empty(n, cout, h, w, device=dev)
+    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, base, negative_slope=0.2, act_exponent=k) is not None
+    kenv.setenv("KBN_DEBUG", "64")
+    out = torch.empty_like(base)
+    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, out, negative_slope=0.2, act_exponent=k) is not None
+    kenv.delenv("KBN_DEBUG")
+    assert not torch.equal(out, base), "the knob selected the other kernel"
+    rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()
+    e = ((out.cpu().double() - ref64) / rms).abs()
+    assert float(e.pow(2).mean().sqrt()) < 1.5e-6 and float(e.max()) < 2e-5
+    assert rel_err(out, base) < TIGHT
+
+
 @pytest.mark.parametrize("ci,cf,cd,cout,hw", [(48, 48, 16, 96, (35, 70)), (96, 96, 32, 192, (19, 44)), (192, 192, 64, 384, (11, 38)),
                                                (48, 0, 16, 48, (38, 67)), (16, 32, 5, 130, (9, 131)), (64, 16, 8, 64, (16, 64))])
 @pytest.mark.parametrize("amag", [1.0, 1e-4, 3e5])
