@@ -131,9 +131,10 @@ class Conv2d(torch.nn.Module):
         self.split_fused_min_filters = 192
         self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
         self.split = True   # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies
-        # the folded up-conv of a layer with at most 16 filters has 16-filter tiles (upconv2x_split16_kernel); measured level
-        # with the fp32 9-product kernel on deconv0 (650 vs 640 us per 32 KITTI frames): off, the fp32 kernel stays
-        self.split_narrow_up = False
+        # the folded up-conv of a layer with at most 16 filters has 16-filter tiles (upconv2x_split16_kernel): deconv0's
+        # 64 -> 12 up-conv.  Level with the fp32 9-product kernel on random operands (650 vs 640 us per 32 KITTI frames),
+        # 8-11 % faster inside the forward (660-690 vs 745 us, tools/layer_profile.py)
+        self.split_narrow_up = True
         self._act_exp = None   # activation exponent of the split kernel's fp16 window, measured on the first call
 
     def run_split(self, srcs, n, h, w, out=None, up2x=False):
