@@ -1275,6 +1275,241 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// The folded up-conv with 64-FILTER tiles (layers whose filter count fills whole 64-wide tiles: KBNet's four wide
+// up-convs, 256 / 128 / 128 / 64 filters).  upconv2x_split_kernel's wave owns two low-resolution rows x one 32-filter
+// block x four parities; here it owns ONE row x TWO 32-filter blocks x four parities -- the same eight accumulator
+// blocks -- so a workgroup covers 8 x 32 low-resolution pixels x 64 filters: per MFMA it stages and splits 340 pixels
+// instead of 612, and every input tile is staged by half as many filter tiles.  On random operands the two kernels
+// take the same time (1770 vs 1768 us over the four up-convs, tools/split_bench.py); inside a KITTI forward this one is
+// 3 % faster (tools/layer_profile.py: 2330 vs 2400 us for the five up-convs).  Eight-row tiles also fit the 11- and 22-row maps better.  A in LDS as before ([part][k-group]
+// [pixel][8 fp16], double buffered, 43 KiB); the sixteen weight sets of a chunk are 64 KiB now, so they go through LDS
+// in HALVES of eight sets (32 KiB, two buffers): the DMA of the next half flies while the current half multiplies; two
+// barriers per chunk.  Weights: [n-tile][chunk][set][part][k-group][64 filters][8 channels] fp16.
+constexpr int U64_NT = 64;
+__host__ __device__ constexpr bool uf_wide(int out_channels) {   // whole 64-wide tiles, no more padding than 32-wide ones
+    return out_channels >= U64_NT && (ceil_div(out_channels, 32) & 1) == 0;
+}
+
+__global__ void uf64_pack_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, _Float16* __restrict__ packed,
+                                 int OC, int Cin, int nchunks, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    constexpr int per_item = 2 * 2 * U64_NT * 8, per_chunk = UF_ITEMS * per_item;
+    int r = (int)(e % per_chunk);
+    const long long q = e / per_chunk;
+    const int chunk = (int)(q % nchunks), nt = (int)(q / nchunks);
+    const int item = r / per_item; r -= item * per_item;
+    const int part = r / (2 * U64_NT * 8); r -= part * 2 * U64_NT * 8;
+    const int g = r / (U64_NT * 8); r -= g * U64_NT * 8;
+    const int n = r >> 3, k = r & 7;
+    const int c = chunk * SP_CK + g * 8 + k, oc = nt * U64_NT + n;
+    _Float16 h = (_Float16)0.f;
+    if (c < Cin && oc < OC) {
+        const UfItem t = uf_item(item);
+        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx) * (1.f / inv_scale[oc]);
+        const _Float16 w1 = (_Float16)ws;
+        h = part == 0 ? w1 : (_Float16)(ws - (float)w1);
+    }
+    packed[e] = h;
+}
+
+__global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const SplitConvParams p) {
+    constexpr int TH = 8, ROWS = TH + 2, COLS = 34, NPIX = ROWS * COLS, NB = 2;
+    constexpr int A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART, PR = (NPIX + 255) / 256;
+    constexpr int B_ITEM = 2 * 2 * U64_NT * 16, HALF = UF_ITEMS / 2, B_HALF = HALF * B_ITEM;   // bytes per weight set / half chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals (see conv3x3_split_kernel)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = low-resolution row oy0 + rg
+    const int lm = lane & 31, g = lane >> 5;
+    int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int nt = bid % p.nTilesN;
+    bid /= p.nTilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int oy0 = ty * TH, ox0 = tx * 32;                            // low-resolution tile origin
+    const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
+    const long long plane = (long long)sH * sW;
+    const int nchunks = p.Cin / SP_CK;
+
+    const int kg_st = rg >> 2, t256 = tid & 255;
+    int goff[PR];
+#pragma unroll
+    for (int u = 0; u < PR; ++u) {
+        const int pix = u * 256 + t256;
+        const int r = pix / COLS, c = pix - r * COLS;
+        const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
+        goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
+    }
+    const unsigned char* wp_nt = reinterpret_cast<const unsigned char*>(p.wp) + (long long)nt * nchunks * (UF_ITEMS * B_ITEM);
+
+    float va[PR][8];
+    auto load_chunk = [&](int chunk) {
+        const float* base = p.src[0] + (long long)n * p.src_bstride[0] + (long long)(chunk * SP_CK + kg_st * 8) * plane;
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const unsigned voff = goff[u] < 0 ? 0u : (unsigned)goff[u];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* sb = base + (long long)k * plane;
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(va[u][k]) : "v"(voff), "s"(sb) : "memory");
+            }
+        }
+    };
+    auto store_round = [&](int buf, int u) {
+        unsigned char* A = smem + buf * A_BYTES + kg_st * NPIX * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));
+        const int pix = u * 256 + t256;
+        if (pix < NPIX) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
+            sph8 h1, h2;
+            sp_split8(v, p.prescale, h1, h2);
+            *reinterpret_cast<sph8*>(A + pix * 16) = h1;
+            *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
+        }
+    };
+    // weights: half chunks (eight sets, 32 KiB) by LDS-DMA into two buffers behind the A buffers
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+    auto stage_half = [&](int hbuf, int chunk, int half) {
+        const float* src = reinterpret_cast<const float*>(wp_nt + ((long long)chunk * UF_ITEMS + half * HALF) * B_ITEM);
+        const unsigned dst = lds0 + (unsigned)(2 * A_BYTES + hbuf * B_HALF);
+        constexpr int n4 = B_HALF / 16;
+        static_assert(n4 % SP_THREADS == 0, "whole rounds of the workgroup");
+#pragma unroll
+        for (int e0 = 0; e0 < n4; e0 += SP_THREADS) {
+            const int eb = e0 + rg * 64;
+            lds_dma16_s(src + eb * 4, (unsigned)(lane * 16), dst + eb * 16);
+        }
+    };
+
+    spf16 acc[2][2][NB];   // [py][px][32-filter block]
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a >> 2][(a >> 1) & 1][a & 1][i] = 0.f;
+
+    const unsigned char* const aptr = smem + (g * NPIX + rg * COLS + lm) * 16;
+    sph8 af[3][2];        // A fragments of staged rows rg + 0..2 at the column offset of their group (two split terms each)
+    auto load_arow = [&](int abuf, int ry, int ox) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            af[ry][t] = *reinterpret_cast<const sph8*>(aptr + abuf + t * A_PART + (ry * COLS + ox) * 16);
+    };
+    const unsigned char* const bptr = smem + 2 * A_BYTES + (g * U64_NT + lm) * 16;   // + part * 2 NT 16 + nb * 32 * 16
+    const bool row_live = oy0 + rg < sH;                                            // wave-uniform
+    constexpr int WAIT_IT = 4;   // set of the first half whose MFMAs follow the wait for the next chunk's inputs (and the second half's weights)
+    static_assert(WAIT_IT + PR <= HALF, "the staging rounds sit in the first half");
+
+    auto half_body = [&](int c, auto half_tag, auto more_tag) {
+        constexpr int HF = decltype(half_tag)::value;
+        constexpr bool MORE = decltype(more_tag)::value;   // a chunk c+1 exists
+        const int abuf = (c & 1) * A_BYTES;
+        const unsigned char* B = bptr + HF * B_HALF;
+        // the other weight buffer was last read in the previous half (a barrier ago): refill it
+        if (HF == 0) {
+            stage_half(1, c, 1);
+            if (MORE) load_chunk(c + 1);
+            load_arow(abuf, 0, 0);
+        } else if (MORE) {
+            stage_half(0, c + 1, 0);
+        }
+        sph8 bwq[2][NB][2];   // (w1, w2) of the current / next set, per 32-filter block
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bwq[0][nb][t] = *reinterpret_cast<const sph8*>(B + (t * 2 * U64_NT + nb * 32) * 16);
+#pragma unroll
+        for (int ih = 0; ih < HALF; ++ih) {
+            constexpr int dummy = 0; (void)dummy;
+            const int it = HF * HALF + ih;
+            const UfItem t = uf_item(it);
+            const bool first_of_group = it == 0 || uf_item(it - 1).s != t.s || uf_item(it - 1).ox != t.ox;
+            if (first_of_group) {   // fetch the row the NEXT group reads
+                if (t.s < 2) load_arow(abuf, t.s + 1, t.ox);
+                else if (t.ox < 2) load_arow(abuf, 0, t.ox + 1);
+            }
+            if (ih + 1 < HALF) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        bwq[(ih + 1) & 1][nb][tt] = *reinterpret_cast<const sph8*>(B + (ih + 1) * B_ITEM + (tt * 2 * U64_NT + nb * 32) * 16);
+            }
+            sph8 bw[NB][3];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bw[nb][0] = bwq[ih & 1][nb][0];
+                bw[nb][1] = bwq[ih & 1][nb][1];
+                bw[nb][2] = bw[nb][0] * (_Float16)0.00048828125f;   // w1 2^-11
+            }
+            if (HF == 0 && MORE && ih == WAIT_IT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's inputs (and this chunk's second half of weights)
+            __builtin_amdgcn_sched_barrier(0);
+            if (row_live) {
+                constexpr int TA[3] = {0, 0, 1};
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[t.py][t.px][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t.s][TA[k]], bw[nb][k], acc[t.py][t.px][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (HF == 0 && MORE && ih >= WAIT_IT && ih - WAIT_IT < PR) store_round((c & 1) ^ 1, ih - WAIT_IT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight DMA issued at the top of the half
+        __syncthreads();
+    };
+
+    load_chunk(0);
+    stage_half(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < PR; ++u) store_round(0, u);
+    __syncthreads();
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        half_body(c, std::integral_constant<int, 0>{}, std::true_type{});
+        half_body(c, std::integral_constant<int, 1>{}, std::true_type{});
+    }
+    half_body(nchunks - 1, std::integral_constant<int, 0>{}, std::false_type{});
+    half_body(nchunks - 1, std::integral_constant<int, 1>{}, std::false_type{});
+
+    // ---- epilogue: acc[py][px][nb][i]: low-resolution x = 8 (i / 4) + 4 g + (i % 4), filter nb * 32 + lm; outputs (2 Y + py, 2 x + px)
+    const long long oplane = (long long)H * W;
+    const int Y = oy0 + rg;
+    if (Y >= sH) return;
+    const float slope = p.act ? p.slope : 1.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int oc = nt * U64_NT + nb * 32 + lm;
+        const float inv = p.inv_scale[oc] * p.unscale;
+        if (oc >= p.OC) continue;
+        float* outc = p.out + (long long)n * p.out_bstride + (long long)oc * oplane;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            float* orow = outc + (long long)(2 * Y + py) * W;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int X = 2 * (ox0 + 8 * q4 + 4 * g);              // first output column of this lane's 8
+                f32x4 v0, v1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[py][j & 1][nb][q4 * 4 + (j >> 1)] * inv;
+                    const float b = acc[py][j & 1][nb][q4 * 4 + 2 + (j >> 1)] * inv;
+                    v0[j] = a > 0.f ? a : a * slope;
+                    v1[j] = b > 0.f ? b : b * slope;
+                }
+                if (X < W) *reinterpret_cast<f32x4*>(orow + X) = v0;
+                if (X + 4 < W) *reinterpret_cast<f32x4*>(orow + X + 4) = v1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // 1x1 stride-2 conv (+ LeakyReLU) on split operands: conv_fused of the KB block, reference src/net_utils.py:1337-1343 and
 // :1366-1368 (cat[image, xyz, fused] -> Conv2d(kernel 1, stride 2)).  The tensor channels (image, fused: multiples of
 // 16) go through the matrix core like the 3x3 kernels' -- one "tap", M = 32 output pixels of a row (input pixels
@@ -1501,7 +1736,9 @@ extern "C" {
 
 // filters per workgroup; the folded up-conv takes 16-filter tiles for narrow layers (upconv2x_split16_kernel)
 static int split_nt(int mode, int out_channels, int in_channels) {
-    return mode == 2 ? 128 : (mode == 3 ? (kbn::uf_narrow(out_channels, in_channels) ? kbn::U16_NT : kbn::UF_NT) : 64);
+    if (mode == 3 && kbn::uf_narrow(out_channels, in_channels)) return kbn::U16_NT;
+    if (mode == 3 && kbn::uf_wide(out_channels) && !(kbn::knob(kbn::KNOB_DEBUG) & 32)) return kbn::U64_NT;   // KBN_DEBUG & 32: 32-filter tiles (A/B runs)
+    return mode == 2 ? 128 : (mode == 3 ? kbn::UF_NT : 64);
 }
 
 size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, int mode) {
@@ -1525,6 +1762,12 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
         if (uf_narrow(out_channels, in_channels)) {
             hipLaunchKernelGGL(uf16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv,
                                wp, out_channels, in_channels, in_channels / U16_CK, total);
+            KBN_CHECK_LAUNCH();
+            return KBN_OK;
+        }
+        if (nt == U64_NT) {
+            hipLaunchKernelGGL(uf64_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv,
+                               wp, out_channels, in_channels, in_channels / SP_CK, total);
             KBN_CHECK_LAUNCH();
             return KBN_OK;
         }
@@ -1602,6 +1845,17 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     int rc;
     if (mode == 3 && uf_narrow(out_channels, cin)) {
         rc = launch(upconv2x_split16_kernel, 2 * 2 * 4 * 18 * 34 * 16, o[4]);
+        if (rc != KBN_OK) return rc;
+        KBN_CHECK_LAUNCH();
+        return KBN_OK;
+    }
+    if (mode == 3 && ntf == U64_NT) {   // 8 x 32 low-resolution pixels x 64 filters per workgroup
+        p.tilesX = ceil_div(p.sW, 32); p.tilesY = ceil_div(p.sH, 8);
+        const long long blocks64 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
+        if (blocks64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+        p.nblocks = (int)blocks64;
+        static DeviceOnce o64;
+        rc = launch(upconv2x_split64_kernel, 2 * (2 * 2 * 10 * 34 * 16) + 2 * (8 * 2 * 2 * 64 * 16), o64);
         if (rc != KBN_OK) return rc;
         KBN_CHECK_LAUNCH();
         return KBN_OK;

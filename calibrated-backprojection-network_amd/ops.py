@@ -500,7 +500,8 @@ def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1, 
     (folded up-conv: 16 products per low-resolution pixel, 16 x 32 low-resolution pixels x 32 filters)."""
     if folded_up2x:
         nt = 16 if (out_channels <= 16 and cin % 32 == 0) else 32   # narrow layers: 16-filter tiles (upconv2x_split16_kernel)
-        return 3 * 2.0 * n * (-(-(height // 2) // 16) * 16) * (-(-(width // 2) // 32) * 32) * cin * 16 * (-(-out_channels // nt) * nt)
+        th = 8 if (out_channels >= 64 and (-(-out_channels // 32)) % 2 == 0) else 16   # whole 64-filter tiles: 8-row tiles (upconv2x_split64_kernel)
+        return 3 * 2.0 * n * (-(-(height // 2) // th) * th) * (-(-(width // 2) // 32) * 32) * cin * 16 * (-(-out_channels // nt) * nt)
     nt = 128 if stride == 2 else 64
     th = 8 if stride == 2 else 16
     return 3 * 2.0 * n * (-(-height // th) * th) * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // nt) * nt)

@@ -504,7 +504,10 @@ def test_conv_head_fused_vs_oracle(dev, kenv, c, shape):
                                                ((512,), 40, (22, 76), "up2x_folded"), ((16,), 33, (70, 8), "up2x_folded"),
                                                # at most 16 filters, Cin % 32 == 0: the 16-filter tiles of upconv2x_split16_kernel
                                                ((64,), 12, (36, 76), "up2x_folded"), ((32,), 16, (70, 8), "up2x_folded"),
-                                               ((96,), 5, (8, 132), "up2x_folded"), ((64,), 12, (66, 140), "up2x_folded")])
+                                               ((96,), 5, (8, 132), "up2x_folded"), ((64,), 12, (66, 140), "up2x_folded"),
+                                               # whole 64-filter tiles: the 8-row tiles of upconv2x_split64_kernel (64 / 128 / 192 filters)
+                                               ((64,), 128, (22, 76), "up2x_folded"), ((16,), 64, (6, 12), "up2x_folded"),
+                                               ((32,), 192, (18, 132), "up2x_folded"), ((48,), 64, (50, 68), "up2x_folded")])
 @pytest.mark.parametrize("amag", [1.0, 1e-4, 3e5])
 def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     """kbn_conv3x3_split_forward: fp32 products as three fp16 MFMAs over two-term splits (csrc/conv_split.hip).  Held to
