@@ -12,8 +12,10 @@ cfg = kb.PRESETS["kitti"]()
 m = kb.modules.KBNetModel.from_config(cfg, dev)
 m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
 fr = [f.to(dev) for f in kb.synthetic.make_frames(B, 352, 1216, "kitti", seed=1)]
-# A/B switches of the host mirror: LP_NARROW_UP=1 (16-filter split tiles for deconv0's up-conv), LP_FUSED_MIN=<filters>
+# A/B switches of the host mirror: LP_KB1_SPLIT=1, LP_NARROW_UP=1 (16-filter split tiles for deconv0's up-conv), LP_FUSED_MIN=<filters>
 # (conv_fused on split operands from this width on)
+if os.environ.get("LP_KB1_SPLIT"):   # KB1's conv_image (48 filters) on the stride-2 split kernel instead of the fused fp32 KB kernel
+    m.encoder.calibrated_backprojection1.split_image = True
 for mod in m.modules():
     for sub in mod.modules():
         if isinstance(sub, kb.modules.Conv2d):
