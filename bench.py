@@ -11,10 +11,12 @@ all-gather of the depth maps.  Frames shard across ranks (weak scaling: 32 frame
 BASELINE.json configs[3]'s per-GPU share of its 256 frames and configs[2]'s single-GPU batch in
 fp32; the batch-8 rate of configs[1] is reported as a side field); there is no other collective on
 the data path.  Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around
-every launch of the dominant kernel (the fp32 MFMA conv variant with the largest total time):
-`achieved` / `frac` are the FLOPs the kernel EXECUTES on the matrix cores (padding included) over
-the pipe's peak -- never above 1 -- and `algorithmic` carries the reference-formulation FLOPs the
-same launches are worth (Winograd and the phase-decomposed up-convs execute fewer);
+every launch of the dominant kernel (the MFMA conv variant with the largest total time):
+`achieved` / `frac` are the FLOPs of the MFMA instructions the kernel ISSUES (padding that is
+issued included, skipped padding not: the figure SQ_INSTS_MFMA x 32768 of the PMC collection gives)
+over the pipe's peak -- never above 1; `useful_frac` prices only the reference's multiply-adds (x 3
+fp16 products each for the split-operand kernels) and `algorithmic` carries the reference-formulation
+FLOPs the same launches are worth;
 `cpu_baseline` times the CPU oracle (the port of the reference, bit-identical to it) on
 this box's host cores over a bounded sample.
 """
@@ -132,7 +134,68 @@ def cpu_baseline(cfg, sds, frames, budget_s=15.0, max_frames=6):
             "sample": f"{done} KITTI 352x1216 frames, batch 1, fp32, oracle/kbnet_oracle.py (torch CPU)"}, ref
 
 
-def main():
+def setup_ranks(gpus: int, backend: str):
+    """One process per GPU, launched as the contract says: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+    environment (torch.distributed.run sets them), `--gpus N` must equal WORLD_SIZE.  backend "nccl" = RCCL: the rank's
+    device is cuda:LOCAL_RANK; "gloo": CPU (tests/test_dist_cpu.py runs this very code at world size 2)."""
+    rank, local_rank, world = kb.dist.env_world()
+    if world != gpus:
+        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run "
+                         f"--nproc-per-node {gpus} bench.py --gpus {gpus} ...`")
+    if backend == "nccl":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+    kb.dist.init(backend)
+    return rank, local_rank, world, dev
+
+
+def device_sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
+def timed_steps(runner, step_inputs, steps: int, warmup: int, dev):
+    """The contract's timed region: W untimed steps, then EXACTLY K steps bracketed by barrier + device synchronise on
+    both sides; returns (seconds = MAX over ranks, gathered output of the last step).  A step = forward of this rank's
+    frames + the asynchronous all-gather of the depth maps (the gather of step i overlaps step i+1's forward; the last
+    one is drained inside the timed region)."""
+    for _ in range(warmup):
+        runner.step_pipelined(step_inputs)
+    runner.drain()
+    device_sync(dev)
+    kb.dist.barrier()
+    device_sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step_pipelined(step_inputs)
+    out = runner.drain()
+    device_sync(dev)
+    kb.dist.barrier()
+    elapsed = time.perf_counter() - t0
+    return kb.dist.max_over_ranks(elapsed, dev), out
+
+
+def base_result(fps, world, steps, warmup, ms_per_step):
+    """The keys the driver's contract names, in one place."""
+    return {"metric": "depth-completion frames/sec at 352x1216", "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+
+
+def emit(result, rank: int):
+    """Rank 0 prints the ONE JSON line."""
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def main(argv=None, backend: str = "nccl", forward_factory=None):
+    """`backend` / `forward_factory` are test hooks (tests/test_dist_cpu.py): with gloo and a stand-in forward --
+    forward_factory(rank, dev, frames) -> callable -- the rank logic above runs end to end on CPU processes; the GPU-only
+    measurements (roofline, side figures, cpu_baseline) are skipped then."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -142,29 +205,35 @@ def main():
     ap.add_argument("--no-void", action="store_true", help="skip the VOID 480x640 side measurement")
     ap.add_argument("--no-side-batch", action="store_true", help="skip the batch-8 (configs[1]) side measurement")
     ap.add_argument("--no-bf16", action="store_true", help="skip the throughput-only bf16 decoder leg (configs[2])")
+    ap.add_argument("--no-fp32-mfma", action="store_true", help="skip the all-fp32-MFMA side measurement (KBN_NO_SPLIT=1)")
     ap.add_argument("--branches", type=int, default=0,
                     help="concurrent sub-batches inside the captured graph (0 = default: 2 for even batches >= 4)")
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of HIP-graph replay")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
-    rank, local_rank, world = kb.dist.init("nccl")
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    cfg = kb.kitti_config()
-    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=WEIGHT_GAIN)
-    model = kb.modules.KBNetModel.from_config(cfg, dev)
-    model.load_state_dicts(*sds)
+    rank, local_rank, world, dev = setup_ranks(args.gpus, backend)
     per = args.frames_per_gpu
     # rank r holds frames [r*per, (r+1)*per) of the global batch (seed 1+rank; frame 0 of
     # rank 0 is the frame the CPU oracle sees)
     frames = kb.synthetic.make_frames(per, HEIGHT, WIDTH, "kitti", seed=1 + rank)
     frames = [f.to(dev) for f in frames]
+    if forward_factory is not None:   # test hook: the plumbing alone
+        runner = kb.dist.ShardedRunner(forward_factory(rank, dev, frames), rank, world)
+        elapsed, out = timed_steps(runner, frames, args.steps, args.warmup, dev)
+        result = base_result(per * world * args.steps / elapsed, world, args.steps, args.warmup, 1e3 * elapsed / args.steps)
+        result["config"] = {"workload": "stand-in forward (plumbing test)", "frames_per_gpu": per, "global_batch": per * world,
+                            "gathered_frames": int(out.shape[0]), "rank_seeds": [1 + r for r in range(world)]}
+        result["roofline"] = None
+        result["cpu_baseline"] = None
+        emit(result, rank)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return result
+
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=WEIGHT_GAIN)
+    model = kb.modules.KBNetModel.from_config(cfg, dev)
+    model.load_state_dicts(*sds)
     # The forward of this batch shape is captured once into a HIP graph; a step replays it (same
     # kernels, no per-launch host round trips).  --eager times the plain launch sequence instead.
     # --branches: concurrent sub-batches inside the graph (default: 2 for even batches >= 4, see GraphedForward)
@@ -174,23 +243,7 @@ def main():
     # loader.InferenceFrameLoader writes there directly, so a step has no input copy.  Eager mode: the frames.
     step_inputs = forward.static_in if hasattr(forward, "static_in") else frames
 
-    # Each step = forward + all-gather of the depth maps; the gather of step i is asynchronous and
-    # overlaps step i+1's forward (the last one is drained inside the timed region).
-    for _ in range(args.warmup):
-        runner.step_pipelined(step_inputs)
-    runner.drain()
-    torch.cuda.synchronize()
-
-    kb.dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.step_pipelined(step_inputs)
-    out = runner.drain()
-    torch.cuda.synchronize()
-    kb.dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = kb.dist.max_over_ranks(elapsed, dev)
+    elapsed, out = timed_steps(runner, step_inputs, args.steps, args.warmup, dev)
     out = out.clone()
 
     # Per-kernel durations for the roofline: the same K steps launched eagerly, every ABI call
@@ -283,6 +336,29 @@ def main():
         model.set_bf16(False)
         del breplay, bout
 
+    # The same forward with every conv on the fp32 MFMAs (KBN_NO_SPLIT=1: Winograd / 9-product up-convs / fused KB kernels,
+    # round 2's v20 path): what the split-operand arithmetic buys, measured by the same driver run.
+    fp32_only_fps = None
+    if not args.no_fp32_mfma and not args.eager:
+        os.environ["KBN_NO_SPLIT"] = "1"
+        kb.ops.reload_env()
+        try:
+            freplay = model.capture(*frames, branches=args.branches or None)
+            for _ in range(3):
+                freplay(*freplay.static_in)
+            torch.cuda.synchronize()
+            kb.dist.barrier()
+            t6 = time.perf_counter()
+            for _ in range(10):
+                freplay(*freplay.static_in)
+            torch.cuda.synchronize()
+            kb.dist.barrier()
+            fp32_only_fps = per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t6, dev)
+            del freplay
+        finally:
+            del os.environ["KBN_NO_SPLIT"]
+            kb.ops.reload_env()
+
     ms_per_step = 1e3 * elapsed / args.steps
     fps = per * world * args.steps / elapsed
     gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
@@ -303,18 +379,21 @@ def main():
     conv_groups = {k: v for k, v in groups.items() if k.startswith("conv_")}
     dom = max(conv_groups, key=lambda k: conv_groups[k][1])
     dwork, dtime, dlaunch, dexec, _ = conv_groups[dom]
-    # `achieved`: FLOPs the dominant kernel EXECUTES on the matrix cores (from its launch plan: tile / channel
-    # padding included; Winograd issues 16 products per 2x2 output tile where the direct form needs 36) per second;
-    # `frac` = achieved / peak is the matrix-pipe fraction and cannot exceed 1.  `algorithmic`: the same launches
-    # priced at the reference's direct-conv FLOPs (2 * N * Hout * Wout * Cin * 9 * Cout), which may exceed the peak.
+    # `achieved`: FLOPs of the MFMA instructions the dominant kernel ISSUES (its launch plan minus the padding the kernel
+    # skips: ops.conv3x3_split_executed_flops agrees with SQ_INSTS_MFMA x 32768 of the PMC collection) per second;
+    # `frac` = achieved / peak is the matrix-pipe fraction and cannot exceed 1.  `useful_frac`: only the reference's
+    # multiply-adds, at the three fp16 products each costs on this pipe.  `algorithmic`: the same launches priced at the
+    # reference's direct-conv FLOPs (2 * N * Hout * Wout * Cin * 9 * Cout) -- fp32 work, which may exceed the fp32 peak.
     achieved = dexec / dtime / 1e12
     peak = pipe_peak(dom)
+    products = 3.0 if dom in SPLIT_KERNELS else 1.0
     mfma_flops = [v[3] for k, v in groups.items() if v[4] and v[3] > 0]
     mfma_time = [v[1] for k, v in groups.items() if v[4] and v[3] > 0]
     # seconds the executed FLOPs of every MFMA kernel would take at the dense peak of the pipe they run on
     pipe_seconds = sum(v[3] / (pipe_peak(k) * 1e12) for k, v in groups.items() if v[4] and v[3] > 0)
     roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "useful_frac": round(products * dwork / dtime / 1e12 / peak, 4), "traffic": None,
                 "launches": dlaunch, "avg_launch_us": round(dtime / dlaunch * 1e6, 2),
                 "flop_per_launch": dexec / dlaunch,
                 "algorithmic": {"flop_per_launch": dwork / dlaunch, "tflops": round(dwork / dtime / 1e12, 3),
@@ -330,9 +409,10 @@ def main():
     if dom in SPLIT_KERNELS:
         roofline["pipe"] = ("fp16 MFMA (matrix core): every fp32 product is taken as three fp16 products over two-term "
                             "splits of both operands, fp32 accumulation (csrc/conv_split.hip); `achieved` counts the "
-                            "fp16 MFMA FLOPs executed, 3x the fp32 products incl. tile padding; a whole-chip stream of "
-                            "nothing but its instruction, v_mfma_f32_32x32x16_f16, sustains 1.66 PFLOP/s on zeros and 1.22 on "
-                            "random operands (profiles/r02/mfma_power_probe.txt): the kernel executes them at that rate")
+                            "fp16 MFMA FLOPs issued, 3x the fp32 products incl. the tile padding that is not skipped; "
+                            "`useful_frac` = 3 x algorithmic / time / peak.  A whole-chip stream of nothing but its instruction, "
+                            "v_mfma_f32_32x32x16_f16, sustains 1.22 PFLOP/s on random operands from registers and 1.69 "
+                            "interleaved with the LDS reads that feed it (profiles/r02/mfma_power_probe.txt)")
     if dom == "conv_wino":
         roofline["algorithm"] = "Winograd F(2x2,3x3) in fp32: 4/9 of the algorithmic multiply-adds reach the MFMAs"
     roofline["measured_on"] = ("eager whole-batch launches, one kernel at a time, HIP events on the launch stream "
@@ -345,10 +425,8 @@ def main():
         roofline["s2d_hbm"] = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_us": round(s2d[1] / s2d[2] * 1e6, 2)}
 
-    result = {
-        "metric": "depth-completion frames/sec at 352x1216", "value": round(fps, 3), "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+    result = base_result(fps, world, args.steps, args.warmup, ms_per_step)
+    result.update({
         "config": {"workload": f"KITTI 352x1216, batch {per}/GPU (BASELINE configs[2] fp32 leg = configs[3] per-GPU share), "
                                "fp32 tensors and accumulation, full KBNet forward in HIP (S2D + KB layers + MFMA convs + head; "
                                "the wide 3x3 convs take their fp32 products as three fp16 MFMAs over split operands), "
@@ -369,10 +447,12 @@ def main():
                    "void_480x640_frames_per_s": None if void_fps is None else round(void_fps, 1),
                    # side measurement: BASELINE configs[1] (batch 8 per GPU), forward only
                    "batch8_frames_per_s": None if side_fps is None else round(side_fps, 1),
+                   # side measurement: the same batch with every conv on the fp32 MFMAs (KBN_NO_SPLIT=1), graph replay
+                   "fp32_mfma_only_frames_per_s": None if fp32_only_fps is None else round(fp32_only_fps, 1),
                    # side measurement: BASELINE configs[2]'s bf16 leg -- throughput only, never `value` (see above)
                    "bf16_leg": bf16_leg},
         "roofline": roofline, "kernels": breakdown,
-    }
+    })
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ref = cpu_baseline(cfg, sds, [f[0:1].cpu() for f in frames])
@@ -380,12 +460,12 @@ def main():
         got = out[0:1].cpu()  # frame 0 of rank 0
         result["parity"] = {"max_rel_err_vs_oracle": float(((got - ref).abs() / ref.abs()).max()),
                             "mae_vs_oracle_m": float((got - ref).abs().mean()), "tolerance": 1e-4}
-    elif rank == 0:
-        result["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    else:
+        result["cpu_baseline"] = None   # rank 0 at N = 1 only (the contract): the host cores are shared by all ranks
+    emit(result, rank)
     if world > 1:
         torch.distributed.destroy_process_group()
+    return result
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ KBN_ERR_UNSUPPORTED = -2
 KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ = 0, 1, 2
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
 KBN_MAX_SRC = 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class KbnError(RuntimeError):
@@ -42,6 +42,7 @@ class ConvSrc(C.Structure):
         ("coordinates", C.c_void_p),
         ("coordinates_batch_stride", C.c_longlong),
         ("kinv", C.c_void_p),
+        ("absmax", C.c_void_p),
     ]
 
 
@@ -62,25 +63,25 @@ SIGNATURES = {
     "kbn_conv2d_packed_weight_bytes": (C.c_size_t, [_I, _I, _I, _I]),
     "kbn_conv2d_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "kbn_conv2d_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I,
-                                _F, _P]),
+                                _F, _P, _P]),
     "kbn_upconv2x_packed_weight_bytes": (C.c_size_t, [_I, _I]),
     "kbn_upconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
-    "kbn_upconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_upconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "kbn_upconv2x_query": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_conv2d_query": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_kb_block_forward": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P,
-                                  _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+                                  _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "kbn_preprocess_forward": (_I, [_P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _P]),
     "kbn_eval_accumulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "kbn_depth_head_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "kbn_conv_head_forward": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P]),
-    "kbn_absmax": (_I, [_P, _L, _I, _L, _P, _P]),
+    "kbn_absmax_frames": (_I, [_P, _L, _I, _L, _P, _P]),
     "kbn_conv3x3_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_conv3x3_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
-    "kbn_conv3x3_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_conv3x3_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "kbn_conv1x1s2_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_conv1x1s2_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
-    "kbn_conv1x1s2_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_conv1x1s2_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "kbn_kb_xyz_s2_forward": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _F, _P, _L, _I, _P]),
     "kbn_conv3x3_bf16_packed_weight_bytes": (C.c_size_t, [_I, _I]),
     "kbn_conv3x3_bf16_pack_weight": (_I, [_P, _P, _I, _I, _P]),

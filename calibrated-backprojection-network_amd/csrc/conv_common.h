@@ -41,6 +41,7 @@ struct ConvParams {
     float slope;
     int dbg;  // ablation switches for tools/conv_bench.py (KBN_DEBUG): 1 no A staging, 2 no B staging, 4 no MFMA
     int epi_lds;  // 1: store through LDS, one channel plane per store instruction (store-bound launches)
+    unsigned* out_absmax;   // per-frame max |out| slots (kbn_common.h), or null
 };
 
 struct ConvPlan {
@@ -110,6 +111,7 @@ struct StoreDst {
     long long out_bstride;
     int outH, outW, OC, TWB, act;
     float slope;
+    unsigned* absmax = nullptr;   // per-frame max |out| slots, or null
 };
 
 template <int NB, int MW>
@@ -120,6 +122,7 @@ __device__ __forceinline__ void store_tile_dst(const StoreDst& p, const f32x4 (&
     float* outn = p.out + (long long)n * p.out_bstride;
     const bool vec_ok = ((p.outW & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
                         ((p.out_bstride & 3) == 0);
+    float amax = 0.f;   // max |stored value| of this thread (folded into p.absmax[n] below)
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         int mb = wave * MW + mi;
@@ -140,13 +143,15 @@ __device__ __forceinline__ void store_tile_dst(const StoreDst& p, const f32x4 (&
             float* o = outn + (long long)oc * HWo + (long long)oy * p.outW + ox;
             if (vec_ok && ox + 3 < p.outW) {
                 *reinterpret_cast<f32x4*>(o) = v;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (ox + r < p.outW) o[r] = v[r];
+                    if (ox + r < p.outW) { o[r] = v[r]; amax = fmaxf(amax, fabsf(v[r])); }
             }
         }
     }
+    if (p.absmax) absmax_commit(p.absmax + n, amax);   // launch-uniform
 }
 
 // Store-bound launches (full-resolution layers with few input channels: conv0, deconv0) use this epilogue instead:
@@ -165,6 +170,7 @@ __device__ __forceinline__ void store_tile_lds(const StoreDst& p, const f32x4 (&
     float* outn = p.out + (long long)n * p.out_bstride;
     const bool vec_ok = ((p.outW & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
                         ((p.out_bstride & 3) == 0);
+    float amax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         __syncthreads();                                  // the K loop's / the previous pass's LDS reads are done
@@ -191,19 +197,21 @@ __device__ __forceinline__ void store_tile_lds(const StoreDst& p, const f32x4 (&
             float* o = outn + (long long)oc * HWo + (long long)oy * p.outW + ox;
             if (vec_ok && ox + 3 < p.outW) {
                 *reinterpret_cast<f32x4*>(o) = v;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (ox + r < p.outW) o[r] = v[r];
+                    if (ox + r < p.outW) { o[r] = v[r]; amax = fmaxf(amax, fabsf(v[r])); }
             }
         }
     }
+    if (p.absmax) absmax_commit(p.absmax + n, amax);   // launch-uniform; every thread of the workgroup gets here
 }
 
 template <int NB, int MW>
 __device__ __forceinline__ void store_tile(const ConvParams& p, const f32x4 (&acc)[MW][NB], int n, int nt,
                                            int oy0, int ox0, int wave, int li, int lk) {
-    const StoreDst d{p.out, p.out_bstride, p.outH, p.outW, p.OC, p.TWB, p.act, p.slope};
+    const StoreDst d{p.out, p.out_bstride, p.outH, p.outW, p.OC, p.TWB, p.act, p.slope, p.out_absmax};
     store_tile_dst<NB, MW>(d, acc, n, nt, oy0, ox0, wave, li, lk);
 }
 
@@ -282,7 +290,7 @@ struct TileChoice { int MW, TWB; };
 // for an invalid candidate), `model` is the analytic choice (used while capturing / when disabled).
 typedef std::array<int, 10> TuneKey;
 bool tune_enabled();
-bool tune_lookup(const TuneKey& key, int* cand);
+bool tune_lookup(const TuneKey& key, int* cand, int ncand);   // false when nothing is cached or the cached index is not in 0..ncand-1
 int tune_pick(const TuneKey& key, int ncand, int model, const std::function<int(int)>& launch, hipStream_t stream);
 
 // conv_wino.hip: Winograd F(2x2,3x3) path for wide 3x3 stride-1 convs.  Eligibility by shape only
@@ -314,6 +322,7 @@ int conv_dma_launch(ConvParams& p, const ConvPlan& pl, TileChoice tc, int kernel
 struct KbPairArgs {
     const float *image, *fused, *depth, *coords, *kinv, *proj, *wp_image, *wp_fused, *wp_depth;
     float *out_image, *out_fused, *out_depth;
+    unsigned *absmax_image, *absmax_fused, *absmax_depth;   // per-frame max |out| slots of the three outputs, or null
     long long image_bstride, fused_bstride, depth_bstride, coords_bstride, out_image_bstride, out_fused_bstride,
         out_depth_bstride;
     int n, height, width, channels_image, channels_depth, channels_fused, filters, filters_depth;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, KBN_WAVES_PER_SIMD) void conv_dma_kernel(const
     }
 
     if (p.epi_lds) {   // launch-uniform
-        const StoreDst d{p.out, p.out_bstride, p.outH, p.outW, p.OC, p.TWB, p.act, p.slope};
+        const StoreDst d{p.out, p.out_bstride, p.outH, p.outW, p.OC, p.TWB, p.act, p.slope, p.out_absmax};
         store_tile_lds<NB, MW>(d, acc, n, nt, oy0, ox0, wave, li, lk, smem, tid);
     } else {
         store_tile<NB, MW>(p, acc, n, nt, oy0, ox0, wave, li, lk);

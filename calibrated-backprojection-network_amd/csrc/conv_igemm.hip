@@ -390,7 +390,7 @@ static int cand_of_tile(TileChoice t) {
 int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
                   long long out_batch_stride, int n, int out_channels, int kernel_size, int stride,
                   int in_height, int in_width, int resize, int apply_activation, float negative_slope,
-                  hipStream_t stream) {
+                  unsigned* out_absmax, hipStream_t stream) {
     if (!srcs || !packed_weight || !out) return KBN_ERR_INVALID_ARGUMENT;
     if (n_src < 1 || n_src > KBN_MAX_SRC || n < 1 || out_channels < 1 || in_height < 1 || in_width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
@@ -440,6 +440,7 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     p.resize = resize; p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.nTilesN = pl.nTilesN;
     p.dbg = knob(KNOB_DEBUG);
+    p.out_absmax = out_absmax;   // folded in the epilogues of conv_dma_kernel / conv_igemm_kernel
     {   // LDS-transposed epilogue for store-bound launches: few multiply-adds per output (conv0, deconv0's conv).
         // KBN_EPI_LDS = 0 never / 2 always (A/B, tests); default: K = channels x taps <= 128
         const int mode = knob_set(KNOB_EPI_LDS) ? knob(KNOB_EPI_LDS) : 1;
@@ -450,6 +451,8 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
     if (kernel_size == 3 && stride == 1 && !knob(KNOB_NO_WINO)) {  // wide 3x3: Winograd F(2x2,3x3)
         int rc = conv_wino_launch(p, stream);
+        if (rc == KBN_OK && out_absmax)   // the Winograd kernel (a fallback since the split-operand convs) has no slot epilogue
+            rc = absmax_frames_launch(out, out_batch_stride, n, (long long)out_channels * p.outH * p.outW, out_absmax, stream);
         if (rc != KBN_ERR_UNSUPPORTED) return rc;
     }
     if (!knob(KNOB_NO_DMA)) {  // fast path: LDS-DMA staging (aligned tensor sources, no resize)
@@ -458,11 +461,11 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
         for (int s = 0; s < n_src; ++s) sig = sig * 4 + srcs[s].kind;
         const TuneKey key{1, n, out_channels, ctot, kernel_size, stride, in_height, in_width, sig, 0};
         int cand = cand_of_tile(tc);
-        if (!forced && tune_lookup(key, &cand)) tc = tile_of_cand(cand);    // tuned earlier / preloaded cache
+        if (!forced && tune_lookup(key, &cand, 12)) tc = tile_of_cand(cand);    // tuned earlier / preloaded cache
         const bool tuning = !forced && tune_enabled();                      // opt-in (kbn_set_autotune)
         ConvParams q = p;
         int rc = conv_dma_launch(q, pl, tc, kernel_size, stride, stream);   // also the eligibility check
-        if (rc == KBN_OK && tuning && !tune_lookup(key, &cand)) {           // first eligible launch of this shape
+        if (rc == KBN_OK && tuning && !tune_lookup(key, &cand, 12)) {           // first eligible launch of this shape
             cand = tune_pick(key, 12, cand_of_tile(tc), [&](int c) {
                 const TileChoice t = tile_of_cand(c);
                 if (t.MW > pl.MW || t.TWB > 4 * t.MW) return (int)KBN_ERR_UNSUPPORTED;
@@ -539,7 +542,7 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
         for (int nsrc = 1; nsrc <= KBN_MAX_SRC; ++nsrc) {
             int sig = nsrc, cand = 0;
             for (int s = 0; s < nsrc; ++s) sig = sig * 4 + KBN_SRC_TENSOR;
-            if (tune_lookup(TuneKey{1, n, out_channels, in_channels, kernel_size, stride, in_height, in_width, sig, 0}, &cand)) {
+            if (tune_lookup(TuneKey{1, n, out_channels, in_channels, kernel_size, stride, in_height, in_width, sig, 0}, &cand, 12)) {
                 tc = tile_of_cand(cand);
                 break;
             }
@@ -563,10 +566,10 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
 int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
                        long long out_batch_stride, int n, int out_channels, int kernel_size,
                        int stride, int in_height, int in_width, int resize, int apply_activation,
-                       float negative_slope, kbn_stream_t stream) {
+                       float negative_slope, unsigned* out_absmax, kbn_stream_t stream) {
     return kbn::conv2d_launch(srcs, n_src, packed_weight, out, out_batch_stride, n, out_channels,
                               kernel_size, stride, in_height, in_width, resize, apply_activation,
-                              negative_slope, (hipStream_t)stream);
+                              negative_slope, out_absmax, (hipStream_t)stream);
 }
 
 }  // extern "C"

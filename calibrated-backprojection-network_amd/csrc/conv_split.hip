@@ -88,8 +88,10 @@ struct SplitConvParams {
     int act;
     float slope;
     int vec4;                   // output rows are 16-byte aligned quads (width % 4 == 0, aligned base and strides)
-    float prescale;             // 2^k on the activations (k = act_exponent of the launch)
+    float prescale;             // 2^k on the activations (k = act_exponent of the launch): used when amax[0] is null
     float unscale;              // 2^-k
+    const unsigned* amax[2];    // per-frame max |a| slots of the sources (kbn_common.h): k follows the data, frame by frame
+    unsigned* out_amax;         // per-frame max |out| slot of the output, or null
     // conv1x1s2_split_kernel: three more input channels taken in fp32 in the epilogue (the KB block's backprojection)
     const float* xyz;           // N x 3 x H x W (output size), or null
     long long xyz_bstride;
@@ -110,6 +112,27 @@ __device__ __forceinline__ void sp_split8(const float (&v)[8], float prescale, s
         h1[k] = c1[0]; h1[k + 1] = c1[1];
         h2[k] = c2[0]; h2[k + 1] = c2[1];
     }
+}
+
+// The activation exponent of frame n: with slots on the sources, k = 14 - floor(log2(max |a|)) puts the frame's largest
+// activation in [2^14, 2^15) of the fp16 window (65504 is the overflow: a factor 2 to spare for the rounding of h1), so
+// |a| 2^k >= 2^-14 -- 29 binades below the maximum -- keeps the full 22 bits and anything smaller is off by less than
+// 2^-40 of the maximum.  An all-zero frame (or a denormal maximum) takes k = 100, Inf / NaN maxima k = -100: finite
+// scales either way.  Wave-uniform: n comes from blockIdx, the loads are scalar.
+__device__ __forceinline__ void sp_act_scale(const SplitConvParams& p, int n, float& prescale, float& unscale) {
+    prescale = p.prescale;
+    unscale = p.unscale;
+    if (p.amax[0]) {   // launch-uniform
+        unsigned b = p.amax[0][n];
+        if (p.amax[1]) b = max(b, p.amax[1][n]);
+        int k = 14 + 127 - (int)(b >> 23);
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        prescale = __uint_as_float((unsigned)(127 + k) << 23);
+        unscale = __uint_as_float((unsigned)(127 - k) << 23);
+    }
+}
+__device__ __forceinline__ float sp_amax4(float m, const f32x4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
 // pass 1 of the pack: per-filter exponent; inv_scale[oc] = 2^-e
@@ -161,16 +184,38 @@ __global__ void pack_split_kernel(const float* __restrict__ w, const float* __re
     packed[e] = h;
 }
 
-// max |x| over n frames of `per_frame` contiguous floats (frames batch_stride apart), folded into *amax_bits with an
-// integer atomic max (the bit patterns of non-negative floats order like the floats; NaNs rank highest and show up)
-__global__ void absmax_kernel(const float* __restrict__ x, long long batch_stride, long long per_frame, unsigned* __restrict__ amax_bits) {
+// max |x| of each of n frames of `per_frame` contiguous floats (frames batch_stride apart) into slots[frame] (integer
+// atomic max of the bit patterns).  HBM bound: 16-byte loads when the frames are 16-byte aligned, four in flight per thread.
+template <bool VEC>
+__global__ __launch_bounds__(256) void absmax_frames_kernel(const float* __restrict__ x, long long batch_stride, long long per_frame,
+                                                            unsigned* __restrict__ slots) {
     const float* xn = x + (long long)blockIdx.y * batch_stride;
-    unsigned m = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_frame; i += (long long)gridDim.x * blockDim.x)
-        m = max(m, __float_as_uint(xn[i]) & 0x7fffffffu);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(amax_bits, m);
+    float m = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    if constexpr (VEC) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(xn);
+        const long long n4 = per_frame >> 2;
+        long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const f32x4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+            m = sp_amax4(sp_amax4(sp_amax4(sp_amax4(m, a), b), c), d);
+        }
+        for (; i < n4; i += stride) m = sp_amax4(m, x4[i]);
+        for (long long t = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; t < per_frame; t += stride) m = fmaxf(m, fabsf(xn[t]));
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_frame; i += stride) m = fmaxf(m, fabsf(xn[i]));
+    }
+    absmax_commit(slots + blockIdx.y, m);
+}
+
+int absmax_frames_launch(const float* x, long long batch_stride, int n, long long per_frame, unsigned* slots, hipStream_t stream) {
+    if (!x || !slots || n < 1 || per_frame < 1) return KBN_ERR_INVALID_ARGUMENT;
+    const bool vec = !((reinterpret_cast<uintptr_t>(x) & 15) || (batch_stride & 3));
+    const int blocks = (int)std::min<long long>(std::max(1, 2048 / n), (per_frame + 4095) / 4096);   // >= 16 floats per thread, ~2048 workgroups
+    if (vec) hipLaunchKernelGGL(absmax_frames_kernel<true>, dim3(blocks, n), dim3(256), 0, stream, x, batch_stride, per_frame, slots);
+    else hipLaunchKernelGGL(absmax_frames_kernel<false>, dim3(blocks, n), dim3(256), 0, stream, x, batch_stride, per_frame, slots);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
 }
 
 template <int N>
@@ -214,6 +259,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / SP_CK;
+    float prescale, unscale;
+    sp_act_scale(p, n, prescale, unscale);
 
     // ---- input staging: waves 0-3 take k-group 0 (channels 0-7 of the chunk), waves 4-7 k-group 1; a thread owns <= PR pixels
     const int kg_st = wave >> 2, t256 = tid & 255;
@@ -255,7 +302,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
             sph8 h1, h2;
-            sp_split8(v, p.prescale, h1, h2);
+            sp_split8(v, prescale, h1, h2);
             *reinterpret_cast<sph8*>(A + slot[u] * 16) = h1;
             *reinterpret_cast<sph8*>(A + G::A_PART + slot[u] * 16) = h2;
         }
@@ -463,10 +510,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     float* outn = p.out + (long long)n * p.out_bstride;
     const float slope = p.act ? p.slope : 1.f;
     const bool vec4 = p.vec4 != 0;
+    float amax = 0.f;   // max |stored value| of this thread, folded into the output's slot
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int oc = nt * NT + fg * 32 * NB + nb * 32 + lm;
-        const float inv = p.inv_scale[oc] * p.unscale;               // 2^-e 2^-k; the table is padded to whole n-tiles
+        const float inv = p.inv_scale[oc] * unscale;               // 2^-e 2^-k; the table is padded to whole n-tiles
         if (oc >= p.OC) continue;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -485,14 +533,16 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 }
                 if (vec4) {                                             // W % 4 == 0: a quad is in or out as a whole, rows 16-byte aligned
                     *reinterpret_cast<f32x4*>(o + 8 * q4) = v;
+                    amax = sp_amax4(amax, v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (X + j < W) o[8 * q4 + j] = v[j];
+                        if (X + j < W) { o[8 * q4 + j] = v[j]; amax = fmaxf(amax, fabsf(v[j])); }
                 }
             }
         }
     }
+    if (p.out_amax) absmax_commit(p.out_amax + n, amax);   // launch-uniform; the loops above only `continue`
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -528,6 +578,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_k32_kernel(const 
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / SP_CK;
+    float prescale, unscale;
+    sp_act_scale(p, n, prescale, unscale);
 
     const int kg_st = rg >> 2, t256 = tid & 255;
     int goff[PR];
@@ -565,7 +617,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_k32_kernel(const 
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
             sph8 h1, h2;
-            sp_split8(v, p.prescale, h1, h2);
+            sp_split8(v, prescale, h1, h2);
             *reinterpret_cast<sph8*>(A + pix * 16) = h1;
             *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
         }
@@ -672,10 +724,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_k32_kernel(const 
     float* outn = p.out + (long long)n * p.out_bstride;
     const float slope = p.act ? p.slope : 1.f;
     const bool vec4 = p.vec4 != 0;
+    float amax = 0.f;
 #pragma unroll
     for (int fq = 0; fq < 4; ++fq) {
         const int oc = nt * NT + fq * 16 + lp;
-        const float inv = p.inv_scale[oc] * p.unscale;               // the table is padded to whole n-tiles
+        const float inv = p.inv_scale[oc] * unscale;               // the table is padded to whole n-tiles
         if (oc >= p.OC) continue;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -694,14 +747,16 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_k32_kernel(const 
                 }
                 if (vec4) {
                     *reinterpret_cast<f32x4*>(o) = v;
+                    amax = sp_amax4(amax, v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (X + j < W) o[j] = v[j];
+                        if (X + j < W) { o[j] = v[j]; amax = fmaxf(amax, fabsf(v[j])); }
                 }
             }
         }
     }
+    if (p.out_amax) absmax_commit(p.out_amax + n, amax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -820,6 +875,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const Spl
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / SP_CK;
+    float prescale, unscale;
+    sp_act_scale(p, n, prescale, unscale);
 
     const int kg_st = rg >> 2, t256 = tid & 255;
     int goff[PR];
@@ -855,7 +912,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const Spl
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
             sph8 h1, h2;
-            sp_split8(v, p.prescale, h1, h2);
+            sp_split8(v, prescale, h1, h2);
             *reinterpret_cast<sph8*>(A + pix * 16) = h1;
             *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
         }
@@ -1018,14 +1075,14 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const Spl
     // ---- epilogue: acc[mb][py][px][i]: low-resolution x = 8 (i / 4) + 4 g + (i % 4), filter lm; outputs (2 Y + py, 2 x + px)
     const long long oplane = (long long)H * W;
     const int oc = nt * UF_NT + lm;
-    const float inv = p.inv_scale[oc] * p.unscale;
-    if (oc >= p.OC) return;
+    const float inv = p.inv_scale[oc] * unscale;
     float* outc = p.out + (long long)n * p.out_bstride + (long long)oc * oplane;
     const float slope = p.act ? p.slope : 1.f;
+    float amax = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const int Y = oy0 + 2 * rg + mb;
-        if (Y >= sH) continue;
+        if (Y >= sH || oc >= p.OC) continue;
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
             float* orow = outc + (long long)(2 * Y + py) * W;
@@ -1040,11 +1097,12 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split_kernel(const Spl
                     v0[j] = a > 0.f ? a : a * slope;
                     v1[j] = b > 0.f ? b : b * slope;
                 }
-                if (X < W) *reinterpret_cast<f32x4*>(orow + X) = v0;
-                if (X + 4 < W) *reinterpret_cast<f32x4*>(orow + X + 4) = v1;
+                if (X < W) { *reinterpret_cast<f32x4*>(orow + X) = v0; amax = sp_amax4(amax, v0); }
+                if (X + 4 < W) { *reinterpret_cast<f32x4*>(orow + X + 4) = v1; amax = sp_amax4(amax, v1); }
             }
         }
     }
+    if (p.out_amax) absmax_commit(p.out_amax + n, amax);
 }
 
 
@@ -1113,6 +1171,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / U16_CK;
+    float prescale, unscale;
+    sp_act_scale(p, n, prescale, unscale);
 
     const int kg_st = wave >> 1, t128 = tid & 127;                     // staging: two waves per k-group
     int goff[PR];
@@ -1148,7 +1208,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
             sph8 h1, h2;
-            sp_split8(v, p.prescale, h1, h2);
+            sp_split8(v, prescale, h1, h2);
             *reinterpret_cast<sph8*>(A + pix * 16) = h1;
             *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
         }
@@ -1247,15 +1307,15 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
     // ---- epilogue: acc[mb][py][px][i]: low-resolution x = 16 mblk + 4 kq + i, filter lp; outputs (2 Y + py, 2 x + px)
     const long long oplane = (long long)H * W;
     const int oc = nt * U16_NT + lp;
-    const float inv = p.inv_scale[oc] * p.unscale;                    // the table is padded to whole n-tiles
-    if (oc >= p.OC) return;
+    const float inv = p.inv_scale[oc] * unscale;                    // the table is padded to whole n-tiles
     float* outc = p.out + (long long)n * p.out_bstride + (long long)oc * oplane;
     const float slope = p.act ? p.slope : 1.f;
     const int X = 2 * (ox0 + 16 * mblk + 4 * kq);                      // first of this lane's 8 output columns
+    float amax = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int Y = oy0 + 4 * rg + mb;
-        if (Y >= sH) continue;
+        if (Y >= sH || oc >= p.OC) continue;
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
             float* orow = outc + (long long)(2 * Y + py) * W;
@@ -1267,10 +1327,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
                 v0[j] = a > 0.f ? a : a * slope;
                 v1[j] = b > 0.f ? b : b * slope;
             }
-            if (X < W) *reinterpret_cast<f32x4*>(orow + X) = v0;
-            if (X + 4 < W) *reinterpret_cast<f32x4*>(orow + X + 4) = v1;
+            if (X < W) { *reinterpret_cast<f32x4*>(orow + X) = v0; amax = sp_amax4(amax, v0); }
+            if (X + 4 < W) { *reinterpret_cast<f32x4*>(orow + X + 4) = v1; amax = sp_amax4(amax, v1); }
         }
     }
+    if (p.out_amax) absmax_commit(p.out_amax + n, amax);
 }
 
 
@@ -1333,6 +1394,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / SP_CK;
+    float prescale, unscale;
+    sp_act_scale(p, n, prescale, unscale);
 
     const int kg_st = rg >> 2, t256 = tid & 255;
     int goff[PR];
@@ -1368,7 +1431,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
             sph8 h1, h2;
-            sp_split8(v, p.prescale, h1, h2);
+            sp_split8(v, prescale, h1, h2);
             *reinterpret_cast<sph8*>(A + pix * 16) = h1;
             *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
         }
@@ -1480,12 +1543,13 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
     // ---- epilogue: acc[py][px][nb][i]: low-resolution x = 8 (i / 4) + 4 g + (i % 4), filter nb * 32 + lm; outputs (2 Y + py, 2 x + px)
     const long long oplane = (long long)H * W;
     const int Y = oy0 + rg;
-    if (Y >= sH) return;
+    if (Y >= sH) return;   // wave-uniform: a wave whose row lies below the map stores nothing
     const float slope = p.act ? p.slope : 1.f;
+    float amax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int oc = nt * U64_NT + nb * 32 + lm;
-        const float inv = p.inv_scale[oc] * p.unscale;
+        const float inv = p.inv_scale[oc] * unscale;
         if (oc >= p.OC) continue;
         float* outc = p.out + (long long)n * p.out_bstride + (long long)oc * oplane;
 #pragma unroll
@@ -1502,11 +1566,12 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
                     v0[j] = a > 0.f ? a : a * slope;
                     v1[j] = b > 0.f ? b : b * slope;
                 }
-                if (X < W) *reinterpret_cast<f32x4*>(orow + X) = v0;
-                if (X + 4 < W) *reinterpret_cast<f32x4*>(orow + X + 4) = v1;
+                if (X < W) { *reinterpret_cast<f32x4*>(orow + X) = v0; amax = sp_amax4(amax, v0); }
+                if (X + 4 < W) { *reinterpret_cast<f32x4*>(orow + X + 4) = v1; amax = sp_amax4(amax, v1); }
             }
         }
     }
+    if (p.out_amax) absmax_commit(p.out_amax + n, amax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1553,6 +1618,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const Sp
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / SP_CK, last = nchunks - 1;
+    float prescale, unscale;
+    sp_act_scale(p, n, prescale, unscale);
 
     // staging: waves 0-3 take k-group 0 of a chunk, waves 4-7 k-group 1; one pixel per thread: output (r, c) reads input (2 r, 2 c)
     const int kg_st = wave >> 2, t256 = tid & 255;
@@ -1578,7 +1645,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const Sp
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = goff >= 0 ? vin[k] : 0.f;
         sph8 h1, h2;
-        sp_split8(v, p.prescale, h1, h2);
+        sp_split8(v, prescale, h1, h2);
         *reinterpret_cast<sph8*>(A + t256 * 16) = h1;
         *reinterpret_cast<sph8*>(A + A_PART + t256 * 16) = h2;
     };
@@ -1657,10 +1724,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const Sp
     const float* xyzn = p.xyz ? p.xyz + (long long)n * p.xyz_bstride : nullptr;
     const float slope = p.act ? p.slope : 1.f;
     const bool vec4 = p.vec4 != 0;
+    float amax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int oc = nt * NT + fg * 32 * NB + nb * 32 + lm;
-        const float inv = p.inv_scale[oc] * p.unscale;               // 2^-e 2^-k; the table is padded to whole n-tiles
+        const float inv = p.inv_scale[oc] * unscale;               // 2^-e 2^-k; the table is padded to whole n-tiles
         if (oc >= p.OC) continue;
         float wx[3] = {0.f, 0.f, 0.f};
         if (xyzn) { wx[0] = p.wxyz[oc * 3]; wx[1] = p.wxyz[oc * 3 + 1]; wx[2] = p.wxyz[oc * 3 + 2]; }
@@ -1685,14 +1753,16 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const Sp
                 }
                 if (vec4) {
                     *reinterpret_cast<f32x4*>(o + 8 * q4) = v;
+                    amax = sp_amax4(amax, v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (X + j < W) o[8 * q4 + j] = v[j];
+                        if (X + j < W) { o[8 * q4 + j] = v[j]; amax = fmaxf(amax, fabsf(v[j])); }
                 }
             }
         }
     }
+    if (p.out_amax) absmax_commit(p.out_amax + n, amax);
 }
 
 // the KB block's backprojection at the positions its stride-2 1x1 conv reads: xyz[:, j, y, x] = (K^-1 [2x 2y 1]^T)_j z,
@@ -1737,7 +1807,9 @@ extern "C" {
 // filters per workgroup; the folded up-conv takes 16-filter tiles for narrow layers (upconv2x_split16_kernel)
 static int split_nt(int mode, int out_channels, int in_channels) {
     if (mode == 3 && kbn::uf_narrow(out_channels, in_channels)) return kbn::U16_NT;
-    if (mode == 3 && kbn::uf_wide(out_channels) && !(kbn::knob(kbn::KNOB_DEBUG) & 32)) return kbn::U64_NT;   // KBN_DEBUG & 32: 32-filter tiles (A/B runs)
+    // a function of the layer's shape ONLY: the blob layout follows it, so no run-time knob may enter here (a switch read
+    // at pack time and again at launch time would let kbn_reload_env() in between walk a blob with the wrong tiling)
+    if (mode == 3 && kbn::uf_wide(out_channels)) return kbn::U64_NT;
     return mode == 2 ? 128 : (mode == 3 ? kbn::UF_NT : 64);
 }
 
@@ -1783,19 +1855,14 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
     return KBN_OK;
 }
 
-int kbn_absmax(const float* x, long long batch_stride, int n, long long per_frame, float* amax, kbn_stream_t stream) {
-    using namespace kbn;
-    if (!x || !amax || n < 1 || per_frame < 1) return KBN_ERR_INVALID_ARGUMENT;
-    const int blocks = (int)std::min<long long>(1024, (per_frame + 255) / 256);
-    hipLaunchKernelGGL(absmax_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, x, batch_stride, per_frame,
-                       reinterpret_cast<unsigned*>(amax));
-    KBN_CHECK_LAUNCH();
-    return KBN_OK;
+int kbn_absmax_frames(const float* x, long long batch_stride, int n, long long per_frame, unsigned* slots, kbn_stream_t stream) {
+    return kbn::absmax_frames_launch(x, batch_stride, n, per_frame, slots, (hipStream_t)stream);
 }
 
 int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
                               long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
-                              int act_exponent, int apply_activation, float negative_slope, kbn_stream_t stream) {
+                              int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
+                              kbn_stream_t stream) {
     using namespace kbn;
     if (act_exponent < -60 || act_exponent > 60) return KBN_ERR_INVALID_ARGUMENT;
     if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || !out || n < 1 || out_channels < 1 || height < 1 || width < 1)
@@ -1822,6 +1889,9 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     if ((long long)p.sH * p.sW > 0x1fffffffLL || (long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
     if (n_src == 1) { p.src[1] = p.src[0]; p.src_bstride[1] = p.src_bstride[0]; p.srcC[1] = 0; }
     p.nsrc = n_src;
+    // the exponent follows the data when EVERY source brings its slots; otherwise the static act_exponent serves
+    if (srcs[0].absmax && (n_src == 1 || srcs[1].absmax)) { p.amax[0] = srcs[0].absmax; p.amax[1] = n_src > 1 ? srcs[1].absmax : nullptr; }
+    p.out_amax = out_absmax;
     const int ntf = split_nt(mode, out_channels, cin);
     p.nTilesN = ceil_div(out_channels, ntf);
     p.inv_scale = static_cast<const float*>(packed_weight);
@@ -1928,7 +1998,7 @@ int kbn_conv1x1s2_split_pack_weight(const float* weight, void* packed, int out_c
 int kbn_conv1x1s2_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, const float* xyz,
                                 long long xyz_batch_stride, float* out, long long out_batch_stride, int n, int out_channels,
                                 int height, int width, int act_exponent, int apply_activation, float negative_slope,
-                                kbn_stream_t stream) {
+                                unsigned* out_absmax, kbn_stream_t stream) {
     using namespace kbn;
     if (act_exponent < -60 || act_exponent > 60) return KBN_ERR_INVALID_ARGUMENT;
     if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || !out || n < 1 || out_channels < 1 || height < 1 || width < 1)
@@ -1948,6 +2018,9 @@ int kbn_conv1x1s2_split_forward(const kbn_conv_src* srcs, int n_src, const void*
     if ((long long)p.sH * p.sW > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
     if (n_src == 1) { p.src[1] = p.src[0]; p.src_bstride[1] = p.src_bstride[0]; p.srcC[1] = 0; }
     p.nsrc = n_src;
+    // the exponent follows the data when EVERY source brings its slots; otherwise the static act_exponent serves
+    if (srcs[0].absmax && (n_src == 1 || srcs[1].absmax)) { p.amax[0] = srcs[0].absmax; p.amax[1] = n_src > 1 ? srcs[1].absmax : nullptr; }
+    p.out_amax = out_absmax;
     p.nTilesN = ceil_div(out_channels, 128);
     p.inv_scale = static_cast<const float*>(packed_weight);
     p.wp = reinterpret_cast<const _Float16*>(p.inv_scale + p.nTilesN * 128);

@@ -866,9 +866,9 @@ int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channel
     return KBN_OK;
 }
 
-int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const float* packed_weight, float* out,
-                         long long out_batch_stride, int n, int in_channels, int out_channels, int src_height,
-                         int src_width, int apply_activation, float negative_slope, kbn_stream_t stream) {
+static int upconv2x_forward_impl(const float* src, long long src_batch_stride, const float* packed_weight, float* out,
+                                 long long out_batch_stride, int n, int in_channels, int out_channels, int src_height,
+                                 int src_width, int apply_activation, float negative_slope, kbn_stream_t stream) {
     using namespace kbn;
     if (!src || !packed_weight || !out || n < 1 || in_channels < 1 || out_channels < 1 || src_height < 1 ||
         src_width < 1)
@@ -980,6 +980,18 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
         case 3: return mw == 1 ? up2x_variant<3, 1, 1>(p, lds, st) : up2x_variant<3, 2, 1>(p, lds, st);
         default: return mw == 1 ? up2x_variant<4, 1, 1>(p, lds, st) : up2x_variant<4, 2, 1>(p, lds, st);
     }
+}
+
+int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const float* packed_weight, float* out,
+                         long long out_batch_stride, int n, int in_channels, int out_channels, int src_height,
+                         int src_width, int apply_activation, float negative_slope, unsigned* out_absmax, kbn_stream_t stream) {
+    int rc = upconv2x_forward_impl(src, src_batch_stride, packed_weight, out, out_batch_stride, n, in_channels, out_channels,
+                                   src_height, src_width, apply_activation, negative_slope, stream);
+    // these fp32 kernels are fallbacks since the folded split-operand up-conv: the slot is filled by a pass of its own
+    if (rc == KBN_OK && out_absmax)
+        rc = kbn::absmax_frames_launch(out, out_batch_stride, n, 4LL * out_channels * src_height * src_width, out_absmax,
+                                       (hipStream_t)stream);
+    return rc;
 }
 
 /* Which algebraic form kbn_upconv2x_forward runs for a problem and what it executes:

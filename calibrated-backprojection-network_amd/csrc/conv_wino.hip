@@ -565,7 +565,7 @@ int wino_query(int n, int oc, int cin, int H, int W, int* RT, int* CT) {
     const WinoPlan wp = wino_plan(oc, cin, 3, 1);
     if (!wp.ok || (W & 3)) return 0;
     int cand = choose_region(H, W, n, wp.nTilesN);
-    tune_lookup(TuneKey{2, n, oc, cin, H, W, 0, 0, 0, 0}, &cand);   // a tuned choice, if this shape has run already
+    tune_lookup(TuneKey{2, n, oc, cin, H, W, 0, 0, 0, 0}, &cand, kNumRegions);   // a tuned choice, if this shape has run already
     *RT = kRegions[cand][0]; *CT = kRegions[cand][1];
     return ceil_div(ceil_div(W, 2), *CT) * ceil_div(ceil_div(H, 2), *RT) * n * wp.nTilesN;
 }

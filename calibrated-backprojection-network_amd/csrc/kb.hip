@@ -83,7 +83,8 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
                          long long out_image_batch_stride, float* out_depth, long long out_depth_batch_stride,
                          float* out_fused, long long out_fused_batch_stride, int n, int height, int width,
                          int channels_image, int channels_depth, int channels_fused, int filters_image,
-                         int filters_depth, int filters_fused, float negative_slope, kbn_stream_t stream) {
+                         int filters_depth, int filters_fused, float negative_slope, unsigned* out_image_absmax,
+                         unsigned* out_depth_absmax, unsigned* out_fused_absmax, kbn_stream_t stream) {
     if (!image || !depth || (!coordinates && !kinv) || !packed_w_image || !packed_w_depth || !proj_weight ||
         !packed_w_fused || !out_image || !out_depth || !out_fused)
         return KBN_ERR_INVALID_ARGUMENT;
@@ -109,6 +110,7 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
         a.channels_fused = channels_fused; a.filters = filters_image; a.slope = negative_slope;
         a.wp_depth = packed_w_depth; a.out_depth = out_depth; a.out_depth_bstride = out_depth_batch_stride;
         a.filters_depth = filters_depth;
+        a.absmax_image = out_image_absmax; a.absmax_fused = out_fused_absmax; a.absmax_depth = out_depth_absmax;
         rc = kbn::kb_pair_launch(a, st, &depth_done);
         if (rc == KBN_OK) paired = true;
         else if (rc != KBN_ERR_UNSUPPORTED) return rc;
@@ -117,7 +119,7 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
     // conv_image = act(conv3x3 s2 (image))                      src/net_utils.py:1348
     if (!paired) {
         rc = kbn::conv2d_launch(&s_img, 1, packed_w_image, out_image, out_image_batch_stride, n, filters_image, 3, 2,
-                                height, width, KBN_RESIZE_NONE, 1, negative_slope, st);
+                                height, width, KBN_RESIZE_NONE, 1, negative_slope, out_image_absmax, st);
         if (rc != KBN_OK) return rc;
     }
 
@@ -133,7 +135,7 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
     }
     if (!depth_done) {
         rc = kbn::conv2d_launch(s_dep, 2, packed_w_depth, out_depth, out_depth_batch_stride, n, filters_depth, 3, 2,
-                                height, width, KBN_RESIZE_NONE, 1, negative_slope, st);
+                                height, width, KBN_RESIZE_NONE, 1, negative_slope, out_depth_absmax, st);
         if (rc != KBN_OK) return rc;
     }
     if (paired) return KBN_OK;
@@ -153,7 +155,7 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
         nsrc = 3;
     }
     return kbn::conv2d_launch(s_fus, nsrc, packed_w_fused, out_fused, out_fused_batch_stride, n, filters_fused, 1,
-                              2, height, width, KBN_RESIZE_NONE, 1, negative_slope, st);
+                              2, height, width, KBN_RESIZE_NONE, 1, negative_slope, out_fused_absmax, st);
 }
 
 }  // extern "C"

@@ -356,13 +356,13 @@ __global__ __launch_bounds__(256, 2) void kb_pair_kernel(const KbPairParams p) {
         cur ^= 1;
     }
 
-    const StoreDst dI{a.out_image, a.out_image_bstride, p.outH, p.outW, a.filters, TWB, 1, a.slope};
+    const StoreDst dI{a.out_image, a.out_image_bstride, p.outH, p.outW, a.filters, TWB, 1, a.slope, a.absmax_image};
     store_tile_dst<NB, MW>(dI, accI, n, nt, oy0, ox0, wave, li, lk);
-    const StoreDst dF{a.out_fused, a.out_fused_bstride, p.outH, p.outW, a.filters, TWB, 1, a.slope};
+    const StoreDst dF{a.out_fused, a.out_fused_bstride, p.outH, p.outW, a.filters, TWB, 1, a.slope, a.absmax_fused};
     store_tile_dst<NB, MW>(dF, accF, n, nt, oy0, ox0, wave, li, lk);
     if constexpr (NBD > 0) {
         if (do_depth) {
-            const StoreDst dD{a.out_depth, a.out_depth_bstride, p.outH, p.outW, a.filters_depth, TWB, 1, a.slope};
+            const StoreDst dD{a.out_depth, a.out_depth_bstride, p.outH, p.outW, a.filters_depth, TWB, 1, a.slope, a.absmax_depth};
             store_tile_dst<NBD, MW>(dD, accD, n, nt, oy0, ox0, wave, li, lk);
         }
     }

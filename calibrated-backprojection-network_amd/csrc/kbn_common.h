@@ -24,6 +24,26 @@ __host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * 
 
 __device__ __forceinline__ float leaky_relu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// ---- per-frame activation statistics ("absmax slots") ------------------------------------------------
+// A slot is one unsigned per frame: the bit pattern of max |a| over a tensor's frame (bit patterns of non-negative
+// floats order like the floats).  The caller zeroes the slots; every conv kernel folds the values it stores into the
+// slot of its output tensor (out_absmax) in its epilogue; the split-operand kernels read the slots of their inputs
+// (kbn_conv_src.absmax) and place their fp16 window on them (sp_act_scale, conv_split.hip) -- the exponent follows the
+// data of THIS forward, frame by frame, with no host round trip and no state between calls.
+// `m` >= 0: this thread's maximum (NaNs never enter: fmaxf drops them).  One atomic per wave, and only when the wave
+// would raise the slot (the plain load may be stale -- then the atomic is merely redundant).
+__device__ __forceinline__ void absmax_commit(unsigned* slot, float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned b = __float_as_uint(m);
+        if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+    }
+}
+// max |x| of each of n frames of per_frame contiguous floats into slots[n] (csrc/conv_split.hip): the stand-alone pass
+// for tensors whose producer did not fill a slot (inputs of a drop-in module call, outputs of the fallback kernels)
+int absmax_frames_launch(const float* x, long long batch_stride, int n, long long per_frame, unsigned* slots, hipStream_t stream);
+
 // ---- per-device one-time kernel setup -------------------------------------------------------------
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel, device): one bit per device
 // ordinal of the calling thread's current device, so that a process driving several GPUs (the reference
@@ -84,6 +104,6 @@ __device__ __forceinline__ int nearest_src_index(int dst, int in_size, int out_s
 int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
                   long long out_batch_stride, int n, int out_channels, int kernel_size, int stride,
                   int in_height, int in_width, int resize, int apply_activation, float negative_slope,
-                  hipStream_t stream);
+                  unsigned* out_absmax, hipStream_t stream);
 
 }  // namespace kbn

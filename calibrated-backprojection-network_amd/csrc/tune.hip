@@ -14,7 +14,11 @@
 // order) and the winner is cached per device for the process.  Never while the stream is being captured.
 // The cache holds integers only.  KBN_TUNE_CACHE=<file> (read when the library is loaded / kbn_reload_env)
 // preloads choices that apply to every device and receives the entries later tuning passes find, so that
-// e.g. a profiled run replays the choices of an earlier run without any timing launches of its own.
+// e.g. a profiled run replays the choices of an earlier run without any timing launches of its own.  The file
+// starts with a line naming the candidate-table version it was written for (kTuneTables: bump it whenever a
+// kernel family's candidate list changes); a file with another version -- or none -- is ignored, and every
+// lookup is range-checked against the caller's candidate count, so a stale file can never select a geometry
+// that does not exist.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -32,11 +36,20 @@ static std::map<DevKey, int> g_cache;
 static std::mutex g_mutex;
 static std::string g_path;
 static std::atomic<int> g_autotune{0};
+constexpr int kTuneTables = 3;   // candidate tables of round 3 (ABI 2)
+static const char kHeaderFmt[] = "kbn-tune-cache abi %d tables %d\n";
 
 static void load_file_locked() {   // g_mutex held
     if (g_path.empty()) return;
     FILE* f = fopen(g_path.c_str(), "r");
     if (!f) return;
+    int abi = -1, tables = -1;
+    if (fscanf(f, "kbn-tune-cache abi %d tables %d", &abi, &tables) != 2 || abi != KBN_ABI_VERSION || tables != kTuneTables) {
+        fclose(f);   // another build's file (or not a cache file): its candidate indices mean nothing here
+        fprintf(stderr, "[kbnet] KBN_TUNE_CACHE %s was not written by this build: ignored\n", g_path.c_str());
+        g_path.clear();
+        return;
+    }
     TuneKey k;
     int cand;
     while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8],
@@ -49,6 +62,8 @@ static void append_file_locked(const TuneKey& k, int cand) {
     if (g_path.empty()) return;
     FILE* f = fopen(g_path.c_str(), "a");
     if (!f) return;
+    fseek(f, 0, SEEK_END);
+    if (ftell(f) == 0) fprintf(f, kHeaderFmt, KBN_ABI_VERSION, kTuneTables);   // new file
     fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], cand);
     fclose(f);
 }
@@ -78,19 +93,19 @@ static int current_device() {
     return hipGetDevice(&dev) == hipSuccess ? dev : 0;
 }
 
-bool tune_lookup(const TuneKey& key, int* cand) {
+bool tune_lookup(const TuneKey& key, int* cand, int ncand) {
     const int dev = current_device();
     std::lock_guard<std::mutex> g(g_mutex);
     auto it = g_cache.find(DevKey(dev, key));
     if (it == g_cache.end()) it = g_cache.find(DevKey(-1, key));
-    if (it == g_cache.end()) return false;
+    if (it == g_cache.end() || it->second < 0 || it->second >= ncand) return false;   // out of range: the cost model serves
     *cand = it->second;
     return true;
 }
 
 int tune_pick(const TuneKey& key, int ncand, int model, const std::function<int(int)>& launch, hipStream_t stream) {
     int cand = model;
-    if (tune_lookup(key, &cand)) return cand;
+    if (tune_lookup(key, &cand, ncand)) return cand;
     if (!tune_enabled()) return model;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return model;

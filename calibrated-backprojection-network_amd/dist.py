@@ -113,18 +113,20 @@ class ShardedRunner:
         return self._finish(self._ring[(self._step - 1) & 1])
 
     # ---- one batch, any split ----------------------------------------------------------------------------
-    def _slots(self, out, per):
-        key = (per, tuple(out.shape[1:]), out.device, out.dtype)
+    def _slots(self, out, per, bucket=0):
+        # `bucket`: several gathers of one step_mixed call are in flight at once, so two buckets of the same frame
+        # shape and slot size must not share a buffer (the second collective would overwrite the first)
+        key = (per, tuple(out.shape[1:]), out.device, out.dtype, bucket)
         buf = self._bufs.get(key)
         if buf is None:
             buf = self._bufs[key] = torch.empty((self.world * per,) + tuple(out.shape[1:]), device=out.device,
                                                 dtype=out.dtype)
         return buf
 
-    def _gather_start(self, out, n_total):
+    def _gather_start(self, out, n_total, bucket=0):
         """-> (buffer, work, per): `out` (N_local frames, N_local possibly 0 < per) into padded slots."""
         per = -(-n_total // self.world)          # slot size (max frames on any rank)
-        buf = self._slots(out, per)
+        buf = self._slots(out, per, bucket)
         if out.shape[0] == per:
             src = out.contiguous()
         else:
@@ -162,7 +164,7 @@ class ShardedRunner:
         One all-gather per shape bucket into that bucket's own buffer; the gather of bucket i is in flight
         while bucket i+1 computes.  Returns the list of N_total x ... tensors, bucket order."""
         pending = []
-        for forward_fn, inputs, n_total, frame_shape in buckets:
+        for bucket, (forward_fn, inputs, n_total, frame_shape) in enumerate(buckets):
             lo, hi = shard_bounds(n_total, self.rank, self.world)
             out = None
             if inputs is not None and hi > lo:
@@ -179,7 +181,7 @@ class ShardedRunner:
                 ref = inputs[0] if inputs is not None else None
                 dev = ref.device if ref is not None else self._default_device()
                 out = torch.empty((0,) + tuple(frame_shape), device=dev, dtype=torch.float32)
-            pending.append(self._gather_start(out, n_total) + (n_total,))
+            pending.append(self._gather_start(out, n_total, bucket) + (n_total,))
         results = []
         for buf, work, per, n_total in pending:
             results.append(buf if work is None else self._gather_finish(buf, work, per, n_total))
@@ -204,9 +206,21 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
-def sum_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized():
-        return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+def sum_over_ranks(values: torch.Tensor) -> torch.Tensor:
+    """Element-wise sum of a small tensor over all ranks (in place; identity without a process group)."""
+    if dist.is_initialized():
+        dist.all_reduce(values, op=dist.ReduceOp.SUM)
+    return values
+
+
+def mean_metrics_over_ranks(per_frame: torch.Tensor) -> torch.Tensor:
+    """The reference's evaluation summary over a sharded run: it averages the per-sample MAE / RMSE / iMAE / iRMSE over
+    ALL samples (reference src/kbnet.py:952-984, np.mean over the arrays filled at :932-950).  `per_frame`: this
+    rank's N_local x 4 metrics from ops.eval_metrics (N_local may be 0 and may differ between ranks); returns the 4
+    means over the frames of every rank (fp64, on per_frame's device).  ONE all-reduce of five numbers."""
+    acc = torch.zeros(5, dtype=torch.float64, device=per_frame.device)
+    if per_frame.numel():
+        acc[:4] = per_frame.to(torch.float64).sum(dim=0)
+    acc[4] = per_frame.shape[0]
+    sum_over_ranks(acc)
+    return acc[:4] / acc[4].clamp_min(1.0)

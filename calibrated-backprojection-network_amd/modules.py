@@ -135,9 +135,22 @@ class Conv2d(torch.nn.Module):
         # 64 -> 12 up-conv.  Level with the fp32 9-product kernel on random operands (650 vs 640 us per 32 KITTI frames),
         # 8-11 % faster inside the forward (660-690 vs 745 us, tools/layer_profile.py)
         self.split_narrow_up = True
-        self._act_exp = None   # activation exponent of the split kernel's fp16 window, measured on the first call
 
-    def run_split(self, srcs, n, h, w, out=None, up2x=False):
+    @staticmethod
+    def _with_slots(srcs, n, dev, stats):
+        """Every tensor source of a split-operand launch carries its per-frame max |a| slot (ops.ActStats): the kernel
+        places its fp16 window on the data of THIS call.  Sources that come without one (a drop-in module called on
+        its own, reference code in front of it) are measured here by a pass over the tensor -- no host sync, no state."""
+        for s in srcs:
+            if s.kind == _lib.KBN_SRC_TENSOR and (not s.absmax or (stats is not None and not stats.usable(s.absmax))):
+                if stats is None:
+                    stats = ops.ActStats(n, dev, capacity=len(srcs))
+                slot = stats.measure(s._keep[0])
+                s.absmax = slot.data_ptr()
+                s._keep = (s._keep[0], slot)
+        return srcs
+
+    def run_split(self, srcs, n, h, w, out=None, up2x=False, out_absmax=None, stats=None):
         """3x3 stride-1 conv with two-term fp16 splits of both operands (ops.conv3x3_split, fp32-grade results); `h` x `w`
         is the OUTPUT size.  None when the layer or the shape does not qualify."""
         if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2
@@ -151,39 +164,28 @@ class Conv2d(torch.nn.Module):
         dev = self.conv.weight.device
         if out is None:
             out = torch.empty((n, self.out_channels, h, w), device=dev, dtype=torch.float32)
-        k = self._act_exp
-        if k is None:
-            # first call of this layer: measure max |a| of its input and place the fp16 window on it (a host sync, once);
-            # while a graph is being captured the ABI default serves (GraphedForward warms up before it captures)
-            if torch.cuda.is_current_stream_capturing():
-                k = -6
-            else:
-                k = self._act_exp = ops.act_exponent_for(ops.absmax_srcs(srcs, n, dev))
+        srcs = self._with_slots(srcs, n, dev, stats)
         packed = (self._packed_split_up.get(self.conv.weight, 1, up2x="split_up") if up2x
                   else self._packed_split.get(self.conv.weight, self.stride, up2x="split"))
         return ops.conv3x3_split(srcs, packed, n, self.out_channels, h, w, out, up2x=up2x, negative_slope=self._slope,
-                                 stride=self.stride, act_exponent=k, folded_up2x=up2x)
+                                 stride=self.stride, folded_up2x=up2x, out_absmax=out_absmax)
 
     def split_fused_qualifies(self, ci, cf):
         return (self.split and self.kernel_size == 1 and self.stride == 2 and ci % 16 == 0 and cf % 16 == 0
                 and self.out_channels >= self.split_fused_min_filters and self.in_channels == ci + 3 + cf)
 
-    def run_split_fused(self, image, fused, xyz, n, h, w, out):
+    def run_split_fused(self, image, fused, xyz, n, h, w, out, amax_image=None, amax_fused=None, out_absmax=None, stats=None):
         """conv_fused of a KB block -- this 1x1 stride-2 conv over cat[image, xyz, fused] -- with the tensor channels on
         split operands and the three xyz channels (ops.kb_xyz_s2) in fp32 (ops.conv1x1s2_split); `h` x `w` is the OUTPUT
         size.  None when the layer or the shapes do not qualify."""
         ci, cf = image.shape[1], (0 if fused is None else fused.shape[1])
         if not self.split_fused_qualifies(ci, cf):
             return None
-        srcs = [ops.tensor_src(image, "image")] + ([] if fused is None else [ops.tensor_src(fused, "fused")])
-        k = self._act_exp
-        if k is None:
-            if torch.cuda.is_current_stream_capturing():
-                k = -6
-            else:
-                k = self._act_exp = ops.act_exponent_for(ops.absmax_srcs(srcs, n, image.device))
+        srcs = [ops.tensor_src(image, "image", amax_image)] + ([] if fused is None else [ops.tensor_src(fused, "fused", amax_fused)])
+        srcs = self._with_slots(srcs, n, image.device, stats)
         packed = self._packed_split_1x1.get(self.conv.weight, 2, up2x=("split_1x1s2", ci))
-        return ops.conv1x1s2_split(srcs, packed, xyz, n, self.out_channels, h, w, out, negative_slope=self._slope, act_exponent=k)
+        return ops.conv1x1s2_split(srcs, packed, xyz, n, self.out_channels, h, w, out, negative_slope=self._slope,
+                                   out_absmax=out_absmax)
 
     def packed(self):
         return self._packed.get(self.conv.weight, self.stride)
@@ -199,7 +201,9 @@ class Conv2d(torch.nn.Module):
         return ops.conv3x3_bf16(srcs, self._packed_bf16.get(self.conv.weight, 1, up2x="bf16"), n, self.out_channels, h, w,
                                 out, up2x=up2x, negative_slope=self._slope, stride=self.stride)
 
-    def run(self, srcs, n, in_h, in_w, out=None, resize=False):
+    def run(self, srcs, n, in_h, in_w, out=None, resize=False, out_absmax=None, stats=None):
+        """`out_absmax`: slot (ops.ActStats) that receives max |out| per frame; `stats`: where slots for unmeasured
+        inputs come from (split-operand launches only)."""
         cin = sum(s.channels for s in srcs)
         if cin != self.in_channels:   # the packed blob carries no size: a wrong count would read past the weight panel
             raise KbnError(f"expected {self.in_channels} input channels in total, got {cin}")
@@ -207,16 +211,18 @@ class Conv2d(torch.nn.Module):
         if self.bf16 and not resize:
             res = self.run_bf16(srcs, n, oh, ow, out=out)
             if res is not None:
+                if stats is not None:
+                    stats.skip(out_absmax)   # the bf16 kernels fold no maxima
                 return res
         if not resize:
-            res = self.run_split(srcs, n, oh, ow, out=out)
+            res = self.run_split(srcs, n, oh, ow, out=out, out_absmax=out_absmax, stats=stats)
             if res is not None:
                 return res
         if out is None:
             out = torch.empty((n, self.out_channels, oh, ow), device=self.conv.weight.device,
                               dtype=torch.float32)
         return ops.conv2d(srcs, self.packed(), n, self.out_channels, self.kernel_size, self.stride,
-                          in_h, in_w, out, resize=resize, negative_slope=self._slope)
+                          in_h, in_w, out, resize=resize, negative_slope=self._slope, out_absmax=out_absmax)
 
     def forward(self, x):
         if x.shape[1] != self.in_channels:
@@ -243,7 +249,9 @@ class UpConv2d(torch.nn.Module):
         self._packed_up2x = _PackedWeight()
         self.split_up = True    # folded 16-product form on split operands (ops.conv3x3_split(folded_up2x=True))
 
-    def forward(self, x, shape):
+    def forward(self, x, shape, amax=None, out_absmax=None, stats=None):
+        """`amax` / `out_absmax` / `stats` (extensions): the per-frame max |a| slot of `x`, the slot to fill for the result,
+        the slot pool of the forward (ops.ActStats)."""
         if x.shape[1] != self.conv.in_channels:
             raise KbnError(f"expected {self.conv.in_channels} input channels, got {x.shape[1]}")
         x = x if _dense(x) else x.contiguous()
@@ -253,16 +261,18 @@ class UpConv2d(torch.nn.Module):
             if self.conv.bf16:
                 res = self.conv.run_bf16([ops.tensor_src(x, "x")], n, oh, ow, up2x=True)
                 if res is not None:
+                    if stats is not None:
+                        stats.skip(out_absmax)
                     return res
             if self.split_up:
-                res = self.conv.run_split([ops.tensor_src(x, "x")], n, oh, ow, up2x=True)
+                res = self.conv.run_split([ops.tensor_src(x, "x", amax)], n, oh, ow, up2x=True, out_absmax=out_absmax, stats=stats)
                 if res is not None:
                     return res
             # exact 2x: four 2x2 phase convs on the low-res input (4/9 of the MACs)
             out = torch.empty((n, self.conv.out_channels, oh, ow), device=x.device, dtype=torch.float32)
             return ops.upconv2x(x, self._packed_up2x.get(self.conv.conv.weight, 1, up2x=True),
-                                self.conv.out_channels, out, self.conv._slope)
-        return self.conv.run([ops.tensor_src(x, "x")], n, oh, ow, resize=True)
+                                self.conv.out_channels, out, self.conv._slope, out_absmax=out_absmax)
+        return self.conv.run([ops.tensor_src(x, "x", amax)], n, oh, ow, resize=True, out_absmax=out_absmax, stats=stats)
 
 
 class VGGNetBlock(torch.nn.Module):
@@ -313,7 +323,11 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         if self._slope is None:
             raise ValueError("the fused KB block needs a (leaky) ReLU activation")
 
-    def run(self, image, depth, coordinates, fused, out_image=None, out_depth=None, out_fused=None):
+    def run(self, image, depth, coordinates, fused, out_image=None, out_depth=None, out_fused=None,
+            amax_image=None, amax_fused=None, out_amax_image=None, out_amax_skip=None, stats=None):
+        """amax_image / amax_fused: per-frame max |a| slots of `image` / `fused` (ops.ActStats; measured here when a
+        split-operand conv needs one that is missing); out_amax_image: slot to fill for conv_image's output;
+        out_amax_skip: ONE slot for conv_fused's and conv_depth's outputs (the encoder keeps them in one skip tensor)."""
         n, ci, h, w = image.shape
         cd, cf = depth.shape[1], (0 if fused is None else fused.shape[1])
         want = (self.conv_image.conv_block[0].in_channels, self.conv_depth.conv_block[0].in_channels - 3,
@@ -337,35 +351,45 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             # their inputs are synthesized in-kernel (K^-1 [x y 1]^T, backprojection) -- stay on the fp32 conv kernels.
             res = ci_conv.run_bf16([ops.tensor_src(image, "image")], n, oh, ow, out=out_image)
             if res is not None:
-                self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth)
+                if stats is not None:
+                    stats.skip(out_amax_image)
+                self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth,
+                                                  out_absmax=out_amax_skip)
                 srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
                 if fused is not None:
                     srcs.append(ops.tensor_src(fused, "fused"))
-                self.conv_fused.run(srcs, n, h, w, out=out_fused)
+                self.conv_fused.run(srcs, n, h, w, out=out_fused, out_absmax=out_amax_skip)
                 return out_image, out_depth, out_fused
         if ci_conv.split and self.split_image and kinv is not None:
             # conv_image (most of the block's FLOPs) on the 16-bit matrix core (fp32-grade split operands); conv_depth and
             # conv_fused -- their inputs are synthesized in-kernel (K^-1 [x y 1]^T, backprojection) -- on the fp32 kernels
-            res = ci_conv.run_split([ops.tensor_src(image, "image")], n, oh, ow, out=out_image)
+            if amax_image is None or (stats is not None and not stats.usable(amax_image.data_ptr())):
+                stats = stats if stats is not None else ops.ActStats(n, dev, capacity=3)
+                amax_image = stats.measure(image)   # conv_image and conv_fused both read `image`: measured once
+            res = ci_conv.run_split([ops.tensor_src(image, "image", amax_image)], n, oh, ow, out=out_image,
+                                    out_absmax=out_amax_image, stats=stats)
             if res is not None:
-                self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth)
+                self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth,
+                                                  out_absmax=out_amax_skip)
                 if (self.split_fused and (fused is None or _dense(fused)) and self.proj_depth._slope is not None
                         and self.conv_fused.split_fused_qualifies(ci, cf)):
                     # conv_fused's tensor channels on the matrix core too; its backprojection channels, computed once at the
                     # pixels a stride-2 1x1 conv reads, enter in fp32
                     xyz = ops.kb_xyz_s2(depth, self.proj_depth.conv.weight, kinv, self.proj_depth._slope)
-                    if self.conv_fused.run_split_fused(image, fused, xyz, n, oh, ow, out_fused) is not None:
+                    if self.conv_fused.run_split_fused(image, fused, xyz, n, oh, ow, out_fused, amax_image, amax_fused,
+                                                       out_absmax=out_amax_skip, stats=stats) is not None:
                         return out_image, out_depth, out_fused
                 srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
                 if fused is not None:
                     srcs.append(ops.tensor_src(fused, "fused"))
-                self.conv_fused.run(srcs, n, h, w, out=out_fused)
+                self.conv_fused.run(srcs, n, h, w, out=out_fused, out_absmax=out_amax_skip)
                 return out_image, out_depth, out_fused
         return ops.kb_block(image, depth, coords, kinv, fused,
                             self.conv_image.conv_block[0].packed(), self.conv_depth.conv_block[0].packed(),
                             self.proj_depth.conv.weight, self.conv_fused.packed(),
                             self.n_filter_image, self.n_filter_depth, self.n_filter_fused,
-                            out_image, out_depth, out_fused, self._slope)
+                            out_image, out_depth, out_fused, self._slope, absmax_image=out_amax_image,
+                            absmax_depth=out_amax_skip, absmax_fused=out_amax_skip)
 
     def forward(self, image, depth, coordinates, fused=None):
         image = image if _dense(image) else image.contiguous()
@@ -390,17 +414,22 @@ class DecoderBlock(torch.nn.Module):
         self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer,
                            activation_func, use_batch_norm, use_instance_norm)
 
-    def forward(self, x, skip=None, shape=None):
+    def forward(self, x, skip=None, shape=None, amax_x=None, amax_skip=None, out_absmax=None, stats=None):
+        """amax_x / amax_skip / out_absmax / stats (extensions): per-frame max |a| slots of the inputs, the slot to fill
+        for the result and the slot pool of the forward (ops.ActStats); missing input slots are measured."""
         if skip is not None:
             shape = skip.shape[2:4]
         elif shape is None:
             shape = (2 * x.shape[2], 2 * x.shape[3])
-        deconv = self.deconv(x, shape=shape)
-        srcs = [ops.tensor_src(deconv, "deconv")]
+        if stats is None:
+            stats = ops.ActStats(x.shape[0], x.device, capacity=4)
+        amax_deconv = stats.new()
+        deconv = self.deconv(x, shape=shape, amax=amax_x, out_absmax=amax_deconv, stats=stats)
+        srcs = [ops.tensor_src(deconv, "deconv", amax_deconv)]
         if self.skip_channels > 0:
             skip = skip if _dense(skip) else skip.contiguous()
-            srcs.append(ops.tensor_src(skip, "skip"))  # torch.cat([deconv, skip]) fused into the K loop
-        return self.conv.run(srcs, x.shape[0], int(shape[0]), int(shape[1]))
+            srcs.append(ops.tensor_src(skip, "skip", amax_skip))  # torch.cat([deconv, skip]) fused into the K loop
+        return self.conv.run(srcs, x.shape[0], int(shape[0]), int(shape[1]), out_absmax=out_absmax, stats=stats)
 
 
 # --------------------------------------------------------------------------- S2D
@@ -485,8 +514,17 @@ class KBNetEncoder(torch.nn.Module):
         return self
 
     def forward(self, image, depth, intrinsics):
+        latent, skips, _, _ = self.encode(image, depth, intrinsics)
+        return latent, skips
+
+    def encode(self, image, depth, intrinsics, stats=None):
+        """forward() plus the per-frame max |a| slots of what it returns: (latent, skips, amax_latent, amax_skips).  Every
+        conv of the encoder folds max |out| into the slot of its output tensor (ops.ActStats); the split-operand convs
+        downstream -- here and in the decoder -- place their fp16 windows on them."""
         fi, fd, ff = self._f
         n, _, h0, w0 = image.shape
+        if stats is None:
+            stats = ops.ActStats(n, image.device)
         dev = image.device
         image = image if _dense(image) else image.contiguous()
         depth = depth if _dense(depth) else depth.contiguous()
@@ -500,10 +538,12 @@ class KBNetEncoder(torch.nn.Module):
         # Q1: every deeper KB level scales K by the level-1 ratio (reference src/networks.py:342-343)
         sx, sy = w1 / w0, h1 / h0
         conv_fused = None
-        skips = []
+        skips, amax_skips = [], []
+        amax_image = amax_skip = None   # slots of the current conv_image tensor / of the previous level's skip tensor
         kinv1 = None   # the level-1 inverse serves every deeper level (Q1): computed once
         for level in range(4):
             oh, ow = (h + 1) // 2, (w + 1) // 2
+            a_img, a_skip = stats.new(), stats.new()
             if level in self.resolutions_backprojection:
                 blk = getattr(self, f"calibrated_backprojection{level + 1}")
                 if level > 0:
@@ -512,24 +552,36 @@ class KBNetEncoder(torch.nn.Module):
                     kinv = kinv1
                 skip = torch.empty((n, ff[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
                 out_fused, out_depth = skip[:, :ff[level]], skip[:, ff[level]:]
-                conv_image, conv_depth, conv_fused = blk.run(conv_image, conv_depth, kinv, conv_fused,
-                                                             None, out_depth, out_fused)
+                conv_image, conv_depth, conv_fused = blk.run(
+                    conv_image, conv_depth, kinv, conv_fused, None, out_depth, out_fused,
+                    amax_image=amax_image if level > 0 else None, amax_fused=amax_skip if conv_fused is not None else None,
+                    out_amax_image=a_img, out_amax_skip=a_skip, stats=stats)
+                amax_image = a_img
             else:
-                src = conv_fused if conv_fused is not None else conv_image
+                # plain level: conv_image lives in the skip tensor, whose slot (a superset: a safe bound) serves it too
+                src, a_src = (conv_fused, amax_skip) if conv_fused is not None else (conv_image, amax_image if level > 0 else None)
                 skip = torch.empty((n, fi[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
                 ci_blk = getattr(self, f"conv{level + 1}_image").conv_block[0]
                 cd_blk = getattr(self, f"conv{level + 1}_depth").conv_block[0]
-                conv_image = ci_blk.run([ops.tensor_src(src)], n, h, w, out=skip[:, :fi[level]])
-                conv_depth = cd_blk.run([ops.tensor_src(conv_depth)], n, h, w, out=skip[:, fi[level]:])
+                conv_image = ci_blk.run([ops.tensor_src(src, "image", a_src)], n, h, w, out=skip[:, :fi[level]], out_absmax=a_skip,
+                                        stats=stats)
+                conv_depth = cd_blk.run([ops.tensor_src(conv_depth, "depth", amax_skip)], n, h, w, out=skip[:, fi[level]:],
+                                        out_absmax=a_skip, stats=stats)
                 conv_fused = None
+                amax_image = a_skip
+            amax_skip = a_skip
             skips.append(skip)
+            amax_skips.append(a_skip)
             h, w = oh, ow
         oh, ow = (h + 1) // 2, (w + 1) // 2
         latent = torch.empty((n, fi[4] + fd[4], oh, ow), device=dev, dtype=torch.float32)
-        src = conv_fused if conv_fused is not None else conv_image
-        self.conv5_image.conv_block[0].run([ops.tensor_src(src)], n, h, w, out=latent[:, :fi[4]])
-        self.conv5_depth.conv_block[0].run([ops.tensor_src(conv_depth)], n, h, w, out=latent[:, fi[4]:])
-        return latent, skips
+        amax_latent = stats.new()
+        src, a_src = (conv_fused, amax_skip) if conv_fused is not None else (conv_image, amax_image)
+        self.conv5_image.conv_block[0].run([ops.tensor_src(src, "image", a_src)], n, h, w, out=latent[:, :fi[4]],
+                                           out_absmax=amax_latent, stats=stats)
+        self.conv5_depth.conv_block[0].run([ops.tensor_src(conv_depth, "depth", amax_skip)], n, h, w, out=latent[:, fi[4]:],
+                                           out_absmax=amax_latent, stats=stats)
+        return latent, skips, amax_latent, amax_skips
 
 
 # ----------------------------------------------------------------------- decoder
@@ -567,30 +619,41 @@ class MultiScaleDecoder(torch.nn.Module):
 
     def features(self, x, skips, shape):
         """Everything up to (not including) output0."""
-        return self.deconv0(self.features_level1(x, skips), None, shape=tuple(shape)[-2:])
+        stats = ops.ActStats(x.shape[0], x.device)
+        x, amax = self.features_level1(x, skips, stats=stats)
+        return self.deconv0(x, None, shape=tuple(shape)[-2:], amax_x=amax, stats=stats)
 
-    def features_level1(self, x, skips):
-        """deconv4 .. deconv1: the half-resolution features deconv0 starts from."""
-        x = self.deconv4(x, skips[3])
-        x = self.deconv3(x, skips[2])
-        x = self.deconv2(x, skips[1])
-        return self.deconv1(x, skips[0])
+    def features_level1(self, x, skips, amax_x=None, amax_skips=None, stats=None):
+        """deconv4 .. deconv1: the half-resolution features deconv0 starts from, and their per-frame max |a| slot.
+        amax_x / amax_skips: the slots of the latent / the skip tensors (KBNetEncoder.encode); missing ones are measured."""
+        if stats is None:
+            stats = ops.ActStats(x.shape[0], x.device)
+        amax_skips = amax_skips if amax_skips is not None else [None] * 4
+        amax = amax_x
+        for blk, i in ((self.deconv4, 3), (self.deconv3, 2), (self.deconv2, 1), (self.deconv1, 0)):
+            a_out = stats.new()
+            x = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats)
+            amax = a_out
+        return x, amax
 
-    def depth(self, x, skips, shape, min_predict_depth, max_predict_depth, return_logits=False, out=None):
+    def depth(self, x, skips, shape, min_predict_depth, max_predict_depth, return_logits=False, out=None,
+              amax_x=None, amax_skips=None, stats=None):
         """The whole decoder + KBNetModel.forward's depth mapping (reference src/kbnet_model.py:179-184).  deconv0's
         second conv, output0 and the sigmoid mapping run as ONE kernel when deconv0 has no skip and its width is a
         multiple of 4 channels (KBNet: 12); otherwise conv, then the fused output0 + mapping head."""
-        x = self.features_level1(x, skips)
+        if stats is None:
+            stats = ops.ActStats(x.shape[0], x.device)
+        x, amax = self.features_level1(x, skips, amax_x, amax_skips, stats)
         d0 = self.deconv0
         if d0.skip_channels == 0:
-            up = d0.deconv(x, shape=tuple(shape)[-2:])
+            up = d0.deconv(x, shape=tuple(shape)[-2:], amax=amax, stats=stats)
             res = ops.conv_head(up, d0.conv.conv.weight, self.output0.conv.weight, min_predict_depth,
                                 max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
             if res is not None:
                 return res
             feats = d0.conv.run([ops.tensor_src(up, "deconv")], up.shape[0], up.shape[2], up.shape[3])
         else:
-            feats = d0(x, None, shape=tuple(shape)[-2:])
+            feats = d0(x, None, shape=tuple(shape)[-2:], amax_x=amax, stats=stats)
         return ops.depth_head(feats, self.output0.conv.weight, min_predict_depth, max_predict_depth,
                               return_logits=return_logits, out=out)
 
@@ -758,10 +821,13 @@ class KBNetModel(object):
             input_depth = torch.cat([sparse_depth, validity_map_depth], dim=1)   # reference src/kbnet_model.py:161
         input_depth = self.sparse_to_dense_pool(input_depth)
         shape = input_depth.shape[-2:]
-        latent, skips = self.encoder(image, input_depth, intrinsics)
+        # per-frame max |a| of every activation tensor, kept on the device: the split-operand convs place their fp16
+        # windows on the data of THIS call (no calibration state, no host round trip; ops.ActStats)
+        stats = ops.ActStats(image.shape[0], image.device)
+        latent, skips, amax_latent, amax_skips = self.encoder.encode(image, input_depth, intrinsics, stats)
         # decoder; its tail (deconv0's second conv + output0 + sigmoid + d_min / (s + d_min/d_max)) is one kernel
         return self.decoder.depth(latent, skips, shape, self.min_predict_depth, self.max_predict_depth,
-                                  return_logits=return_logits, out=out)
+                                  return_logits=return_logits, out=out, amax_x=amax_latent, amax_skips=amax_skips, stats=stats)
 
     def set_bf16(self, enabled: bool = True):
         """THROUGHPUT-ONLY bf16 leg (BASELINE configs[2]): every 3x3 conv with at least 16 (a multiple of 16) input channels
@@ -782,14 +848,6 @@ class KBNetModel(object):
     def weight_state(self):
         """(storage pointer, version) of every parameter: what a captured graph depends on."""
         return [(p.data_ptr(), p._version) for p in self.parameters()]
-
-    def recalibrate(self):
-        """Forgets the activation exponents of the split-operand convs: the next forward measures max |a| of every such
-        layer's input again (inputs whose activations left the 128x headroom of the previous calibration)."""
-        for m in self.modules():
-            for sub in m.modules():
-                if isinstance(sub, Conv2d):
-                    sub._act_exp = None
 
     def refresh_packed(self):
         """Re-packs (in place) the MFMA-ordered blobs of weights that changed since they were packed."""

@@ -138,6 +138,63 @@ def _int_array(values: Sequence[int]):
     return arr
 
 
+# ------------------------------------------------------------- activation statistics
+class ActStats:
+    """Per-frame max |a| slots of the tensors of one forward (include/kbnet_hip.h, "activation statistics"): one zeroed
+    int32 buffer [capacity][n]; `new()` hands out a row.  A conv launch folds max |out| of every frame into the slot
+    it is given (`out_absmax=`); `tensor_src(t, absmax=slot)` hands it to the consumer, whose split-operand kernel
+    derives its fp16 window from it on the device, frame by frame.  Allocated inside the forward (also under graph
+    capture: the zero fill is a node of the graph), so nothing outlives the call."""
+
+    def __init__(self, n: int, device, capacity: int = 40):
+        self.buf = torch.zeros((capacity, n), device=device, dtype=torch.int32)
+        self.n, self.used = n, 0
+        self.unfilled = set()   # data_ptr of slots handed to a launch that does not fill them (the throughput-only bf16 kernels)
+
+    def skip(self, slot: Optional[torch.Tensor]):
+        """A producer that writes (part of) the slot's tensor without folding its maxima: consumers measure the tensor."""
+        if slot is not None:
+            self.unfilled.add(slot.data_ptr())
+
+    def usable(self, slot_ptr) -> bool:
+        return bool(slot_ptr) and slot_ptr not in self.unfilled
+
+    def new(self) -> torch.Tensor:
+        if self.used == self.buf.shape[0]:   # more tensors than foreseen: chain another buffer (one more fill launch)
+            self.buf = torch.zeros_like(self.buf)
+            self.used = 0
+        slot = self.buf[self.used]
+        self.used += 1
+        return slot
+
+    def measure(self, t: torch.Tensor) -> torch.Tensor:
+        """A slot filled by a pass over `t` (kbn_absmax_frames): tensors that come from outside the forward."""
+        return absmax_frames(t, self.new())
+
+
+def _slot_ptr(slot: Optional[torch.Tensor], n: int):
+    if slot is None:
+        return None
+    if slot.dtype != torch.int32 or slot.dim() != 1 or slot.shape[0] != n or not slot.is_contiguous() or not slot.is_cuda:
+        raise KbnError(f"absmax slot: expected a contiguous int32 device tensor of {n} elements")
+    return slot.data_ptr()
+
+
+@_on_tensor_device
+def absmax_frames(t: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
+    """Folds max |t[i]| of every frame i into slot[i] (bit patterns; kbn_absmax_frames).  No synchronisation."""
+    ptr, bs = _planes(t, "t")
+    n, c, h, w = t.shape
+    check(_launch("absmax", 4.0 * n * c * h * w,
+                  lambda: _lib.load().kbn_absmax_frames(ptr, bs, n, c * h * w, _slot_ptr(slot, n), _stream())), "kbn_absmax_frames")
+    return slot
+
+
+def slot_values(slot: torch.Tensor) -> torch.Tensor:
+    """The per-frame maxima a slot holds, as floats (diagnostics, tests; synchronises when read)."""
+    return slot.view(torch.float32)
+
+
 # ----------------------------------------------------------------------------- S2D
 @_on_tensor_device
 def s2d_forward(x, w_pool_convs: List[torch.Tensor], w_conv, min_pool_sizes, max_pool_sizes,
@@ -234,7 +291,8 @@ def pack_conv_weight(weight: torch.Tensor, stride: int = 1, out: Optional[torch.
     return packed
 
 
-def tensor_src(t: torch.Tensor, name="src") -> ConvSrc:
+def tensor_src(t: torch.Tensor, name="src", absmax: Optional[torch.Tensor] = None) -> ConvSrc:
+    """`absmax`: the tensor's per-frame max |a| slot (ActStats), when its producer filled one."""
     ptr, bs = _planes(t, name)
     s = ConvSrc()
     s.kind = _lib.KBN_SRC_TENSOR
@@ -242,6 +300,8 @@ def tensor_src(t: torch.Tensor, name="src") -> ConvSrc:
     s.data = ptr
     s.batch_stride = bs
     s.src_height, s.src_width = t.shape[2], t.shape[3]
+    s.absmax = _slot_ptr(absmax, t.shape[0])
+    s._keep = (t, absmax)   # the struct holds raw pointers
     return s
 
 
@@ -251,6 +311,7 @@ def coords_src(kinv: torch.Tensor) -> ConvSrc:
     s.kind = _lib.KBN_SRC_COORDS
     s.channels = 3
     s.kinv = kinv.data_ptr()
+    s._keep = (kinv,)   # the struct holds raw pointers: the tensors live as long as it does
     return s
 
 
@@ -266,14 +327,16 @@ def xyz_src(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: torch.Tensor) 
     s.aux_channels = depth.shape[1]
     s.proj_weight = proj_weight.data_ptr()
     s.kinv = kinv.data_ptr()
+    s._keep = (depth, proj_weight, kinv)
     return s
 
 
 @_on_tensor_device
 def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int,
            kernel_size: int, stride: int, in_height: int, in_width: int, out: torch.Tensor,
-           resize: bool = False, negative_slope: Optional[float] = 0.2):
-    """`out` is an N x out_channels x ceil(H/s) x ceil(W/s) tensor or channel slice."""
+           resize: bool = False, negative_slope: Optional[float] = 0.2, out_absmax: Optional[torch.Tensor] = None):
+    """`out` is an N x out_channels x ceil(H/s) x ceil(W/s) tensor or channel slice; `out_absmax`: slot that receives
+    max |out| per frame."""
     lib = _lib.load()
     arr = (ConvSrc * len(srcs))(*srcs)
     optr, obs = _planes(out, "out")
@@ -296,7 +359,7 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
                                                  _lib.KBN_RESIZE_NEAREST if resize else _lib.KBN_RESIZE_NONE,
                                                  0 if negative_slope is None else 1,
                                                  0.0 if negative_slope is None else float(negative_slope),
-                                                 _stream()),
+                                                 _slot_ptr(out_absmax, n), _stream()),
                   executed=lambda: conv_executed_flops(n, out_channels, cin, kernel_size, stride, in_height, in_width,
                                                        resize)), "kbn_conv2d_forward")
     return out
@@ -321,7 +384,7 @@ def pack_upconv2x_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = Non
 
 @_on_tensor_device
 def upconv2x(x: torch.Tensor, packed_weight: torch.Tensor, out_channels: int, out: torch.Tensor,
-             negative_slope: Optional[float] = 0.2):
+             negative_slope: Optional[float] = 0.2, out_absmax: Optional[torch.Tensor] = None):
     """nearest 2x upsample + conv3x3 (+ LeakyReLU): x N x C x h x w -> out N x out_channels x 2h x 2w."""
     lib = _lib.load()
     xptr, xbs = _planes(x, "x")
@@ -334,7 +397,7 @@ def upconv2x(x: torch.Tensor, packed_weight: torch.Tensor, out_channels: int, ou
                   lambda: lib.kbn_upconv2x_forward(xptr, xbs, packed_weight.data_ptr(), optr, obs, n, cin,
                                                    out_channels, h, w, 0 if negative_slope is None else 1,
                                                    0.0 if negative_slope is None else float(negative_slope),
-                                                   _stream()),
+                                                   _slot_ptr(out_absmax, n), _stream()),
                   executed=lambda: upconv2x_executed_flops(n, cin, out_channels, h, w)), "kbn_upconv2x_forward")
     return out
 
@@ -343,8 +406,10 @@ def upconv2x(x: torch.Tensor, packed_weight: torch.Tensor, out_channels: int, ou
 @_on_tensor_device
 def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_depth, proj_weight,
              packed_w_fused, filters_image: int, filters_depth: int, filters_fused: int,
-             out_image, out_depth, out_fused, negative_slope: float = 0.2):
-    """Inputs/outputs may be channel slices; exactly one of coordinates / kinv may be None."""
+             out_image, out_depth, out_fused, negative_slope: float = 0.2, absmax_image=None, absmax_depth=None,
+             absmax_fused=None):
+    """Inputs/outputs may be channel slices; exactly one of coordinates / kinv may be None.  absmax_*: slots that
+    receive max |out| per frame of the three outputs (two may be the same slot)."""
     lib = _lib.load()
     n, ci, h, w = image.shape
     iptr, ibs = _planes(image, "image")
@@ -382,7 +447,8 @@ def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_de
                                                    packed_w_image.data_ptr(), packed_w_depth.data_ptr(),
                                                    pw.data_ptr(), packed_w_fused.data_ptr(), oi, oibs, od, odbs,
                                                    of, ofbs, n, h, w, ci, cd, cf, filters_image, filters_depth,
-                                                   filters_fused, float(negative_slope), _stream()),
+                                                   filters_fused, float(negative_slope), _slot_ptr(absmax_image, n),
+                                                   _slot_ptr(absmax_depth, n), _slot_ptr(absmax_fused, n), _stream()),
                   executed=flops),   # direct convs: executed = algorithmic (tile padding not counted)
           "kbn_kb_block_forward")
     return out_image, out_depth, out_fused
@@ -475,47 +541,41 @@ def pack_conv3x3_split_weight(weight: torch.Tensor, out: Optional[torch.Tensor] 
     return packed
 
 
-def absmax_srcs(srcs: List[ConvSrc], n: int, device) -> float:
-    """max |x| over the tensor sources of a conv (kbn_absmax); synchronizes -- calibration only, never while capturing."""
-    lib = _lib.load()
-    with torch.cuda.device(device):
-        amax = torch.zeros(1, device=device, dtype=torch.float32)
-        for s in srcs:
-            check(lib.kbn_absmax(s.data, s.batch_stride, n, s.channels * s.src_height * s.src_width, amax.data_ptr(), _stream()),
-                  "kbn_absmax")
-        return float(amax.item())
-
-
 def act_exponent_for(amax: float) -> int:
-    """Exponent k that puts max |a| of a layer input in (2^8, 2^9] of the split kernel's fp16 window: 128x of headroom
-    below fp16's 65504, full 22-bit precision down to 2^-23 of the maximum.  Degenerate maxima take the ABI default."""
-    import math
-    if not (amax > 0.0) or math.isinf(amax) or math.isnan(amax):
-        return -6
-    return max(-60, min(60, 9 - math.ceil(math.log2(amax))))
+    """The exponent the split kernels derive on the device from a frame's max |a| (sp_act_scale, csrc/conv_split.hip):
+    k = 14 - floor(log2(max |a|)) puts the maximum in [2^14, 2^15) of the fp16 window (overflow at 65504); zero or
+    denormal maxima take 100, Inf / NaN -100.  Host-side restatement for tests and for callers of the static
+    `act_exponent` argument."""
+    import struct
+    b = struct.unpack("<I", struct.pack("<f", abs(amax)))[0] if amax == amax else 0x7fc00000
+    return max(-100, min(100, 14 + 127 - (b >> 23)))
 
 
 def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1, folded_up2x=False):
-    """fp16 MFMA FLOPs the split kernel executes: three products per fp32 product, whole (16 | 8) x 32 x (64 | 128) tiles
-    (folded up-conv: 16 products per low-resolution pixel, 16 x 32 low-resolution pixels x 32 filters)."""
+    """fp16 MFMA FLOPs the split kernels ISSUE (what SQ_INSTS_MFMA x 32768 counts, profiles/*/traffic.json): three
+    products per fp32 product over M = 32 output pixels of a row x N = 32 filters (16 for the narrow folded up-conv)
+    x K = 16 channels per instruction.  Padding that is issued: the columns of the last 32-pixel segment of a row and
+    the filters of the last 32-filter block.  Padding that is NOT issued since the kernels skip it (wave-uniform tests,
+    csrc/conv_split.hip): output rows below the map and 32-filter blocks that lie entirely past the last filter of a
+    64- / 128-wide tile.  Folded up-conv: 16 products per low-resolution pixel instead of 36 per output pixel quad."""
     if folded_up2x:
-        nt = 16 if (out_channels <= 16 and cin % 32 == 0) else 32   # narrow layers: 16-filter tiles (upconv2x_split16_kernel)
-        th = 8 if (out_channels >= 64 and (-(-out_channels // 32)) % 2 == 0) else 16   # whole 64-filter tiles: 8-row tiles (upconv2x_split64_kernel)
-        return 3 * 2.0 * n * (-(-(height // 2) // th) * th) * (-(-(width // 2) // 32) * 32) * cin * 16 * (-(-out_channels // nt) * nt)
-    nt = 128 if stride == 2 else 64
-    th = 8 if stride == 2 else 16
-    return 3 * 2.0 * n * (-(-height // th) * th) * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // nt) * nt)
+        nblk = 16 if (out_channels <= 16 and cin % 32 == 0) else 32   # narrow layers: v_mfma_f32_16x16x32_f16, 16-pixel segments
+        seg = 16 if nblk == 16 else 32
+        return 3 * 2.0 * n * (height // 2) * (-(-(width // 2) // seg) * seg) * cin * 16 * (-(-out_channels // nblk) * nblk)
+    return 3 * 2.0 * n * height * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // 32) * 32)
 
 
 @_on_tensor_device
 def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
                   out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1,
-                  act_exponent: int = -6, folded_up2x: bool = False):
+                  act_exponent: int = -6, folded_up2x: bool = False, out_absmax: Optional[torch.Tensor] = None):
     """3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
     `stride` 2: sources are the 2x larger input planes), fp32 in / fp32 out, every product taken as three fp16 MFMAs
     over two-term splits of both operands (kbn_conv3x3_split_forward): fp32-grade accuracy at 3/16 of the fp32 MFMA's
-    time.  `height` x `width` is the OUTPUT size; `act_exponent` k places the fp16 window (|a| 2^k < 65504; full precision
-    for |a| 2^k >= 2^-14); `folded_up2x` (with `up2x`): the folded 16-product form, weights from
+    time.  `height` x `width` is the OUTPUT size.  The fp16 window follows the data when every source carries its absmax
+    slot (tensor_src(absmax=)): per frame, on the device; only sources without slots fall back to the static
+    `act_exponent` k (|a| 2^k < 65504).  `out_absmax`: slot that receives max |out| per frame.
+    `folded_up2x` (with `up2x`): the folded 16-product form, weights from
     pack_conv3x3_split_weight(folded_up2x=True).  Returns None when the shape does not qualify (the caller stays on the
     fp32-MFMA kernels)."""
     if up2x and stride != 1:
@@ -531,10 +591,10 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     status = _launch(("conv_split", "conv_split_up", "conv_split_s2", "conv_split_upfold")[mode], flops,
                      lambda: lib.kbn_conv3x3_split_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
                                                            out_channels, height, width,
-                                                           mode, int(act_exponent),
+                                                           mode, max(-60, min(60, int(act_exponent))),
                                                            0 if negative_slope is None else 1,
                                                            0.0 if negative_slope is None else float(negative_slope),
-                                                           _stream()),
+                                                           _slot_ptr(out_absmax, n), _stream()),
                      executed=conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride, up2x and folded_up2x))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
@@ -589,7 +649,8 @@ def kb_xyz_s2(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: torch.Tensor
 
 @_on_tensor_device
 def conv1x1s2_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, xyz: Optional[torch.Tensor], n: int, out_channels: int,
-                    height: int, width: int, out: torch.Tensor, negative_slope: Optional[float] = 0.2, act_exponent: int = -6):
+                    height: int, width: int, out: torch.Tensor, negative_slope: Optional[float] = 0.2, act_exponent: int = -6,
+                    out_absmax: Optional[torch.Tensor] = None):
     """1x1 stride-2 conv (+ LeakyReLU) of one or two tensor sources (+ the three fp32 xyz channels of `xyz`, from
     kb_xyz_s2) on split operands (kbn_conv1x1s2_split_forward); `height` x `width` is the OUTPUT size.  None when the
     shape does not qualify."""
@@ -605,13 +666,13 @@ def conv1x1s2_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, xyz: Optio
         xptr, xbs = _planes(xyz, "xyz")
     cin = sum(s.channels for s in srcs)
     flops = 2.0 * n * height * width * (cin + (3 if xyz is not None else 0)) * out_channels
-    executed = 3 * 2.0 * n * (-(-height // 8) * 8) * (-(-width // 32) * 32) * cin * (-(-out_channels // 128) * 128)
+    executed = 3 * 2.0 * n * (-(-height // 8) * 8) * (-(-width // 32) * 32) * cin * (-(-out_channels // 128) * 128)   # this kernel skips nothing
     status = _launch("conv_split_1x1s2", flops,
                      lambda: lib.kbn_conv1x1s2_split_forward(arr, len(srcs), packed_weight.data_ptr(), xptr, xbs, optr, obs, n,
-                                                             out_channels, height, width, int(act_exponent),
+                                                             out_channels, height, width, max(-60, min(60, int(act_exponent))),
                                                              0 if negative_slope is None else 1,
                                                              0.0 if negative_slope is None else float(negative_slope),
-                                                             _stream()), executed=executed)
+                                                             _slot_ptr(out_absmax, n), _stream()), executed=executed)
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()

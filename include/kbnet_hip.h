@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KBN_ABI_VERSION 1
+#define KBN_ABI_VERSION 2
 
 typedef void* kbn_stream_t; /* hipStream_t */
 
@@ -127,7 +127,23 @@ typedef struct kbn_conv_src {
     const float* coordinates;  /* KBN_SRC_XYZ, optional                           */
     long long coordinates_batch_stride;
     const float* kinv;      /* KBN_SRC_COORDS / KBN_SRC_XYZ without coordinates    */
+    const unsigned* absmax; /* KBN_SRC_TENSOR, optional: the per-frame max |a| slots of this tensor (see
+                             * "activation statistics" below); read by the split-operand convs only   */
 } kbn_conv_src;
+
+/* ----------------------------------------------- activation statistics ("absmax slots") --
+ * The split-operand convs further down represent an activation as two fp16 terms under a per-frame
+ * exponent, which has to follow the magnitude of the data.  It does so on the device: a SLOT is an array of
+ * n unsigned values, one per frame, holding the bit pattern of max |a| over that frame of a tensor
+ * (bit patterns of non-negative floats order like the floats).  Every conv entry point takes `out_absmax`
+ * (may be NULL): the kernel folds the values it stores into out_absmax[frame] with an atomic max in its epilogue
+ * (several launches may fill channel slices of one tensor into one slot); the caller zeroes a slot before its first
+ * producer.  A consumer is handed the slot through kbn_conv_src.absmax.  kbn_absmax_frames is the stand-alone
+ * pass for tensors that come from elsewhere.  No host synchronisation, no state between calls: the result of a
+ * forward is a function of its inputs and weights alone, frame by frame (the reference's convs are exactly
+ * that: src/net_utils.py:120-141). */
+int kbn_absmax_frames(const float* x, long long batch_stride, int n, long long per_frame, unsigned* slots,
+                      kbn_stream_t stream);
 
 #define KBN_RESIZE_NONE 0
 #define KBN_RESIZE_NEAREST 1
@@ -149,11 +165,11 @@ int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels,
  * (sources are nearest-resized to that size first when resize = KBN_RESIZE_NEAREST).
  * out: frames `out_batch_stride` elements apart (lets the caller write straight into a
  * channel slice of a larger skip tensor), out_channels x ceil(in_h/stride) x ceil(in_w/stride).
- * kernel_size in {1, 3}; stride in {1, 2}. */
+ * kernel_size in {1, 3}; stride in {1, 2}.  out_absmax: n slots of max |out| per frame, or NULL. */
 int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_weight, float* out,
                        long long out_batch_stride, int n, int out_channels, int kernel_size,
                        int stride, int in_height, int in_width, int resize, int apply_activation,
-                       float negative_slope, kbn_stream_t stream);
+                       float negative_slope, unsigned* out_absmax, kbn_stream_t stream);
 
 /* ------------------------------------------------------------ up-conv 2x -------
  * net_utils.UpConv2d.forward when the target size is exactly twice the input:
@@ -174,7 +190,7 @@ int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channel
 int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const float* packed_weight,
                          float* out, long long out_batch_stride, int n, int in_channels,
                          int out_channels, int src_height, int src_width, int apply_activation,
-                         float negative_slope, kbn_stream_t stream);
+                         float negative_slope, unsigned* out_absmax, kbn_stream_t stream);
 
 /* Which algebraic form kbn_upconv2x_forward runs for a problem (diagnostics, roofline accounting):
  * info[4] = {channel products per low-resolution pixel: 16 four 2x2 phases / 12 three-product columns /
@@ -193,9 +209,11 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
  * cat[deconv, skip]) and the stride-2 image convs of the KB blocks run through them when the shape
  * qualifies.
  *   act_exponent  k: places the fp16 window on the activations: |a| 2^k must stay below 65504 (beyond: inf),
- *             |a| 2^k >= 2^-14 keeps the full 22 bits, smaller activations keep 11.  -6 covers 0.0039 .. 4.2e6;
- *             a caller that knows max |a| of the layer input puts it near 2^9 (the Python mirror measures it
- *             once per layer, modules.Conv2d.run_split).  Range -60 .. 60.
+ *             |a| 2^k >= 2^-14 keeps the full 22 bits, smaller activations are carried by the scaled residual
+ *             alone (absolute error below 2^-40 of the window's top).  USED ONLY WHEN A SOURCE HAS NO absmax SLOT:
+ *             with slots on every source the kernel derives k per frame from the data, max |a| 2^k in [2^14, 2^15)
+ *             (the Python mirror always provides slots; a static k is for callers that know their range: -6
+ *             covers 0.0039 .. 4.2e6).  Range -60 .. 60.
  *   mode      0: 3x3 stride 1 over height x width sources; 1: nearest-2x up-conv (ONE source with
  *             (height/2) x (width/2) planes); 2: 3x3 stride 2 (source planes h x w with ceil(h/2) = height,
  *             ceil(w/2) = width: the image convs of the KB blocks, reference src/net_utils.py:1348)
@@ -205,15 +223,13 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
  *   out       N x out_channels x height x width fp32, frames out_batch_stride elements apart
  * Modes 1 and 3 return KBN_ERR_UNSUPPORTED unless width % 4 == 0 and `out` is 16-byte aligned (callers fall back
  * to kbn_upconv2x_forward); modes 0 and 2 store element-wise in that case.  KBN_NO_SPLIT=1: always unsupported. */
-/* Folds max |x| over n frames of per_frame contiguous floats (frames batch_stride elements apart) into *amax
- * (device float, the caller zeroes it first): what a caller needs to pick act_exponent. */
-int kbn_absmax(const float* x, long long batch_stride, int n, long long per_frame, float* amax, kbn_stream_t stream);
 size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, int mode);
 int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int mode,
                                   kbn_stream_t stream);
 int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
                               long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
-                              int act_exponent, int apply_activation, float negative_slope, kbn_stream_t stream);
+                              int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
+                              kbn_stream_t stream);
 
 /* conv_fused of the KB block on split operands -- reference src/net_utils.py:1337-1343 (Conv2d(in_channels_fused + 3,
  * n_filter_fused, kernel_size=1, stride=2)) applied to cat[image, xyz, fused] (:1352-1368).  The tensor channels
@@ -232,7 +248,7 @@ int kbn_conv1x1s2_split_pack_weight(const float* weight, void* packed, int out_c
 int kbn_conv1x1s2_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, const float* xyz,
                                 long long xyz_batch_stride, float* out, long long out_batch_stride, int n, int out_channels,
                                 int height, int width, int act_exponent, int apply_activation, float negative_slope,
-                                kbn_stream_t stream);
+                                unsigned* out_absmax, kbn_stream_t stream);
 int kbn_kb_xyz_s2_forward(const float* depth, long long depth_batch_stride, int depth_channels, int height, int width,
                           const float* proj_weight, const float* kinv, int apply_activation, float negative_slope, float* xyz,
                           long long xyz_batch_stride, int n, kbn_stream_t stream);
@@ -286,6 +302,7 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
  *   *_batch_stride  elements between frames (inputs/outputs may be channel slices of a
  *                   larger NCHW tensor, e.g. the encoder's skip buffers; `coordinates`, when
  *                   given, is contiguous N x 3 x H x W)
+ *   out_*_absmax    per-frame max |out| slots of the three outputs (each may be NULL; two may be the same slot)
  */
 int kbn_kb_block_forward(const float* image, long long image_batch_stride, const float* depth,
                          long long depth_batch_stride, const float* coordinates, const float* kinv,
@@ -297,7 +314,8 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
                          long long out_fused_batch_stride, int n, int height, int width,
                          int channels_image, int channels_depth, int channels_fused,
                          int filters_image, int filters_depth, int filters_fused,
-                         float negative_slope, kbn_stream_t stream);
+                         float negative_slope, unsigned* out_image_absmax, unsigned* out_depth_absmax,
+                         unsigned* out_fused_absmax, kbn_stream_t stream);
 
 /* ------------------------------------------------------------ depth head -------
  * MultiScaleDecoder.output0 (3x3, linear)           reference src/networks.py:1842-1851, 1985

@@ -126,3 +126,85 @@ def test_sharded_runner_world2_gloo(n_total):
     results = _spawn(_worker, 2, n_total)
     assert all(ok for _, ok, _ in results)
     assert all(t == 1.0 for _, _, t in results)
+
+
+# ---- bench.py's rank logic, end to end at world size 2 (gloo, stand-in forward) --------------------------------------
+# What the first real `bench.py --gpus 8` executes besides the HIP forward: the --gpus / WORLD_SIZE check, per-rank frame
+# seeds, the timed region (barrier + synchronise on both sides, exactly K steps, MAX over ranks), the pipelined
+# all-gather, rank-0-only printing of ONE JSON line, cpu_baseline null for N > 1.
+def _bench_worker(rank, world, port, outdir, q):
+    import contextlib
+    import importlib.util
+    import io
+    import json
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    bench.HEIGHT, bench.WIDTH = 16, 24          # tiny frames: this is a plumbing test
+    seen = {}
+
+    def factory(r, dev, frames):
+        seen["rank"], seen["dev"], seen["first"] = r, dev, float(frames[0].flatten()[0])
+        return _fake_forward
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--frames-per-gpu", "4"],
+                         backend="gloo", forward_factory=factory)
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+    ok = seen["rank"] == rank and seen["dev"].type == "cpu"
+    if rank == 0:
+        ok = ok and len(lines) == 1
+        line = json.loads(lines[0])
+        ok = ok and line["n_gpus"] == world and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+        ok = ok and line["cpu_baseline"] is None and line["vs_baseline"] is None and line["higher_is_better"] is True
+        ok = ok and line["config"]["global_batch"] == 4 * world and line["config"]["gathered_frames"] == 4 * world
+        ok = ok and abs(line["value"] - 4 * world * 3 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]
+    else:
+        ok = ok and not lines                  # only rank 0 prints
+    q.put((rank, ok, seen["first"]))
+
+
+def test_bench_rank_logic_world2_gloo(tmp_path):
+    results = _spawn(_bench_worker, 2, str(tmp_path))
+    assert all(ok for _, ok, _ in results)
+    firsts = {r: f for r, _, f in results}
+    assert firsts[0] != firsts[1], "ranks draw different frames (seed 1 + rank)"
+
+
+def test_bench_refuses_gpus_without_matching_world(monkeypatch):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit, match="WORLD_SIZE=1"):
+        bench.main(["--gpus", "2"], backend="gloo", forward_factory=lambda *a: _fake_forward)
+
+
+# ---- evaluation metrics over a sharded run (reference src/kbnet.py:932-984 averages over ALL samples) ----------------
+def _metrics_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    kb.dist.init("gloo")
+    g = torch.Generator().manual_seed(3)
+    per_frame = torch.rand(5, 4, generator=g, dtype=torch.float64) * 100.0     # what ops.eval_metrics returns per frame
+    lo, hi = kb.dist.shard_bounds(5, rank, world)                               # ragged: 3 + 2 frames
+    got = kb.dist.mean_metrics_over_ranks(per_frame[lo:hi])
+    ok = torch.allclose(got, per_frame.mean(dim=0), rtol=1e-12, atol=0)
+    empty = kb.dist.mean_metrics_over_ranks(per_frame[:0] if rank == 1 else per_frame)   # a rank without frames
+    ok = ok and torch.allclose(empty, per_frame.mean(dim=0), rtol=1e-12, atol=0)
+    kb.dist.barrier()
+    q.put((rank, ok, 1.0))
+    dist.destroy_process_group()
+
+
+def test_eval_metrics_mean_over_ranks_world2_gloo():
+    assert all(ok for _, ok, _ in _spawn(_metrics_worker, 2))
+    one = kb.dist.mean_metrics_over_ranks(torch.tensor([[1.0, 2.0, 3.0, 4.0], [3.0, 4.0, 5.0, 6.0]]))   # no process group
+    assert torch.equal(one, torch.tensor([2.0, 3.0, 4.0, 5.0], dtype=torch.float64))

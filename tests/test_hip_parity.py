@@ -228,7 +228,6 @@ def test_split_matches_fp32_kernels(dev, kenv):
     x = torch.randn(2, 96, 30, 44, generator=g).to(dev)
     conv = kb.modules.Conv2d(96, 64, 3, 1, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
     a = conv(x).clone()
-    assert conv._act_exp is not None  # the first call measured max |a| of the input
     kenv.setenv("KBN_NO_SPLIT", "1")
     b = conv(x).clone()
     assert rel_err(a, b) < TIGHT
@@ -514,8 +513,10 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     the accuracy class of the fp32 kernels: against an fp64 evaluation its error may not exceed 3.5x the error of the
     oracle's own fp32 conv (a blocked CPU summation, itself 3-6x more accurate than an fp32 MFMA / fmaf chain of the same
     length; both in units of the output's rms), and it stays below 1.5e-6 rms / 2e-5 max.  Activation magnitudes of
-    1e-4 and 3e5 sit outside the default fp16 window: the exponent measured from max |a| (ops.act_exponent_for, what
-    modules.Conv2d does on a layer's first call) moves the window onto them."""
+    1e-4 and 3e5 sit outside the window of the ABI's static default exponent: with per-frame absmax slots on the sources
+    (ops.ActStats; what every layer of the host mirror passes) the kernel places the window on each FRAME's own maximum --
+    frame 1 is 81x smaller than frame 0 here -- and fills the slot of its output; a static exponent (no slots) serves
+    callers that know their range."""
     h, w = hw                                   # output size
     g = torch.Generator().manual_seed(sum(cins) + cout + h)
     n = 2
@@ -523,6 +524,8 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     up2x, folded = kind.startswith("up2x"), kind == "up2x_folded"
     sh, sw = (h // 2, w // 2) if up2x else ((2 * h - 1, 2 * w) if stride == 2 else (h, w))
     xs = [amag * torch.nn.functional.leaky_relu(torch.randn(n, c, sh, sw, generator=g), 0.2) for c in cins]
+    for x in xs:
+        x[1] *= 0.0123                           # frames of different magnitude: the exponent is per frame
     cin = sum(cins)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     wt[1] *= 1e-3                                # filters of very different magnitude: the per-filter exponent
@@ -535,16 +538,27 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     assert tuple(ref32.shape[-2:]) == (h, w)
     xd = [x.to(dev) for x in xs]
     out = torch.empty(n, cout, h, w, device=dev)
-    srcs = [kb.ops.tensor_src(x) for x in xd]
-    amax = kb.ops.absmax_srcs(srcs, n, dev)
-    assert amax == max(float(x.abs().max()) for x in xs)
+    stats = kb.ops.ActStats(n, dev)
+    slots = [stats.measure(x) for x in xd]
+    for x, sl in zip(xs, slots):                 # kbn_absmax_frames: the per-frame maxima, bit for bit
+        assert torch.equal(kb.ops.slot_values(sl).cpu(), x.abs().amax(dim=(1, 2, 3)))
+    amax = max(float(x.abs().max()) for x in xs)
     k = kb.ops.act_exponent_for(amax)
-    assert 2.0 ** 8 < amax * 2.0 ** k <= 2.0 ** 9
-    res = kb.ops.conv3x3_split(srcs, kb.ops.pack_conv3x3_split_weight(wt.to(dev), stride=stride, folded_up2x=folded), n, cout, h, w,
-                               out, up2x=up2x, negative_slope=0.2, stride=stride, act_exponent=k if amag != 1.0 else -6,
-                               folded_up2x=folded)
+    assert 2.0 ** 14 <= amax * 2.0 ** k < 2.0 ** 15
+    srcs = [kb.ops.tensor_src(x, "x", sl) for x, sl in zip(xd, slots)]
+    packed = kb.ops.pack_conv3x3_split_weight(wt.to(dev), stride=stride, folded_up2x=folded)
+    out_slot = stats.new()
+    res = kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, out, up2x=up2x, negative_slope=0.2, stride=stride,
+                               folded_up2x=folded, out_absmax=out_slot)
     assert res is not None
-    rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()       # per filter: the filters differ by 5e4 in scale
+    assert torch.equal(kb.ops.slot_values(out_slot), out.abs().amax(dim=(1, 2, 3))), "the epilogue's max |out| per frame"
+    # no slots: the static exponent of the call (here the one that fits frame 0; frame 1 sits 6 binades lower in the window)
+    out_static = torch.empty_like(out)
+    assert kb.ops.conv3x3_split([kb.ops.tensor_src(x) for x in xd], packed, n, cout, h, w, out_static, up2x=up2x, negative_slope=0.2,
+                                stride=stride, act_exponent=k, folded_up2x=folded) is not None
+    assert rel_err(out_static, out) < TIGHT
+    rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()       # per filter and frame: filters differ by 5e4 in scale, frames by 81
+    rms = ref64.pow(2).mean(dim=(2, 3), keepdim=True).sqrt()
     e_hip = ((out.cpu().double() - ref64) / rms).abs()
     e_orc = ((ref32.double() - ref64) / rms).abs()
     print(f"split conv vs fp64: max {float(e_hip.max()):.2e} rms {float(e_hip.pow(2).mean().sqrt()):.2e}; "
@@ -567,14 +581,16 @@ def test_conv3x3_split_k32_form(dev, kenv, cins, cout, hw):
     wt[1] *= 1e-3
     ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.cat(xs, 1).double(), wt.double(), padding=1), 0.2)
     srcs_t = [x.to(dev) for x in xs]
-    srcs = [kb.ops.tensor_src(x) for x in srcs_t]
+    stats = kb.ops.ActStats(n, dev)
+    srcs = [kb.ops.tensor_src(x, "x", stats.measure(x)) for x in srcs_t]
     packed = kb.ops.pack_conv3x3_split_weight(wt.to(dev))
-    k = kb.ops.act_exponent_for(kb.ops.absmax_srcs(srcs, n, dev))
     base = torch.empty(n, cout, h, w, device=dev)
-    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, base, negative_slope=0.2, act_exponent=k) is not None
+    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, base, negative_slope=0.2) is not None
     kenv.setenv("KBN_DEBUG", "64")
     out = torch.empty_like(base)
-    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, out, negative_slope=0.2, act_exponent=k) is not None
+    slot = stats.new()
+    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, out, negative_slope=0.2, out_absmax=slot) is not None
+    assert torch.equal(kb.ops.slot_values(slot), out.abs().amax(dim=(1, 2, 3)))
     kenv.delenv("KBN_DEBUG")
     assert not torch.equal(out, base), "the knob selected the other kernel"
     rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()
@@ -620,12 +636,14 @@ def test_conv1x1s2_split_kernel(dev, ci, cf, cd, cout, hw, amag):
     fd = fused.to(dev) if cf else None
     xyz = kb.ops.kb_xyz_s2(dd, proj.to(dev), kinv, 0.2)
     assert rel_err(xyz, xyz64[:, :, ::2, ::2].float()) < TIGHT
-    srcs = [kb.ops.tensor_src(imd)] + ([kb.ops.tensor_src(fd)] if cf else [])
-    k = kb.ops.act_exponent_for(kb.ops.absmax_srcs(srcs, n, dev))
+    stats = kb.ops.ActStats(n, dev)
+    srcs = [kb.ops.tensor_src(imd, "image", stats.measure(imd))] + ([kb.ops.tensor_src(fd, "fused", stats.measure(fd))] if cf else [])
     out = torch.empty(n, cout, oh, ow, device=dev)
+    slot = stats.new()
     res = kb.ops.conv1x1s2_split(srcs, kb.ops.pack_conv1x1s2_split_weight(wt.to(dev), ci), xyz, n, cout, oh, ow, out,
-                                 negative_slope=0.2, act_exponent=k if amag != 1.0 else -6)
+                                 negative_slope=0.2, out_absmax=slot)
     assert res is not None
+    assert torch.equal(kb.ops.slot_values(slot), out.abs().amax(dim=(1, 2, 3)))
     rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()
     e_hip = ((out.cpu().double() - ref64) / rms).abs()
     e_orc = ((ref32.double() - ref64) / rms).abs()
@@ -640,8 +658,10 @@ def test_conv1x1s2_split_kernel(dev, ci, cf, cd, cout, hw, amag):
     assert rel_err(out, out32) < TIGHT
     # without xyz channels: a plain 1x1 stride-2 conv of the tensor sources
     wt_t = torch.cat([wt[:, :ci], wt[:, ci + 3:]], 1).contiguous()
-    res = kb.ops.conv1x1s2_split(srcs, kb.ops.pack_conv1x1s2_split_weight(wt_t.to(dev)), None, n, cout, oh, ow, out,
-                                 negative_slope=None, act_exponent=k if amag != 1.0 else -6)
+    k = kb.ops.act_exponent_for(amag * 4.0)      # the static form: no slots on the sources
+    res = kb.ops.conv1x1s2_split([kb.ops.tensor_src(imd)] + ([kb.ops.tensor_src(fd)] if cf else []),
+                                 kb.ops.pack_conv1x1s2_split_weight(wt_t.to(dev)), None, n, cout, oh, ow, out,
+                                 negative_slope=None, act_exponent=k)
     ref = orc.conv2d(torch.cat([image] + ([fused] if cf else []), 1), wt_t, 2, None)
     assert res is not None and rel_err(out, ref) < TIGHT
 
@@ -799,46 +819,84 @@ def test_forward_batch32_full_size_vs_oracle(dev):
     assert worst < TOL, f"max relative error {worst:.3e}"
 
 
-def test_recalibrate_follows_input_scale(dev):
-    """The split-operand convs place their fp16 window on max |a| of each layer's input, measured on the first forward.
-    Weights rescaled so that the same frames produce activations 2^14 times the calibrated ones (conv0 x 2^14, output0
-    x 2^-14: the same network function, LeakyReLU being positively homogeneous) leave the window's 128x headroom: the
-    stale exponents must not pass silently (non-finite depths, or at least a worse result), and
-    KBNetModel.recalibrate() restores parity."""
-    cfg = kb.PRESETS["void"]()
-    h, w = 96, 160
-    frames = kb.synthetic.make_frames(1, h, w, "void", seed=5)
-    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.45)
+def test_forward_follows_input_scale_without_calibration(dev):
+    """The forward is a function of its inputs and weights alone (reference src/net_utils.py:120-141: a conv holds no
+    state).  The split-operand convs take their fp16 windows from per-frame absmax slots that every producer fills on
+    the device (ops.ActStats), so ONE captured graph, recorded on KITTI-statistics frames, must stay as close to the
+    oracle for inputs of any other scale: images not normalised (x 255), sparse depths x 10 and x 0.1, an all-zero sparse
+    map, VOID-statistics frames -- and for weights rescaled so that every activation between conv0 and output0 is 2^14
+    times larger (in-place load_state_dicts under the same graph).  Frames of one batch carry different scales at once:
+    the exponent is per frame.
+    The bar, per frame: against an fp64 evaluation of the same network the HIP result is at most 2x as far from the exact
+    depth as the fp32 oracle is; and wherever the oracle itself is a meaningful reference for north_star's 1e-4 (its own
+    fp32 rounding stays below 4e-5 of the exact result) the HIP result is within 1e-4 of it.  (On the x 255 / x 10 inputs
+    the oracle's fp32 evaluation is 1.3e-4 / 2.0e-4 away from the exact result: two fp32 evaluation orders cannot agree
+    to 1e-4 there, split kernels or not -- tests/analysis/input_scale_margin.py prints both paths.)"""
+    cfg = kb.kitti_config()
+    h, w = 352, 1216
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
     m = kb.modules.KBNetModel.from_config(cfg, dev)
     m.load_state_dicts(*sds)
-    ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
-    assert _worst_rel(m.forward(*to(dev, *frames)), ref) < TOL          # calibrated on these activations
-    exps = [sub._act_exp for mod in m.modules() for sub in mod.modules() if isinstance(sub, kb.modules.Conv2d) and sub._act_exp is not None]
-    assert len(exps) >= 6, "the wide convs of encoder and decoder run on the split kernel and hold a measured exponent"
-    # first encoder convs x 2^14, last decoder conv x 2^-14 (LeakyReLU is positively homogeneous: same network function
-    # up to rounding, every activation in between 2^14 times larger)
+    image, sparse, valid, k = kb.synthetic.make_frames(2, h, w, "kitti", seed=1, jitter_intrinsics=0.1)
+    replay = m.capture(*to(dev, image, sparse, valid, k))
+    oracle = lambda fr, sd=sds: orc.kbnet_forward(*fr, *sd, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth,
+                                                  cfg.max_predict_depth)
+
+    def oracle64(fr, sd=sds):
+        torch.set_default_dtype(torch.float64)      # the oracle's pixel grid follows the default dtype (reference quirk Q8)
+        try:
+            return orc.kbnet_forward(*[f.double() for f in fr], *[{k_: v.double() for k_, v in d.items()} for d in sd],
+                                     cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+        finally:
+            torch.set_default_dtype(torch.float32)
+
+    def check(name, got, fr, sd=sds):
+        ref, ref64 = oracle(fr, sd), oracle64(fr, sd)
+        rel = lambda a, b: float(((a.double() - b.double()).abs() / b.double().abs()).max())
+        err32, hip64, orc64 = rel(got.cpu(), ref), rel(got.cpu(), ref64), rel(ref, ref64)
+        print(f"{name}: HIP vs fp32 oracle {err32:.2e} | HIP vs fp64 {hip64:.2e} | fp32 oracle vs fp64 {orc64:.2e}")
+        assert hip64 <= 2.0 * orc64 + 5e-7, f"{name}: HIP {hip64:.3e} from the exact result, the fp32 oracle {orc64:.3e}"
+        if orc64 < 4e-5:
+            assert err32 < TOL, f"{name}: {err32:.3e} vs the fp32 oracle"
+
+    vi, vs, vv, vk = kb.synthetic.make_frames(2, h, w, "void", seed=4, jitter_intrinsics=0.1)
+    cases = {
+        "recorded frames": (image, sparse, valid, k),
+        "image x 255 | depth x 10": (torch.cat([image[:1] * 255.0, image[1:]]), torch.cat([sparse[:1], sparse[1:] * 10.0]), valid, k),
+        "depth x 0.1 | empty sparse map": (image, torch.cat([sparse[:1] * 0.1, torch.zeros_like(sparse[1:])]),
+                                           torch.cat([valid[:1], torch.zeros_like(valid[1:])]), k),
+        "VOID statistics": (vi, vs, vv, vk),
+    }
+    for name, fr in cases.items():
+        out = replay(*to(dev, *fr)).clone()
+        assert torch.isfinite(out).all(), name
+        for i in range(2):
+            check(f"{name}, frame {i}", out[i:i + 1], [f[i:i + 1] for f in fr])
+        assert torch.equal(m.forward(*to(dev, *[f[1:2] for f in fr])), out[1:2]), "a frame alone gives the bits it gave in the batch"
+    # first encoder convs x 2^14, last decoder conv x 2^-14 (LeakyReLU is positively homogeneous: the same network function
+    # up to rounding, every activation in between 2^14 times larger), loaded in place under the captured graph
     big = [dict(sd) for sd in sds]
-    enc, dec = big[1], big[2]
     for kname in ("conv0_image.conv.weight", "conv0_depth.conv.weight"):
-        enc[kname] = enc[kname] * 2.0 ** 14
-    dec["output0.conv.weight"] = dec["output0.conv.weight"] * 2.0 ** -14
+        big[1][kname] = big[1][kname] * 2.0 ** 14
+    big[2]["output0.conv.weight"] = big[2]["output0.conv.weight"] * 2.0 ** -14
     m.load_state_dicts(*big)
-    out_stale = m.forward(*to(dev, *frames))
-    m.recalibrate()
-    out_fresh = m.forward(*to(dev, *frames))
-    ref_big = orc.kbnet_forward(*frames, *big, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
-    assert not torch.isfinite(out_stale).all() or _worst_rel(out_stale, ref_big) > _worst_rel(out_fresh, ref_big), \
-        "activations 2^14 above the calibrated window must not pass silently"
-    assert torch.isfinite(out_fresh).all() and _worst_rel(out_fresh, ref_big) < TOL
+    fr = cases["recorded frames"]
+    out = replay(*to(dev, *fr))
+    assert torch.isfinite(out).all()
+    check("activations x 2^14, frame 0", out[:1], [f[:1] for f in fr], big)
 
 
 @pytest.mark.parametrize("preset,shape", [("kitti", (352, 1216)), ("void", (480, 640)), ("nyu_v2", (416, 576))])
 def test_forward_full_size_seed_sweep(dev, preset, shape):
-    """Parity margin: five weight / input seeds per preset at BASELINE's sizes, the worst element-wise relative error
-    of the depth map asserted below north_star's 1e-4 and printed (pytest -s / the failure message)."""
+    """Parity margin: seven weight / input seeds per preset at BASELINE's sizes (4 and 6 are the worst KITTI seeds of the
+    16-seed runs, profiles/r02/parity_margin_v29.txt).  Two assertions per seed: the worst element-wise relative error
+    against the fp32 oracle stays below north_star's 1e-4, and -- the one that discriminates: two fp32 evaluation orders
+    of a 35-conv network cannot agree better with each other than each agrees with the truth -- against an fp64
+    evaluation of the same network the HIP path is at most 2x as far from the exact result as the fp32 oracle is."""
     cfg = kb.PRESETS[preset]()
-    worst, per_seed = 0.0, []
-    for seed in (0, 3, 7, 11, 19):
+    seeds = (0, 3, 4, 6, 7, 11, 19)
+    per_seed, vs64 = [], []
+    for seed in seeds:
         sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3 if preset == "kitti" else 1.45)
         frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
         m = kb.modules.KBNetModel.from_config(cfg, dev)
@@ -847,29 +905,20 @@ def test_forward_full_size_seed_sweep(dev, preset, shape):
         ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth,
                                 cfg.max_predict_depth)
         per_seed.append(_worst_rel(out, ref))
-        worst = max(worst, per_seed[-1])
-    print(f"{preset} {shape}: max rel err per seed " + " ".join(f"{e:.2e}" for e in per_seed))
-    assert worst < TOL, f"{preset}: worst of 5 seeds {worst:.3e} (per seed: {per_seed})"
-    # How much of that is the ORACLE's own fp32 rounding?  The WORST seed again, against an fp64 evaluation of the same
-    # network (tests/analysis/oracle_fp64_distance.py): the HIP path must be about as close to the exact result as the
-    # fp32 oracle is -- two fp32 evaluation orders cannot agree better with each other than with the truth.
-    seed = (0, 3, 7, 11, 19)[per_seed.index(worst)]
-    sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3 if preset == "kitti" else 1.45)
-    frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
-    m = kb.modules.KBNetModel.from_config(cfg, dev)
-    m.load_state_dicts(*sds)
-    out = m.forward(*to(dev, *frames))
-    ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
-    torch.set_default_dtype(torch.float64)      # the oracle's pixel grid follows the default dtype (reference quirk Q8)
-    try:
-        ref64 = orc.kbnet_forward(*[f.double() for f in frames], *[{k: v.double() for k, v in sd.items()} for sd in sds],
-                                  cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
-    finally:
-        torch.set_default_dtype(torch.float32)
-    hip64 = float(((out.cpu().double() - ref64).abs() / ref64.abs()).max())
-    orc64 = float(((ref.double() - ref64).abs() / ref64.abs()).max())
-    print(f"{preset} seed {seed} (worst) vs fp64: HIP {hip64:.2e}, fp32 oracle {orc64:.2e}")
-    assert hip64 < TOL and hip64 < 3.0 * orc64 + 1e-5, (hip64, orc64)
+        torch.set_default_dtype(torch.float64)      # the oracle's pixel grid follows the default dtype (reference quirk Q8)
+        try:
+            ref64 = orc.kbnet_forward(*[f.double() for f in frames], *[{k: v.double() for k, v in sd.items()} for sd in sds],
+                                      cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        hip64 = float(((out.cpu().double() - ref64).abs() / ref64.abs()).max())
+        orc64 = float(((ref.double() - ref64).abs() / ref64.abs()).max())
+        vs64.append((hip64, orc64))
+    print(f"{preset} {shape}: max rel err vs the fp32 oracle per seed " + " ".join(f"{e:.2e}" for e in per_seed))
+    print(f"{preset} {shape}: vs fp64, HIP / fp32 oracle per seed " + " ".join(f"{a:.2e}/{b:.2e}" for a, b in vs64))
+    assert max(per_seed) < TOL, f"{preset}: worst of {len(seeds)} seeds {max(per_seed):.3e} (per seed: {per_seed})"
+    for seed, (hip64, orc64) in zip(seeds, vs64):
+        assert hip64 < TOL and hip64 <= 2.0 * orc64, f"{preset} seed {seed}: HIP {hip64:.3e} vs fp64, fp32 oracle {orc64:.3e}"
 
 
 def test_intermediate_tensors_elementwise_full_size(dev):

@@ -52,11 +52,32 @@ def test_split_product_representation_error(amag, folded):
 
 
 def test_act_exponent_rule():
-    for amax in (1e-6, 0.0039, 1.0, 255.9, 256.0, 300.0, 65504.0, 4.0e6, 3.0e30):
+    """ops.act_exponent_for restates the device rule (sp_act_scale, csrc/conv_split.hip): the frame's maximum lands in
+    [2^14, 2^15) of the fp16 window -- below the overflow at 65504 even after h1's rounding -- and degenerate maxima
+    give finite scales."""
+    for amax in (1e-30, 1e-6, 0.0039, 1.0, 255.9, 256.0, 300.0, 65504.0, 4.0e6, 3.0e30):
         k = kb.ops.act_exponent_for(amax)
-        assert 2.0 ** 8 < amax * 2.0 ** k <= 2.0 ** 9 or k in (-60, 60)
-    assert kb.ops.act_exponent_for(0.0) == -6 and kb.ops.act_exponent_for(float("inf")) == -6
-    assert kb.ops.act_exponent_for(float("nan")) == -6
+        assert 2.0 ** 14 <= amax * 2.0 ** k < 2.0 ** 15 or k in (-100, 100)
+        assert float(np.float16(np.float32(amax) * np.float32(2.0 ** k))) <= 32768.0
+    assert kb.ops.act_exponent_for(0.0) == 100 and kb.ops.act_exponent_for(1e-45) == 100
+    assert kb.ops.act_exponent_for(float("inf")) == -100 and kb.ops.act_exponent_for(float("nan")) == -100
+
+
+def test_window_slack_costs_nothing():
+    """Why the window may sit anywhere within ~2^16 of the data: an activation below the full-precision range (h1 flushed)
+    is carried by the scaled residual alone, with an ABSOLUTE error below 2^-40 of the window's top -- a frame whose
+    maximum is 2^-16 of the top still has every value within 2^-24 of its maximum."""
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal(4096) * 2.0 ** -7).astype(np.float32)      # max |a| 2^k ~ 2^-5: 20 binades below the top
+    k = 0
+    ap = a * np.float32(2.0 ** k)
+    h1 = ap.astype(np.float16)
+    h1 = np.where(np.abs(h1.astype(np.float32)) < 2.0 ** -14, np.float16(0), h1)     # the kernels flush subnormal halves
+    h2 = ((ap - h1.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    h2 = np.where(np.abs(h2.astype(np.float32)) < 2.0 ** -14, np.float16(0), h2)
+    back = h1.astype(np.float64) + h2.astype(np.float64) * 2.0 ** -11
+    err = np.abs(back - ap.astype(np.float64)).max()
+    assert err <= 2.0 ** -25 and err / np.abs(ap).max() < 2.0 ** -19
 
 
 def test_default_window_limits():
