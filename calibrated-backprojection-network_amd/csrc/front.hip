@@ -1,0 +1,452 @@
+// front.hip -- the full-resolution front of the encoder's image branch in ONE kernel, on the 16-bit matrix core:
+//     conv0_image = act(conv3x3(image))                                  reference src/networks.py:364-365 (net_utils.Conv2d)
+//     conv_image  = act(conv3x3 s2 (conv0_image))                        reference src/net_utils.py:1348   (KB block, level 0)
+//     conv_fused  = act(conv1x1 s2 (cat[conv0_image, xyz]))              reference src/net_utils.py:1352-1369
+// conv0_image -- 48 channels at full resolution, 82 MB per KITTI frame -- is consumed by these two convs only, so it is
+// computed per tile (+ halo) and kept in LDS: it never reaches HBM (round 2 wrote and re-read 5.3 GB of it per 32-frame
+// step: conv0_image at 4.1 TB/s + the fused fp32 KB kernel, 2.45 ms of a 12.8 ms step on the fp32 pipe).  All three convs take
+// their fp32 products as three fp16 MFMAs over two-term splits of both operands, like csrc/conv_split.hip:
+//     a 2^k = h1 + 2^-11 h2,   w 2^e = w1 + 2^-11 w2'   ->   a w 2^(e+k) = h1 w1 + 2^-11 (h1 w2' + h2 w1)
+// with fp32 accumulators for the main and the small term.  The windows follow the data on the device: k of the image from its
+// per-frame absmax slot; k of the on-chip conv0 output from the BOUND  max |conv0| <= (max_f sum |w0_f|) max |image|
+// (the true maximum is not known before the values are written; the bound is within a few binades of it, and a window may
+// sit 2^16 above the data before anything is lost -- tests/test_split_math_cpu.py).  Outputs are fp32 NCHW with their absmax
+// slots filled, like every other conv.
+//
+// Tile = 8 x 16 output pixels (half resolution) of one frame per workgroup of 8 waves; v_mfma_f32_16x16x32_f16 throughout.
+//   A  the (2*8+3) x (2*16+3) image pixels the tile's conv0 outputs read: loaded, split, one 16-byte granule [8 channels]
+//      per pixel and split term (channels >= c_in are zero).
+//   B  conv0, 16 filters at a time: D[filter][pixel], A operand = weights, B operand = pixels; K = (tap, channel): k-group =
+//      tap, so a B fragment is ONE ds_read_b128 of the granule at (pixel + tap offset).  The 16 x 16 result blocks hold 4
+//      consecutive CHANNELS of a pixel per lane: LeakyReLU, zero outside the image (it is the padding of the next conv),
+//      split with the bound's exponent, ds_write_b64 into X [term][k-group][17 x 33 pixels, columns de-interleaved][8 ch].
+//   C  conv_image (nine taps, two per MFMA: K = [16 ch of tap t | 16 ch of tap t+1]) and conv_fused (centre tap) over
+//      these 16 channels: D[pixel][filter], A operand = pixels of one output row per wave (stride-2 reads of X are
+//      consecutive granules thanks to the de-interleave), B operand = weights from LDS (double buffered, LDS-DMA).
+//   D  after the last chunk: scales, xyz channels of conv_fused in fp32 (kbn_kb_xyz_s2_forward computes them once per block),
+//      LeakyReLU, 16-byte NCHW stores (a lane holds 4 consecutive pixels of a filter), absmax.
+#include "conv_common.h"
+
+namespace kbn {
+
+typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fh4 __attribute__((ext_vector_type(4)));
+typedef _Float16 fh2 __attribute__((ext_vector_type(2)));
+typedef float ff4 __attribute__((ext_vector_type(4)));
+
+constexpr int FR_TH = 8, FR_TW = 16, FR_THREADS = 512;
+constexpr int FR_R1H = 2 * FR_TH + 1, FR_R1W = 2 * FR_TW + 1, FR_NP1 = FR_R1H * FR_R1W;     // conv0 outputs a tile needs: 17 x 33
+constexpr int FR_R0H = FR_R1H + 2, FR_R0W = FR_R1W + 2, FR_NP0 = FR_R0H * FR_R0W;           // image pixels they read: 19 x 35
+constexpr int FR_NP0P = 672;                                                                 // padded to whole 16-pixel rounds
+constexpr int FR_WEXP = 13;                                                                  // largest |w 2^e| of a filter in [2^12, 2^13)
+constexpr int FR_TAB = 400;                                                                  // floats: [L1max0, 0, 0, 0][inv0 64][invI 64][invF 64][wxyz 64 x 3]
+constexpr int FR_NB0 = (FR_NP1 + 15) / 16;                                                   // 16-pixel blocks of conv0 outputs: 36
+
+struct FrontParams {
+    const float* image;
+    long long image_bstride;
+    const unsigned* amax_image;   // per-frame max |image| slot
+    const float* tab;             // scales / xyz weights (FR_TAB floats)
+    const _Float16* w0;           // [chunk][3 k-steps][term][4 k-groups][16 filters][8] -- k-group = tap, 8 = channels
+    const _Float16* wc;           // [chunk][6 k-steps][term][4 k-groups][FI filters][8] -- k-steps 0-4: tap pairs, 5: conv_fused
+    const float* xyz;             // N x 3 x h x w or null
+    long long xyz_bstride;
+    float* out_image;
+    long long out_image_bstride;
+    float* out_fused;
+    long long out_fused_bstride;
+    unsigned* amax_out_image;
+    unsigned* amax_out_fused;
+    int N, Cin, H, W, h, w, tilesX, tilesY, ntiles;
+    float slope0, slope1;
+    int vec4;
+};
+
+__device__ __forceinline__ void fr_scales(unsigned bits, float& pre, float& un) {   // max in [2^14, 2^15) of the fp16 window
+    int k = 14 + 127 - (int)(bits >> 23);
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    pre = __uint_as_float((unsigned)(127 + k) << 23);
+    un = __uint_as_float((unsigned)(127 - k) << 23);
+}
+
+template <int NC0, int NBI>   // conv0 filters / 16, conv_image = conv_fused filters / 16
+__global__ __launch_bounds__(FR_THREADS, 1) void kb1_front_kernel(const FrontParams p) {
+    constexpr int FI = NBI * 16;
+    constexpr int IN_PART = FR_NP0P * 16, IN_BYTES = 2 * IN_PART;
+    constexpr int X_KG = FR_NP1 * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
+    constexpr int W0_KS = 2 * 64 * 16, W0_BYTES = NC0 * 3 * W0_KS;          // per k-step: two terms x 64 lanes x 16 B
+    constexpr int WC_KQ = FI * 16, WC_PART = 4 * WC_KQ, WC_KS = 2 * WC_PART, WC_CHUNK = 6 * WC_KS;
+    constexpr int OFF_X = IN_BYTES, OFF_W0 = OFF_X + X_BYTES, OFF_WC = OFF_W0 + W0_BYTES;
+    static_assert(OFF_WC + 2 * WC_CHUNK <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals (see conv3x3_split_kernel)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    int bid = xcd_remap(blockIdx.x, p.ntiles);
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int oy0 = ty * FR_TH, ox0 = tx * FR_TW;
+    const int H = p.H, W = p.W;
+    const long long plane = (long long)H * W;
+
+    // ---- windows: the image's from its slot, conv0's output from the bound L1max0 * max |image|
+    const unsigned abits = p.amax_image[n];
+    float pre_img, un_img, pre0, un0;
+    fr_scales(abits, pre_img, un_img);
+    fr_scales(__float_as_uint(p.tab[0] * __uint_as_float(abits)), pre0, un0);
+
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+    auto dma = [&](const void* src, int dst_off, int bytes) {   // whole-workgroup copy, 16 bytes per lane and round
+        const int n4 = bytes / 16;
+        for (int e0 = 0; e0 < n4; e0 += FR_THREADS) {
+            const int eb = e0 + wave * 64;
+            if (eb + lane < n4) lds_dma16_s(reinterpret_cast<const float*>(src) + eb * 4, (unsigned)(lane * 16), lds0 + (unsigned)(dst_off + eb * 16));
+        }
+    };
+    dma(p.w0, OFF_W0, W0_BYTES);
+    dma(p.wc, OFF_WC, WC_CHUNK);
+
+    // ---- A: image tile -> split granules
+    {
+        const float* img = p.image + (long long)n * p.image_bstride;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pix = u * FR_THREADS + tid;
+            if (pix < FR_NP0) {
+                const int r = pix / FR_R0W, c = pix - r * FR_R0W;
+                const int Y = 2 * oy0 - 2 + r, X = 2 * ox0 - 2 + c;
+                const bool ok = Y >= 0 && Y < H && X >= 0 && X < W;
+                const float* src = img + (long long)(ok ? Y : 0) * W + (ok ? X : 0);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (ok && j < p.Cin) ? src[(long long)j * plane] : 0.f;
+                fh8 h1, h2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float s = v[j] * pre_img;
+                    const _Float16 a = (_Float16)s;
+                    h1[j] = a;
+                    h2[j] = (_Float16)((s - (float)a) * 2048.f);
+                }
+                *reinterpret_cast<fh8*>(smem + pix * 16) = h1;
+                *reinterpret_cast<fh8*>(smem + IN_PART + pix * 16) = h2;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMAs
+    __syncthreads();
+
+    // per-lane fragment offsets (bytes)
+    int tapoff[3];   // conv0: k-group kq of k-step ks is tap 4 ks + kq (taps past the ninth carry zero weights: any valid address)
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const int tap = min(4 * ks + kq, 8);
+        tapoff[ks] = ((tap / 3) * FR_R0W + tap % 3) * 16;
+    }
+    // conv_image: k-step s covers taps 2 s, 2 s + 1 (k-groups 0-1 / 2-3), k-group parity = which 8 of the chunk's 16 channels
+    const int yrow = wave;   // this wave's output row of the tile
+    int aoff[5], aoff_f;
+    {
+        const int kg = kq & 1, tsel = kq >> 1;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int tap = min(2 * s + tsel, 8);
+            const int ky = tap / 3, kx = tap % 3;
+            const int col = kx == 0 ? l15 : (kx == 1 ? (FR_R1W + 1) / 2 + l15 : l15 + 1);
+            aoff[s] = (kg * FR_NP1 + (2 * yrow + ky) * FR_R1W + col) * 16;
+        }
+        aoff_f = (kg * FR_NP1 + (2 * yrow + 1) * FR_R1W + (FR_R1W + 1) / 2 + l15) * 16;
+    }
+    const bool row_live = oy0 + yrow < p.h;   // wave-uniform
+
+    ff4 mI[NBI], sI[NBI], mF[NBI], sF[NBI];
+#pragma unroll
+    for (int nb = 0; nb < NBI; ++nb) {
+        mI[nb] = (ff4){0.f, 0.f, 0.f, 0.f}; sI[nb] = mI[nb]; mF[nb] = mI[nb]; sF[nb] = mI[nb];
+    }
+    const float* inv0 = p.tab + 4;
+
+#pragma unroll 1
+    for (int c = 0; c < NC0; ++c) {
+        if (c + 1 < NC0) dma(p.wc + (long long)(c + 1) * (WC_CHUNK / 2), OFF_WC + ((c + 1) & 1) * WC_CHUNK, WC_CHUNK);
+        // ---- B: conv0, filters 16 c .. 16 c + 15, over the 561 pixels of the tile's halo region
+        {
+            fh8 a1[3], a2[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                a1[ks] = *reinterpret_cast<const fh8*>(smem + OFF_W0 + (c * 3 + ks) * W0_KS + lane * 16);
+                a2[ks] = *reinterpret_cast<const fh8*>(smem + OFF_W0 + (c * 3 + ks) * W0_KS + 64 * 16 + lane * 16);
+            }
+            const ff4 sc = *reinterpret_cast<const ff4*>(inv0 + 16 * c + 4 * kq);   // 2^-e of this lane's four filters
+            for (int j = wave; j < FR_NB0; j += 8) {
+                const int q = 16 * j + l15, qc = min(q, FR_NP1 - 1);
+                const int r1 = qc / FR_R1W, c1 = qc - r1 * FR_R1W;
+                const unsigned char* inb = smem + (r1 * FR_R0W + c1) * 16;
+                ff4 m = (ff4){0.f, 0.f, 0.f, 0.f}, s = m;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const fh8 b1 = *reinterpret_cast<const fh8*>(inb + tapoff[ks]);
+                    const fh8 b2 = *reinterpret_cast<const fh8*>(inb + IN_PART + tapoff[ks]);
+                    m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b1, m, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2, s, 0, 0, 0);
+                }
+                const int Y = 2 * oy0 - 1 + r1, X = 2 * ox0 - 1 + c1;
+                const bool inside = q < FR_NP1 && Y >= 0 && Y < H && X >= 0 && X < W;
+                fh4 h1, h2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = __builtin_fmaf(s[r], 0.00048828125f, m[r]) * sc[r] * un_img;
+                    v = v > 0.f ? v : v * p.slope0;
+                    v = inside ? v * pre0 : 0.f;
+                    const _Float16 a = (_Float16)v;
+                    h1[r] = a;
+                    h2[r] = (_Float16)((v - (float)a) * 2048.f);
+                }
+                if (q < FR_NP1) {
+                    const int xi = r1 * FR_R1W + ((c1 & 1) ? (FR_R1W + 1) / 2 + (c1 >> 1) : (c1 >> 1));   // columns de-interleaved
+                    unsigned char* xo = smem + OFF_X + (kq >> 1) * X_KG + xi * 16 + (kq & 1) * 8;
+                    *reinterpret_cast<fh4*>(xo) = h1;
+                    *reinterpret_cast<fh4*>(xo + X_PART) = h2;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's weights: issued a conv0 pass ago
+        __syncthreads();
+        // ---- C: conv_image (taps in pairs) and conv_fused (centre tap) over these 16 channels
+        if (row_live) {
+            const unsigned char* xs = smem + OFF_X;
+            const unsigned char* wcb = smem + OFF_WC + (c & 1) * WC_CHUNK + kq * WC_KQ + l15 * 16;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int ao = s < 5 ? aoff[s] : aoff_f;
+                const fh8 a1 = *reinterpret_cast<const fh8*>(xs + ao);
+                const fh8 a2 = *reinterpret_cast<const fh8*>(xs + X_PART + ao);
+#pragma unroll
+                for (int nb = 0; nb < NBI; ++nb) {
+                    const fh8 b1 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + nb * 256);
+                    const fh8 b2 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + WC_PART + nb * 256);
+                    if (s < 5) {
+                        mI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mI[nb], 0, 0, 0);
+                        sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sI[nb], 0, 0, 0);
+                        sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sI[nb], 0, 0, 0);
+                    } else {
+                        mF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mF[nb], 0, 0, 0);
+                        sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sF[nb], 0, 0, 0);
+                        sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sF[nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // X and this weight buffer are free again
+    }
+
+    // ---- D: a lane holds pixels x = 4 kq .. 4 kq + 3 of row yrow for filter 16 nb + l15
+    const int Yo = oy0 + yrow, Xo = ox0 + 4 * kq;
+    float amI = 0.f, amF = 0.f;
+    if (row_live && Xo < p.w) {
+        const long long oplane = (long long)p.h * p.w;
+        const long long pix = (long long)Yo * p.w + Xo;
+        float xz[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                xz[j][r] = (p.xyz && Xo + r < p.w) ? p.xyz[(long long)n * p.xyz_bstride + j * oplane + pix + r] : 0.f;
+        const float* invI = p.tab + 4 + 64;
+        const float* invF = p.tab + 4 + 128;
+        const float* wx = p.tab + 4 + 192;
+#pragma unroll
+        for (int nb = 0; nb < NBI; ++nb) {
+            const int f = nb * 16 + l15;
+            const float scI = invI[f] * un0, scF = invF[f] * un0;
+            const float w0x = wx[f * 3], w1x = wx[f * 3 + 1], w2x = wx[f * 3 + 2];
+            ff4 vI, vF;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = __builtin_fmaf(sI[nb][r], 0.00048828125f, mI[nb][r]) * scI;
+                vI[r] = a > 0.f ? a : a * p.slope1;
+                float b = __builtin_fmaf(sF[nb][r], 0.00048828125f, mF[nb][r]) * scF;
+                b += w0x * xz[0][r] + w1x * xz[1][r] + w2x * xz[2][r];
+                vF[r] = b > 0.f ? b : b * p.slope1;
+            }
+            float* oi = p.out_image + (long long)n * p.out_image_bstride + f * oplane + pix;
+            float* of = p.out_fused + (long long)n * p.out_fused_bstride + f * oplane + pix;
+            if (p.vec4) {
+                *reinterpret_cast<ff4*>(oi) = vI;
+                *reinterpret_cast<ff4*>(of) = vF;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { amI = fmaxf(amI, fabsf(vI[r])); amF = fmaxf(amF, fabsf(vF[r])); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (Xo + r < p.w) {
+                        oi[r] = vI[r]; of[r] = vF[r];
+                        amI = fmaxf(amI, fabsf(vI[r])); amF = fmaxf(amF, fabsf(vF[r]));
+                    }
+            }
+        }
+    }
+    if (p.amax_out_image) absmax_commit(p.amax_out_image + n, amI);
+    if (p.amax_out_fused) absmax_commit(p.amax_out_fused + n, amF);
+}
+
+// ---- weight packing ---------------------------------------------------------------------------------------------
+// table: per-filter 2^-e (largest |w 2^e| in [2^12, 2^13)), the bound factor L1max0 = max_f sum |w0_f|, the fp32 xyz weights
+__global__ void front_table_kernel(const float* __restrict__ w0, const float* __restrict__ wi, const float* __restrict__ wf,
+                                   float* __restrict__ tab, int Cin, int F0, int FI) {
+    __shared__ float red[256], red2[256];
+    const int which = blockIdx.y, f = blockIdx.x;   // which 0: conv0, 1: conv_image, 2: conv_fused
+    const int nf = which == 0 ? F0 : FI;
+    const int per = which == 0 ? Cin * 9 : (which == 1 ? F0 * 9 : F0 + 3);
+    const float* w = which == 0 ? w0 : (which == 1 ? wi : wf);
+    float m = 0.f, l1 = 0.f;
+    if (f < nf)
+        for (int i = threadIdx.x; i < per; i += 256) {
+            const float a = fabsf(w[(long long)f * per + i]);
+            m = fmaxf(m, a);
+            l1 += a;
+        }
+    red[threadIdx.x] = m;
+    red2[threadIdx.x] = l1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+            red2[threadIdx.x] += red2[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int ex = FR_WEXP;
+        if (red[0] > 0.f && red[0] < 3.0e38f) (void)frexpf(red[0], &ex);
+        int e = FR_WEXP - ex;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        tab[4 + 64 * which + f] = ldexpf(1.f, -e);
+        if (which == 0 && f < F0) atomicMax(reinterpret_cast<unsigned*>(tab), __float_as_uint(red2[0]));   // L1max0 (non-negative floats order like their bits)
+        if (which == 2 && f < FI)
+            for (int j = 0; j < 3; ++j) tab[4 + 192 + f * 3 + j] = wf[(long long)f * (F0 + 3) + F0 + j];
+    }
+}
+
+__device__ __forceinline__ _Float16 fr_term(float ws, int term) {
+    const _Float16 w1 = (_Float16)ws;
+    return term == 0 ? w1 : (_Float16)((ws - (float)w1) * 2048.f);
+}
+
+// conv0 panel: [chunk][k-step 3][term][k-group 4][filter 16][channel 8]; k-group of k-step ks = tap 4 ks + kq (< 9, else zero)
+__global__ void front_pack0_kernel(const float* __restrict__ w0, const float* __restrict__ tab, _Float16* __restrict__ out, int Cin, int F0,
+                                   int total) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    int r = e;
+    const int j = r & 7; r >>= 3;
+    const int m = r & 15; r >>= 4;
+    const int kq = r & 3; r >>= 2;
+    const int term = r & 1; r >>= 1;
+    const int ks = r % 3, c = r / 3;
+    const int tap = 4 * ks + kq, f = 16 * c + m;
+    _Float16 h = (_Float16)0.f;
+    if (tap < 9 && j < Cin && f < F0) h = fr_term(w0[((long long)f * Cin + j) * 9 + tap] / tab[4 + f], term);
+    out[e] = h;
+}
+
+// conv_image + conv_fused panel: [chunk][k-step 6][term][k-group 4][filter FI][channel 8]; k-steps 0-4: tap 2 s + (kq >> 1)
+// (< 9, else zero), channel 16 chunk + 8 (kq & 1) + j of conv_image; k-step 5: conv_fused's weight of that channel for kq < 2
+__global__ void front_packc_kernel(const float* __restrict__ wi, const float* __restrict__ wf, const float* __restrict__ tab,
+                                   _Float16* __restrict__ out, int F0, int FI, int total) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    int r = e;
+    const int j = r & 7; r >>= 3;
+    const int f = r % FI; r /= FI;
+    const int kq = r & 3; r >>= 2;
+    const int term = r & 1; r >>= 1;
+    const int s = r % 6, c = r / 6;
+    const int ch = 16 * c + 8 * (kq & 1) + j;
+    _Float16 h = (_Float16)0.f;
+    if (ch < F0) {
+        if (s < 5) {
+            const int tap = 2 * s + (kq >> 1);
+            if (tap < 9) h = fr_term(wi[((long long)f * F0 + ch) * 9 + tap] / tab[4 + 64 + f], term);
+        } else if ((kq >> 1) == 0) {
+            h = fr_term(wf[(long long)f * (F0 + 3) + ch] / tab[4 + 128 + f], term);
+        }
+    }
+    out[e] = h;
+}
+
+}  // namespace kbn
+
+extern "C" {
+
+static bool front_shape_ok(int c_in, int f0, int fi) { return c_in >= 1 && c_in <= 8 && f0 == 48 && fi == 48; }
+
+size_t kbn_kb1_front_packed_weight_bytes(int image_channels, int conv0_filters, int kb_filters) {
+    if (!front_shape_ok(image_channels, conv0_filters, kb_filters)) return 0;
+    const int nc0 = conv0_filters / 16;
+    return (size_t)kbn::FR_TAB * 4 + (size_t)nc0 * 3 * 2 * 64 * 16 + (size_t)nc0 * 6 * 2 * 4 * kb_filters * 16;
+}
+
+int kbn_kb1_front_pack_weight(const float* w_conv0, const float* w_conv_image, const float* w_conv_fused, void* packed,
+                              int image_channels, int conv0_filters, int kb_filters, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!w_conv0 || !w_conv_image || !w_conv_fused || !packed) return KBN_ERR_INVALID_ARGUMENT;
+    if (!front_shape_ok(image_channels, conv0_filters, kb_filters)) return KBN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    float* tab = static_cast<float*>(packed);
+    if (hipMemsetAsync(tab, 0, FR_TAB * 4, st) != hipSuccess) return KBN_ERR_LAUNCH;
+    hipLaunchKernelGGL(front_table_kernel, dim3(64, 3), dim3(256), 0, st, w_conv0, w_conv_image, w_conv_fused, tab, image_channels,
+                       conv0_filters, kb_filters);
+    const int nc0 = conv0_filters / 16;
+    _Float16* p0 = reinterpret_cast<_Float16*>(tab + FR_TAB);
+    const int t0 = nc0 * 3 * 2 * 64 * 8;
+    hipLaunchKernelGGL(front_pack0_kernel, dim3((t0 + 255) / 256), dim3(256), 0, st, w_conv0, tab, p0, image_channels, conv0_filters, t0);
+    const int tc = nc0 * 6 * 2 * 4 * kb_filters * 8;
+    hipLaunchKernelGGL(front_packc_kernel, dim3((tc + 255) / 256), dim3(256), 0, st, w_conv_image, w_conv_fused, tab, p0 + t0, conv0_filters,
+                       kb_filters, tc);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const unsigned* image_absmax, const void* packed_weight,
+                          const float* xyz, long long xyz_batch_stride, float* out_image, long long out_image_batch_stride,
+                          float* out_fused, long long out_fused_batch_stride, int n, int image_channels, int conv0_filters,
+                          int kb_filters, int height, int width, float conv0_negative_slope, float kb_negative_slope,
+                          unsigned* out_image_absmax, unsigned* out_fused_absmax, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!image || !image_absmax || !packed_weight || !out_image || !out_fused || n < 1 || height < 1 || width < 1)
+        return KBN_ERR_INVALID_ARGUMENT;
+    if (!front_shape_ok(image_channels, conv0_filters, kb_filters) || knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
+    if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
+    FrontParams p{};
+    p.image = image; p.image_bstride = image_batch_stride; p.amax_image = image_absmax;
+    p.tab = static_cast<const float*>(packed_weight);
+    p.w0 = reinterpret_cast<const _Float16*>(p.tab + FR_TAB);
+    p.wc = p.w0 + (conv0_filters / 16) * 3 * 2 * 64 * 8;
+    p.xyz = xyz; p.xyz_bstride = xyz_batch_stride;
+    p.out_image = out_image; p.out_image_bstride = out_image_batch_stride;
+    p.out_fused = out_fused; p.out_fused_bstride = out_fused_batch_stride;
+    p.amax_out_image = out_image_absmax; p.amax_out_fused = out_fused_absmax;
+    p.N = n; p.Cin = image_channels; p.H = height; p.W = width;
+    p.h = ceil_div(height, 2); p.w = ceil_div(width, 2);
+    p.tilesX = ceil_div(p.w, FR_TW); p.tilesY = ceil_div(p.h, FR_TH);
+    const long long tiles = (long long)p.tilesX * p.tilesY * n;
+    if (tiles > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.ntiles = (int)tiles;
+    p.slope0 = conv0_negative_slope; p.slope1 = kb_negative_slope;
+    p.vec4 = !((p.w & 3) || (reinterpret_cast<uintptr_t>(out_image) & 15) || (reinterpret_cast<uintptr_t>(out_fused) & 15) ||
+               (out_image_batch_stride & 3) || (out_fused_batch_stride & 3)) ? 1 : 0;
+    auto kern = kb1_front_kernel<3, 3>;
+    constexpr size_t lds = 2 * FR_NP0P * 16 + 2 * 2 * FR_NP1 * 16 + 3 * 3 * 2 * 64 * 16 + 2 * (6 * 2 * 4 * 48 * 16);
+    static DeviceOnce once;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+}  // extern "C"

@@ -101,6 +101,27 @@ class _PackedWeight:
             self.get(weight, *self._args)
 
 
+class _PackedFront:
+    """The blob of ops.kb1_front, rebuilt (in place when possible) when one of its three weights changes."""
+
+    def __init__(self):
+        self._key = None
+        self._packed = None
+        self._args = None
+
+    def get(self, w0, wi, wf):
+        key = tuple((w.data_ptr(), w._version, w.device) for w in (w0, wi, wf))
+        if key != self._key:
+            self._packed = ops.pack_kb1_front_weight(w0, wi, wf, out=self._packed)
+            self._key = key
+            self._args = (w0, wi, wf)
+        return self._packed
+
+    def refresh(self):
+        if self._packed is not None:
+            self.get(*self._args)
+
+
 # ------------------------------------------------------------------------ layers
 class Conv2d(torch.nn.Module):
     """Bias-free conv (padding k//2) + activation; kernel sizes 1 and 3, strides 1 and 2."""
@@ -503,6 +524,38 @@ class KBNetEncoder(torch.nn.Module):
         self.conv5_image = VGGNetBlock(fi[3], fi[4], n_convolutions_image[4], 2, weight_initializer, act)
         self.conv5_depth = VGGNetBlock(fd[3], fd[4], n_convolutions_depth[4], 2, weight_initializer, act)
         self._f = (list(fi), list(fd), list(ff))
+        # conv0_image + the level-0 KB block's conv_image / conv_fused as ONE launch, conv0's output kept on the CU
+        # (ops.kb1_front, csrc/front.hip): KBNet's level 0 (48 / 48 filters) in all presets; other widths keep the
+        # separate kernels
+        self.front = True
+        self._packed_front = _PackedFront()
+
+    def _front(self, image, conv_depth0, kinv, stats):
+        """Level 0 with conv0_image fused in: (skip, conv_image, conv_depth, conv_fused, amax_image, amax_skip), or None when
+        the shapes are outside ops.kb1_front's (the caller runs conv0_image and the block on their own)."""
+        blk = self.calibrated_backprojection1
+        ci, cf, cd = blk.conv_image.conv_block[0], blk.conv_fused, blk.conv_depth.conv_block[0]
+        c0 = self.conv0_image
+        if (not self.front or not c0.split or not ci.split or ci.bf16 or c0._slope is None or blk.proj_depth._slope is None
+                or cf.in_channels != c0.out_channels + 3 or not _dense(image)):
+            return None
+        packed = self._packed_front.get(c0.conv.weight, ci.conv.weight, cf.conv.weight)
+        if packed is None:
+            return None
+        fi, fd, ff = self._f
+        n, _, h, w = image.shape
+        oh, ow = (h + 1) // 2, (w + 1) // 2
+        dev = image.device
+        skip = torch.empty((n, ff[0] + fd[0], oh, ow), device=dev, dtype=torch.float32)
+        out_fused, out_depth = skip[:, :ff[0]], skip[:, ff[0]:]
+        out_image = torch.empty((n, fi[0], oh, ow), device=dev, dtype=torch.float32)
+        a_img, a_skip = stats.new(), stats.new()
+        xyz = ops.kb_xyz_s2(conv_depth0, blk.proj_depth.conv.weight, kinv, blk.proj_depth._slope)
+        if ops.kb1_front(image, stats.measure(image), packed, xyz, c0.out_channels, ci.out_channels, out_image, out_fused,
+                         c0._slope, blk._slope, a_img, a_skip) is None:
+            return None
+        cd.run([ops.tensor_src(conv_depth0, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth, out_absmax=a_skip)
+        return skip, out_image, out_depth, out_fused, a_img, a_skip
 
     def set_bf16(self, enabled: bool = True):
         """THROUGHPUT-ONLY switch (see MultiScaleDecoder.set_bf16): the stride-2 image convs of the KB blocks and both
@@ -530,9 +583,10 @@ class KBNetEncoder(torch.nn.Module):
         depth = depth if _dense(depth) else depth.contiguous()
         intrinsics = intrinsics.contiguous()
 
-        conv_image = self.conv0_image(image)
         conv_depth = self.conv0_depth(depth)
         kinv = ops.intrinsics_inverse(intrinsics, 1.0, 1.0)
+        front = self._front(image, conv_depth, kinv, stats) if 0 in self.resolutions_backprojection else None
+        conv_image = self.conv0_image(image) if front is None else None
         h, w = h0, w0
         h1, w1 = (h0 + 1) // 2, (w0 + 1) // 2
         # Q1: every deeper KB level scales K by the level-1 ratio (reference src/networks.py:342-343)
@@ -544,7 +598,9 @@ class KBNetEncoder(torch.nn.Module):
         for level in range(4):
             oh, ow = (h + 1) // 2, (w + 1) // 2
             a_img, a_skip = stats.new(), stats.new()
-            if level in self.resolutions_backprojection:
+            if level == 0 and front is not None:
+                skip, conv_image, conv_depth, conv_fused, amax_image, a_skip = front
+            elif level in self.resolutions_backprojection:
                 blk = getattr(self, f"calibrated_backprojection{level + 1}")
                 if level > 0:
                     if kinv1 is None:
@@ -861,6 +917,8 @@ class KBNetModel(object):
                     sub._packed_split_1x1.refresh(sub.conv.weight)
                 elif isinstance(sub, UpConv2d):
                     sub._packed_up2x.refresh(sub.conv.conv.weight)
+                elif isinstance(sub, KBNetEncoder):
+                    sub._packed_front.refresh()
 
     # -- nn.Module-like plumbing the reference driver uses ------------------------
     def modules(self):

@@ -681,6 +681,68 @@ def conv1x1s2_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, xyz: Optio
     return out
 
 
+# ----------------------------------------------------- encoder front: conv0_image + KB1's conv_image / conv_fused in one launch
+@_on_tensor_device
+def pack_kb1_front_weight(w_conv0: torch.Tensor, w_conv_image: torch.Tensor, w_conv_fused: torch.Tensor,
+                          out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Blob of `kb1_front` (kbn_kb1_front_pack_weight) from conv0_image's weight (F0 x C x 3 x 3), the level-0 KB block's
+    conv_image weight (FI x F0 x 3 x 3) and conv_fused weight (FI x (F0 + 3) x 1 x 1).  None when the shapes are outside
+    the kernel's (F0 = FI = 48, C <= 8)."""
+    lib = _lib.load()
+    w0, wi, wf = (w.detach().contiguous() for w in (w_conv0, w_conv_image, w_conv_fused))
+    for w, nm in ((w0, "w_conv0"), (wi, "w_conv_image"), (wf, "w_conv_fused")):
+        _require(w, nm, 4)
+    f0, c = w0.shape[0], w0.shape[1]
+    fi = wi.shape[0]
+    if tuple(w0.shape[2:]) != (3, 3) or tuple(wi.shape) != (fi, f0, 3, 3) or tuple(wf.shape) != (fi, f0 + 3, 1, 1):
+        return None
+    nbytes = lib.kbn_kb1_front_packed_weight_bytes(c, f0, fi)
+    if nbytes == 0:
+        return None
+    packed = out if _reusable(out, nbytes // 4, w0) else torch.empty(nbytes // 4, device=w0.device, dtype=torch.float32)
+    check(lib.kbn_kb1_front_pack_weight(w0.data_ptr(), wi.data_ptr(), wf.data_ptr(), packed.data_ptr(), c, f0, fi, _stream()),
+          "kbn_kb1_front_pack_weight")
+    return packed
+
+
+@_on_tensor_device
+def kb1_front(image: torch.Tensor, image_absmax: torch.Tensor, packed_weight: torch.Tensor, xyz: Optional[torch.Tensor],
+              conv0_filters: int, kb_filters: int, out_image: torch.Tensor, out_fused: torch.Tensor,
+              conv0_negative_slope: float = 0.2, kb_negative_slope: float = 0.2, out_image_absmax=None, out_fused_absmax=None):
+    """conv0_image -> (conv_image, conv_fused) of the level-0 KB block in one launch, conv0's output kept on the CU
+    (kbn_kb1_front_forward).  `xyz`: the backprojection channels from kb_xyz_s2.  None when the shape does not qualify."""
+    lib = _lib.load()
+    iptr, ibs = _planes(image, "image")
+    n, c, h, w = image.shape
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    for t, nm in ((out_image, "out_image"), (out_fused, "out_fused")):
+        if tuple(t.shape) != (n, kb_filters, oh, ow):
+            raise KbnError(f"{nm} has shape {tuple(t.shape)}, expected {(n, kb_filters, oh, ow)}")
+    oi, oibs = _planes(out_image, "out_image")
+    of, ofbs = _planes(out_fused, "out_fused")
+    xptr, xbs = (None, 0)
+    if xyz is not None:
+        if tuple(xyz.shape) != (n, 3, oh, ow):
+            raise KbnError(f"xyz has shape {tuple(xyz.shape)}, expected {(n, 3, oh, ow)}")
+        xptr, xbs = _planes(xyz, "xyz")
+    flops = 2.0 * n * (h * w * c * 9 * conv0_filters + oh * ow * conv0_filters * 9 * kb_filters + oh * ow * (conv0_filters + 3) * kb_filters)
+    # issued fp16 MFMA FLOPs: per 8 x 16 tile and 16-filter chunk 36 x 9 (conv0) + 8 x 6 x 3 x 3 (conv_image, conv_fused) MFMAs of 16 x 16 x 32
+    tiles = n * (-(-oh // 8)) * (-(-ow // 16))
+    executed = tiles * (conv0_filters // 16) * (36 * 9 + 8 * 6 * (kb_filters // 16) * 3) * 2.0 * 16 * 16 * 32
+    status = _launch("kb1_front", flops,
+                     lambda: lib.kbn_kb1_front_forward(iptr, ibs, _slot_ptr(image_absmax, n), packed_weight.data_ptr(), xptr, xbs,
+                                                       oi, oibs, of, ofbs, n, c, conv0_filters, kb_filters, h, w,
+                                                       float(conv0_negative_slope), float(kb_negative_slope),
+                                                       _slot_ptr(out_image_absmax, n), _slot_ptr(out_fused_absmax, n), _stream()),
+                     executed=executed)
+    if status == _lib.KBN_ERR_UNSUPPORTED:
+        if PROFILE is not None:
+            PROFILE.pop()
+        return None
+    check(status, "kbn_kb1_front_forward")
+    return out_image, out_fused
+
+
 # ----------------------------------------------------- bf16 leg (throughput-only)
 @_on_tensor_device
 def pack_conv3x3_bf16_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -317,6 +317,33 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
                          float negative_slope, unsigned* out_image_absmax, unsigned* out_depth_absmax,
                          unsigned* out_fused_absmax, kbn_stream_t stream);
 
+/* ------------------------------------------- encoder front (image branch) ------
+ * conv0_image and the two convs of the level-0 KB block that read it, in ONE launch:
+ *     conv0_image = act(conv3x3(image))                          reference src/networks.py:364-365
+ *     conv_image  = act(conv3x3 s2 (conv0_image))                reference src/net_utils.py:1348
+ *     conv_fused  = act(conv1x1 s2 (cat[conv0_image, xyz]))      reference src/net_utils.py:1352-1369 (level 0: no `fused` input)
+ * conv0_image (conv0_filters channels at full resolution) is consumed by nothing else, so it is computed per tile and kept
+ * on the CU: it never reaches HBM.  All three convs on split fp16 operands (see the split-operand section above; same
+ * accuracy class, same parity gate); csrc/front.hip.
+ *   image           N x image_channels x H x W (image_channels <= 8), frames image_batch_stride apart
+ *   image_absmax    the image's per-frame max |x| slots (kbn_absmax_frames) -- required: the fp16 windows follow them
+ *   packed_weight   from kbn_kb1_front_pack_weight: conv0_image.conv.weight (conv0_filters x image_channels x 3 x 3),
+ *                   the block's conv_image weight (kb_filters x conv0_filters x 3 x 3) and conv_fused weight
+ *                   (kb_filters x (conv0_filters + 3) x 1 x 1, input order [image channels, xyz])
+ *   xyz             N x 3 x ceil(H/2) x ceil(W/2) from kbn_kb_xyz_s2_forward (depth = conv0_depth's output), or NULL
+ *   out_image/fused N x kb_filters x ceil(H/2) x ceil(W/2) each, with their own batch strides and absmax slots
+ * KBN_ERR_UNSUPPORTED unless conv0_filters == kb_filters == 48 (KBNet's level 0 in all three presets) -- the caller then
+ * runs kbn_conv2d_forward + kbn_kb_block_forward. */
+size_t kbn_kb1_front_packed_weight_bytes(int image_channels, int conv0_filters, int kb_filters);
+int kbn_kb1_front_pack_weight(const float* w_conv0, const float* w_conv_image, const float* w_conv_fused, void* packed,
+                              int image_channels, int conv0_filters, int kb_filters, kbn_stream_t stream);
+int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const unsigned* image_absmax,
+                          const void* packed_weight, const float* xyz, long long xyz_batch_stride, float* out_image,
+                          long long out_image_batch_stride, float* out_fused, long long out_fused_batch_stride, int n,
+                          int image_channels, int conv0_filters, int kb_filters, int height, int width,
+                          float conv0_negative_slope, float kb_negative_slope, unsigned* out_image_absmax,
+                          unsigned* out_fused_absmax, kbn_stream_t stream);
+
 /* ------------------------------------------------------------ depth head -------
  * MultiScaleDecoder.output0 (3x3, linear)           reference src/networks.py:1842-1851, 1985
  * + KBNetModel.forward's sigmoid / depth mapping    reference src/kbnet_model.py:181-184

@@ -666,6 +666,60 @@ def test_conv1x1s2_split_kernel(dev, ci, cf, cd, cout, hw, amag):
     assert res is not None and rel_err(out, ref) < TIGHT
 
 
+@pytest.mark.parametrize("hw", [(32, 64), (35, 70), (16, 32), (52, 100), (33, 47)])
+@pytest.mark.parametrize("amag", [1.0, 255.0, 1e-3])
+def test_kb1_front_kernel(dev, hw, amag):
+    """kbn_kb1_front_forward: conv0_image -> conv_image (3x3 s2) and conv_fused (1x1 s2 over cat[conv0_image, xyz]) in one
+    launch on split fp16 operands, conv0's output kept on the CU (csrc/front.hip).  Same bars as the other split kernels:
+    against an fp64 evaluation of the three convs its error stays within 3.5x the oracle's fp32 convs' (in units of the
+    output's rms per filter), and within the suite's single-op tolerance of the oracle.  Odd sizes, widths that are not
+    multiples of 4, tiles cut by the border; image magnitudes that move both fp16 windows; frame 1 scaled differently
+    from frame 0 (the windows are per frame)."""
+    h, w = hw
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    g = torch.Generator().manual_seed(h * w)
+    n, c, f0, fi = 2, 3, 48, 48
+    lrelu = torch.nn.functional.leaky_relu
+    image = amag * torch.rand(n, c, h, w, generator=g)
+    image[1] *= 0.037
+    w0 = torch.randn(f0, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    wi = torch.randn(fi, f0, 3, 3, generator=g) / (f0 * 9) ** 0.5
+    wf = torch.randn(fi, f0 + 3, 1, 1, generator=g) / (f0 + 3) ** 0.5
+    w0[1] *= 1e-3; wi[2] *= 40.0; wf[3] *= 1e-2            # filters of very different magnitude: per-filter exponents
+    xyz = amag * torch.randn(n, 3, oh, ow, generator=g)
+    c64 = lambda x, wt, stride: lrelu(torch.nn.functional.conv2d(x.double(), wt.double(), stride=stride, padding=wt.shape[-1] // 2), 0.2)
+    x0_64 = c64(image, w0, 1)
+    img_64 = c64(x0_64, wi, 2)
+    up = torch.zeros(n, 3, h, w, dtype=torch.float64)
+    up[:, :, ::2, ::2] = xyz.double()                       # a 1x1 stride-2 conv reads the even pixels only
+    fus_64 = lrelu(torch.nn.functional.conv2d(torch.cat([x0_64, up], 1), wf.double(), stride=2), 0.2)
+    x0_32 = orc.conv2d(image, w0, 1, 0.2)
+    img_32 = orc.conv2d(x0_32, wi, 2, 0.2)
+    fus_32 = orc.conv2d(torch.cat([x0_32, up.float()], 1), wf, 2, 0.2)
+    assert tuple(img_32.shape) == (n, fi, oh, ow)
+    stats = kb.ops.ActStats(n, dev)
+    imd = image.to(dev)
+    packed = kb.ops.pack_kb1_front_weight(w0.to(dev), wi.to(dev), wf.to(dev))
+    assert packed is not None
+    out_i = torch.full((n, fi, oh, ow), float("nan"), device=dev)
+    out_f = torch.full((n, fi, oh, ow), float("nan"), device=dev)
+    s_i, s_f = stats.new(), stats.new()
+    res = kb.ops.kb1_front(imd, stats.measure(imd), packed, xyz.to(dev), f0, fi, out_i, out_f, 0.2, 0.2, s_i, s_f)
+    assert res is not None
+    assert torch.equal(kb.ops.slot_values(s_i), out_i.abs().amax(dim=(1, 2, 3)))
+    assert torch.equal(kb.ops.slot_values(s_f), out_f.abs().amax(dim=(1, 2, 3)))
+    for name, got, r64, r32 in (("conv_image", out_i, img_64, img_32), ("conv_fused", out_f, fus_64, fus_32)):
+        rms = r64.pow(2).mean(dim=(2, 3), keepdim=True).sqrt()       # per filter and frame
+        e_hip = ((got.cpu().double() - r64) / rms).abs()
+        e_orc = ((r32.double() - r64) / rms).abs()
+        print(f"front {name} vs fp64: max {float(e_hip.max()):.2e} rms {float(e_hip.pow(2).mean().sqrt()):.2e}; "
+              f"oracle fp32 convs vs fp64: max {float(e_orc.max()):.2e} rms {float(e_orc.pow(2).mean().sqrt()):.2e}")
+        assert float(e_hip.pow(2).mean().sqrt()) < max(3.5 * float(e_orc.pow(2).mean().sqrt()), 6e-7), name
+        assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5, name
+        for i in range(n):
+            assert rel_err(got[i], r32[i]) < TIGHT, (name, i)
+
+
 @pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [(48, 16, 48, 96, 32, 34, 72), (96, 32, 96, 192, 64, 19, 44), (48, 16, 0, 96, 32, 21, 37)])
 def test_kb_block_split_fused(dev, ci, cd, cf, fi, fd, h, w):
     """A KB block whose conv_image AND conv_fused run on split operands (KBNet's KB2-KB4 shapes) against the oracle, and
