@@ -37,7 +37,7 @@ typedef float ff4 __attribute__((ext_vector_type(4)));
 constexpr int FR_TH = 8, FR_TW = 16, FR_THREADS = 512;
 constexpr int FR_R1H = 2 * FR_TH + 1, FR_R1W = 2 * FR_TW + 1, FR_NP1 = FR_R1H * FR_R1W;     // conv0 outputs a tile needs: 17 x 33
 constexpr int FR_R0H = FR_R1H + 2, FR_R0W = FR_R1W + 2, FR_NP0 = FR_R0H * FR_R0W;           // image pixels they read: 19 x 35
-constexpr int FR_NP0P = 672;                                                                 // padded to whole 16-pixel rounds
+constexpr int FR_NIN = 672;                                                                  // image entries in LDS: the 665 pixels + zeroed slack (a column pair may start at the last one)
 constexpr int FR_WEXP = 13;                                                                  // largest |w 2^e| of a filter in [2^12, 2^13)
 constexpr int FR_TAB = 400;                                                                  // floats: [L1max0, 0, 0, 0][inv0 64][invI 64][invF 64][wxyz 64 x 3]
 constexpr int FR_NB0 = (FR_NP1 + 15) / 16;                                                   // 16-pixel blocks of conv0 outputs: 36
@@ -47,8 +47,8 @@ struct FrontParams {
     long long image_bstride;
     const unsigned* amax_image;   // per-frame max |image| slot
     const float* tab;             // scales / xyz weights (FR_TAB floats)
-    const _Float16* w0;           // [chunk][3 k-steps][term][4 k-groups][16 filters][8] -- k-group = tap, 8 = channels
-    const _Float16* wc;           // [chunk][6 k-steps][term][4 k-groups][FI filters][8] -- k-steps 0-4: tap pairs, 5: conv_fused
+    const _Float16* w0;           // [chunk][2 k-steps][term][4 k-groups][16 filters][8] -- k-group = (tap row, column pair), 8 = 2 pixels x 4 channels
+    const _Float16* wc;           // [chunk]{[5 k-steps][term][4 k-groups][FI filters][8] (tap pairs) | [term][2 k-groups][FI][8] (conv_fused)}
     const float* xyz;             // N x 3 x h x w or null
     long long xyz_bstride;
     float* out_image;
@@ -69,15 +69,32 @@ __device__ __forceinline__ void fr_scales(unsigned bits, float& pre, float& un) 
     un = __uint_as_float((unsigned)(127 - k) << 23);
 }
 
+// two-term split of four scaled values: h1 = fp16(v), h2 = fp16((v - h1) 2^11)
+__device__ __forceinline__ void fr_split4(const ff4& v, fh4& h1, fh4& h2) {
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        const f32x2 a = {v[k], v[k + 1]};
+        const fh2 c1 = __builtin_convertvector(a, fh2);
+        const f32x2 f = {(float)c1[0], (float)c1[1]};
+        const f32x2 hi = a * 2048.f;
+        const f32x2 r = {__builtin_fmaf(f[0], -2048.f, hi[0]), __builtin_fmaf(f[1], -2048.f, hi[1])};
+        const fh2 c2 = __builtin_convertvector(r, fh2);
+        h1[k] = c1[0]; h1[k + 1] = c1[1];
+        h2[k] = c2[0]; h2[k + 1] = c2[1];
+    }
+}
+
+// LDS per workgroup: IN 10.5 KB + X 35.1 KB + one chunk of conv_image / conv_fused weights 33 KB = 78.6 KB: TWO workgroups
+// per CU, so that one's image loads, barriers and stores hide under the other's MFMAs.
 template <int NC0, int NBI>   // conv0 filters / 16, conv_image = conv_fused filters / 16
-__global__ __launch_bounds__(FR_THREADS, 1) void kb1_front_kernel(const FrontParams p) {
+__global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontParams p) {
     constexpr int FI = NBI * 16;
-    constexpr int IN_PART = FR_NP0P * 16, IN_BYTES = 2 * IN_PART;
+    constexpr int IN_PART = FR_NIN * 8, IN_BYTES = 2 * IN_PART;            // [term][pixel][4 channels] fp16
     constexpr int X_KG = FR_NP1 * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
-    constexpr int W0_KS = 2 * 64 * 16, W0_BYTES = NC0 * 3 * W0_KS;          // per k-step: two terms x 64 lanes x 16 B
-    constexpr int WC_KQ = FI * 16, WC_PART = 4 * WC_KQ, WC_KS = 2 * WC_PART, WC_CHUNK = 6 * WC_KS;
-    constexpr int OFF_X = IN_BYTES, OFF_W0 = OFF_X + X_BYTES, OFF_WC = OFF_W0 + W0_BYTES;
-    static_assert(OFF_WC + 2 * WC_CHUNK <= 160 * 1024, "LDS budget");
+    constexpr int WC_KQ = FI * 16, WC_PART = 4 * WC_KQ, WC_KS = 2 * WC_PART, WC_FUSED = 2 * 2 * WC_KQ, WC_CHUNK = 5 * WC_KS + WC_FUSED;
+    constexpr int OFF_X = IN_BYTES, OFF_WC = OFF_X + X_BYTES;
+    static_assert(OFF_WC + WC_CHUNK <= 80 * 1024, "two workgroups per CU");
+    constexpr int NBLK = (FR_NB0 + 7) / 8;                                  // conv0 pixel blocks per wave: 5 (waves 4-7: 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals (see conv3x3_split_kernel)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,53 +116,68 @@ __global__ __launch_bounds__(FR_THREADS, 1) void kb1_front_kernel(const FrontPar
     fr_scales(__float_as_uint(p.tab[0] * __uint_as_float(abits)), pre0, un0);
 
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
-    auto dma = [&](const void* src, int dst_off, int bytes) {   // whole-workgroup copy, 16 bytes per lane and round
-        const int n4 = bytes / 16;
+    auto dma_wc = [&](int chunk) {   // whole-workgroup copy of one chunk's weights, 16 bytes per lane and round
+        const float* src = reinterpret_cast<const float*>(p.wc + (long long)chunk * (WC_CHUNK / 2));
+        constexpr int n4 = WC_CHUNK / 16;
+#pragma unroll
         for (int e0 = 0; e0 < n4; e0 += FR_THREADS) {
             const int eb = e0 + wave * 64;
-            if (eb + lane < n4) lds_dma16_s(reinterpret_cast<const float*>(src) + eb * 4, (unsigned)(lane * 16), lds0 + (unsigned)(dst_off + eb * 16));
+            if (eb + lane < n4) lds_dma16_s(src + eb * 4, (unsigned)(lane * 16), lds0 + (unsigned)(OFF_WC + eb * 16));
         }
     };
-    dma(p.w0, OFF_W0, W0_BYTES);
-    dma(p.wc, OFF_WC, WC_CHUNK);
+    dma_wc(0);
 
-    // ---- A: image tile -> split granules
+    // ---- A: image tile -> split entries [4 channels] per pixel (two pixels = one 16-byte K group of conv0)
     {
         const float* img = p.image + (long long)n * p.image_bstride;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int pix = u * FR_THREADS + tid;
-            if (pix < FR_NP0) {
+            if (pix < FR_NIN) {
                 const int r = pix / FR_R0W, c = pix - r * FR_R0W;
                 const int Y = 2 * oy0 - 2 + r, X = 2 * ox0 - 2 + c;
-                const bool ok = Y >= 0 && Y < H && X >= 0 && X < W;
+                const bool ok = pix < FR_NP0 && Y >= 0 && Y < H && X >= 0 && X < W;   // entries past the tile stay zero (pair reads touch one)
                 const float* src = img + (long long)(ok ? Y : 0) * W + (ok ? X : 0);
-                float v[8];
+                ff4 v;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (ok && j < p.Cin) ? src[(long long)j * plane] : 0.f;
-                fh8 h1, h2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float s = v[j] * pre_img;
-                    const _Float16 a = (_Float16)s;
-                    h1[j] = a;
-                    h2[j] = (_Float16)((s - (float)a) * 2048.f);
-                }
-                *reinterpret_cast<fh8*>(smem + pix * 16) = h1;
-                *reinterpret_cast<fh8*>(smem + IN_PART + pix * 16) = h2;
+                for (int j = 0; j < 4; ++j) v[j] = (ok && j < p.Cin) ? src[(long long)(j < p.Cin ? j : 0) * plane] * pre_img : 0.f;
+                fh4 h1, h2;
+                fr_split4(v, h1, h2);
+                *reinterpret_cast<fh4*>(smem + pix * 8) = h1;
+                *reinterpret_cast<fh4*>(smem + IN_PART + pix * 8) = h2;
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMAs
-    __syncthreads();
 
-    // per-lane fragment offsets (bytes)
-    int tapoff[3];   // conv0: k-group kq of k-step ks is tap 4 ks + kq (taps past the ninth carry zero weights: any valid address)
+    // ---- per-lane offsets, computed once per tile
+    // conv0: k-group g = 4 ks + kq = (tap row g >> 1, column pair g & 1: columns 0-1 / 2-3, the fourth carries zero weights);
+    // groups 6, 7 are all zero weights: any valid address
+    int goff[2];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-        const int tap = min(4 * ks + kq, 8);
-        tapoff[ks] = ((tap / 3) * FR_R0W + tap % 3) * 16;
+    for (int ks = 0; ks < 2; ++ks) {
+        const int g = min(4 * ks + kq, 5);
+        goff[ks] = ((g >> 1) * FR_R0W + 2 * (g & 1)) * 8;
     }
+    // conv0 block j (0..35) of the 17 x 33 region: j < 34: row j >> 1, columns 16 (j & 1) + l15; 34, 35: the last column (32),
+    // rows l15 / 16 + l15.  Wave w takes blocks w, w + 8, .. (five for waves 0-3, four for the others).
+    int inoff[NBLK], xoff[NBLK];
+    unsigned inside = 0, valid = 0;
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int j = wave + 8 * i;
+        const int r1 = j < 34 ? (j >> 1) : (j == 34 ? l15 : 16 + l15);
+        const int c1 = j < 34 ? 16 * (j & 1) + l15 : 32;
+        const bool ok = r1 < FR_R1H;
+        const int r1c = ok ? r1 : FR_R1H - 1;
+        const int Y = 2 * oy0 - 1 + r1c, X = 2 * ox0 - 1 + c1;
+        inoff[i] = (r1c * FR_R0W + c1) * 8;
+        const int xi = r1c * FR_R1W + ((c1 & 1) ? (FR_R1W + 1) / 2 + (c1 >> 1) : (c1 >> 1));   // columns de-interleaved
+        xoff[i] = OFF_X + (kq >> 1) * X_KG + xi * 16 + (kq & 1) * 8;
+        if (ok) valid |= 1u << i;
+        if (ok && Y >= 0 && Y < H && X >= 0 && X < W) inside |= 1u << i;
+    }
+    // a tile whose halo region lies inside the image needs no zero padding of conv0's output (workgroup-uniform)
+    const bool interior = 2 * oy0 - 1 >= 0 && 2 * oy0 - 1 + FR_R1H <= H && 2 * ox0 - 1 >= 0 && 2 * ox0 - 1 + FR_R1W <= W;
     // conv_image: k-step s covers taps 2 s, 2 s + 1 (k-groups 0-1 / 2-3), k-group parity = which 8 of the chunk's 16 channels
     const int yrow = wave;   // this wave's output row of the tile
     int aoff[5], aoff_f;
@@ -156,11 +188,12 @@ __global__ __launch_bounds__(FR_THREADS, 1) void kb1_front_kernel(const FrontPar
             const int tap = min(2 * s + tsel, 8);
             const int ky = tap / 3, kx = tap % 3;
             const int col = kx == 0 ? l15 : (kx == 1 ? (FR_R1W + 1) / 2 + l15 : l15 + 1);
-            aoff[s] = (kg * FR_NP1 + (2 * yrow + ky) * FR_R1W + col) * 16;
+            aoff[s] = OFF_X + (kg * FR_NP1 + (2 * yrow + ky) * FR_R1W + col) * 16;
         }
-        aoff_f = (kg * FR_NP1 + (2 * yrow + 1) * FR_R1W + (FR_R1W + 1) / 2 + l15) * 16;
+        aoff_f = OFF_X + (kg * FR_NP1 + (2 * yrow + 1) * FR_R1W + (FR_R1W + 1) / 2 + l15) * 16;
     }
     const bool row_live = oy0 + yrow < p.h;   // wave-uniform
+    const int nblk = wave + 8 * (NBLK - 1) < FR_NB0 ? NBLK : NBLK - 1;   // wave-uniform
 
     ff4 mI[NBI], sI[NBI], mF[NBI], sF[NBI];
 #pragma unroll
@@ -168,80 +201,97 @@ __global__ __launch_bounds__(FR_THREADS, 1) void kb1_front_kernel(const FrontPar
         mI[nb] = (ff4){0.f, 0.f, 0.f, 0.f}; sI[nb] = mI[nb]; mF[nb] = mI[nb]; sF[nb] = mI[nb];
     }
     const float* inv0 = p.tab + 4;
+    const float sc0 = un_img * pre0;   // conv0's result leaves the accumulators already in the next window's scale
+    __syncthreads();   // IN complete
 
 #pragma unroll 1
     for (int c = 0; c < NC0; ++c) {
-        if (c + 1 < NC0) dma(p.wc + (long long)(c + 1) * (WC_CHUNK / 2), OFF_WC + ((c + 1) & 1) * WC_CHUNK, WC_CHUNK);
         // ---- B: conv0, filters 16 c .. 16 c + 15, over the 561 pixels of the tile's halo region
         {
-            fh8 a1[3], a2[3];
+            fh8 a1[2], a2[2];   // weights straight from L2 / L1: 4 KB per chunk
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                a1[ks] = *reinterpret_cast<const fh8*>(smem + OFF_W0 + (c * 3 + ks) * W0_KS + lane * 16);
-                a2[ks] = *reinterpret_cast<const fh8*>(smem + OFF_W0 + (c * 3 + ks) * W0_KS + 64 * 16 + lane * 16);
+            for (int ks = 0; ks < 2; ++ks) {
+                a1[ks] = *reinterpret_cast<const fh8*>(p.w0 + ((c * 2 + ks) * 2 + 0) * 512 + lane * 8);
+                a2[ks] = *reinterpret_cast<const fh8*>(p.w0 + ((c * 2 + ks) * 2 + 1) * 512 + lane * 8);
             }
-            const ff4 sc = *reinterpret_cast<const ff4*>(inv0 + 16 * c + 4 * kq);   // 2^-e of this lane's four filters
-            for (int j = wave; j < FR_NB0; j += 8) {
-                const int q = 16 * j + l15, qc = min(q, FR_NP1 - 1);
-                const int r1 = qc / FR_R1W, c1 = qc - r1 * FR_R1W;
-                const unsigned char* inb = smem + (r1 * FR_R0W + c1) * 16;
+            ff4 sc = *reinterpret_cast<const ff4*>(inv0 + 16 * c + 4 * kq);   // 2^-e of this lane's four filters
+            sc *= sc0;
+            const f32x2 sc01 = {sc[0], sc[1]}, sc23 = {sc[2], sc[3]};
+            auto block = [&](int i, auto border_tag) {
+                constexpr bool BORDER = decltype(border_tag)::value;
+                const unsigned char* inb = smem + inoff[i];
                 ff4 m = (ff4){0.f, 0.f, 0.f, 0.f}, s = m;
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const fh8 b1 = *reinterpret_cast<const fh8*>(inb + tapoff[ks]);
-                    const fh8 b2 = *reinterpret_cast<const fh8*>(inb + IN_PART + tapoff[ks]);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const fh4 b1l = *reinterpret_cast<const fh4*>(inb + goff[ks]);
+                    const fh4 b1h = *reinterpret_cast<const fh4*>(inb + goff[ks] + 8);
+                    const fh4 b2l = *reinterpret_cast<const fh4*>(inb + IN_PART + goff[ks]);
+                    const fh4 b2h = *reinterpret_cast<const fh4*>(inb + IN_PART + goff[ks] + 8);
+                    const fh8 b1 = __builtin_shufflevector(b1l, b1h, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const fh8 b2 = __builtin_shufflevector(b2l, b2h, 0, 1, 2, 3, 4, 5, 6, 7);
                     m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b1, m, 0, 0, 0);
                     s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1, s, 0, 0, 0);
                     s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2, s, 0, 0, 0);
                 }
-                const int Y = 2 * oy0 - 1 + r1, X = 2 * ox0 - 1 + c1;
-                const bool inside = q < FR_NP1 && Y >= 0 && Y < H && X >= 0 && X < W;
+                // (main + 2^-11 small) 2^-e 2^(k0 - k), LeakyReLU as max(t, slope t) (0 <= slope <= 1), in packed fp32
+                f32x2 t01 = (f32x2){s[0], s[1]} * 0.00048828125f + (f32x2){m[0], m[1]};
+                f32x2 t23 = (f32x2){s[2], s[3]} * 0.00048828125f + (f32x2){m[2], m[3]};
+                t01 *= sc01; t23 *= sc23;
+                const f32x2 u01 = t01 * p.slope0, u23 = t23 * p.slope0;
+                ff4 v = {fmaxf(t01[0], u01[0]), fmaxf(t01[1], u01[1]), fmaxf(t23[0], u23[0]), fmaxf(t23[1], u23[1])};
+                if (BORDER && !((inside >> i) & 1)) v = (ff4){0.f, 0.f, 0.f, 0.f};   // outside the image: the zero padding of conv_image
                 fh4 h1, h2;
+                fr_split4(v, h1, h2);
+                if (!BORDER || ((valid >> i) & 1)) {
+                    *reinterpret_cast<fh4*>(smem + xoff[i]) = h1;
+                    *reinterpret_cast<fh4*>(smem + xoff[i] + X_PART) = h2;
+                }
+            };
+            if (interior) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = __builtin_fmaf(s[r], 0.00048828125f, m[r]) * sc[r] * un_img;
-                    v = v > 0.f ? v : v * p.slope0;
-                    v = inside ? v * pre0 : 0.f;
-                    const _Float16 a = (_Float16)v;
-                    h1[r] = a;
-                    h2[r] = (_Float16)((v - (float)a) * 2048.f);
-                }
-                if (q < FR_NP1) {
-                    const int xi = r1 * FR_R1W + ((c1 & 1) ? (FR_R1W + 1) / 2 + (c1 >> 1) : (c1 >> 1));   // columns de-interleaved
-                    unsigned char* xo = smem + OFF_X + (kq >> 1) * X_KG + xi * 16 + (kq & 1) * 8;
-                    *reinterpret_cast<fh4*>(xo) = h1;
-                    *reinterpret_cast<fh4*>(xo + X_PART) = h2;
-                }
+                for (int i = 0; i < NBLK - 1; ++i) block(i, std::false_type{});     // blocks 0 .. 31: whole rows of 16 pixels
+                if (NBLK - 1 < nblk) block(NBLK - 1, std::true_type{});              // 32 .. 35: the last row / the last column
+            } else {
+#pragma unroll
+                for (int i = 0; i < NBLK; ++i)
+                    if (i < nblk) block(i, std::true_type{});
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's weights: issued a conv0 pass ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's conv_image / conv_fused weights (DMA issued a stage ago)
         __syncthreads();
         // ---- C: conv_image (taps in pairs) and conv_fused (centre tap) over these 16 channels
         if (row_live) {
-            const unsigned char* xs = smem + OFF_X;
-            const unsigned char* wcb = smem + OFF_WC + (c & 1) * WC_CHUNK + kq * WC_KQ + l15 * 16;
+            const unsigned char* wcb = smem + OFF_WC + kq * WC_KQ + l15 * 16;
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const int ao = s < 5 ? aoff[s] : aoff_f;
-                const fh8 a1 = *reinterpret_cast<const fh8*>(xs + ao);
-                const fh8 a2 = *reinterpret_cast<const fh8*>(xs + X_PART + ao);
+            for (int s = 0; s < 5; ++s) {
+                const fh8 a1 = *reinterpret_cast<const fh8*>(smem + aoff[s]);
+                const fh8 a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff[s]);
 #pragma unroll
                 for (int nb = 0; nb < NBI; ++nb) {
                     const fh8 b1 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + nb * 256);
                     const fh8 b2 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + WC_PART + nb * 256);
-                    if (s < 5) {
-                        mI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mI[nb], 0, 0, 0);
-                        sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sI[nb], 0, 0, 0);
-                        sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sI[nb], 0, 0, 0);
-                    } else {
-                        mF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mF[nb], 0, 0, 0);
-                        sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sF[nb], 0, 0, 0);
-                        sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sF[nb], 0, 0, 0);
-                    }
+                    mI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mI[nb], 0, 0, 0);
+                    sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sI[nb], 0, 0, 0);
+                    sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sI[nb], 0, 0, 0);
+                }
+            }
+            {   // conv_fused: K = this chunk's 16 channels at the centre tap; k-groups 2, 3 of the MFMA are zeroed on the A side
+                fh8 a1 = *reinterpret_cast<const fh8*>(smem + aoff_f);
+                fh8 a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff_f);
+                if (kq >= 2) { a1 = (fh8)(_Float16)0.f; a2 = a1; }
+                const unsigned char* wf = smem + OFF_WC + 5 * WC_KS + (kq & 1) * WC_KQ + l15 * 16;
+#pragma unroll
+                for (int nb = 0; nb < NBI; ++nb) {
+                    const fh8 b1 = *reinterpret_cast<const fh8*>(wf + nb * 256);
+                    const fh8 b2 = *reinterpret_cast<const fh8*>(wf + 2 * WC_KQ + nb * 256);
+                    mF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mF[nb], 0, 0, 0);
+                    sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sF[nb], 0, 0, 0);
+                    sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sF[nb], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();   // X and this weight buffer are free again
+        __syncthreads();   // X and the weight buffer are free again
+        if (c + 1 < NC0) dma_wc(c + 1);
     }
 
     // ---- D: a lane holds pixels x = 4 kq .. 4 kq + 3 of row yrow for filter 16 nb + l15
@@ -250,12 +300,21 @@ __global__ __launch_bounds__(FR_THREADS, 1) void kb1_front_kernel(const FrontPar
     if (row_live && Xo < p.w) {
         const long long oplane = (long long)p.h * p.w;
         const long long pix = (long long)Yo * p.w + Xo;
-        float xz[3][4];
+        ff4 xz[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j) {
+            xz[j] = (ff4){0.f, 0.f, 0.f, 0.f};
+            if (p.xyz) {
+                const float* xp = p.xyz + (long long)n * p.xyz_bstride + j * oplane + pix;
+                if (p.vec4) {   // w % 4 == 0: the quad is inside the row (the caller checked xyz's alignment with the outputs')
+                    xz[j] = *reinterpret_cast<const ff4*>(xp);
+                } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                xz[j][r] = (p.xyz && Xo + r < p.w) ? p.xyz[(long long)n * p.xyz_bstride + j * oplane + pix + r] : 0.f;
+                    for (int r = 0; r < 4; ++r)
+                        if (Xo + r < p.w) xz[j][r] = xp[r];
+                }
+            }
+        }
         const float* invI = p.tab + 4 + 64;
         const float* invF = p.tab + 4 + 128;
         const float* wx = p.tab + 4 + 192;
@@ -337,7 +396,8 @@ __device__ __forceinline__ _Float16 fr_term(float ws, int term) {
     return term == 0 ? w1 : (_Float16)((ws - (float)w1) * 2048.f);
 }
 
-// conv0 panel: [chunk][k-step 3][term][k-group 4][filter 16][channel 8]; k-group of k-step ks = tap 4 ks + kq (< 9, else zero)
+// conv0 panel: [chunk][k-step 2][term][k-group 4][filter 16][8]; k-group g = 4 ks + kq = (tap row g >> 1, column pair g & 1),
+// slot j = (column 2 (g & 1) + (j >> 2), channel j & 3); groups >= 6, column 3, channels >= Cin: zero
 __global__ void front_pack0_kernel(const float* __restrict__ w0, const float* __restrict__ tab, _Float16* __restrict__ out, int Cin, int F0,
                                    int total) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,34 +407,41 @@ __global__ void front_pack0_kernel(const float* __restrict__ w0, const float* __
     const int m = r & 15; r >>= 4;
     const int kq = r & 3; r >>= 2;
     const int term = r & 1; r >>= 1;
-    const int ks = r % 3, c = r / 3;
-    const int tap = 4 * ks + kq, f = 16 * c + m;
+    const int ks = r & 1, c = r >> 1;
+    const int g = 4 * ks + kq, f = 16 * c + m;
+    const int ky = g >> 1, kx = 2 * (g & 1) + (j >> 2), ch = j & 3;
     _Float16 h = (_Float16)0.f;
-    if (tap < 9 && j < Cin && f < F0) h = fr_term(w0[((long long)f * Cin + j) * 9 + tap] / tab[4 + f], term);
+    if (g < 6 && kx < 3 && ch < Cin && f < F0) h = fr_term(w0[((long long)f * Cin + ch) * 9 + ky * 3 + kx] / tab[4 + f], term);
     out[e] = h;
 }
 
-// conv_image + conv_fused panel: [chunk][k-step 6][term][k-group 4][filter FI][channel 8]; k-steps 0-4: tap 2 s + (kq >> 1)
-// (< 9, else zero), channel 16 chunk + 8 (kq & 1) + j of conv_image; k-step 5: conv_fused's weight of that channel for kq < 2
+// conv_image + conv_fused panel, per chunk: [k-step 5][term][k-group 4][filter FI][8]: tap 2 s + (kq >> 1) (< 9, else zero),
+// channel 16 chunk + 8 (kq & 1) + j of conv_image; then [term][k-group 2][filter FI][8]: conv_fused's weights of channels
+// 16 chunk + 8 kq + j
 __global__ void front_packc_kernel(const float* __restrict__ wi, const float* __restrict__ wf, const float* __restrict__ tab,
                                    _Float16* __restrict__ out, int F0, int FI, int total) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    int r = e;
-    const int j = r & 7; r >>= 3;
-    const int f = r % FI; r /= FI;
-    const int kq = r & 3; r >>= 2;
-    const int term = r & 1; r >>= 1;
-    const int s = r % 6, c = r / 6;
-    const int ch = 16 * c + 8 * (kq & 1) + j;
+    const int per_chunk = (5 * 2 * 4 + 2 * 2) * FI * 8;
+    const int c = e / per_chunk;
+    int r = e - c * per_chunk;
     _Float16 h = (_Float16)0.f;
-    if (ch < F0) {
-        if (s < 5) {
-            const int tap = 2 * s + (kq >> 1);
-            if (tap < 9) h = fr_term(wi[((long long)f * F0 + ch) * 9 + tap] / tab[4 + 64 + f], term);
-        } else if ((kq >> 1) == 0) {
-            h = fr_term(wf[(long long)f * (F0 + 3) + ch] / tab[4 + 128 + f], term);
-        }
+    if (r < 5 * 2 * 4 * FI * 8) {
+        const int j = r & 7; r >>= 3;
+        const int f = r % FI; r /= FI;
+        const int kq = r & 3; r >>= 2;
+        const int term = r & 1; r >>= 1;
+        const int s = r;
+        const int ch = 16 * c + 8 * (kq & 1) + j, tap = 2 * s + (kq >> 1);
+        if (ch < F0 && tap < 9) h = fr_term(wi[((long long)f * F0 + ch) * 9 + tap] / tab[4 + 64 + f], term);
+    } else {
+        r -= 5 * 2 * 4 * FI * 8;
+        const int j = r & 7; r >>= 3;
+        const int f = r % FI; r /= FI;
+        const int kg = r & 1; r >>= 1;
+        const int term = r;
+        const int ch = 16 * c + 8 * kg + j;
+        if (ch < F0) h = fr_term(wf[(long long)f * (F0 + 3) + ch] / tab[4 + 128 + f], term);
     }
     out[e] = h;
 }
@@ -383,12 +450,13 @@ __global__ void front_packc_kernel(const float* __restrict__ wi, const float* __
 
 extern "C" {
 
-static bool front_shape_ok(int c_in, int f0, int fi) { return c_in >= 1 && c_in <= 8 && f0 == 48 && fi == 48; }
+static bool front_shape_ok(int c_in, int f0, int fi) { return c_in >= 1 && c_in <= 4 && f0 == 48 && fi == 48; }
+static size_t front_w0_halves(int f0) { return (size_t)(f0 / 16) * 2 * 2 * 64 * 8; }
+static size_t front_wc_halves(int f0, int fi) { return (size_t)(f0 / 16) * (5 * 2 * 4 + 2 * 2) * fi * 8; }
 
 size_t kbn_kb1_front_packed_weight_bytes(int image_channels, int conv0_filters, int kb_filters) {
     if (!front_shape_ok(image_channels, conv0_filters, kb_filters)) return 0;
-    const int nc0 = conv0_filters / 16;
-    return (size_t)kbn::FR_TAB * 4 + (size_t)nc0 * 3 * 2 * 64 * 16 + (size_t)nc0 * 6 * 2 * 4 * kb_filters * 16;
+    return (size_t)kbn::FR_TAB * 4 + 2 * (front_w0_halves(conv0_filters) + front_wc_halves(conv0_filters, kb_filters));
 }
 
 int kbn_kb1_front_pack_weight(const float* w_conv0, const float* w_conv_image, const float* w_conv_fused, void* packed,
@@ -401,11 +469,10 @@ int kbn_kb1_front_pack_weight(const float* w_conv0, const float* w_conv_image, c
     if (hipMemsetAsync(tab, 0, FR_TAB * 4, st) != hipSuccess) return KBN_ERR_LAUNCH;
     hipLaunchKernelGGL(front_table_kernel, dim3(64, 3), dim3(256), 0, st, w_conv0, w_conv_image, w_conv_fused, tab, image_channels,
                        conv0_filters, kb_filters);
-    const int nc0 = conv0_filters / 16;
     _Float16* p0 = reinterpret_cast<_Float16*>(tab + FR_TAB);
-    const int t0 = nc0 * 3 * 2 * 64 * 8;
+    const int t0 = (int)front_w0_halves(conv0_filters);
     hipLaunchKernelGGL(front_pack0_kernel, dim3((t0 + 255) / 256), dim3(256), 0, st, w_conv0, tab, p0, image_channels, conv0_filters, t0);
-    const int tc = nc0 * 6 * 2 * 4 * kb_filters * 8;
+    const int tc = (int)front_wc_halves(conv0_filters, kb_filters);
     hipLaunchKernelGGL(front_packc_kernel, dim3((tc + 255) / 256), dim3(256), 0, st, w_conv_image, w_conv_fused, tab, p0 + t0, conv0_filters,
                        kb_filters, tc);
     KBN_CHECK_LAUNCH();
@@ -426,7 +493,7 @@ int kbn_kb1_front_forward(const float* image, long long image_batch_stride, cons
     p.image = image; p.image_bstride = image_batch_stride; p.amax_image = image_absmax;
     p.tab = static_cast<const float*>(packed_weight);
     p.w0 = reinterpret_cast<const _Float16*>(p.tab + FR_TAB);
-    p.wc = p.w0 + (conv0_filters / 16) * 3 * 2 * 64 * 8;
+    p.wc = p.w0 + front_w0_halves(conv0_filters);
     p.xyz = xyz; p.xyz_bstride = xyz_batch_stride;
     p.out_image = out_image; p.out_image_bstride = out_image_batch_stride;
     p.out_fused = out_fused; p.out_fused_bstride = out_fused_batch_stride;
@@ -438,12 +505,14 @@ int kbn_kb1_front_forward(const float* image, long long image_batch_stride, cons
     if (tiles > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
     p.ntiles = (int)tiles;
     p.slope0 = conv0_negative_slope; p.slope1 = kb_negative_slope;
+    if (!(conv0_negative_slope >= 0.f && conv0_negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;   // LeakyReLU as max(t, slope t)
     p.vec4 = !((p.w & 3) || (reinterpret_cast<uintptr_t>(out_image) & 15) || (reinterpret_cast<uintptr_t>(out_fused) & 15) ||
-               (out_image_batch_stride & 3) || (out_fused_batch_stride & 3)) ? 1 : 0;
+               (out_image_batch_stride & 3) || (out_fused_batch_stride & 3) || (reinterpret_cast<uintptr_t>(xyz) & 15) ||
+               (xyz_batch_stride & 3)) ? 1 : 0;
     auto kern = kb1_front_kernel<3, 3>;
-    constexpr size_t lds = 2 * FR_NP0P * 16 + 2 * 2 * FR_NP1 * 16 + 3 * 3 * 2 * 64 * 16 + 2 * (6 * 2 * 4 * 48 * 16);
+    constexpr size_t lds = 2 * FR_NIN * 8 + 2 * 2 * FR_NP1 * 16 + (5 * 2 * 4 + 2 * 2) * 48 * 16;
     static DeviceOnce once;
-    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;

@@ -687,7 +687,7 @@ def pack_kb1_front_weight(w_conv0: torch.Tensor, w_conv_image: torch.Tensor, w_c
                           out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Blob of `kb1_front` (kbn_kb1_front_pack_weight) from conv0_image's weight (F0 x C x 3 x 3), the level-0 KB block's
     conv_image weight (FI x F0 x 3 x 3) and conv_fused weight (FI x (F0 + 3) x 1 x 1).  None when the shapes are outside
-    the kernel's (F0 = FI = 48, C <= 8)."""
+    the kernel's (F0 = FI = 48, C <= 4)."""
     lib = _lib.load()
     w0, wi, wf = (w.detach().contiguous() for w in (w_conv0, w_conv_image, w_conv_fused))
     for w, nm in ((w0, "w_conv0"), (wi, "w_conv_image"), (wf, "w_conv_fused")):

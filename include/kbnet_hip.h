@@ -325,7 +325,7 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
  * conv0_image (conv0_filters channels at full resolution) is consumed by nothing else, so it is computed per tile and kept
  * on the CU: it never reaches HBM.  All three convs on split fp16 operands (see the split-operand section above; same
  * accuracy class, same parity gate); csrc/front.hip.
- *   image           N x image_channels x H x W (image_channels <= 8), frames image_batch_stride apart
+ *   image           N x image_channels x H x W (image_channels <= 4), frames image_batch_stride apart
  *   image_absmax    the image's per-frame max |x| slots (kbn_absmax_frames) -- required: the fp16 windows follow them
  *   packed_weight   from kbn_kb1_front_pack_weight: conv0_image.conv.weight (conv0_filters x image_channels x 3 x 3),
  *                   the block's conv_image weight (kb_filters x conv0_filters x 3 x 3) and conv_fused weight
