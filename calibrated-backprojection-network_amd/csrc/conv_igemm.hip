@@ -451,7 +451,7 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     TileChoice tc = choose_tile(p.outH, p.outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
     if (kernel_size == 3 && stride == 1 && !knob(KNOB_NO_WINO)) {  // wide 3x3: Winograd F(2x2,3x3)
         int rc = conv_wino_launch(p, stream);
-        if (rc == KBN_OK && out_absmax)   // the Winograd kernel (a fallback since the split-operand convs) has no slot epilogue
+        if (rc == KBN_OK && out_absmax && !knob(KNOB_NO_SPLIT))   // (KBN_NO_SPLIT: nothing reads slots) the Winograd kernel (a fallback since the split-operand convs) has no slot epilogue
             rc = absmax_frames_launch(out, out_batch_stride, n, (long long)out_channels * p.outH * p.outW, out_absmax, stream);
         if (rc != KBN_ERR_UNSUPPORTED) return rc;
     }

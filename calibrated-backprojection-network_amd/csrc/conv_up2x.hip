@@ -988,7 +988,7 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
     int rc = upconv2x_forward_impl(src, src_batch_stride, packed_weight, out, out_batch_stride, n, in_channels, out_channels,
                                    src_height, src_width, apply_activation, negative_slope, stream);
     // these fp32 kernels are fallbacks since the folded split-operand up-conv: the slot is filled by a pass of its own
-    if (rc == KBN_OK && out_absmax)
+    if (rc == KBN_OK && out_absmax && !kbn::knob(kbn::KNOB_NO_SPLIT))   // KBN_NO_SPLIT: nothing reads slots
         rc = kbn::absmax_frames_launch(out, out_batch_stride, n, 4LL * out_channels * src_height * src_width, out_absmax,
                                        (hipStream_t)stream);
     return rc;

@@ -7,11 +7,11 @@
 // step: conv0_image at 4.1 TB/s + the fused fp32 KB kernel, 2.45 ms of a 12.8 ms step on the fp32 pipe).  All three convs take
 // their fp32 products as three fp16 MFMAs over two-term splits of both operands, like csrc/conv_split.hip:
 //     a 2^k = h1 + 2^-11 h2,   w 2^e = w1 + 2^-11 w2'   ->   a w 2^(e+k) = h1 w1 + 2^-11 (h1 w2' + h2 w1)
-// with fp32 accumulators for the main and the small term.  The windows follow the data on the device: k of the image from its
-// per-frame absmax slot; k of the on-chip conv0 output from the BOUND  max |conv0| <= (max_f sum |w0_f|) max |image|
-// (the true maximum is not known before the values are written; the bound is within a few binades of it, and a window may
-// sit 2^16 above the data before anything is lost -- tests/test_split_math_cpu.py).  Outputs are fp32 NCHW with their absmax
-// slots filled, like every other conv.
+// with fp32 accumulators for the main and the small term.  The windows follow the data inside the kernel, tile by tile: k of
+// the image from max |image| over the pixels the workgroup loads; k of the on-chip conv0 output from the BOUND
+// max |conv0| <= (max_f sum |w0_f|) max |image| (the true maximum is not known before the values are written; the bound
+// is within a few binades of it, and a window may sit 2^16 above the data before anything is lost --
+// tests/test_split_math_cpu.py).  Outputs are fp32 NCHW with their absmax slots filled, like every other conv.
 //
 // Tile = 8 x 16 output pixels (half resolution) of one frame per workgroup of 8 waves; v_mfma_f32_16x16x32_f16 throughout.
 //   A  the (2*8+3) x (2*16+3) image pixels the tile's conv0 outputs read: loaded, split, one 16-byte granule [8 channels]
@@ -45,7 +45,6 @@ constexpr int FR_NB0 = (FR_NP1 + 15) / 16;                                      
 struct FrontParams {
     const float* image;
     long long image_bstride;
-    const unsigned* amax_image;   // per-frame max |image| slot
     const float* tab;             // scales / xyz weights (FR_TAB floats)
     const _Float16* w0;           // [chunk][2 k-steps][term][4 k-groups][16 filters][8] -- k-group = (tap row, column pair), 8 = 2 pixels x 4 channels
     const _Float16* wc;           // [chunk]{[5 k-steps][term][4 k-groups][FI filters][8] (tap pairs) | [term][2 k-groups][FI][8] (conv_fused)}
@@ -67,6 +66,15 @@ __device__ __forceinline__ void fr_scales(unsigned bits, float& pre, float& un) 
     k = k > 100 ? 100 : (k < -100 ? -100 : k);
     pre = __uint_as_float((unsigned)(127 + k) << 23);
     un = __uint_as_float((unsigned)(127 - k) << 23);
+}
+
+__device__ __forceinline__ _Float16 fr_term(float ws, int term) {
+    const _Float16 w1 = (_Float16)ws;
+    return term == 0 ? w1 : (_Float16)((ws - (float)w1) * 2048.f);
+}
+
+__device__ __forceinline__ float sp_amax4f(float m, const ff4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
 // two-term split of four scaled values: h1 = fp16(v), h2 = fp16((v - h1) 2^11)
@@ -109,12 +117,6 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontPar
     const int H = p.H, W = p.W;
     const long long plane = (long long)H * W;
 
-    // ---- windows: the image's from its slot, conv0's output from the bound L1max0 * max |image|
-    const unsigned abits = p.amax_image[n];
-    float pre_img, un_img, pre0, un0;
-    fr_scales(abits, pre_img, un_img);
-    fr_scales(__float_as_uint(p.tab[0] * __uint_as_float(abits)), pre0, un0);
-
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
     auto dma_wc = [&](int chunk) {   // whole-workgroup copy of one chunk's weights, 16 bytes per lane and round
         const float* src = reinterpret_cast<const float*>(p.wc + (long long)chunk * (WC_CHUNK / 2));
@@ -127,22 +129,42 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontPar
     };
     dma_wc(0);
 
-    // ---- A: image tile -> split entries [4 channels] per pixel (two pixels = one 16-byte K group of conv0)
+    // ---- A: image tile -> split entries [4 channels] per pixel (two pixels = one 16-byte K group of conv0).  The fp16
+    // windows are the TILE's own: max |image| over the pixels this workgroup reads (one LDS reduction) places the image's, the
+    // bound L1max0 * that maximum conv0's -- no pass over the image beforehand, and a tile never pays for a bright spot elsewhere.
+    float pre_img, un_img, pre0, un0;
     {
         const float* img = p.image + (long long)n * p.image_bstride;
+        ff4 raw[2];
+        float tm = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pix = u * FR_THREADS + tid;
+            const int r = pix / FR_R0W, c = pix - r * FR_R0W;
+            const int Y = 2 * oy0 - 2 + r, X = 2 * ox0 - 2 + c;
+            const bool ok = pix < FR_NP0 && Y >= 0 && Y < H && X >= 0 && X < W;   // entries past the tile stay zero (pair reads touch one)
+            const float* src = img + (long long)(ok ? Y : 0) * W + (ok ? X : 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                raw[u][j] = (ok && j < p.Cin) ? src[(long long)(j < p.Cin ? j : 0) * plane] : 0.f;
+                tm = fmaxf(tm, fabsf(raw[u][j]));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+        float* red = reinterpret_cast<float*>(smem + OFF_X);   // X is idle until conv0 writes it (after the next barrier)
+        if (lane == 0) red[wave] = tm;
+        __syncthreads();
+        tm = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+        const unsigned abits = __builtin_amdgcn_readfirstlane(__float_as_uint(tm));
+        fr_scales(abits, pre_img, un_img);
+        fr_scales(__float_as_uint(p.tab[0] * __uint_as_float(abits)), pre0, un0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int pix = u * FR_THREADS + tid;
             if (pix < FR_NIN) {
-                const int r = pix / FR_R0W, c = pix - r * FR_R0W;
-                const int Y = 2 * oy0 - 2 + r, X = 2 * ox0 - 2 + c;
-                const bool ok = pix < FR_NP0 && Y >= 0 && Y < H && X >= 0 && X < W;   // entries past the tile stay zero (pair reads touch one)
-                const float* src = img + (long long)(ok ? Y : 0) * W + (ok ? X : 0);
-                ff4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (ok && j < p.Cin) ? src[(long long)(j < p.Cin ? j : 0) * plane] * pre_img : 0.f;
                 fh4 h1, h2;
-                fr_split4(v, h1, h2);
+                fr_split4(raw[u] * pre_img, h1, h2);
                 *reinterpret_cast<fh4*>(smem + pix * 8) = h1;
                 *reinterpret_cast<fh4*>(smem + IN_PART + pix * 8) = h2;
             }
@@ -353,6 +375,354 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontPar
     if (p.amax_out_fused) absmax_commit(p.amax_out_fused + n, amF);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The depth branch of the same front, the same way:
+//     conv0_depth = act(conv3x3(depth))                                    reference src/networks.py:366-367
+//     conv_depth  = act(conv3x3 s2 (cat[conv0_depth, coordinates]))        reference src/net_utils.py:1351
+//     xyz         = coordinates * act(proj_depth(conv0_depth))             reference src/net_utils.py:1354-1360, at the pixels
+//                                                                          (2y, 2x) conv_fused's stride-2 1x1 conv reads
+// conv0_depth (16 channels at full resolution) stays on the CU.  `depth` = the S2D output (<= 8 channels: one 16-byte K group
+// per pixel and tap, nine groups in three K steps of conv0); conv_depth's 16 tensor channels go through the matrix core
+// (taps in pairs), its three coordinate channels K^-1 [x y 1]^T -- affine in the pixel position -- enter in fp32 in the
+// epilogue: for a pixel whose nine taps lie inside the image sum_tap w_tap c_j(tap) = c_j(centre) sum w + k_j0 sum w (kx - 1)
+// + k_j1 sum w (ky - 1), three pre-summed weights per filter and coordinate; border pixels run the 27 masked terms.
+struct DepthFrontParams {
+    const float* depth;           // N x Cin x H x W (S2D output)
+    long long depth_bstride;
+    const float* kinv;            // N x 3 x 3
+    const float* tab;             // DF_TAB floats, see depth_front_table_kernel
+    const _Float16* w0;           // [3 k-steps][term][4 k-groups = taps][16 filters][8 channels]
+    const _Float16* wc;           // [5 k-steps][term][4 k-groups][16 filters][8]: tap 2 s + (kq >> 1), channels 8 (kq & 1) + j
+    float* out_depth;
+    long long out_depth_bstride;
+    float* xyz;                   // N x 3 x h x w
+    long long xyz_bstride;
+    unsigned* amax_out_depth;
+    int N, Cin, H, W, h, w, tilesX, tilesY, ntiles;
+    float slope0, slope1, slope_proj;
+    int act_proj, vec4;
+};
+// table (floats): [0] L1max of conv0_depth, [4..19] inv0, [20..35] invC, [36..51] proj, [52..) per filter f (16): S0[3], Sx[3],
+// Sy[3] (9), then [196..) the raw coordinate weights wc[f][j][tap] (16 x 27)
+constexpr int DF_TAB = 640, DF_SUM = 52, DF_RAW = DF_SUM + 16 * 9;
+
+__global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const DepthFrontParams p) {
+    constexpr int IN_PART = FR_NIN * 16, IN_BYTES = 2 * IN_PART;            // [term][pixel][8 channels] fp16
+    constexpr int X_KG = FR_NP1 * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
+    constexpr int WC_KQ = 16 * 16, WC_PART = 4 * WC_KQ, WC_KS = 2 * WC_PART, WC_BYTES = 5 * WC_KS;   // 10 KB
+    constexpr int OFF_X = IN_BYTES, OFF_WC = OFF_X + X_BYTES;
+    static_assert(OFF_WC + WC_BYTES <= 80 * 1024, "two workgroups per CU");
+    constexpr int NBLK = (FR_NB0 + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    int bid = xcd_remap(blockIdx.x, p.ntiles);
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int oy0 = ty * FR_TH, ox0 = tx * FR_TW;
+    const int H = p.H, W = p.W;
+    const long long plane = (long long)H * W;
+
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+    {   // conv_depth's weights: 10 KB by LDS-DMA, awaited in front of the second barrier
+        constexpr int n4 = WC_BYTES / 16;
+#pragma unroll
+        for (int e0 = 0; e0 < n4; e0 += FR_THREADS) {
+            const int eb = e0 + wave * 64;
+            if (eb + lane < n4) lds_dma16_s(reinterpret_cast<const float*>(p.wc) + eb * 4, (unsigned)(lane * 16), lds0 + (unsigned)(OFF_WC + eb * 16));
+        }
+    }
+
+    // ---- A: depth-feature tile -> split granules [8 channels] per pixel; windows from the tile's own maximum (see kb1_front_kernel)
+    float pre_in, un_in, pre0, un0;
+    {
+        const float* src0 = p.depth + (long long)n * p.depth_bstride;
+        float raw[2][8];
+        float tm = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pix = u * FR_THREADS + tid;
+            const int r = pix / FR_R0W, c = pix - r * FR_R0W;
+            const int Y = 2 * oy0 - 2 + r, X = 2 * ox0 - 2 + c;
+            const bool ok = pix < FR_NP0 && Y >= 0 && Y < H && X >= 0 && X < W;
+            const float* src = src0 + (long long)(ok ? Y : 0) * W + (ok ? X : 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                raw[u][j] = (ok && j < p.Cin) ? src[(long long)(j < p.Cin ? j : 0) * plane] : 0.f;
+                tm = fmaxf(tm, fabsf(raw[u][j]));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+        float* red = reinterpret_cast<float*>(smem + OFF_X);
+        if (lane == 0) red[wave] = tm;
+        __syncthreads();
+        tm = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+        const unsigned abits = __builtin_amdgcn_readfirstlane(__float_as_uint(tm));
+        fr_scales(abits, pre_in, un_in);
+        fr_scales(__float_as_uint(p.tab[0] * __uint_as_float(abits)), pre0, un0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pix = u * FR_THREADS + tid;
+            if (pix < FR_NIN) {
+                fh4 a1, a2, b1, b2;
+                fr_split4((ff4){raw[u][0], raw[u][1], raw[u][2], raw[u][3]} * pre_in, a1, a2);
+                fr_split4((ff4){raw[u][4], raw[u][5], raw[u][6], raw[u][7]} * pre_in, b1, b2);
+                *reinterpret_cast<fh8*>(smem + pix * 16) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<fh8*>(smem + IN_PART + pix * 16) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    }
+
+    // ---- per-lane offsets
+    int tapoff[3];   // conv0: k-group kq of k-step ks is tap 4 ks + kq (taps past the ninth carry zero weights: any valid address)
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const int tap = min(4 * ks + kq, 8);
+        tapoff[ks] = ((tap / 3) * FR_R0W + tap % 3) * 16;
+    }
+    int inoff[NBLK], xoff[NBLK];
+    unsigned inside = 0, valid = 0;
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int j = wave + 8 * i;
+        const int r1 = j < 34 ? (j >> 1) : (j == 34 ? l15 : 16 + l15);
+        const int c1 = j < 34 ? 16 * (j & 1) + l15 : 32;
+        const bool ok = r1 < FR_R1H;
+        const int r1c = ok ? r1 : FR_R1H - 1;
+        const int Y = 2 * oy0 - 1 + r1c, X = 2 * ox0 - 1 + c1;
+        inoff[i] = (r1c * FR_R0W + c1) * 16;
+        const int xi = r1c * FR_R1W + ((c1 & 1) ? (FR_R1W + 1) / 2 + (c1 >> 1) : (c1 >> 1));
+        xoff[i] = OFF_X + (kq >> 1) * X_KG + xi * 16 + (kq & 1) * 8;
+        if (ok) valid |= 1u << i;
+        if (ok && Y >= 0 && Y < H && X >= 0 && X < W) inside |= 1u << i;
+    }
+    const bool interior = 2 * oy0 - 1 >= 0 && 2 * oy0 - 1 + FR_R1H <= H && 2 * ox0 - 1 >= 0 && 2 * ox0 - 1 + FR_R1W <= W;
+    const int yrow = wave;
+    int aoff[5];
+    {
+        const int kg = kq & 1, tsel = kq >> 1;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int tap = min(2 * s + tsel, 8);
+            const int ky = tap / 3, kx = tap % 3;
+            const int col = kx == 0 ? l15 : (kx == 1 ? (FR_R1W + 1) / 2 + l15 : l15 + 1);
+            aoff[s] = OFF_X + (kg * FR_NP1 + (2 * yrow + ky) * FR_R1W + col) * 16;
+        }
+    }
+    const int zoff = OFF_X + ((kq >> 1) * FR_NP1 + (2 * yrow + 1) * FR_R1W + (FR_R1W + 1) / 2 + l15) * 16 + (kq & 1) * 8;   // centre tap, this lane's 4 channels
+    const bool row_live = oy0 + yrow < p.h;
+    const int nblk = wave + 8 * (NBLK - 1) < FR_NB0 ? NBLK : NBLK - 1;
+    __syncthreads();   // IN complete
+
+    // ---- B: conv0_depth over the 561 pixels of the halo region
+    {
+        fh8 a1[3], a2[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            a1[ks] = *reinterpret_cast<const fh8*>(p.w0 + (ks * 2 + 0) * 512 + lane * 8);
+            a2[ks] = *reinterpret_cast<const fh8*>(p.w0 + (ks * 2 + 1) * 512 + lane * 8);
+        }
+        ff4 sc = *reinterpret_cast<const ff4*>(p.tab + 4 + 4 * kq);
+        sc *= un_in * pre0;
+        const f32x2 sc01 = {sc[0], sc[1]}, sc23 = {sc[2], sc[3]};
+        auto block = [&](int i, auto border_tag) {
+            constexpr bool BORDER = decltype(border_tag)::value;
+            const unsigned char* inb = smem + inoff[i];
+            ff4 m = (ff4){0.f, 0.f, 0.f, 0.f}, s = m;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const fh8 b1 = *reinterpret_cast<const fh8*>(inb + tapoff[ks]);
+                const fh8 b2 = *reinterpret_cast<const fh8*>(inb + IN_PART + tapoff[ks]);
+                m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b1, m, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2, s, 0, 0, 0);
+            }
+            f32x2 t01 = (f32x2){s[0], s[1]} * 0.00048828125f + (f32x2){m[0], m[1]};
+            f32x2 t23 = (f32x2){s[2], s[3]} * 0.00048828125f + (f32x2){m[2], m[3]};
+            t01 *= sc01; t23 *= sc23;
+            const f32x2 u01 = t01 * p.slope0, u23 = t23 * p.slope0;
+            ff4 v = {fmaxf(t01[0], u01[0]), fmaxf(t01[1], u01[1]), fmaxf(t23[0], u23[0]), fmaxf(t23[1], u23[1])};
+            if (BORDER && !((inside >> i) & 1)) v = (ff4){0.f, 0.f, 0.f, 0.f};
+            fh4 h1, h2;
+            fr_split4(v, h1, h2);
+            if (!BORDER || ((valid >> i) & 1)) {
+                *reinterpret_cast<fh4*>(smem + xoff[i]) = h1;
+                *reinterpret_cast<fh4*>(smem + xoff[i] + X_PART) = h2;
+            }
+        };
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < NBLK - 1; ++i) block(i, std::false_type{});
+            if (NBLK - 1 < nblk) block(NBLK - 1, std::true_type{});
+        } else {
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i)
+                if (i < nblk) block(i, std::true_type{});
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // conv_depth's weights
+    __syncthreads();
+
+    if (!row_live) return;   // wave-uniform; no barrier follows
+    // ---- C: conv_depth's tensor channels (taps in pairs)
+    ff4 mD = (ff4){0.f, 0.f, 0.f, 0.f}, sD = mD;
+    {
+        const unsigned char* wcb = smem + OFF_WC + kq * WC_KQ + l15 * 16;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const fh8 a1 = *reinterpret_cast<const fh8*>(smem + aoff[s]);
+            const fh8 a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff[s]);
+            const fh8 b1 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS);
+            const fh8 b2 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + WC_PART);
+            mD = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mD, 0, 0, 0);
+            sD = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sD, 0, 0, 0);
+            sD = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sD, 0, 0, 0);
+        }
+    }
+    const float* ki = p.kinv + (long long)n * 9;
+    const float k00 = ki[0], k01 = ki[1], k02 = ki[2], k10 = ki[3], k11 = ki[4], k12 = ki[5], k20 = ki[6], k21 = ki[7], k22 = ki[8];
+    const int Yo = oy0 + yrow;
+    const long long oplane = (long long)p.h * p.w;
+    // ---- z = act(proj . conv0_depth) at (2 Yo, 2 x): lane (x = l15, kq) sums its 4 channels, the 4 lanes of a pixel share the sum;
+    // lane kq = j < 3 then stores xyz channel j of pixel x
+    {
+        const fh4 h1 = *reinterpret_cast<const fh4*>(smem + zoff);
+        const fh4 h2 = *reinterpret_cast<const fh4*>(smem + zoff + X_PART);
+        const ff4 pw = *reinterpret_cast<const ff4*>(p.tab + 36 + 4 * kq);
+        float z = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z = __builtin_fmaf(__builtin_fmaf((float)h2[r], 0.00048828125f, (float)h1[r]), pw[r], z);
+        z += __shfl_xor(z, 16);
+        z += __shfl_xor(z, 32);
+        z *= un0;
+        if (p.act_proj) z = z > 0.f ? z : z * p.slope_proj;
+        const int Xz = ox0 + l15;
+        if (kq < 3 && Xz < p.w) {
+            const float X = (float)(2 * Xz), Y = (float)(2 * Yo);
+            const float c = kq == 0 ? (__builtin_fmaf(k01, Y, k00 * X) + k02) : (kq == 1 ? (__builtin_fmaf(k11, Y, k10 * X) + k12) : (__builtin_fmaf(k21, Y, k20 * X) + k22));
+            p.xyz[(long long)n * p.xyz_bstride + kq * oplane + (long long)Yo * p.w + Xz] = c * z;
+        }
+    }
+    // ---- D: a lane holds pixels x = 4 kq .. 4 kq + 3 of row Yo for filter l15; coordinate channels in fp32
+    const int Xo = ox0 + 4 * kq;
+    float am = 0.f;
+    if (Xo < p.w) {
+        const int f = l15;
+        const float scD = p.tab[20 + f] * un0;
+        const float* sm = p.tab + DF_SUM + f * 9;   // S0[3], Sx[3], Sy[3]
+        const float kj0[3] = {k00, k10, k20}, kj1[3] = {k01, k11, k21}, kj2[3] = {k02, k12, k22};
+        float cst = 0.f;                             // sum_j k_j0 Sx_j + k_j1 Sy_j
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cst += kj0[j] * sm[3 + j] + kj1[j] * sm[6 + j];
+        ff4 v;
+        const bool rows_in = 2 * Yo - 1 >= 0 && 2 * Yo + 1 < H;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int Xc = 2 * (Xo + r), Yc = 2 * Yo;
+            float cterm;
+            if (rows_in && Xc - 1 >= 0 && Xc + 1 < W) {
+                cterm = cst;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) cterm += (__builtin_fmaf(kj1[j], (float)Yc, kj0[j] * (float)Xc) + kj2[j]) * sm[j];
+            } else {   // a tap outside the image reads the zero padding: the 27 terms one by one
+                const float* wr = p.tab + DF_RAW + f * 27;
+                cterm = 0.f;
+                for (int j = 0; j < 3; ++j)
+                    for (int t = 0; t < 9; ++t) {
+                        const int Yt = Yc + t / 3 - 1, Xt = Xc + t % 3 - 1;
+                        if (Yt >= 0 && Yt < H && Xt >= 0 && Xt < W) cterm += (__builtin_fmaf(kj1[j], (float)Yt, kj0[j] * (float)Xt) + kj2[j]) * wr[j * 9 + t];
+                    }
+            }
+            const float a = __builtin_fmaf(sD[r], 0.00048828125f, mD[r]) * scD + cterm;
+            v[r] = a > 0.f ? a : a * p.slope1;
+        }
+        float* o = p.out_depth + (long long)n * p.out_depth_bstride + f * oplane + (long long)Yo * p.w + Xo;
+        if (p.vec4) {
+            *reinterpret_cast<ff4*>(o) = v;
+            am = sp_amax4f(am, v);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (Xo + r < p.w) { o[r] = v[r]; am = fmaxf(am, fabsf(v[r])); }
+        }
+    }
+    if (p.amax_out_depth) absmax_commit(p.amax_out_depth + n, am);
+}
+
+// table of the depth front: scales, the bound factor, proj, pre-summed and raw coordinate weights
+__global__ void depth_front_table_kernel(const float* __restrict__ w0, const float* __restrict__ wc, const float* __restrict__ proj,
+                                         float* __restrict__ tab, int Cin) {
+    __shared__ float red[256], red2[256];
+    const int which = blockIdx.y, f = blockIdx.x;   // which 0: conv0_depth (Cin x 9 per filter), 1: conv_depth (19 x 9)
+    const int per = which == 0 ? Cin * 9 : 19 * 9;
+    const float* w = which == 0 ? w0 : wc;
+    float m = 0.f, l1 = 0.f;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const float a = fabsf(w[(long long)f * per + i]);
+        m = fmaxf(m, a);
+        l1 += a;
+    }
+    red[threadIdx.x] = m;
+    red2[threadIdx.x] = l1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+            red2[threadIdx.x] += red2[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int ex = FR_WEXP;
+        if (red[0] > 0.f && red[0] < 3.0e38f) (void)frexpf(red[0], &ex);
+        int e = FR_WEXP - ex;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        tab[4 + 16 * which + f] = ldexpf(1.f, -e);
+        if (which == 0) {
+            atomicMax(reinterpret_cast<unsigned*>(tab), __float_as_uint(red2[0]));
+            tab[36 + f] = proj[f];
+        } else {
+            for (int j = 0; j < 3; ++j) {
+                float s0 = 0.f, sx = 0.f, sy = 0.f;
+                for (int t = 0; t < 9; ++t) {
+                    const float wv = wc[((long long)f * 19 + 16 + j) * 9 + t];
+                    tab[DF_RAW + f * 27 + j * 9 + t] = wv;
+                    s0 += wv; sx += wv * (float)(t % 3 - 1); sy += wv * (float)(t / 3 - 1);
+                }
+                tab[DF_SUM + f * 9 + j] = s0; tab[DF_SUM + f * 9 + 3 + j] = sx; tab[DF_SUM + f * 9 + 6 + j] = sy;
+            }
+        }
+    }
+}
+
+__global__ void depth_front_pack_kernel(const float* __restrict__ w0, const float* __restrict__ wc, const float* __restrict__ tab,
+                                        _Float16* __restrict__ out0, _Float16* __restrict__ outc, int Cin) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 3 * 2 * 64 * 8) {   // conv0_depth: [ks 3][term][kq 4][m 16][j 8], tap = 4 ks + kq
+        int r = e;
+        const int j = r & 7; r >>= 3;
+        const int m = r & 15; r >>= 4;
+        const int kq = r & 3; r >>= 2;
+        const int term = r & 1; r >>= 1;
+        const int tap = 4 * r + kq;
+        out0[e] = (tap < 9 && j < Cin) ? fr_term(w0[((long long)m * Cin + j) * 9 + tap] / tab[4 + m], term) : (_Float16)0.f;
+    }
+    if (e < 5 * 2 * 64 * 8) {   // conv_depth: [s 5][term][kq 4][n 16][j 8], tap = 2 s + (kq >> 1), channel 8 (kq & 1) + j
+        int r = e;
+        const int j = r & 7; r >>= 3;
+        const int nf = r & 15; r >>= 4;
+        const int kq = r & 3; r >>= 2;
+        const int term = r & 1; r >>= 1;
+        const int tap = 2 * r + (kq >> 1), ch = 8 * (kq & 1) + j;
+        outc[e] = tap < 9 ? fr_term(wc[((long long)nf * 19 + ch) * 9 + tap] / tab[20 + nf], term) : (_Float16)0.f;
+    }
+}
+
 // ---- weight packing ---------------------------------------------------------------------------------------------
 // table: per-filter 2^-e (largest |w 2^e| in [2^12, 2^13)), the bound factor L1max0 = max_f sum |w0_f|, the fp32 xyz weights
 __global__ void front_table_kernel(const float* __restrict__ w0, const float* __restrict__ wi, const float* __restrict__ wf,
@@ -391,10 +761,6 @@ __global__ void front_table_kernel(const float* __restrict__ w0, const float* __
     }
 }
 
-__device__ __forceinline__ _Float16 fr_term(float ws, int term) {
-    const _Float16 w1 = (_Float16)ws;
-    return term == 0 ? w1 : (_Float16)((ws - (float)w1) * 2048.f);
-}
 
 // conv0 panel: [chunk][k-step 2][term][k-group 4][filter 16][8]; k-group g = 4 ks + kq = (tap row g >> 1, column pair g & 1),
 // slot j = (column 2 (g & 1) + (j >> 2), channel j & 3); groups >= 6, column 3, channels >= Cin: zero
@@ -479,18 +845,18 @@ int kbn_kb1_front_pack_weight(const float* w_conv0, const float* w_conv_image, c
     return KBN_OK;
 }
 
-int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const unsigned* image_absmax, const void* packed_weight,
+int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const void* packed_weight,
                           const float* xyz, long long xyz_batch_stride, float* out_image, long long out_image_batch_stride,
                           float* out_fused, long long out_fused_batch_stride, int n, int image_channels, int conv0_filters,
                           int kb_filters, int height, int width, float conv0_negative_slope, float kb_negative_slope,
                           unsigned* out_image_absmax, unsigned* out_fused_absmax, kbn_stream_t stream) {
     using namespace kbn;
-    if (!image || !image_absmax || !packed_weight || !out_image || !out_fused || n < 1 || height < 1 || width < 1)
+    if (!image || !packed_weight || !out_image || !out_fused || n < 1 || height < 1 || width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
     if (!front_shape_ok(image_channels, conv0_filters, kb_filters) || knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
     if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
     FrontParams p{};
-    p.image = image; p.image_bstride = image_batch_stride; p.amax_image = image_absmax;
+    p.image = image; p.image_bstride = image_batch_stride;
     p.tab = static_cast<const float*>(packed_weight);
     p.w0 = reinterpret_cast<const _Float16*>(p.tab + FR_TAB);
     p.wc = p.w0 + front_w0_halves(conv0_filters);
@@ -514,6 +880,64 @@ int kbn_kb1_front_forward(const float* image, long long image_batch_stride, cons
     static DeviceOnce once;
     if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+static bool depth_front_shape_ok(int c_in, int f0, int fd) { return c_in >= 1 && c_in <= 8 && f0 == 16 && fd == 16; }
+
+size_t kbn_kb1_depth_front_packed_weight_bytes(int depth_channels, int conv0_filters, int kb_filters) {
+    if (!depth_front_shape_ok(depth_channels, conv0_filters, kb_filters)) return 0;
+    return (size_t)kbn::DF_TAB * 4 + 2 * (3 * 2 * 64 * 8 + 5 * 2 * 64 * 8);
+}
+
+int kbn_kb1_depth_front_pack_weight(const float* w_conv0, const float* w_conv_depth, const float* w_proj, void* packed,
+                                    int depth_channels, int conv0_filters, int kb_filters, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!w_conv0 || !w_conv_depth || !w_proj || !packed) return KBN_ERR_INVALID_ARGUMENT;
+    if (!depth_front_shape_ok(depth_channels, conv0_filters, kb_filters)) return KBN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    float* tab = static_cast<float*>(packed);
+    if (hipMemsetAsync(tab, 0, DF_TAB * 4, st) != hipSuccess) return KBN_ERR_LAUNCH;
+    hipLaunchKernelGGL(depth_front_table_kernel, dim3(16, 2), dim3(256), 0, st, w_conv0, w_conv_depth, w_proj, tab, depth_channels);
+    _Float16* p0 = reinterpret_cast<_Float16*>(tab + DF_TAB);
+    hipLaunchKernelGGL(depth_front_pack_kernel, dim3((5 * 2 * 64 * 8 + 255) / 256), dim3(256), 0, st, w_conv0, w_conv_depth, tab, p0,
+                       p0 + 3 * 2 * 64 * 8, depth_channels);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride, const float* kinv, const void* packed_weight,
+                                float* out_depth, long long out_depth_batch_stride, float* xyz, long long xyz_batch_stride, int n,
+                                int depth_channels, int conv0_filters, int kb_filters, int height, int width,
+                                float conv0_negative_slope, float kb_negative_slope, int proj_activation, float proj_negative_slope,
+                                unsigned* out_depth_absmax, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!depth || !kinv || !packed_weight || !out_depth || !xyz || n < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if (!depth_front_shape_ok(depth_channels, conv0_filters, kb_filters) || knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
+    if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
+    if (!(conv0_negative_slope >= 0.f && conv0_negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;
+    DepthFrontParams p{};
+    p.depth = depth; p.depth_bstride = depth_batch_stride; p.kinv = kinv;
+    p.tab = static_cast<const float*>(packed_weight);
+    p.w0 = reinterpret_cast<const _Float16*>(p.tab + DF_TAB);
+    p.wc = p.w0 + 3 * 2 * 64 * 8;
+    p.out_depth = out_depth; p.out_depth_bstride = out_depth_batch_stride;
+    p.xyz = xyz; p.xyz_bstride = xyz_batch_stride;
+    p.amax_out_depth = out_depth_absmax;
+    p.N = n; p.Cin = depth_channels; p.H = height; p.W = width;
+    p.h = ceil_div(height, 2); p.w = ceil_div(width, 2);
+    p.tilesX = ceil_div(p.w, FR_TW); p.tilesY = ceil_div(p.h, FR_TH);
+    const long long tiles = (long long)p.tilesX * p.tilesY * n;
+    if (tiles > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+    p.ntiles = (int)tiles;
+    p.slope0 = conv0_negative_slope; p.slope1 = kb_negative_slope;
+    p.act_proj = proj_activation ? 1 : 0; p.slope_proj = proj_negative_slope;
+    p.vec4 = !((p.w & 3) || (reinterpret_cast<uintptr_t>(out_depth) & 15) || (out_depth_batch_stride & 3)) ? 1 : 0;
+    constexpr size_t lds = 2 * FR_NIN * 16 + 2 * 2 * FR_NP1 * 16 + 5 * 2 * 4 * 16 * 16;
+    static DeviceOnce once;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kb1_depth_front_kernel), 80 * 1024)) return rc;
+    hipLaunchKernelGGL(kb1_depth_front_kernel, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }

@@ -102,17 +102,19 @@ class _PackedWeight:
 
 
 class _PackedFront:
-    """The blob of ops.kb1_front, rebuilt (in place when possible) when one of its three weights changes."""
+    """The blob of ops.kb1_front / ops.kb1_depth_front (`pack`), rebuilt (in place when possible) when one of its three
+    weights changes."""
 
-    def __init__(self):
+    def __init__(self, pack=None):
         self._key = None
         self._packed = None
         self._args = None
+        self._pack = pack or ops.pack_kb1_front_weight
 
     def get(self, w0, wi, wf):
         key = tuple((w.data_ptr(), w._version, w.device) for w in (w0, wi, wf))
         if key != self._key:
-            self._packed = ops.pack_kb1_front_weight(w0, wi, wf, out=self._packed)
+            self._packed = self._pack(w0, wi, wf, out=self._packed)
             self._key = key
             self._args = (w0, wi, wf)
         return self._packed
@@ -529,10 +531,12 @@ class KBNetEncoder(torch.nn.Module):
         # separate kernels
         self.front = True
         self._packed_front = _PackedFront()
+        self._packed_depth_front = _PackedFront(ops.pack_kb1_depth_front_weight)
 
-    def _front(self, image, conv_depth0, kinv, stats):
-        """Level 0 with conv0_image fused in: (skip, conv_image, conv_depth, conv_fused, amax_image, amax_skip), or None when
-        the shapes are outside ops.kb1_front's (the caller runs conv0_image and the block on their own)."""
+    def _front(self, image, depth, kinv, stats):
+        """Level 0 with conv0_image / conv0_depth fused in (their outputs stay on the CU): (skip, conv_image, conv_depth,
+        conv_fused, amax_image, amax_skip), or None when the shapes are outside ops.kb1_front's (the caller runs the conv0s
+        and the block on their own).  `depth`: the S2D output."""
         blk = self.calibrated_backprojection1
         ci, cf, cd = blk.conv_image.conv_block[0], blk.conv_fused, blk.conv_depth.conv_block[0]
         c0 = self.conv0_image
@@ -550,11 +554,22 @@ class KBNetEncoder(torch.nn.Module):
         out_fused, out_depth = skip[:, :ff[0]], skip[:, ff[0]:]
         out_image = torch.empty((n, fi[0], oh, ow), device=dev, dtype=torch.float32)
         a_img, a_skip = stats.new(), stats.new()
-        xyz = ops.kb_xyz_s2(conv_depth0, blk.proj_depth.conv.weight, kinv, blk.proj_depth._slope)
-        if ops.kb1_front(image, stats.measure(image), packed, xyz, c0.out_channels, ci.out_channels, out_image, out_fused,
+        # depth branch: conv0_depth -> conv_depth (+ xyz) in one launch too, or the separate kernels
+        c0d = self.conv0_depth
+        xyz = None
+        packed_d = (self._packed_depth_front.get(c0d.conv.weight, cd.conv.weight, blk.proj_depth.conv.weight)
+                    if (c0d.split and cd.split and c0d._slope is not None and _dense(depth)) else None)
+        if packed_d is not None:
+            res = ops.kb1_depth_front(depth, kinv, packed_d, c0d.out_channels, cd.out_channels, out_depth, c0d._slope, blk._slope,
+                                      blk.proj_depth._slope, out_depth_absmax=a_skip)
+            xyz = res[1] if res is not None else None
+        if xyz is None:
+            conv_depth0 = c0d(depth)
+            xyz = ops.kb_xyz_s2(conv_depth0, blk.proj_depth.conv.weight, kinv, blk.proj_depth._slope)
+            cd.run([ops.tensor_src(conv_depth0, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth, out_absmax=a_skip)
+        if ops.kb1_front(image, packed, xyz, c0.out_channels, ci.out_channels, out_image, out_fused,
                          c0._slope, blk._slope, a_img, a_skip) is None:
             return None
-        cd.run([ops.tensor_src(conv_depth0, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth, out_absmax=a_skip)
         return skip, out_image, out_depth, out_fused, a_img, a_skip
 
     def set_bf16(self, enabled: bool = True):
@@ -583,10 +598,11 @@ class KBNetEncoder(torch.nn.Module):
         depth = depth if _dense(depth) else depth.contiguous()
         intrinsics = intrinsics.contiguous()
 
-        conv_depth = self.conv0_depth(depth)
         kinv = ops.intrinsics_inverse(intrinsics, 1.0, 1.0)
-        front = self._front(image, conv_depth, kinv, stats) if 0 in self.resolutions_backprojection else None
-        conv_image = self.conv0_image(image) if front is None else None
+        front = self._front(image, depth, kinv, stats) if 0 in self.resolutions_backprojection else None
+        if front is None:
+            conv_image = self.conv0_image(image)
+            conv_depth = self.conv0_depth(depth)
         h, w = h0, w0
         h1, w1 = (h0 + 1) // 2, (w0 + 1) // 2
         # Q1: every deeper KB level scales K by the level-1 ratio (reference src/networks.py:342-343)
@@ -919,6 +935,7 @@ class KBNetModel(object):
                     sub._packed_up2x.refresh(sub.conv.conv.weight)
                 elif isinstance(sub, KBNetEncoder):
                     sub._packed_front.refresh()
+                    sub._packed_depth_front.refresh()
 
     # -- nn.Module-like plumbing the reference driver uses ------------------------
     def modules(self):

@@ -706,7 +706,7 @@ def pack_kb1_front_weight(w_conv0: torch.Tensor, w_conv_image: torch.Tensor, w_c
 
 
 @_on_tensor_device
-def kb1_front(image: torch.Tensor, image_absmax: torch.Tensor, packed_weight: torch.Tensor, xyz: Optional[torch.Tensor],
+def kb1_front(image: torch.Tensor, packed_weight: torch.Tensor, xyz: Optional[torch.Tensor],
               conv0_filters: int, kb_filters: int, out_image: torch.Tensor, out_fused: torch.Tensor,
               conv0_negative_slope: float = 0.2, kb_negative_slope: float = 0.2, out_image_absmax=None, out_fused_absmax=None):
     """conv0_image -> (conv_image, conv_fused) of the level-0 KB block in one launch, conv0's output kept on the CU
@@ -730,7 +730,7 @@ def kb1_front(image: torch.Tensor, image_absmax: torch.Tensor, packed_weight: to
     tiles = n * (-(-oh // 8)) * (-(-ow // 16))
     executed = tiles * (conv0_filters // 16) * (36 * 9 + 8 * 6 * (kb_filters // 16) * 3) * 2.0 * 16 * 16 * 32
     status = _launch("kb1_front", flops,
-                     lambda: lib.kbn_kb1_front_forward(iptr, ibs, _slot_ptr(image_absmax, n), packed_weight.data_ptr(), xptr, xbs,
+                     lambda: lib.kbn_kb1_front_forward(iptr, ibs, packed_weight.data_ptr(), xptr, xbs,
                                                        oi, oibs, of, ofbs, n, c, conv0_filters, kb_filters, h, w,
                                                        float(conv0_negative_slope), float(kb_negative_slope),
                                                        _slot_ptr(out_image_absmax, n), _slot_ptr(out_fused_absmax, n), _stream()),
@@ -741,6 +741,65 @@ def kb1_front(image: torch.Tensor, image_absmax: torch.Tensor, packed_weight: to
         return None
     check(status, "kbn_kb1_front_forward")
     return out_image, out_fused
+
+
+@_on_tensor_device
+def pack_kb1_depth_front_weight(w_conv0: torch.Tensor, w_conv_depth: torch.Tensor, w_proj: torch.Tensor,
+                                out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Blob of `kb1_depth_front` from conv0_depth's weight (16 x C x 3 x 3), the level-0 KB block's conv_depth weight
+    (16 x 19 x 3 x 3) and proj_depth weight (1 x 16 x 1 x 1).  None when the shapes are outside the kernel's."""
+    lib = _lib.load()
+    w0, wc, wp = (w.detach().contiguous() for w in (w_conv0, w_conv_depth, w_proj))
+    for w, nm in ((w0, "w_conv0"), (wc, "w_conv_depth"), (wp, "w_proj")):
+        _require(w, nm, 4)
+    f0, c = w0.shape[0], w0.shape[1]
+    fd = wc.shape[0]
+    if tuple(w0.shape[2:]) != (3, 3) or tuple(wc.shape) != (fd, f0 + 3, 3, 3) or wp.numel() != f0:
+        return None
+    nbytes = lib.kbn_kb1_depth_front_packed_weight_bytes(c, f0, fd)
+    if nbytes == 0:
+        return None
+    packed = out if _reusable(out, nbytes // 4, w0) else torch.empty(nbytes // 4, device=w0.device, dtype=torch.float32)
+    check(lib.kbn_kb1_depth_front_pack_weight(w0.data_ptr(), wc.data_ptr(), wp.data_ptr(), packed.data_ptr(), c, f0, fd, _stream()),
+          "kbn_kb1_depth_front_pack_weight")
+    return packed
+
+
+@_on_tensor_device
+def kb1_depth_front(depth: torch.Tensor, kinv: torch.Tensor, packed_weight: torch.Tensor, conv0_filters: int, kb_filters: int,
+                    out_depth: torch.Tensor, conv0_negative_slope: float = 0.2, kb_negative_slope: float = 0.2,
+                    proj_negative_slope: Optional[float] = 0.2, out_depth_absmax=None, xyz: Optional[torch.Tensor] = None):
+    """conv0_depth -> conv_depth of the level-0 KB block (coordinate channels in fp32) and the backprojection channels xyz, in
+    one launch (kbn_kb1_depth_front_forward).  Returns (out_depth, xyz) or None when the shape does not qualify."""
+    lib = _lib.load()
+    dptr, dbs = _planes(depth, "depth")
+    n, c, h, w = depth.shape
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    if tuple(out_depth.shape) != (n, kb_filters, oh, ow):
+        raise KbnError(f"out_depth has shape {tuple(out_depth.shape)}, expected {(n, kb_filters, oh, ow)}")
+    if tuple(kinv.shape) != (n, 3, 3) or not kinv.is_contiguous():
+        raise KbnError("kinv must be a dense N x 3 x 3")
+    _require(kinv, "kinv", 3)
+    if xyz is None:
+        xyz = torch.empty((n, 3, oh, ow), device=depth.device, dtype=torch.float32)
+    optr, obs = _planes(out_depth, "out_depth")
+    xptr, xbs = _planes(xyz, "xyz")
+    flops = 2.0 * n * (h * w * c * 9 * conv0_filters + oh * ow * ((conv0_filters + 3) * 9 * kb_filters + conv0_filters))
+    tiles = n * (-(-oh // 8)) * (-(-ow // 16))
+    executed = tiles * (36 * 9 + 8 * 15) * 2.0 * 16 * 16 * 32
+    status = _launch("kb1_depth_front", flops,
+                     lambda: lib.kbn_kb1_depth_front_forward(dptr, dbs, kinv.data_ptr(), packed_weight.data_ptr(), optr, obs, xptr, xbs,
+                                                             n, c, conv0_filters, kb_filters, h, w, float(conv0_negative_slope),
+                                                             float(kb_negative_slope), 0 if proj_negative_slope is None else 1,
+                                                             0.0 if proj_negative_slope is None else float(proj_negative_slope),
+                                                             _slot_ptr(out_depth_absmax, n), _stream()),
+                     executed=executed)
+    if status == _lib.KBN_ERR_UNSUPPORTED:
+        if PROFILE is not None:
+            PROFILE.pop()
+        return None
+    check(status, "kbn_kb1_depth_front_forward")
+    return out_depth, xyz
 
 
 # ----------------------------------------------------- bf16 leg (throughput-only)

@@ -326,7 +326,7 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
  * on the CU: it never reaches HBM.  All three convs on split fp16 operands (see the split-operand section above; same
  * accuracy class, same parity gate); csrc/front.hip.
  *   image           N x image_channels x H x W (image_channels <= 4), frames image_batch_stride apart
- *   image_absmax    the image's per-frame max |x| slots (kbn_absmax_frames) -- required: the fp16 windows follow them
+ *                   (the fp16 windows of the image and of conv0's on-chip output follow the data tile by tile, inside the kernel)
  *   packed_weight   from kbn_kb1_front_pack_weight: conv0_image.conv.weight (conv0_filters x image_channels x 3 x 3),
  *                   the block's conv_image weight (kb_filters x conv0_filters x 3 x 3) and conv_fused weight
  *                   (kb_filters x (conv0_filters + 3) x 1 x 1, input order [image channels, xyz])
@@ -337,12 +337,32 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
 size_t kbn_kb1_front_packed_weight_bytes(int image_channels, int conv0_filters, int kb_filters);
 int kbn_kb1_front_pack_weight(const float* w_conv0, const float* w_conv_image, const float* w_conv_fused, void* packed,
                               int image_channels, int conv0_filters, int kb_filters, kbn_stream_t stream);
-int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const unsigned* image_absmax,
-                          const void* packed_weight, const float* xyz, long long xyz_batch_stride, float* out_image,
+int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const void* packed_weight, const float* xyz, long long xyz_batch_stride, float* out_image,
                           long long out_image_batch_stride, float* out_fused, long long out_fused_batch_stride, int n,
                           int image_channels, int conv0_filters, int kb_filters, int height, int width,
                           float conv0_negative_slope, float kb_negative_slope, unsigned* out_image_absmax,
                           unsigned* out_fused_absmax, kbn_stream_t stream);
+
+/* The depth branch of the same front:
+ *     conv0_depth = act(conv3x3(depth))                                 reference src/networks.py:366-367
+ *     conv_depth  = act(conv3x3 s2 (cat[conv0_depth, coordinates]))     reference src/net_utils.py:1351
+ *     xyz         = coordinates * act(proj_depth(conv0_depth))          reference src/net_utils.py:1354-1360, sampled at (2y, 2x)
+ * conv0_depth stays on the CU; the tensor channels on split fp16 operands, the three coordinate channels K^-1 [x y 1]^T in fp32.
+ *   depth           N x depth_channels x H x W (the S2D output, depth_channels <= 8)
+ *   kinv            N x 3 x 3 inverse intrinsics of level 0 (kbn_intrinsics_inverse)
+ *   packed_weight   from kbn_kb1_depth_front_pack_weight: conv0_depth.conv.weight (16 x depth_channels x 3 x 3), the block's
+ *                   conv_depth weight (16 x (16 + 3) x 3 x 3, input order [depth channels, coordinates]) and proj_depth weight (16)
+ *   out_depth       N x 16 x ceil(H/2) x ceil(W/2) (frames out_depth_batch_stride apart), out_depth_absmax its slot (or NULL)
+ *   xyz             N x 3 x ceil(H/2) x ceil(W/2): what kbn_kb1_front_forward / kbn_conv1x1s2_split_forward take
+ * KBN_ERR_UNSUPPORTED unless conv0_filters == kb_filters == 16. */
+size_t kbn_kb1_depth_front_packed_weight_bytes(int depth_channels, int conv0_filters, int kb_filters);
+int kbn_kb1_depth_front_pack_weight(const float* w_conv0, const float* w_conv_depth, const float* w_proj, void* packed,
+                                    int depth_channels, int conv0_filters, int kb_filters, kbn_stream_t stream);
+int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride, const float* kinv, const void* packed_weight,
+                                float* out_depth, long long out_depth_batch_stride, float* xyz, long long xyz_batch_stride, int n,
+                                int depth_channels, int conv0_filters, int kb_filters, int height, int width,
+                                float conv0_negative_slope, float kb_negative_slope, int proj_activation, float proj_negative_slope,
+                                unsigned* out_depth_absmax, kbn_stream_t stream);
 
 /* ------------------------------------------------------------ depth head -------
  * MultiScaleDecoder.output0 (3x3, linear)           reference src/networks.py:1842-1851, 1985

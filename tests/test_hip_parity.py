@@ -704,7 +704,7 @@ def test_kb1_front_kernel(dev, hw, amag):
     out_i = torch.full((n, fi, oh, ow), float("nan"), device=dev)
     out_f = torch.full((n, fi, oh, ow), float("nan"), device=dev)
     s_i, s_f = stats.new(), stats.new()
-    res = kb.ops.kb1_front(imd, stats.measure(imd), packed, xyz.to(dev), f0, fi, out_i, out_f, 0.2, 0.2, s_i, s_f)
+    res = kb.ops.kb1_front(imd, packed, xyz.to(dev), f0, fi, out_i, out_f, 0.2, 0.2, s_i, s_f)
     assert res is not None
     assert torch.equal(kb.ops.slot_values(s_i), out_i.abs().amax(dim=(1, 2, 3)))
     assert torch.equal(kb.ops.slot_values(s_f), out_f.abs().amax(dim=(1, 2, 3)))
@@ -714,6 +714,58 @@ def test_kb1_front_kernel(dev, hw, amag):
         e_orc = ((r32.double() - r64) / rms).abs()
         print(f"front {name} vs fp64: max {float(e_hip.max()):.2e} rms {float(e_hip.pow(2).mean().sqrt()):.2e}; "
               f"oracle fp32 convs vs fp64: max {float(e_orc.max()):.2e} rms {float(e_orc.pow(2).mean().sqrt()):.2e}")
+        assert float(e_hip.pow(2).mean().sqrt()) < max(3.5 * float(e_orc.pow(2).mean().sqrt()), 6e-7), name
+        assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5, name
+        for i in range(n):
+            assert rel_err(got[i], r32[i]) < TIGHT, (name, i)
+
+
+@pytest.mark.parametrize("hw", [(32, 64), (35, 70), (16, 32), (52, 100), (33, 47)])
+@pytest.mark.parametrize("amag", [1.0, 80.0, 1e-3])
+def test_kb1_depth_front_kernel(dev, hw, amag):
+    """kbn_kb1_depth_front_forward: conv0_depth -> conv_depth (3x3 s2 over cat[conv0_depth, K^-1 [x y 1]^T]) and the
+    backprojection channels xyz = coordinates * act(proj_depth(conv0_depth)) at the even pixels, in one launch; conv0_depth
+    stays on the CU, the tensor channels run on split fp16 operands, the coordinate channels in fp32 (pre-summed weights
+    for interior pixels, the 27 masked terms on the border).  Same bars as test_kb1_front_kernel."""
+    h, w = hw
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    g = torch.Generator().manual_seed(h * w + 1)
+    n, c, f0, fd = 2, 8, 16, 16
+    lrelu = torch.nn.functional.leaky_relu
+    depth = amag * lrelu(torch.randn(n, c, h, w, generator=g), 0.2)
+    depth[1] *= 0.021
+    w0 = torch.randn(f0, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    wc = torch.randn(fd, f0 + 3, 3, 3, generator=g) / ((f0 + 3) * 9) ** 0.5
+    wc[:, f0:] *= amag                                      # keeps the coordinate term comparable to the tensor term
+    proj = torch.randn(1, f0, 1, 1, generator=g) / f0 ** 0.5
+    w0[1] *= 1e-3; wc[2] *= 40.0
+    kmat = torch.tensor([[[60.0, 0.0, w / 2.0], [0.0, 58.0, h / 2.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1)
+    kmat[1, 0, 0] = 71.0
+    coords = orc.camera_coordinates(kmat, h, w)
+    c64 = lambda x, wt, stride: lrelu(torch.nn.functional.conv2d(x.double(), wt.double(), stride=stride, padding=wt.shape[-1] // 2), 0.2)
+    x0_64 = c64(depth, w0, 1)
+    dep_64 = c64(torch.cat([x0_64, coords.double()], 1), wc, 2)
+    xyz_64 = (coords.double() * c64(x0_64, proj, 1))[:, :, ::2, ::2]
+    x0_32 = orc.conv2d(depth, w0, 1, 0.2)
+    dep_32 = orc.conv2d(torch.cat([x0_32, coords], 1), wc, 2, 0.2)
+    xyz_32 = (coords * orc.conv2d(x0_32, proj, 1, 0.2))[:, :, ::2, ::2]
+    assert tuple(dep_32.shape) == (n, fd, oh, ow)
+    stats = kb.ops.ActStats(n, dev)
+    packed = kb.ops.pack_kb1_depth_front_weight(w0.to(dev), wc.to(dev), proj.to(dev))
+    assert packed is not None
+    kinv = kb.ops.intrinsics_inverse(kmat.to(dev))
+    out_d = torch.full((n, fd, oh, ow), float("nan"), device=dev)
+    slot = stats.new()
+    res = kb.ops.kb1_depth_front(depth.to(dev), kinv, packed, f0, fd, out_d, 0.2, 0.2, 0.2, out_depth_absmax=slot)
+    assert res is not None
+    xyz = res[1]
+    assert torch.equal(kb.ops.slot_values(slot), out_d.abs().amax(dim=(1, 2, 3)))
+    for name, got, r64, r32 in (("conv_depth", out_d, dep_64, dep_32), ("xyz", xyz, xyz_64, xyz_32)):
+        rms = r64.pow(2).mean(dim=(2, 3), keepdim=True).sqrt()
+        e_hip = ((got.cpu().double() - r64) / rms).abs()
+        e_orc = ((r32.double() - r64) / rms).abs()
+        print(f"depth front {name} vs fp64: max {float(e_hip.max()):.2e} rms {float(e_hip.pow(2).mean().sqrt()):.2e}; "
+              f"oracle fp32 vs fp64: max {float(e_orc.max()):.2e} rms {float(e_orc.pow(2).mean().sqrt()):.2e}")
         assert float(e_hip.pow(2).mean().sqrt()) < max(3.5 * float(e_orc.pow(2).mean().sqrt()), 6e-7), name
         assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5, name
         for i in range(n):

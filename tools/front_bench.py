@@ -19,9 +19,8 @@ packed = kb.ops.pack_kb1_front_weight(w0, wi, wf)
 oi = torch.empty(B, 48, h // 2, w // 2, device=dev)
 of = torch.empty_like(oi)
 stats = kb.ops.ActStats(B, dev)
-slot = stats.measure(image)
 a, b = stats.new(), stats.new()
-run = lambda: kb.ops.kb1_front(image, slot, packed, xyz, 48, 48, oi, of, 0.2, 0.2, a, b)
+run = lambda: kb.ops.kb1_front(image, packed, xyz, 48, 48, oi, of, 0.2, 0.2, a, b)
 for _ in range(5):
     run()
 torch.cuda.synchronize()
