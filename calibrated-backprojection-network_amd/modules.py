@@ -101,6 +101,27 @@ class _PackedWeight:
             self.get(weight, *self._args)
 
 
+class _PackedTail:
+    """The blob of ops.conv_tail, rebuilt (in place when possible) when the weight changes."""
+
+    def __init__(self):
+        self._key = None
+        self._packed = None
+        self._w = None
+
+    def get(self, w):
+        key = (w.data_ptr(), w._version, w.device)
+        if key != self._key:
+            self._packed = ops.pack_conv_tail_weight(w, out=self._packed)
+            self._key = key
+            self._w = w
+        return self._packed
+
+    def refresh(self):
+        if self._packed is not None:
+            self.get(self._w)
+
+
 class _PackedFront:
     """The blob of ops.kb1_front / ops.kb1_depth_front (`pack`), rebuilt (in place when possible) when one of its three
     weights changes."""
@@ -679,6 +700,7 @@ class MultiScaleDecoder(torch.nn.Module):
                                              deconv_type=deconv_type))
             cin = n_filters[i]
         self.output0 = Conv2d(n_filters[4], output_channels, 3, 1, weight_initializer, None)
+        self._packed_tail = _PackedTail()
 
     def set_bf16(self, enabled: bool = True):
         """THROUGHPUT-ONLY switch (BASELINE configs[2]'s bf16 figure): the decoder's 3x3 stride-1 convs with at least 16
@@ -719,6 +741,12 @@ class MultiScaleDecoder(torch.nn.Module):
         d0 = self.deconv0
         if d0.skip_channels == 0:
             up = d0.deconv(x, shape=tuple(shape)[-2:], amax=amax, stats=stats)
+            if d0.conv.split:   # the 12 -> 12 conv of the tail on split fp16 operands (csrc/tail.hip)
+                packed = self._packed_tail.get(d0.conv.conv.weight)
+                res = None if packed is None else ops.conv_tail(up, packed, self.output0.conv.weight, min_predict_depth,
+                                                                  max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
+                if res is not None:
+                    return res
             res = ops.conv_head(up, d0.conv.conv.weight, self.output0.conv.weight, min_predict_depth,
                                 max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
             if res is not None:
@@ -933,6 +961,8 @@ class KBNetModel(object):
                     sub._packed_split_1x1.refresh(sub.conv.weight)
                 elif isinstance(sub, UpConv2d):
                     sub._packed_up2x.refresh(sub.conv.conv.weight)
+                elif isinstance(sub, MultiScaleDecoder):
+                    sub._packed_tail.refresh()
                 elif isinstance(sub, KBNetEncoder):
                     sub._packed_front.refresh()
                     sub._packed_depth_front.refresh()

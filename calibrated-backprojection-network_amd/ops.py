@@ -521,6 +521,61 @@ def conv_head(x, w_conv, w_out, min_predict_depth: float, max_predict_depth: flo
     return (depth, logits) if return_logits else depth
 
 
+@_on_tensor_device
+def pack_conv_tail_weight(w_conv: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Blob of `conv_tail` from the raw C x C x 3 x 3 weight of deconv0's second conv (kbn_conv_tail_pack_weight); None when
+    C is outside the kernel's range."""
+    lib = _lib.load()
+    w = w_conv.detach().contiguous()
+    _require(w, "w_conv", 4)
+    c = w.shape[0]
+    if tuple(w.shape) != (c, c, 3, 3):
+        return None
+    nbytes = lib.kbn_conv_tail_packed_weight_bytes(c)
+    if nbytes == 0:
+        return None
+    packed = out if _reusable(out, nbytes // 4, w) else torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    check(lib.kbn_conv_tail_pack_weight(w.data_ptr(), packed.data_ptr(), c, _stream()), "kbn_conv_tail_pack_weight")
+    return packed
+
+
+@_on_tensor_device
+def conv_tail(x, packed_w_conv, w_out, min_predict_depth: float, max_predict_depth: float,
+              negative_slope: Optional[float] = 0.2, return_logits=False, out=None):
+    """deconv0's second conv (on split fp16 operands) + output0 + depth mapping in one launch (kbn_conv_tail_forward).
+    Returns None when the shape does not qualify: the caller runs conv_head / the two-launch path."""
+    lib = _lib.load()
+    xptr, xbs = _planes(x, "x")
+    n, c, h, wd = x.shape
+    wo = w_out.detach().contiguous()
+    _require(wo, "w_out", 4)
+    if tuple(wo.shape) != (1, c, 3, 3):
+        raise KbnError(f"conv_tail: w_out must be 1 x {c} x 3 x 3")
+    if out is None:
+        depth = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32)
+    else:
+        _require(out, "out", 4)
+        if tuple(out.shape) != (n, 1, h, wd) or not out.is_contiguous():
+            raise KbnError(f"out must be a contiguous {(n, 1, h, wd)} tensor")
+        depth = out
+    logits = torch.empty_like(depth) if return_logits else None
+    flops = 2.0 * n * h * wd * c * 9 * c
+    tiles = n * (-(-h // 16)) * (-(-wd // 32))
+    status = _launch("conv_tail", flops,
+                     lambda: lib.kbn_conv_tail_forward(xptr, xbs, packed_w_conv.data_ptr(), wo.data_ptr(), depth.data_ptr(),
+                                                       logits.data_ptr() if return_logits else None, n, c, h, wd,
+                                                       0 if negative_slope is None else 1,
+                                                       0.0 if negative_slope is None else float(negative_slope),
+                                                       float(min_predict_depth), float(max_predict_depth), _stream()),
+                     executed=tiles * 39 * 15 * 2.0 * 16 * 16 * 32)   # 39 pixel blocks x 15 MFMAs of 16 x 16 x 32 per tile
+    if status == _lib.KBN_ERR_UNSUPPORTED:
+        if PROFILE is not None:
+            PROFILE.pop()
+        return None
+    check(status, "kbn_conv_tail_forward")
+    return (depth, logits) if return_logits else depth
+
+
 # ----------------------------------------------------- fp32-grade convs on the 16-bit matrix core (split operands)
 @_on_tensor_device
 def pack_conv3x3_split_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None, stride: int = 1,

@@ -386,6 +386,16 @@ int kbn_conv_head_forward(const float* x, long long x_batch_stride, const float*
                           int apply_activation, float negative_slope, float min_predict_depth,
                           float max_predict_depth, kbn_stream_t stream);
 
+/* The same tail with the channels -> channels conv on split fp16 operands (csrc/tail.hip; see the split-operand section: same
+ * accuracy class, same parity gate): on the fp32 MFMAs that conv was what bound kbn_conv_head_forward.  packed_w_conv from
+ * kbn_conv_tail_pack_weight (raw channels x channels x 3 x 3 weight in); w_out raw.  No alignment requirements.
+ * KBN_ERR_UNSUPPORTED for channels > 12 (the caller runs kbn_conv_head_forward or the two-launch path). */
+size_t kbn_conv_tail_packed_weight_bytes(int channels);
+int kbn_conv_tail_pack_weight(const float* w_conv, void* packed, int channels, kbn_stream_t stream);
+int kbn_conv_tail_forward(const float* x, long long x_batch_stride, const void* packed_w_conv, const float* w_out, float* depth,
+                          float* logits, int n, int channels, int height, int width, int apply_activation, float negative_slope,
+                          float min_predict_depth, float max_predict_depth, kbn_stream_t stream);
+
 /* ------------------------------------------------- pre-model stage --
  * What the reference's run loop does between the host->device copy and the model call:
  *   validity = where(sparse > 0, 1, sparse)                        reference src/kbnet.py:899-902

@@ -492,6 +492,46 @@ def test_conv_head_fused_vs_oracle(dev, kenv, c, shape):
     assert kb.ops.conv_head(x[:, :, :, :wd - 2].contiguous().to(dev), wc.to(dev), wo.to(dev), 1.5, 100.0, 0.2) is None
 
 
+@pytest.mark.parametrize("c,shape", [(12, (37, 72)), (4, (16, 64)), (12, (70, 101)), (12, (5, 200)), (8, (130, 67)), (12, (33, 31))])
+@pytest.mark.parametrize("amag", [1.0, 300.0, 1e-3])
+def test_conv_tail_kernel(dev, kenv, c, shape, amag):
+    """kbn_conv_tail_forward: deconv0's second conv on split fp16 operands + output0 + depth mapping in one launch
+    (csrc/tail.hip) against the oracle's conv -> conv -> mapping, the logits also against an fp64 evaluation (same bar as
+    the other split kernels: within 3.5x the fp32 oracle's own error), and against conv_head's fp32-MFMA form.  Any width
+    (no alignment requirement), frames of different magnitude (the fp16 window is per tile)."""
+    h, wd = shape
+    g = torch.Generator().manual_seed(c * 1000 + h)
+    x = amag * torch.randn(2, c, h, wd, generator=g)
+    x[1] *= 0.013
+    wc = torch.randn(c, c, 3, 3, generator=g) * (1.3 / (c * 9) ** 0.5)
+    wc[1] *= 1e-2
+    wo = torch.randn(1, c, 3, 3, generator=g) * (0.5 / amag)
+    lrelu = torch.nn.functional.leaky_relu
+    feats = orc.conv2d(x, wc, 1, 0.2)
+    logits = orc.conv2d(feats, wo, 1, None)
+    ref = orc.depth_head(logits, 1.5, 100.0)
+    f64 = lrelu(torch.nn.functional.conv2d(x.double(), wc.double(), padding=1), 0.2)
+    l64 = torch.nn.functional.conv2d(f64, wo.double(), padding=1)
+    packed = kb.ops.pack_conv_tail_weight(wc.to(dev))
+    res = kb.ops.conv_tail(x.to(dev), packed, wo.to(dev), 1.5, 100.0, 0.2, return_logits=True)
+    assert res is not None
+    d, lg = res
+    rms = l64.pow(2).mean(dim=(1, 2, 3), keepdim=True).sqrt()
+    e_hip = float((((lg.cpu().double() - l64) / rms).pow(2).mean()).sqrt())
+    e_orc = float((((logits.double() - l64) / rms).pow(2).mean()).sqrt())
+    print(f"tail logits vs fp64: rms {e_hip:.2e}; oracle fp32 vs fp64: rms {e_orc:.2e}")
+    assert e_hip < max(3.5 * e_orc, 6e-7) and e_hip < 1.5e-6
+    for i in range(2):
+        assert rel_err(lg[i], logits[i]) < TIGHT
+    assert float(((d.cpu() - ref).abs() / ref).max()) < TOL
+    if wd % 4 == 0 and c % 4 == 0:   # the fp32-MFMA form of the same fusion
+        d2, lg2 = kb.ops.conv_head(x.to(dev), wc.to(dev), wo.to(dev), 1.5, 100.0, 0.2, return_logits=True)
+        assert rel_err(lg, lg2) < TIGHT and not torch.equal(lg, lg2)
+    kenv.setenv("KBN_NO_SPLIT", "1")
+    assert kb.ops.conv_tail(x.to(dev), packed, wo.to(dev), 1.5, 100.0, 0.2) is None
+    kenv.delenv("KBN_NO_SPLIT")
+
+
 # ------------------------------------------------- bf16 leg (throughput-only, never parity-gated)
 @pytest.mark.parametrize("cins,cout,hw,kind", [((32,), 48, (16, 64), "plain"), ((64, 64), 64, (22, 76), "plain"),
                                                ((128,), 64, (20, 36), "up2x"), ((16, 32), 130, (9, 40), "plain"),
