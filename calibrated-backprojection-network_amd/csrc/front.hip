@@ -25,22 +25,9 @@
 //      consecutive granules thanks to the de-interleave), B operand = weights from LDS (double buffered, LDS-DMA).
 //   D  after the last chunk: scales, xyz channels of conv_fused in fp32 (kbn_kb_xyz_s2_forward computes them once per block),
 //      LeakyReLU, 16-byte NCHW stores (a lane holds 4 consecutive pixels of a filter), absmax.
-#include "conv_common.h"
+#include "front_common.h"
 
 namespace kbn {
-
-typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
-typedef _Float16 fh4 __attribute__((ext_vector_type(4)));
-typedef _Float16 fh2 __attribute__((ext_vector_type(2)));
-typedef float ff4 __attribute__((ext_vector_type(4)));
-
-constexpr int FR_TH = 8, FR_TW = 16, FR_THREADS = 512;
-constexpr int FR_R1H = 2 * FR_TH + 1, FR_R1W = 2 * FR_TW + 1, FR_NP1 = FR_R1H * FR_R1W;     // conv0 outputs a tile needs: 17 x 33
-constexpr int FR_R0H = FR_R1H + 2, FR_R0W = FR_R1W + 2, FR_NP0 = FR_R0H * FR_R0W;           // image pixels they read: 19 x 35
-constexpr int FR_NIN = 672;                                                                  // image entries in LDS: the 665 pixels + zeroed slack (a column pair may start at the last one)
-constexpr int FR_WEXP = 13;                                                                  // largest |w 2^e| of a filter in [2^12, 2^13)
-constexpr int FR_TAB = 400;                                                                  // floats: [L1max0, 0, 0, 0][inv0 64][invI 64][invF 64][wxyz 64 x 3]
-constexpr int FR_NB0 = (FR_NP1 + 15) / 16;                                                   // 16-pixel blocks of conv0 outputs: 36
 
 struct FrontParams {
     const float* image;
@@ -60,37 +47,6 @@ struct FrontParams {
     float slope0, slope1;
     int vec4;
 };
-
-__device__ __forceinline__ void fr_scales(unsigned bits, float& pre, float& un) {   // max in [2^14, 2^15) of the fp16 window
-    int k = 14 + 127 - (int)(bits >> 23);
-    k = k > 100 ? 100 : (k < -100 ? -100 : k);
-    pre = __uint_as_float((unsigned)(127 + k) << 23);
-    un = __uint_as_float((unsigned)(127 - k) << 23);
-}
-
-__device__ __forceinline__ _Float16 fr_term(float ws, int term) {
-    const _Float16 w1 = (_Float16)ws;
-    return term == 0 ? w1 : (_Float16)((ws - (float)w1) * 2048.f);
-}
-
-__device__ __forceinline__ float sp_amax4f(float m, const ff4& v) {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-}
-
-// two-term split of four scaled values: h1 = fp16(v), h2 = fp16((v - h1) 2^11)
-__device__ __forceinline__ void fr_split4(const ff4& v, fh4& h1, fh4& h2) {
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {
-        const f32x2 a = {v[k], v[k + 1]};
-        const fh2 c1 = __builtin_convertvector(a, fh2);
-        const f32x2 f = {(float)c1[0], (float)c1[1]};
-        const f32x2 hi = a * 2048.f;
-        const f32x2 r = {__builtin_fmaf(f[0], -2048.f, hi[0]), __builtin_fmaf(f[1], -2048.f, hi[1])};
-        const fh2 c2 = __builtin_convertvector(r, fh2);
-        h1[k] = c1[0]; h1[k + 1] = c1[1];
-        h2[k] = c2[0]; h2[k + 1] = c2[1];
-    }
-}
 
 // LDS per workgroup: IN 10.5 KB + X 35.1 KB + one chunk of conv_image / conv_fused weights 33 KB = 78.6 KB: TWO workgroups
 // per CU, so that one's image loads, barriers and stores hide under the other's MFMAs.
