@@ -50,6 +50,12 @@
 #ifndef KBN_SPLIT_STRAIGHT
 #define KBN_SPLIT_STRAIGHT 1
 #endif
+// A/B builds (KBN_HIPCC_FLAGS=-DKBN_SPLIT_PRIO=n): 1 s_setprio(1) around every MFMA group of the concat kernel, 2 once for
+// waves 4-7.  Measured inside the forward (four concat convs, 32 KITTI frames): 4168-4312 us without, 4334-4360 with 1, 4165 with 2:
+// the waves of this kernel move in lockstep, there is nothing for the arbiter to prefer.  Off.
+#ifndef KBN_SPLIT_PRIO
+#define KBN_SPLIT_PRIO 0
+#endif
 
 namespace kbn {
 
@@ -420,7 +426,13 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 // (tools/probe/mfma_power_probe: a dense 32x32x16 stream is held at 1.22 PFLOP/s, one interleaved with
                 // its LDS reads runs at 1.70)
                 __builtin_amdgcn_sched_barrier(0x8);
+#if KBN_SPLIT_PRIO == 1
+                __builtin_amdgcn_s_setprio(1);
+#endif
                 mfma_group(chk_tag, ac, bw, grp);
+#if KBN_SPLIT_PRIO == 1
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 __builtin_amdgcn_sched_barrier(0x8);
                 if (MORE && tap >= 5) {   // split + write one staging round per group: the vector ALU works beside the MFMAs
                     const int u = (tap - 5) * GPT + gi;   // (staggering the two waves of a SIMD -- taps 2-4 / 5-7 -- measured slower)
@@ -435,6 +447,9 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
 #pragma unroll
         for (int u = 0; u < PR; ++u) store_round(0, u);
         __syncthreads();
+#if KBN_SPLIT_PRIO == 2
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the younger half of the workgroup (cdna_hip_programming.md T5, static form)
+#endif
         auto k_loop = [&](auto chk_tag) {
             for (int c = 0; c + 1 < nchunks; ++c) body(c, std::true_type{}, chk_tag);
             body(nchunks - 1, std::false_type{}, chk_tag);
