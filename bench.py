@@ -41,7 +41,7 @@ SIDE_BATCH = 8           # configs[1]
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32, dense (the fp32 vector datapath)
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/fp16 MFMA (the matrix core proper)
 SPLIT_KERNELS = {"conv_split": "conv3x3_split_kernel<0, 8,", "conv_split_up": "conv3x3_split_kernel<1, 8,",
-                 "conv_split_s2": "conv3x3_split_kernel<2, 4,", "conv_split_upfold": "upconv2x_split_kernel"}
+                 "conv_split_s2": "conv3x3_split_kernel<2, 2,", "conv_split_upfold": "upconv2x_split_kernel"}
 
 
 def pipe_peak(name):

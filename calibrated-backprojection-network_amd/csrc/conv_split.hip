@@ -224,9 +224,11 @@ int absmax_frames_launch(const float* x, long long batch_stride, int n, long lon
     return KBN_OK;
 }
 
-template <int N>
-__device__ __forceinline__ void sp_wait_b(f32x4 (&b)[2][2]) {   // vmcnt(N), tied to the registers it guards
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+template <int N, int NBX>
+__device__ __forceinline__ void sp_wait_b(f32x4 (&b)[NBX][2]) {   // vmcnt(N), tied to the registers it guards
+    static_assert(NBX == 1 || NBX == 2, "one or two 32-filter blocks per wave");
+    if constexpr (NBX == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0][0]), "+v"(b[0][1]) : "n"(N));
 }
 
 // RG row groups x (8 / RG) filter groups of waves; a wave owns MB = TH / RG rows (m-blocks) x two 32-filter n-blocks.
@@ -236,13 +238,13 @@ __device__ __forceinline__ void sp_wait_b(f32x4 (&b)[2][2]) {   // vmcnt(N), tie
 // access of chunk c+1 is issued at the start of chunk c and awaited once, in front of the barrier that ends chunk c --
 // no vmcnt wait sits between MFMAs (waves retire their loads in order: with the weights fetched per tap into registers,
 // the tap-2 wait also had to wait for the next chunk's inputs, +28 % on the decoder's concat convs).
-template <int MODE, int RG, bool APART, bool BLDS>
+template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2>   // NBW: 32-filter blocks per wave
 __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
     static_assert(APART, "the two small terms share the scale 2^11 and an accumulator of their own");
     using G = SpGeom<MODE>;
     constexpr bool UP = G::UP, S2 = G::S2;
-    constexpr int NB = 2, FG = 8 / RG;
-    constexpr int NT = 64 * FG, NPIX = G::NPIX, PR = G::PR, COLS = G::COLS;
+    constexpr int NB = NBW, FG = 8 / RG;
+    constexpr int NT = 32 * NB * FG, NPIX = G::NPIX, PR = G::PR, COLS = G::COLS;
     constexpr int MB = G::TH / RG;
     static_assert(MB == 2 || MB == 4, "groups per chunk must be even (ping-pong A fragments)");
     constexpr int B_TAP = 2 * 2 * NT * 16;                               // bytes: [part][k-group][filter][8 fp16]
@@ -1959,7 +1961,14 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
             }
             break;
         case 1: rc = launch(conv3x3_split_kernel<1, 8, true, false>, SpGeom<1>::LDS, o[1]); break;
-        case 2: rc = launch(conv3x3_split_kernel<2, 4, true, false>, SpGeom<2>::LDS, o[2]); break;
+        case 2:
+            // 2 row groups x 4 filter groups of waves (a wave: 4 rows x ONE 32-filter block): every weight fragment is fetched from
+            // L2 by two waves instead of four -- half the vector-memory traffic of a chunk -- for twice the A fragment reads
+            // from LDS.  Inside the forward (KB2 / KB3 / KB4 / conv5 image / conv5 depth, 32 KITTI frames): 397 / 337 / 314 /
+            // 247 / 60 us against 414 / 360 / 322 / 281 / 69 with 4 x 2 waves of 2 rows x two blocks (KBN_DEBUG & 128: that form)
+            if (knob(KNOB_DEBUG) & 128) { static DeviceOnce o2b; rc = launch(conv3x3_split_kernel<2, 4, true, false, 2>, SpGeom<2>::LDS, o2b); }
+            else rc = launch(conv3x3_split_kernel<2, 2, true, false, 1>, SpGeom<2>::LDS, o[2]);
+            break;
         default:
             if (knob(KNOB_DEBUG) & 16) {   // weights fetched per set into registers (the form before the LDS stage), for A/B runs
                 static DeviceOnce o3r;
