@@ -1605,17 +1605,21 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
 // used) and the MFMAs are skipped: the vmcnt arithmetic is the same in every iteration and the kernel holds two copies
 // of the body (seven tail variants spilled).  The loop is bound by memory latency, not by its MFMAs (a wave-private
 // variant without LDS and barriers, every lane fetching its own fragment, measured 15 % slower: twice the loads).
-template <int N>
-__device__ __forceinline__ void c1_wait_b(f32x4 (&b)[2][2]) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+template <int N, int NBX>
+__device__ __forceinline__ void c1_wait_b(f32x4 (&b)[NBX][2]) {
+    static_assert(NBX == 1 || NBX == 2, "one or two 32-filter blocks per wave");
+    if constexpr (NBX == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0][0]), "+v"(b[0][1]) : "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void c1_wait_a(float (&v)[8]) {
     asm volatile("s_waitcnt vmcnt(%8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "n"(N));
 }
 
+template <int RG, int NB>   // RG row groups x 8 / RG filter groups of waves; a wave: 8 / RG rows x NB 32-filter blocks (RG * NB = 4: 128 filters per tile)
 __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const SplitConvParams p) {
-    constexpr int TH = 8, RG = 4, MB = 2, NB = 2, NT = 128, NPIX = TH * SP_TW;
+    constexpr int TH = 8, MB = TH / RG, NT = 128, NPIX = TH * SP_TW;
+    static_assert(32 * NB * (8 / RG) == NT, "128 filters per workgroup");
     constexpr int A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART;          // [part][k-group][pixel][8 fp16]
     constexpr int B_CHUNK = 2 * 2 * NT * 16;                             // bytes: [part][k-group][filter][8 fp16]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2059,7 +2063,10 @@ int kbn_conv1x1s2_split_forward(const kbn_conv_src* srcs, int n_src, const void*
     p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.prescale = ldexpf(1.f, act_exponent); p.unscale = ldexpf(1.f, -act_exponent);
     p.vec4 = !((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3)) ? 1 : 0;
-    hipLaunchKernelGGL(conv1x1s2_split_kernel, dim3(p.nblocks), dim3(SP_THREADS), 2 * 2 * 2 * 256 * 16, (hipStream_t)stream, p);
+    // 2 row groups x 4 filter groups (a wave: 4 rows x one 32-filter block): every weight fragment is fetched by two waves
+    // instead of four (KBN_DEBUG & 128: the 4 x 2 form, for A/B runs)
+    if (knob(KNOB_DEBUG) & 128) hipLaunchKernelGGL((conv1x1s2_split_kernel<4, 2>), dim3(p.nblocks), dim3(SP_THREADS), 2 * 2 * 2 * 256 * 16, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv1x1s2_split_kernel<2, 1>), dim3(p.nblocks), dim3(SP_THREADS), 2 * 2 * 2 * 256 * 16, (hipStream_t)stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }
