@@ -1165,10 +1165,19 @@ __global__ void uf16_pack_kernel(const float* __restrict__ w, const float* __res
     packed[e] = h;
 }
 
-__global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const SplitConvParams p) {
-    constexpr int COLS = 34, NPIX = 18 * COLS, KG = 4;
+// NW waves per workgroup.  8: tile 16 x 32 low-resolution pixels, the staged chunk double buffered (157 KB of LDS, one
+// workgroup per CU).  4 (the launch default): tile 8 x 32, ONE staging buffer (43.5 KB) refilled from registers between
+// two barriers, two workgroups per CU -- with only Cin / 32 = 2 chunks per tile the first fetch and the stores are most
+// of a workgroup's life, and a second resident workgroup multiplies meanwhile: 700 -> 616 us for deconv0's up-conv.
+// (Measured and not kept, DESIGN.md round 3: persistent workgroups, with the weights from L2 as here or resident in LDS.)
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_kernel(const SplitConvParams p) {
+    static_assert(NW == 8 || NW == 4, "8 waves (16-row tiles) or 4 waves (8-row tiles)");
+    constexpr bool DB = NW == 8;
+    constexpr int ROWS = 2 * NW, TPG = 16 * NW;                        // low-resolution rows per tile; threads per k-group in staging
+    constexpr int COLS = 34, NPIX = (ROWS + 2) * COLS, KG = 4;
     constexpr int A_PART = KG * NPIX * 16, A_BYTES = 2 * A_PART;      // [part][k-group][pixel][8 fp16]
-    constexpr int PR = (NPIX + 127) / 128, NA_ALL = PR * 8;           // staging rounds of a 128-thread quarter (one k-group each)
+    constexpr int PR = (NPIX + TPG - 1) / TPG, NA_ALL = PR * 8;       // staging rounds of a quarter of the threads (one k-group each)
     constexpr int B_ITEM = 2 * KG * U16_NT * 16, NBL = 2, D = 3;      // bytes per weight set; loads per set; sets fetched ahead
     static_assert(D * NBL + NA_ALL < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1184,18 +1193,18 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
     bid /= p.tilesX;
     const int ty = bid % p.tilesY;
     const int n = bid / p.tilesY;
-    const int oy0 = ty * 16, ox0 = tx * 32;                            // low-resolution tile origin
+    const int oy0 = ty * ROWS, ox0 = tx * 32;                            // low-resolution tile origin
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / U16_CK;
     float prescale, unscale;
     sp_act_scale(p, n, prescale, unscale);
 
-    const int kg_st = wave >> 1, t128 = tid & 127;                     // staging: two waves per k-group
+    const int kg_st = wave / (NW / 4), t128 = tid & (TPG - 1);         // staging: NW / 4 waves per k-group
     int goff[PR];
 #pragma unroll
     for (int u = 0; u < PR; ++u) {
-        const int pix = u * 128 + t128;
+        const int pix = u * TPG + t128;
         const int r = pix / COLS, c = pix - r * COLS;
         const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
         goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
@@ -1219,7 +1228,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
         unsigned char* A = smem + buf * A_BYTES + kg_st * NPIX * 16;
 #pragma unroll
         for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));
-        const int pix = u * 128 + t128;
+        const int pix = u * TPG + t128;
         if (pix < NPIX) {
             float v[8];
 #pragma unroll
@@ -1260,7 +1269,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
     auto chunk_body = [&](int c, auto more_tag, auto chk_tag) {
         constexpr bool MORE = decltype(more_tag)::value, CHK = decltype(chk_tag)::value;
         constexpr int NA = MORE ? NA_ALL : 0;
-        const int abuf = (c & 1) * A_BYTES;
+        const int abuf = DB ? (c & 1) * A_BYTES : 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) load_arow(abuf, r, 0);
 #pragma unroll
@@ -1300,9 +1309,14 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
                                                                                   acc[mb][t.py][t.px], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (MORE && it > D + 1 && it - D - 2 < PR) store_round((c & 1) ^ 1, it - D - 2);   // the wait of set D+1 covered the inputs
+            if (DB && MORE && it > D + 1 && it - D - 2 < PR) store_round((c & 1) ^ 1, it - D - 2);   // the wait of set D+1 covered the inputs
         }
         __syncthreads();
+        if (!DB && MORE) {       // one buffer: every wave has read its last fragment of chunk c; the inputs arrived under set D+1's wait
+#pragma unroll
+            for (int u = 0; u < PR; ++u) store_round(0, u);
+            __syncthreads();
+        }
     };
 
     load_chunk(0);
@@ -1318,7 +1332,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split16_kernel(const S
         for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{}, chk_tag);
         chunk_body(nchunks - 1, std::false_type{}, chk_tag);
     };
-    if (!KBN_SPLIT_STRAIGHT || oy0 + 16 > sH) k_loop(std::true_type{});   // tile with rows below the map (workgroup-uniform)
+    if (!KBN_SPLIT_STRAIGHT || oy0 + ROWS > sH) k_loop(std::true_type{});   // tile with rows below the map (workgroup-uniform)
     else k_loop(std::false_type{});
 
     // ---- epilogue: acc[mb][py][px][i]: low-resolution x = 16 mblk + 4 kq + i, filter lp; outputs (2 Y + py, 2 x + px)
@@ -1935,7 +1949,16 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     static DeviceOnce o[5];
     int rc;
     if (mode == 3 && uf_narrow(out_channels, cin)) {
-        rc = launch(upconv2x_split16_kernel, 2 * 2 * 4 * 18 * 34 * 16, o[4]);
+        if (knob(KNOB_DEBUG) & 128) rc = launch(upconv2x_split16_kernel<8>, 2 * 2 * 4 * 18 * 34 * 16, o[4]);   // A/B: 16-row tiles, one workgroup per CU
+        else {               // 8 x 32 low-resolution pixels per workgroup of 4 waves, two workgroups per CU
+            p.tilesY = ceil_div(p.sH, 8);
+            const long long blocks8 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
+            if (blocks8 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+            p.nblocks = (int)blocks8;
+            static DeviceOnce o16;
+            if ((rc = set_max_dynamic_lds(o16, reinterpret_cast<const void*>(upconv2x_split16_kernel<4>), 160 * 1024))) return rc;
+            hipLaunchKernelGGL(upconv2x_split16_kernel<4>, dim3(p.nblocks), dim3(256), 2 * 4 * 10 * 34 * 16, (hipStream_t)stream, p);
+        }
         if (rc != KBN_OK) return rc;
         KBN_CHECK_LAUNCH();
         return KBN_OK;
