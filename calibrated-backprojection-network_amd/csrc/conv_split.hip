@@ -381,7 +381,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     };
     const bool padded_tile = !KBN_SPLIT_STRAIGHT || oy0 + G::TH > H || (nt + 1) * NT - 32 >= p.OC;   // workgroup-uniform
 
-    f32x4 bq0[NB][2], bq1[NB][2];   // fetched weights (w1, w2) of the current / next tap
+    f32x4 bq[3][NB][2];             // fetched weights (w1, w2): tap t lives in bq[t % 3] (nine taps: the ring closes over a chunk)
     constexpr int AD = 1;           // A fragments fetched AD groups ahead (2 measured the same)
     static_assert(NGROUP % (AD + 1) == 0, "the fragment rotation must close over a chunk");
     sph8 aq[AD + 1][GM][2];
@@ -459,9 +459,11 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
         if (padded_tile) k_loop(std::true_type{});
         else k_loop(std::false_type{});
     } else {
-    // one chunk: nine taps, weights of tap t+1 in flight under the MFMAs of tap t (fetching two taps ahead measured the
-    // same and costs 16 registers); the next chunk's inputs are fetched during taps 0-1 and written (split) into the
-    // other A buffer from tap 3 on; ONE barrier per chunk
+    // one chunk: nine taps, weights of taps t+1 and t+2 in flight under the MFMAs of tap t.  The vmcnt queue is in order: a
+    // weight set fetched AFTER the next chunk's inputs cannot be consumed before they land, so the inputs (issued at tap 0
+    // behind the fetch of tap 2) have taps 0-2 to arrive -- one tap more than with a single set in flight -- and the ring
+    // of three closes over the nine taps (no register copy, no drained queue at the end of a chunk); they are written
+    // (split) into the other A buffer from tap 4 on; ONE barrier per chunk
     auto chunk_body = [&](int c, auto more_tag, auto chk_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         constexpr int NA = MORE ? G::NLOADA : 0, NBL = 2 * NB;
@@ -472,17 +474,18 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
 #pragma unroll
         for (int grp = 0; grp < NGROUP; ++grp) {
             const int tap = grp / GPT, gi = grp % GPT;
-            f32x4 (&bc)[NB][2] = (tap & 1) ? bq1 : bq0;
-            f32x4 (&bn)[NB][2] = (tap & 1) ? bq0 : bq1;
+            f32x4 (&bc)[NB][2] = bq[tap % 3];
+            f32x4 (&bn)[NB][2] = bq[(tap + 2) % 3];
             sph8 (&ac)[GM][2] = aq[grp % (AD + 1)];
             if (grp + AD < NGROUP) load_a(aq[(grp + AD) % (AD + 1)], abuf, grp + AD);
             if (gi == 0) {
-                if (tap < 8) load_b(bn, c, tap + 1);
-                else if (MORE) load_b(bn, c + 1, 0);
+                if (tap + 2 < 9) load_b(bn, c, tap + 2);
+                else if (MORE) load_b(bn, c + 1, tap + 2 - 9);
                 if (tap == 0 && MORE) load_chunk(c + 1);
-                // outstanding, oldest first: [b(tap)] b(tap+1) [inputs, taps 0-1]; b(tap) is what the MFMAs below need
-                if (tap <= 1) sp_wait_b<NBL + NA>(bc);
-                else if (tap < 8 || MORE) sp_wait_b<NBL>(bc);
+                // outstanding, oldest first: [b(tap)] b(tap+1) b(tap+2) with the inputs behind b(2); b(tap) is what the MFMAs below need
+                if (tap <= 2) sp_wait_b<2 * NBL + NA>(bc);
+                else if (tap < 7 || MORE) sp_wait_b<2 * NBL>(bc);
+                else if (tap == 7) sp_wait_b<NBL>(bc);
                 else sp_wait_b<0>(bc);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -493,23 +496,18 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             __builtin_amdgcn_sched_barrier(0);
             mfma_group(chk_tag, ac, bw, grp);
             __builtin_amdgcn_sched_barrier(0);
-            if (MORE && tap >= 3) {   // the wait of tap 2 covered the input loads; one staging round per group
-                const int u = (tap - 3) * GPT + gi;
+            static_assert(5 * GPT >= PR, "taps 4-8 hold the staging rounds");
+            if (MORE && tap >= 4) {   // the wait of tap 3 covered the input loads; one staging round per group
+                const int u = (tap - 4) * GPT + gi;
                 if (u < PR) store_round((c & 1) ^ 1, u);
             }
-        }
-        if (MORE) {
-            sp_wait_b<0>(bq1);   // the fetch issued at tap 8 must have landed before its registers are copied
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) bq0[nb][t] = bq1[nb][t];   // tap 8 used bq0 and fetched the next chunk's tap 0 into bq1
         }
         __syncthreads();
     };
 
     load_chunk(0);
-    load_b(bq0, 0, 0);
+    load_b(bq[0], 0, 0);
+    load_b(bq[1], 0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int u = 0; u < PR; ++u) store_round(0, u);
@@ -1992,9 +1990,8 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
             // 2 row groups x 4 filter groups of waves (a wave: 4 rows x ONE 32-filter block): every weight fragment is fetched from
             // L2 by two waves instead of four -- half the vector-memory traffic of a chunk -- for twice the A fragment reads
             // from LDS.  Inside the forward (KB2 / KB3 / KB4 / conv5 image / conv5 depth, 32 KITTI frames): 397 / 337 / 314 /
-            // 247 / 60 us against 414 / 360 / 322 / 281 / 69 with 4 x 2 waves of 2 rows x two blocks (KBN_DEBUG & 128: that form)
-            if (knob(KNOB_DEBUG) & 128) { static DeviceOnce o2b; rc = launch(conv3x3_split_kernel<2, 4, true, false, 2>, SpGeom<2>::LDS, o2b); }
-            else rc = launch(conv3x3_split_kernel<2, 2, true, false, 1>, SpGeom<2>::LDS, o[2]);
+            // 247 / 60 us against 414 / 360 / 322 / 281 / 69 with 4 x 2 waves of 2 rows x two blocks
+            rc = launch(conv3x3_split_kernel<2, 2, true, false, 1>, SpGeom<2>::LDS, o[2]);
             break;
         default:
             if (knob(KNOB_DEBUG) & 16) {   // weights fetched per set into registers (the form before the LDS stage), for A/B runs
