@@ -19,6 +19,7 @@ drop-ins), but every `forward` is a sequence of HIP launches through the C ABI
 
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -275,6 +276,45 @@ class Conv2d(torch.nn.Module):
         return self.run([ops.tensor_src(x, "x")], x.shape[0], x.shape[2], x.shape[3])
 
 
+class _SideBranch:
+    """Launches issued inside the `with` block go to a side stream that forks from the current stream at the point where
+    the object was CREATED and joins it when the block ends -- independent kernels of one level (the KB block's conv_depth
+    and conv_fused beside its conv_image) then share the GPU instead of queueing.  Works eagerly and under HIP-graph
+    capture (the fork / join become graph edges).  Tensors that outlive the block must be allocated outside it (on the
+    current stream); what is allocated inside must also die inside.  KBN_NO_OVERLAP=1 keeps everything on one stream."""
+
+    _streams = {}
+    enabled = os.environ.get("KBN_NO_OVERLAP", "0") in ("", "0")
+    only_from = None      # raw handle of the one stream that may fork (set while a multi-branch graph is captured), or None
+
+    def __init__(self, device):
+        # under capture only: eagerly the extra events cost more host time than the overlap returns (batch 1: 1.59 -> 1.68 ms)
+        self.on = bool(_SideBranch.enabled and device.type == "cuda" and torch.cuda.is_current_stream_capturing())
+        if self.on:
+            self.cur = torch.cuda.current_stream(device)
+            if _SideBranch.only_from is not None and self.cur.cuda_stream != _SideBranch.only_from:
+                self.on = False
+                return
+            key = (device.index, self.cur.cuda_stream)
+            self.side = _SideBranch._streams.get(key)
+            if self.side is None:
+                self.side = _SideBranch._streams[key] = torch.cuda.Stream(device=device)
+            self.fork = self.cur.record_event()
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_event(self.fork)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+            self.cur.wait_stream(self.side)
+        return False
+
+
 def _dense(t):
     return t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == t.shape[2] * t.shape[3]
 
@@ -410,23 +450,13 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             if amax_image is None or (stats is not None and not stats.usable(amax_image.data_ptr())):
                 stats = stats if stats is not None else ops.ActStats(n, dev, capacity=3)
                 amax_image = stats.measure(image)   # conv_image and conv_fused both read `image`: measured once
+            branch = _SideBranch(dev)   # forks HERE: conv_depth and conv_fused read nothing that conv_image writes
             res = ci_conv.run_split([ops.tensor_src(image, "image", amax_image)], n, oh, ow, out=out_image,
                                     out_absmax=out_amax_image, stats=stats)
             if res is not None:
-                self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth,
-                                                  out_absmax=out_amax_skip)
-                if (self.split_fused and (fused is None or _dense(fused)) and self.proj_depth._slope is not None
-                        and self.conv_fused.split_fused_qualifies(ci, cf)):
-                    # conv_fused's tensor channels on the matrix core too; its backprojection channels, computed once at the
-                    # pixels a stride-2 1x1 conv reads, enter in fp32
-                    xyz = ops.kb_xyz_s2(depth, self.proj_depth.conv.weight, kinv, self.proj_depth._slope)
-                    if self.conv_fused.run_split_fused(image, fused, xyz, n, oh, ow, out_fused, amax_image, amax_fused,
-                                                       out_absmax=out_amax_skip, stats=stats) is not None:
-                        return out_image, out_depth, out_fused
-                srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
-                if fused is not None:
-                    srcs.append(ops.tensor_src(fused, "fused"))
-                self.conv_fused.run(srcs, n, h, w, out=out_fused, out_absmax=out_amax_skip)
+                with branch:
+                    self._depth_and_fused(image, depth, fused, kinv, n, h, w, oh, ow, out_depth, out_fused, ci, cf,
+                                          amax_image, amax_fused, out_amax_skip, stats)
                 return out_image, out_depth, out_fused
         return ops.kb_block(image, depth, coords, kinv, fused,
                             self.conv_image.conv_block[0].packed(), self.conv_depth.conv_block[0].packed(),
@@ -434,6 +464,24 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
                             self.n_filter_image, self.n_filter_depth, self.n_filter_fused,
                             out_image, out_depth, out_fused, self._slope, absmax_image=out_amax_image,
                             absmax_depth=out_amax_skip, absmax_fused=out_amax_skip)
+
+    def _depth_and_fused(self, image, depth, fused, kinv, n, h, w, oh, ow, out_depth, out_fused, ci, cf, amax_image, amax_fused,
+                         out_amax_skip, stats):
+        """conv_depth and conv_fused of the split path (their inputs are synthesized in-kernel: K^-1 [x y 1]^T, backprojection)."""
+        self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth,
+                                          out_absmax=out_amax_skip)
+        if (self.split_fused and (fused is None or _dense(fused)) and self.proj_depth._slope is not None
+                and self.conv_fused.split_fused_qualifies(ci, cf)):
+            # conv_fused's tensor channels on the matrix core too; its backprojection channels, computed once at the
+            # pixels a stride-2 1x1 conv reads, enter in fp32
+            xyz = ops.kb_xyz_s2(depth, self.proj_depth.conv.weight, kinv, self.proj_depth._slope)
+            if self.conv_fused.run_split_fused(image, fused, xyz, n, oh, ow, out_fused, amax_image, amax_fused,
+                                               out_absmax=out_amax_skip, stats=stats) is not None:
+                return
+        srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
+        if fused is not None:
+            srcs.append(ops.tensor_src(fused, "fused"))
+        self.conv_fused.run(srcs, n, h, w, out=out_fused, out_absmax=out_amax_skip)
 
     def forward(self, image, depth, coordinates, fused=None):
         image = image if _dense(image) else image.contiguous()
@@ -656,10 +704,12 @@ class KBNetEncoder(torch.nn.Module):
                 skip = torch.empty((n, fi[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
                 ci_blk = getattr(self, f"conv{level + 1}_image").conv_block[0]
                 cd_blk = getattr(self, f"conv{level + 1}_depth").conv_block[0]
+                branch = _SideBranch(dev)
                 conv_image = ci_blk.run([ops.tensor_src(src, "image", a_src)], n, h, w, out=skip[:, :fi[level]], out_absmax=a_skip,
                                         stats=stats)
-                conv_depth = cd_blk.run([ops.tensor_src(conv_depth, "depth", amax_skip)], n, h, w, out=skip[:, fi[level]:],
-                                        out_absmax=a_skip, stats=stats)
+                with branch:
+                    conv_depth = cd_blk.run([ops.tensor_src(conv_depth, "depth", amax_skip)], n, h, w, out=skip[:, fi[level]:],
+                                            out_absmax=a_skip, stats=stats)
                 conv_fused = None
                 amax_image = a_skip
             amax_skip = a_skip
@@ -670,10 +720,12 @@ class KBNetEncoder(torch.nn.Module):
         latent = torch.empty((n, fi[4] + fd[4], oh, ow), device=dev, dtype=torch.float32)
         amax_latent = stats.new()
         src, a_src = (conv_fused, amax_skip) if conv_fused is not None else (conv_image, amax_image)
+        branch = _SideBranch(dev)   # the two convs of level 4 are independent
         self.conv5_image.conv_block[0].run([ops.tensor_src(src, "image", a_src)], n, h, w, out=latent[:, :fi[4]],
                                            out_absmax=amax_latent, stats=stats)
-        self.conv5_depth.conv_block[0].run([ops.tensor_src(conv_depth, "depth", amax_skip)], n, h, w, out=latent[:, fi[4]:],
-                                           out_absmax=amax_latent, stats=stats)
+        with branch:
+            self.conv5_depth.conv_block[0].run([ops.tensor_src(conv_depth, "depth", amax_skip)], n, h, w, out=latent[:, fi[4]:],
+                                               out_absmax=amax_latent, stats=stats)
         return latent, skips, amax_latent, amax_skips
 
 
@@ -835,14 +887,21 @@ class GraphedForward:
                 cur = torch.cuda.current_stream()
                 h, w = self.static_in[1].shape[-2:]
                 self.static_out = torch.empty((n, 1, h, w), device=self.static_in[0].device, dtype=torch.float32)
-                for s in self._streams:
-                    s.wait_stream(cur)
-                for i, s in enumerate(self._streams):   # every branch writes its frames of the one output tensor
-                    with torch.cuda.stream(s):
-                        model.forward(*parts[i + 1], out=self.static_out[(i + 1) * per:(i + 2) * per])
-                model.forward(*parts[0], out=self.static_out[0:per])
-                for s in self._streams:
-                    cur.wait_stream(s)
+                # a fork inside a forked branch (and any wait between two forked streams) crashes hipStreamEndCapture on
+                # ROCm 7.2 (tools/probe/fork_capture_bisect.py), and forking only the capturing stream's sub-batch measured no
+                # gain (2795-2812 vs 2816-2845 frames/s): the per-level side branches stay off under sub-batch branches
+                _SideBranch.only_from = 0
+                try:
+                    for s in self._streams:
+                        s.wait_stream(cur)
+                    for i, s in enumerate(self._streams):   # every branch writes its frames of the one output tensor
+                        with torch.cuda.stream(s):
+                            model.forward(*parts[i + 1], out=self.static_out[(i + 1) * per:(i + 2) * per])
+                    model.forward(*parts[0], out=self.static_out[0:per])
+                    for s in self._streams:
+                        cur.wait_stream(s)
+                finally:
+                    _SideBranch.only_from = None
 
     def __call__(self, image, sparse_depth, validity_map_depth, intrinsics):
         with torch.cuda.device(self.static_out.device):

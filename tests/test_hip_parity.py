@@ -1187,6 +1187,24 @@ def test_graph_replay_with_concurrent_branches(dev):
         m.forward(*a, out=torch.zeros(4, 1, 64, 90, device=dev))
 
 
+def test_graph_replay_with_level_side_branches(dev):
+    """A single-branch graph (batches below 4 frames) forks the independent convs of an encoder level -- conv_depth and
+    conv_fused beside conv_image, conv5_depth beside conv5_image -- onto a side stream inside the capture
+    (modules._SideBranch): same bits as the eager forward, which keeps one stream, and the forks really happened."""
+    cfg = kb.kitti_config()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.3))
+    a = to(dev, *kb.synthetic.make_frames(2, 96, 160, "kitti", seed=5))
+    b = to(dev, *kb.synthetic.make_frames(2, 96, 160, "kitti", seed=6))
+    eager_a, eager_b = m.forward(*a).clone(), m.forward(*b).clone()
+    kb.modules._SideBranch._streams.clear()
+    replay = m.capture(*a)
+    assert replay.branches == 1 and len(kb.modules._SideBranch._streams) == 1
+    assert torch.equal(replay(*a), eager_a)
+    assert torch.equal(replay(*b), eager_b)
+    assert torch.equal(replay(*a), eager_a)
+
+
 def test_mixed_shape_stream_two_weight_sets(dev):
     """BASELINE.json config 4 in miniature: an interleaved stream of VOID 480x640, NYUv2 416x576 (both on
     the VOID preset) and KITTI 352x1216 frames with per-frame intrinsics, two weight sets resident, one
