@@ -13,7 +13,8 @@ timeout 600 python $R/bench.py < /dev/null > $O/${TAG}_bench.json 2> $O/${TAG}_b
 timeout 300 python $R/bench.py --branches 1 --no-cpu-baseline --no-void --no-side-batch --no-fp32-mfma --no-bf16 < /dev/null > /dev/null 2>&1   # whole-batch shapes into the cache
 for mode in "" "--branches 1"; do
   sfx=$( [ -z "$mode" ] && echo "" || echo "_branches1" )
-  rm -rf /tmp/kbn_prof; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kbn_prof -o p -- \
+  # the whole-batch pass is the per-launch table: one kernel at a time (no level side branches in its single-branch graph)
+  rm -rf /tmp/kbn_prof; KBN_NO_OVERLAP=$( [ -z "$mode" ] && echo 0 || echo 1 ) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kbn_prof -o p -- \
       python $R/bench.py $mode --no-cpu-baseline --no-void --no-side-batch --no-fp32-mfma --no-bf16 < /dev/null > $O/${TAG}_prof$sfx.log 2>&1
   cp $(find /tmp/kbn_prof -name "p_kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats$sfx.csv
 done
