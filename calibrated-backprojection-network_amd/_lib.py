@@ -18,10 +18,10 @@ LIB_PATH = os.path.join(HERE, "libkbnet_hip.so")
 
 KBN_OK = 0
 KBN_ERR_UNSUPPORTED = -2
-KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ = 0, 1, 2
+KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ, KBN_SRC_PAIR = 0, 1, 2, 3
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
 KBN_MAX_SRC = 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class KbnError(RuntimeError):
@@ -43,6 +43,7 @@ class ConvSrc(C.Structure):
         ("coordinates_batch_stride", C.c_longlong),
         ("kinv", C.c_void_p),
         ("absmax", C.c_void_p),
+        ("scale", C.c_void_p),
     ]
 
 
@@ -87,7 +88,7 @@ SIGNATURES = {
     "kbn_absmax_frames": (_I, [_P, _L, _I, _L, _P, _P]),
     "kbn_conv3x3_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_conv3x3_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
-    "kbn_conv3x3_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "kbn_conv3x3_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _L, _P, _P]),
     "kbn_conv1x1s2_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_conv1x1s2_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "kbn_conv1x1s2_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

@@ -63,6 +63,7 @@ typedef _Float16 sph8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sph2 __attribute__((ext_vector_type(2)));
 typedef float spf16 __attribute__((ext_vector_type(16)));
 typedef float spf4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sph4 __attribute__((ext_vector_type(4)));
 
 constexpr int SP_TW = 32, SP_CK = 16, SP_MB = 4, SP_TH = 16, SP_THREADS = 512;
 constexpr int SP_WEXP = 13;                // largest |w 2^e| of a filter in [2^12, 2^13)
@@ -98,6 +99,14 @@ struct SplitConvParams {
     float unscale;              // 2^-k
     const unsigned* amax[2];    // per-frame max |a| slots of the sources (kbn_common.h): k follows the data, frame by frame
     unsigned* out_amax;         // per-frame max |out| slot of the output, or null
+    // producer-written split format ("pair" tensors, see below): source 0 and / or the output as fp16 pairs
+    const _Float16* pair_src;   // source 0 in pair format, or null (then src[0] is an fp32 NCHW tensor)
+    long long pair_src_bstride; // halves per frame
+    const float* pair_src_scale;// per frame: the 2^k its producer applied
+    _Float16* pair_out;         // the output in pair format, or null (then `out`)
+    long long pair_out_bstride;
+    float* pair_out_scale;      // per frame: the 2^k applied here (every workgroup of a frame writes the same value)
+    const float* l1;            // per 16-channel chunk: max over filters of sum |w| (the table behind the packed weights)
     // conv1x1s2_split_kernel: three more input channels taken in fp32 in the epilogue (the KB block's backprojection)
     const float* xyz;           // N x 3 x H x W (output size), or null
     long long xyz_bstride;
@@ -139,6 +148,72 @@ __device__ __forceinline__ void sp_act_scale(const SplitConvParams& p, int n, fl
 }
 __device__ __forceinline__ float sp_amax4(float m, const f32x4& v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// PAIR tensors: the producer-written split format.  A consumer that splits its fp32 inputs itself does so once per
+// (input value x halo x filter tile of the consumer) -- 2.4 to 4.8 times per value in the decoder -- on the vector ALU,
+// beside the MFMAs it feeds (staging ablation in DESIGN.md: 10-13 % of the decoder kernels).  A producer that knows its
+// output is only read by split-operand kernels writes the two fp16 terms itself, once, in the layout the consumers
+// stage: per frame [k-group = channel / 8][term h1 | h2][H * W + 1 pixels][8 channels] fp16 -- the same 4 bytes per
+// value as fp32 -- and a consumer's staging is then one 16-byte LDS-DMA per pixel, k-group and term, no vector ALU
+// work and no staging registers.  The extra granule at the end of every plane is ZERO (written by the producer): the
+// per-lane DMA offset of a halo pixel outside the map points there.
+//   The 2^k of a pair tensor is fixed by its producer BEFORE it has seen its output: from the bound
+// |out| <= sum over sources (max |a_s| of the frame, from the source's slot) x (sum over the source's 16-channel chunks
+// of max over filters of sum |w|), the table `l1` behind the packed weights), placed in [2^14, 2^15) like the measured
+// maxima of sp_act_scale.  The bound overshoots the true maximum by a few binades (never accumulating over layers: every
+// layer starts from the MEASURED maxima of its inputs), and a window up to 2^16 too high costs nothing (the terms keep
+// 22 bits down to 2^-29 of the window, tests/test_split_math_cpu.py).  Every workgroup of a frame computes the same k
+// and writes it to the tensor's per-frame scale slot; consumers read it there.  With two sources in different formats
+// the accumulators are rescaled by the exact power of two between the two windows when the K loop changes source.
+__host__ __device__ constexpr long long pair_plane_halves(int h, int w) { return ((long long)h * w + 1) * 8; }
+
+__device__ __forceinline__ float sp_scale_of_bound(float bound) {   // 2^k with bound 2^k in [2^14, 2^15); finite for 0 / Inf / NaN
+    int k = 14 + 127 - (int)(__float_as_uint(bound) >> 23 & 255u);
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return __uint_as_float((unsigned)(127 + k) << 23);
+}
+// the 2^k of this launch's pair output for frame n (wave-uniform: scalar loads)
+__device__ __forceinline__ float sp_pair_out_scale(const SplitConvParams& p, int n) {
+    const int nchunks = p.Cin / SP_CK, n0 = p.nsrc > 1 ? p.srcC[0] / SP_CK : nchunks;
+    float w0 = 0.f, w1 = 0.f;
+    for (int c = 0; c < n0; ++c) w0 += p.l1[c];
+    for (int c = n0; c < nchunks; ++c) w1 += p.l1[c];
+    float bound = __uint_as_float(p.amax[0][n]) * w0;
+    if (p.nsrc > 1) bound += __uint_as_float(p.amax[1][n]) * w1;
+    return sp_scale_of_bound(bound);
+}
+// window of ONE source from its slot (the other source of the launch is a pair tensor with a scale of its own)
+__device__ __forceinline__ void sp_act_scale_of(const SplitConvParams& p, int s, int n, float& prescale, float& unscale) {
+    prescale = p.prescale;
+    unscale = p.unscale;
+    if (p.amax[s]) {
+        int k = 14 + 127 - (int)(p.amax[s][n] >> 23);
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        prescale = __uint_as_float((unsigned)(127 + k) << 23);
+        unscale = __uint_as_float((unsigned)(127 - k) << 23);
+    }
+}
+// Halves of two granules -> one whole granule per lane.  In the pair epilogues lane (pixel, g = lane >> 5) holds channels
+// 4 g .. 4 g + 3 of every k-group of its 32 filters; `a` is its piece of k-group q, `b` of k-group q + 1.  One
+// v_permlane32_swap per dword hands lanes 0-31 the whole granule q and lanes 32-63 the whole granule q + 1: 16-byte stores.
+typedef unsigned spu2 __attribute__((ext_vector_type(2)));
+typedef unsigned spu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ spu4 sp_pair_exchange(const sph4& a, const sph4& b) {
+    const spu2 A = __builtin_bit_cast(spu2, a), B = __builtin_bit_cast(spu2, b);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(A[0], B[0], false, false);   // {A.lo | B.lo , A.hi | B.hi} by lane half
+    const auto r1 = __builtin_amdgcn_permlane32_swap(A[1], B[1], false, false);
+    return (spu4){r0[0], r1[0], r0[1], r1[1]};
+}
+// two-term split of 4 floats already in window units (t = a 2^k)
+__device__ __forceinline__ void sp_split4(const f32x4& t, sph4& h1, sph4& h2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 c1 = (_Float16)t[j];
+        h1[j] = c1;
+        h2[j] = (_Float16)((t[j] - (float)c1) * 2048.f);
+    }
 }
 
 // pass 1 of the pack: per-filter exponent; inv_scale[oc] = 2^-e
@@ -192,6 +267,27 @@ __global__ void pack_split_kernel(const float* __restrict__ w, const float* __re
 
 // max |x| of each of n frames of `per_frame` contiguous floats (frames batch_stride apart) into slots[frame] (integer
 // atomic max of the bit patterns).  HBM bound: 16-byte loads when the frames are 16-byte aligned, four in flight per thread.
+// the bound table of the pair format: l1[c] = max over filters of sum |w| over the 16 input channels of chunk c (all taps);
+// one block per chunk.  For the folded up-convs the unfolded 3 x 3 weights bound the folded ones (triangle inequality).
+__global__ __launch_bounds__(256) void split_l1_kernel(const float* __restrict__ w, float* __restrict__ l1, int OC, int Cin, int taps) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float m = 0.f;
+    for (int oc = threadIdx.x; oc < OC; oc += 256) {
+        const float* wp = w + ((long long)oc * Cin + c * SP_CK) * taps;
+        float sum = 0.f;
+        for (int e = 0; e < SP_CK * taps; ++e) sum += fabsf(wp[e]);
+        m = fmaxf(m, sum);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) l1[c] = red[0];
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void absmax_frames_kernel(const float* __restrict__ x, long long batch_stride, long long per_frame,
                                                             unsigned* __restrict__ slots) {
@@ -238,9 +334,13 @@ __device__ __forceinline__ void sp_wait_b(f32x4 (&b)[NBX][2]) {   // vmcnt(N), t
 // access of chunk c+1 is issued at the start of chunk c and awaited once, in front of the barrier that ends chunk c --
 // no vmcnt wait sits between MFMAs (waves retire their loads in order: with the weights fetched per tap into registers,
 // the tap-2 wait also had to wait for the next chunk's inputs, +28 % on the decoder's concat convs).
-template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2>   // NBW: 32-filter blocks per wave
+// PIN0: source 0 is a pair tensor (its chunks are staged by LDS-DMA; a second, fp32 source is split here as before and the
+// accumulators change window between the two); POUT: the output is written as a pair tensor (MFMA operands swapped: a
+// lane's accumulator registers run over the FILTERS of one pixel).  Both: MODE 0 with the weights through LDS.
+template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2, bool PIN0 = false, bool POUT = false>   // NBW: 32-filter blocks per wave
 __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
     static_assert(APART, "the two small terms share the scale 2^11 and an accumulator of their own");
+    static_assert(!(PIN0 || POUT) || (MODE == 0 && BLDS), "pair tensors: the concat kernel");
     using G = SpGeom<MODE>;
     constexpr bool UP = G::UP, S2 = G::S2;
     constexpr int NB = NBW, FG = 8 / RG;
@@ -267,8 +367,16 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / SP_CK;
-    float prescale, unscale;
-    sp_act_scale(p, n, prescale, unscale);
+    float prescale, unscale;      // window of the source(s) split here, and what undoes the window the accumulators end in
+    float acc_rescale = 1.f;      // PIN0 with a second source: 2^(k1 - k0), applied when the K loop changes source
+    if constexpr (PIN0) {
+        const float unscale0 = 1.f / p.pair_src_scale[n];
+        prescale = 0.f; unscale = unscale0;
+        if (p.nsrc > 1) {
+            sp_act_scale_of(p, 1, n, prescale, unscale);
+            acc_rescale = prescale * unscale0;
+        }
+    } else sp_act_scale(p, n, prescale, unscale);
 
     // ---- input staging: waves 0-3 take k-group 0 (channels 0-7 of the chunk), waves 4-7 k-group 1; a thread owns <= PR pixels
     const int kg_st = wave >> 2, t256 = tid & 255;
@@ -376,7 +484,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                     if (CHK && oy0 + MB * rg + mb0 + m >= H) continue;
                     if (CHK && !(nb == 0 ? nb0_live : nb1_live)) continue;
                     spf16& c = (APART && t > 0) ? lo[mb0 + m][nb] : acc[mb0 + m][nb];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][TA[t]], b[nb][TBP[t]], c, 0, 0, 0);
+                    c = POUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[nb][TBP[t]], a[m][TA[t]], c, 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][TA[t]], b[nb][TBP[t]], c, 0, 0, 0);
                 }
     };
     const bool padded_tile = !KBN_SPLIT_STRAIGHT || oy0 + G::TH > H || (nt + 1) * NT - 32 >= p.OC;   // workgroup-uniform
@@ -399,13 +508,44 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             }
         };
         const unsigned char* const bptr = smem + 2 * G::A_BYTES + boff;
-        auto body = [&](int c, auto more_tag, auto chk_tag) {
-            constexpr bool MORE = decltype(more_tag)::value;
+        // pair source: a staged chunk is 4 planes (term, k-group) x NPIX granules; wave-wide DMA id = plane * NR + round, wave w
+        // issues ids w, w + 8, ..; a halo pixel outside the map reads the plane's zero granule
+        constexpr int NR = (NPIX + 63) / 64, NDMA = 4 * NR, DPW = NDMA / 8;
+        static_assert(NDMA % 8 == 0, "the same number of DMAs in every wave");
+        unsigned dvoff[PIN0 ? DPW : 1];
+        if constexpr (PIN0) {
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) {
+                const int pix = ((wave + 8 * i) % NR) * 64 + lane;
+                const int r = pix / COLS, cc = pix - r * COLS;
+                const int Y = oy0 - 1 + r, X = ox0 - 1 + cc;
+                dvoff[i] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (unsigned)(Y * sW + X) * 16u : (unsigned)(sH * sW) * 16u;
+            }
+        }
+        const long long pplane = pair_plane_halves(sH, sW);
+        auto dma_chunk = [&](int buf, int chunk) __attribute__((always_inline)) {
+            const _Float16* pn = p.pair_src + (long long)n * p.pair_src_bstride + (long long)(2 * chunk) * 2 * pplane;
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) {
+                const int id = wave + 8 * i, plane = id / NR, j = id - plane * NR;
+                const int t = plane >> 1, kgl = plane & 1;
+                const unsigned long long mask = (j == NR - 1 && (NPIX & 63)) ? ((1ull << (NPIX & 63)) - 1) : ~0ull;
+                lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kgl * 2 + t) * pplane), dvoff[i],
+                             lds0 + (unsigned)(buf * G::A_BYTES + t * G::A_PART + (kgl * NPIX + j * 64) * 16), mask);
+            }
+        };
+        // next_tag: what follows chunk c -- 0 nothing, 1 a chunk of an fp32 source (fetched, then split), 2 a chunk of the
+        // pair source (LDS-DMA).  One body per kind: an asm fetch and its wait stay in straight-line code.
+        auto body = [&](int c_in, auto next_tag, auto chk_tag) __attribute__((always_inline)) {
+            const int c = PIN0 ? __builtin_amdgcn_readfirstlane(c_in) : c_in;   // the chunk index is workgroup-uniform: keep its pointers in SGPRs
+            constexpr int NEXT = decltype(next_tag)::value;
+            constexpr bool MORE = NEXT != 0;
             const int abuf = (c & 1) * G::A_BYTES;
             const unsigned char* B = bptr + (c & 1) * B_CHUNK;
             if (MORE) {
                 stage_b((c & 1) ^ 1, c + 1);
-                load_chunk(c + 1);
+                if constexpr (NEXT == 2) dma_chunk((c & 1) ^ 1, c + 1);
+                else load_chunk(c + 1);
             }
             load_a(aq[0], abuf, 0);
             sph8 bw[NB][2];
@@ -436,25 +576,50 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                 __builtin_amdgcn_s_setprio(0);
 #endif
                 __builtin_amdgcn_sched_barrier(0x8);
-                if (MORE && tap >= 5) {   // split + write one staging round per group: the vector ALU works beside the MFMAs
+                if (NEXT == 1 && tap >= 5) {   // split + write one staging round per group: the vector ALU works beside the MFMAs
                     const int u = (tap - 5) * GPT + gi;   // (staggering the two waves of a SIMD -- taps 2-4 / 5-7 -- measured slower)
                     if (u < PR) store_round((c & 1) ^ 1, u);
                 }
             }
             __syncthreads();
         };
-        load_chunk(0);
+        if constexpr (PIN0) dma_chunk(0, 0);
+        else load_chunk(0);
         stage_b(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!PIN0) {
 #pragma unroll
-        for (int u = 0; u < PR; ++u) store_round(0, u);
+            for (int u = 0; u < PR; ++u) store_round(0, u);
+        }
         __syncthreads();
 #if KBN_SPLIT_PRIO == 2
         if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the younger half of the workgroup (cdna_hip_programming.md T5, static form)
 #endif
+        using Next0 = std::integral_constant<int, 0>;
+        using Next1 = std::integral_constant<int, 1>;
+        using Next2 = std::integral_constant<int, 2>;
         auto k_loop = [&](auto chk_tag) {
-            for (int c = 0; c + 1 < nchunks; ++c) body(c, std::true_type{}, chk_tag);
-            body(nchunks - 1, std::false_type{}, chk_tag);
+            if constexpr (PIN0) {
+                // two sources, at least two chunks each (the launcher checks): loops that always run keep the 128 accumulator
+                // registers out of bypass edges (with zero-trip loops the allocator spilled 460 registers)
+                const int n0 = p.srcC[0] / SP_CK;   // chunks of the pair source
+                int c = 0;
+                do body(c, Next2{}, chk_tag); while (++c < n0 - 1);
+                body(n0 - 1, Next1{}, chk_tag);
+                // the accumulators hold sums in the pair source's window: move them to the window of the source split here
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { acc[mb][nb][i] *= acc_rescale; lo[mb][nb][i] *= acc_rescale; }
+                c = n0;
+                do body(c, Next1{}, chk_tag); while (++c < nchunks - 1);
+                body(nchunks - 1, Next0{}, chk_tag);
+            } else {
+                for (int c = 0; c + 1 < nchunks; ++c) body(c, Next1{}, chk_tag);
+                body(nchunks - 1, Next0{}, chk_tag);
+            }
         };
         if (padded_tile) k_loop(std::true_type{});
         else k_loop(std::false_type{});
@@ -520,12 +685,62 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     else k_loop(std::false_type{});
     }
 
+    const float slope = p.act ? p.slope : 1.f;
+    float amax = 0.f;   // max |stored value| of this thread, folded into the output's slot
+    if constexpr (POUT) {
+        // ---- pair epilogue: acc[mb][nb][i]: pixel x = lm of row MB rg + mb, filter fg * 32 NB + nb * 32 + 8 (i / 4) + 4 g + (i % 4):
+        // a lane holds channels 4 g .. 4 g + 3 of k-group (filter block) / 8 + i / 4 -- half a granule
+        const float ps_out = sp_pair_out_scale(p, n);
+        const long long oph = pair_plane_halves(H, W);
+        _Float16* const pn = p.pair_out + (long long)n * p.pair_out_bstride;
+        if (tid == 0) p.pair_out_scale[n] = ps_out;
+        if (tx == 0 && ty == 0 && wave == 0 && lane < NT / 4) {   // the zero granules of this filter tile's NT / 8 k-groups x 2 terms
+            const int kgz = nt * (NT / 8) + (lane >> 1);
+            if (kgz * 8 < p.OC)
+                *reinterpret_cast<f32x4*>(pn + (long long)(kgz * 2 + (lane & 1)) * oph + (long long)H * W * 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int X = ox0 + lm;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {     // k-groups 2 qp, 2 qp + 1 of the block: after the exchange this lane stores k-group 2 qp + g whole
+                const int kg0 = (nt * NT + fg * 32 * NB + nb * 32) / 8 + 2 * qp;
+                if (kg0 * 8 >= p.OC) continue;   // wave-uniform; pair outputs have whole k-groups (OC % 8 == 0)
+                const f32x4 invA = *reinterpret_cast<const f32x4*>(p.inv_scale + kg0 * 8 + 4 * g) * unscale;
+                const f32x4 invB = *reinterpret_cast<const f32x4*>(p.inv_scale + kg0 * 8 + 8 + 4 * g) * unscale;   // the table is padded to whole tiles
+                const bool mine = (kg0 + g) * 8 < p.OC;
+                _Float16* const k0 = pn + (long long)((kg0 + g) * 2) * oph;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int Y = oy0 + MB * rg + mb;
+                    if (Y >= H) continue;        // wave-uniform
+                    f32x4 va, vb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ta = __builtin_fmaf(lo[mb][nb][qp * 8 + j], 0.00048828125f, acc[mb][nb][qp * 8 + j]) * invA[j];
+                        const float tb = __builtin_fmaf(lo[mb][nb][qp * 8 + 4 + j], 0.00048828125f, acc[mb][nb][qp * 8 + 4 + j]) * invB[j];
+                        va[j] = ta > 0.f ? ta : ta * slope;
+                        vb[j] = tb > 0.f ? tb : tb * slope;
+                    }
+                    if (X < W) amax = sp_amax4(sp_amax4(amax, va), vb);
+                    sph4 a1, a2, b1, b2;
+                    sp_split4(va * ps_out, a1, a2);
+                    sp_split4(vb * ps_out, b1, b2);
+                    const spu4 g1 = sp_pair_exchange(a1, b1), g2 = sp_pair_exchange(a2, b2);   // every lane takes part
+                    if (X < W && mine) {
+                        const long long o = ((long long)Y * W + X) * 8;
+                        *reinterpret_cast<spu4*>(k0 + o) = g1;
+                        *reinterpret_cast<spu4*>(k0 + oph + o) = g2;
+                    }
+                }
+            }
+        if (p.out_amax) absmax_commit(p.out_amax + n, amax);
+        return;
+    }
     // ---- epilogue: acc[mb][nb][i]: pixel x = 8 (i / 4) + 4 g + (i % 4) of row 4 rg + mb, filter fg * 32 NB + nb * 32 + lm
     const long long oplane = (long long)H * W;
     float* outn = p.out + (long long)n * p.out_bstride;
-    const float slope = p.act ? p.slope : 1.f;
     const bool vec4 = p.vec4 != 0;
-    float amax = 0.f;   // max |stored value| of this thread, folded into the output's slot
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int oc = nt * NT + fg * 32 * NB + nb * 32 + lm;
@@ -1168,14 +1383,18 @@ __global__ void uf16_pack_kernel(const float* __restrict__ w, const float* __res
 // two barriers, two workgroups per CU -- with only Cin / 32 = 2 chunks per tile the first fetch and the stores are most
 // of a workgroup's life, and a second resident workgroup multiplies meanwhile: 700 -> 616 us for deconv0's up-conv.
 // (Measured and not kept, DESIGN.md round 3: persistent workgroups, with the weights from L2 as here or resident in LDS.)
-template <int NW>
+template <int NW, bool PIN>   // PIN: the input is a pair tensor, staged by LDS-DMA (see upconv2x_split64_kernel)
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_kernel(const SplitConvParams p) {
     static_assert(NW == 8 || NW == 4, "8 waves (16-row tiles) or 4 waves (8-row tiles)");
     constexpr bool DB = NW == 8;
     constexpr int ROWS = 2 * NW, TPG = 16 * NW;                        // low-resolution rows per tile; threads per k-group in staging
     constexpr int COLS = 34, NPIX = (ROWS + 2) * COLS, KG = 4;
     constexpr int A_PART = KG * NPIX * 16, A_BYTES = 2 * A_PART;      // [part][k-group][pixel][8 fp16]
-    constexpr int PR = (NPIX + TPG - 1) / TPG, NA_ALL = PR * 8;       // staging rounds of a quarter of the threads (one k-group each)
+    constexpr int PR = (NPIX + TPG - 1) / TPG;                         // staging rounds of a quarter of the threads (one k-group each)
+    // pair input: a staged chunk is 8 planes (term, k-group) x NPIX granules; wave-wide DMA id = plane * NR + round
+    constexpr int NR = (NPIX + 63) / 64, NDMA = 2 * KG * NR, DPW = NDMA / NW;
+    static_assert(NDMA % NW == 0, "the same number of DMAs in every wave (the vmcnt arithmetic counts them)");
+    constexpr int NA_ALL = PIN ? DPW : PR * 8;                         // vector-memory operations of a wave per staged chunk
     constexpr int B_ITEM = 2 * KG * U16_NT * 16, NBL = 2, D = 3;      // bytes per weight set; loads per set; sets fetched ahead
     static_assert(D * NBL + NA_ALL < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1196,7 +1415,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / U16_CK;
     float prescale, unscale;
-    sp_act_scale(p, n, prescale, unscale);
+    if constexpr (PIN) { prescale = 0.f; unscale = 1.f / p.pair_src_scale[n]; }
+    else sp_act_scale(p, n, prescale, unscale);
 
     const int kg_st = wave / (NW / 4), t128 = tid & (TPG - 1);         // staging: NW / 4 waves per k-group
     int goff[PR];
@@ -1237,6 +1457,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
             *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
         }
     };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+    unsigned dvoff[PIN ? DPW : 1];
+    if constexpr (PIN) {
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int pix = ((wave + NW * i) % NR) * 64 + lane;
+            const int r = pix / COLS, c = pix - r * COLS;
+            const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
+            dvoff[i] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (unsigned)(Y * sW + X) * 16u : (unsigned)(sH * sW) * 16u;
+        }
+    }
+    const long long pplane = pair_plane_halves(sH, sW);
+    auto dma_chunk = [&](int buf, int chunk) {
+        const _Float16* pn = p.pair_src + (long long)n * p.pair_src_bstride + (long long)(KG * chunk) * 2 * pplane;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int id = wave + NW * i, plane = id / NR, j = id - plane * NR;
+            const int t = plane / KG, kgl = plane - t * KG;
+            const unsigned long long mask = (j == NR - 1 && (NPIX & 63)) ? ((1ull << (NPIX & 63)) - 1) : ~0ull;
+            lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kgl * 2 + t) * pplane), dvoff[i],
+                         lds0 + (unsigned)(buf * A_BYTES + t * A_PART + (kgl * NPIX + j * 64) * 16), mask);
+        }
+    };
     const unsigned boff = (unsigned)(lane * 16);                       // [k-group kq][filter lp][8 channels]
     auto load_b = [&](f32x4 (&b)[2], int chunk, int item) {
         const unsigned char* base = wp_nt + ((long long)chunk * UF_ITEMS + item) * B_ITEM;
@@ -1266,7 +1509,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
     f32x4 bq[4][2];       // weight sets in flight: set `it` lives in bq[it % 4]
     auto chunk_body = [&](int c, auto more_tag, auto chk_tag) {
         constexpr bool MORE = decltype(more_tag)::value, CHK = decltype(chk_tag)::value;
-        constexpr int NA = MORE ? NA_ALL : 0;
+        constexpr int NA = (MORE && (DB || !PIN)) ? NA_ALL : 0;   // one buffer + pair input: the DMA follows the chunk's barrier
         const int abuf = DB ? (c & 1) * A_BYTES : 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) load_arow(abuf, r, 0);
@@ -1285,7 +1528,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
             f32x4 (&bc)[2] = bq[it % 4];
             if (it + D < UF_ITEMS) load_b(bq[(it + D) % 4], c, it + D);
             else if (MORE) load_b(bq[(it + D) % 4], c + 1, it + D - UF_ITEMS);
-            if (it == 0 && MORE) load_chunk(c + 1);
+            if (it == 0 && MORE) {
+                if constexpr (!PIN) load_chunk(c + 1);
+                else if (DB) dma_chunk((c & 1) ^ 1, c + 1);   // the other buffer was last read a chunk (a barrier) ago
+            }
             // outstanding, oldest first: b(it) b(it+1) b(it+2) [b(it+3) | inputs in issue order]
             if (it <= D) uf_wait_b<D * NBL + NA>(bc);
             else if (MORE || it + D < UF_ITEMS) uf_wait_b<D * NBL>(bc);
@@ -1307,20 +1553,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
                                                                                   acc[mb][t.py][t.px], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (DB && MORE && it > D + 1 && it - D - 2 < PR) store_round((c & 1) ^ 1, it - D - 2);   // the wait of set D+1 covered the inputs
+            if (!PIN && DB && MORE && it > D + 1 && it - D - 2 < PR) store_round((c & 1) ^ 1, it - D - 2);   // the wait of set D+1 covered the inputs
         }
         __syncthreads();
         if (!DB && MORE) {       // one buffer: every wave has read its last fragment of chunk c; the inputs arrived under set D+1's wait
+            if constexpr (PIN) {
+                // the first weight sets of chunk c+1 (fetched above, MORE) are in flight too: vmcnt(0) covers both
+                dma_chunk(0, c + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
 #pragma unroll
-            for (int u = 0; u < PR; ++u) store_round(0, u);
+                for (int u = 0; u < PR; ++u) store_round(0, u);
+            }
             __syncthreads();
         }
     };
 
-    load_chunk(0);
+    if constexpr (PIN) dma_chunk(0, 0);
+    else load_chunk(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!PIN) {
 #pragma unroll
-    for (int u = 0; u < PR; ++u) store_round(0, u);
+        for (int u = 0; u < PR; ++u) store_round(0, u);
+    }
     __syncthreads();
     auto k_loop = [&](auto chk_tag) {
         // the first weight fetches are issued INSIDE the variant that awaits them: a register copy at the branch between an
@@ -1403,6 +1658,10 @@ __global__ void uf64_pack_kernel(const float* __restrict__ w, const float* __res
     packed[e] = h;
 }
 
+// PIN: the input is a pair tensor (staged by LDS-DMA, nothing to split); POUT: the output is written as one (the MFMA
+// operands swap roles, so that a lane's accumulator registers run over FILTERS of one pixel: four consecutive channels
+// = half a granule per store).
+template <bool PIN, bool POUT>
 __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const SplitConvParams p) {
     constexpr int TH = 8, ROWS = TH + 2, COLS = 34, NPIX = ROWS * COLS, NB = 2;
     constexpr int A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART, PR = (NPIX + 255) / 256;
@@ -1424,7 +1683,8 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
     const long long plane = (long long)sH * sW;
     const int nchunks = p.Cin / SP_CK;
     float prescale, unscale;
-    sp_act_scale(p, n, prescale, unscale);
+    if constexpr (PIN) { prescale = 0.f; unscale = 1.f / p.pair_src_scale[n]; }
+    else sp_act_scale(p, n, prescale, unscale);
 
     const int kg_st = rg >> 2, t256 = tid & 255;
     int goff[PR];
@@ -1467,6 +1727,32 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
     };
     // weights: half chunks (eight sets, 32 KiB) by LDS-DMA into two buffers behind the A buffers
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+    // pair input: a staged chunk is 4 planes (term, k-group) x NPIX granules; wave-wide DMA id = plane * NR + round, wave rg
+    // issues ids rg, rg + 8, ..; a halo pixel outside the map reads the plane's zero granule
+    constexpr int NR = (NPIX + 63) / 64, NDMA = 4 * NR, DPW = NDMA / 8;
+    static_assert(NDMA % 8 == 0, "the same number of DMAs in every wave");
+    unsigned dvoff[DPW];
+    if constexpr (PIN) {
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int pix = ((rg + 8 * i) % NR) * 64 + lane;
+            const int r = pix / COLS, c = pix - r * COLS;
+            const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
+            dvoff[i] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (unsigned)(Y * sW + X) * 16u : (unsigned)(sH * sW) * 16u;
+        }
+    }
+    const long long pplane = pair_plane_halves(sH, sW);
+    auto dma_chunk = [&](int buf, int chunk) {
+        const _Float16* pn = p.pair_src + (long long)n * p.pair_src_bstride + (long long)(2 * chunk) * 2 * pplane;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int id = rg + 8 * i, plane = id / NR, j = id - plane * NR;
+            const int t = plane >> 1, kgl = plane & 1;
+            const unsigned long long mask = (j == NR - 1 && (NPIX & 63)) ? ((1ull << (NPIX & 63)) - 1) : ~0ull;
+            lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kgl * 2 + t) * pplane), dvoff[i],
+                         lds0 + (unsigned)(buf * A_BYTES + t * A_PART + (kgl * NPIX + j * 64) * 16), mask);
+        }
+    };
     auto stage_half = [&](int hbuf, int chunk, int half) {
         const float* src = reinterpret_cast<const float*>(wp_nt + ((long long)chunk * UF_ITEMS + half * HALF) * B_ITEM);
         const unsigned dst = lds0 + (unsigned)(2 * A_BYTES + hbuf * B_HALF);
@@ -1505,7 +1791,10 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
         // the other weight buffer was last read in the previous half (a barrier ago): refill it
         if (HF == 0) {
             stage_half(1, c, 1);
-            if (MORE) load_chunk(c + 1);
+            if (MORE) {
+                if constexpr (PIN) dma_chunk((c & 1) ^ 1, c + 1);   // the other buffer was last read a chunk (two barriers) ago
+                else load_chunk(c + 1);
+            }
             load_arow(abuf, 0, 0);
         } else if (MORE) {
             stage_half(0, c + 1, 0);
@@ -1539,7 +1828,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
                 bw[nb][1] = bwq[ih & 1][nb][1];
                 bw[nb][2] = bw[nb][0] * (_Float16)0.00048828125f;   // w1 2^-11
             }
-            if (HF == 0 && MORE && ih == WAIT_IT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's inputs (and this chunk's second half of weights)
+            if (!PIN && HF == 0 && MORE && ih == WAIT_IT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's inputs (and this chunk's second half of weights)
             __builtin_amdgcn_sched_barrier(0);
             if (row_live) {
                 constexpr int TA[3] = {0, 0, 1};
@@ -1547,20 +1836,24 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        acc[t.py][t.px][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t.s][TA[k]], bw[nb][k], acc[t.py][t.px][nb], 0, 0, 0);
+                        acc[t.py][t.px][nb] = POUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[nb][k], af[t.s][TA[k]], acc[t.py][t.px][nb], 0, 0, 0)
+                                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t.s][TA[k]], bw[nb][k], acc[t.py][t.px][nb], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (HF == 0 && MORE && ih >= WAIT_IT && ih - WAIT_IT < PR) store_round((c & 1) ^ 1, ih - WAIT_IT);
+            if (!PIN && HF == 0 && MORE && ih >= WAIT_IT && ih - WAIT_IT < PR) store_round((c & 1) ^ 1, ih - WAIT_IT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight DMA issued at the top of the half
         __syncthreads();
     };
 
-    load_chunk(0);
+    if constexpr (PIN) dma_chunk(0, 0);
+    else load_chunk(0);
     stage_half(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!PIN) {
 #pragma unroll
-    for (int u = 0; u < PR; ++u) store_round(0, u);
+        for (int u = 0; u < PR; ++u) store_round(0, u);
+    }
     __syncthreads();
     for (int c = 0; c + 1 < nchunks; ++c) {
         half_body(c, std::integral_constant<int, 0>{}, std::true_type{});
@@ -1569,12 +1862,63 @@ __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const S
     half_body(nchunks - 1, std::integral_constant<int, 0>{}, std::false_type{});
     half_body(nchunks - 1, std::integral_constant<int, 1>{}, std::false_type{});
 
+    const float slope = p.act ? p.slope : 1.f;
+    float amax = 0.f;
+    if constexpr (POUT) {
+        // ---- pair epilogue: acc[py][px][nb][i]: low-resolution x = lm, filter nb * 32 + 8 (i / 4) + 4 g + (i % 4): a lane holds
+        // channels 4 g .. 4 g + 3 of k-group (nt 64 + nb 32) / 8 + i / 4 -- half a granule -- of outputs (2 Y + py, 2 x + px)
+        const float ps_out = sp_pair_out_scale(p, n);
+        const long long oph = pair_plane_halves(H, W);
+        _Float16* const pn = p.pair_out + (long long)n * p.pair_out_bstride;
+        if (tid == 0) p.pair_out_scale[n] = ps_out;
+        if (tx == 0 && ty == 0 && rg == 0 && lane < 16) {   // the zero granules of this filter tile's 8 k-groups x 2 terms
+            const int kgz = nt * (U64_NT / 8) + (lane >> 1);
+            if (kgz * 8 < p.OC)
+                *reinterpret_cast<f32x4*>(pn + (long long)(kgz * 2 + (lane & 1)) * oph + (long long)H * W * 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int Y = oy0 + rg, x = ox0 + lm;
+        if (Y >= sH) return;   // wave-uniform
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {     // k-groups 2 qp, 2 qp + 1 of the block: after the exchange this lane stores k-group 2 qp + g whole
+                const int kg0 = nt * (U64_NT / 8) + nb * 4 + 2 * qp;
+                if (kg0 * 8 >= p.OC) continue;   // wave-uniform; pair outputs have whole k-groups (OC % 8 == 0)
+                const f32x4 invA = *reinterpret_cast<const f32x4*>(p.inv_scale + kg0 * 8 + 4 * g) * unscale;
+                const f32x4 invB = *reinterpret_cast<const f32x4*>(p.inv_scale + kg0 * 8 + 8 + 4 * g) * unscale;   // the table is padded to whole tiles
+                const bool mine = (kg0 + g) * 8 < p.OC;
+                _Float16* const k0 = pn + (long long)((kg0 + g) * 2) * oph;
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        f32x4 va, vb;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float ta = acc[py][px][nb][qp * 8 + j] * invA[j];
+                            const float tb = acc[py][px][nb][qp * 8 + 4 + j] * invB[j];
+                            va[j] = ta > 0.f ? ta : ta * slope;
+                            vb[j] = tb > 0.f ? tb : tb * slope;
+                        }
+                        if (x < sW) amax = sp_amax4(sp_amax4(amax, va), vb);
+                        sph4 a1, a2, b1, b2;
+                        sp_split4(va * ps_out, a1, a2);
+                        sp_split4(vb * ps_out, b1, b2);
+                        const spu4 g1 = sp_pair_exchange(a1, b1), g2 = sp_pair_exchange(a2, b2);   // every lane takes part
+                        if (x < sW && mine) {
+                            const long long o = ((long long)(2 * Y + py) * W + 2 * x + px) * 8;
+                            *reinterpret_cast<spu4*>(k0 + o) = g1;
+                            *reinterpret_cast<spu4*>(k0 + oph + o) = g2;
+                        }
+                    }
+            }
+        if (p.out_amax) absmax_commit(p.out_amax + n, amax);
+        return;
+    }
     // ---- epilogue: acc[py][px][nb][i]: low-resolution x = 8 (i / 4) + 4 g + (i % 4), filter nb * 32 + lm; outputs (2 Y + py, 2 x + px)
     const long long oplane = (long long)H * W;
     const int Y = oy0 + rg;
     if (Y >= sH) return;   // wave-uniform: a wave whose row lies below the map stores nothing
-    const float slope = p.act ? p.slope : 1.f;
-    float amax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int oc = nt * U64_NT + nb * 32 + lm;
@@ -1850,7 +2194,8 @@ size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, 
     using namespace kbn;
     if (out_channels < 1 || in_channels < 1 || (in_channels % SP_CK) != 0 || mode < 0 || mode > 3) return 0;
     const int nt = split_nt(mode, out_channels, in_channels), tiles = ceil_div(out_channels, nt);
-    return (size_t)tiles * nt * 4 + (size_t)tiles * (in_channels / SP_CK) * ((mode == 3 ? UF_ITEMS : 9) * 2 * 2 * nt * 16);   // per 16 channels: [set][part][2 k-groups][nt][8] fp16
+    return (size_t)tiles * nt * 4 + (size_t)tiles * (in_channels / SP_CK) * ((mode == 3 ? UF_ITEMS : 9) * 2 * 2 * nt * 16)   // per 16 channels: [set][part][2 k-groups][nt][8] fp16
+           + (size_t)(in_channels / SP_CK) * 4;                                                                                  // the bound table of the pair format (split_l1_kernel)
 }
 
 int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_channels, int in_channels, int mode,
@@ -1861,7 +2206,10 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
     const int nt = split_nt(mode, out_channels, in_channels), ocpad = ceil_div(out_channels, nt) * nt;
     float* inv = static_cast<float*>(packed);
     _Float16* wp = reinterpret_cast<_Float16*>(inv + ocpad);
-    const long long total = (long long)((bytes - (size_t)ocpad * 4) / 2);
+    const size_t l1_bytes = (size_t)(in_channels / SP_CK) * 4;
+    const long long total = (long long)((bytes - (size_t)ocpad * 4 - l1_bytes) / 2);
+    hipLaunchKernelGGL(split_l1_kernel, dim3(in_channels / SP_CK), dim3(256), 0, (hipStream_t)stream, weight,
+                       reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + bytes - l1_bytes), out_channels, in_channels, 9);
     if (mode == 3) {
         hipLaunchKernelGGL(uf_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels);
         if (uf_narrow(out_channels, in_channels)) {
@@ -1895,26 +2243,41 @@ int kbn_absmax_frames(const float* x, long long batch_stride, int n, long long p
 int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
                               long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
                               int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
-                              kbn_stream_t stream) {
+                              void* pair_out, long long pair_out_batch_stride, float* pair_out_scale, kbn_stream_t stream) {
     using namespace kbn;
     if (act_exponent < -60 || act_exponent > 60) return KBN_ERR_INVALID_ARGUMENT;
-    if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || !out || n < 1 || out_channels < 1 || height < 1 || width < 1)
+    if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || (!out && !pair_out) || n < 1 || out_channels < 1 || height < 1 || width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
     if (mode < 0 || mode > 3) return KBN_ERR_INVALID_ARGUMENT;
     if (knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
-    const bool vec4 = !((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3));
+    const bool vec4 = pair_out || !((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3));
     if (!vec4 && (mode == 1 || mode == 3)) return KBN_ERR_UNSUPPORTED;   // the up-convs only store whole quads
     if ((mode == 1 || mode == 3) && (n_src != 1 || (height & 1) || (width & 1))) return KBN_ERR_UNSUPPORTED;
     SplitConvParams p{};
     int cin = 0;
     for (int s = 0; s < n_src; ++s) {
         const kbn_conv_src& a = srcs[s];
-        if (a.kind != KBN_SRC_TENSOR || !a.data || a.channels < 1 || (a.channels % SP_CK) != 0) return KBN_ERR_UNSUPPORTED;
+        const bool pair = a.kind == KBN_SRC_PAIR;
+        if ((a.kind != KBN_SRC_TENSOR && !pair) || !a.data || a.channels < 1 || (a.channels % SP_CK) != 0) return KBN_ERR_UNSUPPORTED;
         if (s == 0) { p.sH = a.src_height; p.sW = a.src_width; }
         if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
-        p.src[s] = a.data; p.src_bstride[s] = a.batch_stride; p.srcC[s] = a.channels;
+        if (pair) {   // source 0 of the concat conv / the input of a folded up-conv, written by a split-operand producer
+            if (s != 0 || (mode != 0 && mode != 3) || (knob(KNOB_DEBUG) & (16 | 64))) return KBN_ERR_UNSUPPORTED;
+            // the concat kernel's K loop: a pair source beside an fp32 one, at least two 16-channel chunks each
+            if (mode == 0 && (n_src != 2 || a.channels < 2 * SP_CK || srcs[1].kind != KBN_SRC_TENSOR || srcs[1].channels < 2 * SP_CK))
+                return KBN_ERR_UNSUPPORTED;
+            if (!a.scale || (reinterpret_cast<uintptr_t>(a.data) & 15) || (a.batch_stride & 7) ||
+                a.batch_stride < (long long)(a.channels / 8) * 2 * pair_plane_halves(a.src_height, a.src_width))
+                return KBN_ERR_INVALID_ARGUMENT;
+            if ((long long)a.src_height * a.src_width >= 0x0fffffffLL) return KBN_ERR_UNSUPPORTED;   // 32-bit DMA offsets
+            p.pair_src = reinterpret_cast<const _Float16*>(a.data); p.pair_src_bstride = a.batch_stride; p.pair_src_scale = a.scale;
+        } else {
+            p.src[s] = a.data; p.src_bstride[s] = a.batch_stride;
+        }
+        p.srcC[s] = a.channels;
         cin += a.channels;
     }
+    if (p.pair_src && !p.src[0]) { p.src[0] = p.src[1]; p.src_bstride[0] = p.src_bstride[1]; }   // never dereferenced: the kernels stage source 0 by DMA
     const bool dims_ok = mode == 0 ? (p.sH == height && p.sW == width)
                        : mode != 2 ? (2 * p.sH == height && 2 * p.sW == width)
                                    : (ceil_div(p.sH, 2) == height && ceil_div(p.sW, 2) == width);
@@ -1924,11 +2287,24 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     p.nsrc = n_src;
     // the exponent follows the data when EVERY source brings its slots; otherwise the static act_exponent serves
     if (srcs[0].absmax && (n_src == 1 || srcs[1].absmax)) { p.amax[0] = srcs[0].absmax; p.amax[1] = n_src > 1 ? srcs[1].absmax : nullptr; }
+    else if (p.pair_src && n_src > 1 && srcs[1].absmax) p.amax[1] = srcs[1].absmax;   // the fp32 source beside a pair source: its own window
     p.out_amax = out_absmax;
     const int ntf = split_nt(mode, out_channels, cin);
     p.nTilesN = ceil_div(out_channels, ntf);
     p.inv_scale = static_cast<const float*>(packed_weight);
     p.wp = reinterpret_cast<const _Float16*>(p.inv_scale + p.nTilesN * ntf);
+    p.l1 = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed_weight) +
+                                          kbn_conv3x3_split_packed_weight_bytes(out_channels, cin, mode) - (size_t)(cin / SP_CK) * 4);
+    if (pair_out) {   // the output as a pair tensor: concat convs and the 64-filter folded up-convs; its 2^k needs every source's slot
+        const bool kernel_ok = (mode == 0 && !(knob(KNOB_DEBUG) & 64)) || (mode == 3 && ntf == U64_NT && !uf_narrow(out_channels, cin));
+        if (!kernel_ok || (out_channels & 7)) return KBN_ERR_UNSUPPORTED;
+        if (!p.amax[0] || (n_src > 1 && !p.amax[1]) || !pair_out_scale || (reinterpret_cast<uintptr_t>(pair_out) & 15) ||
+            (pair_out_batch_stride & 7) || pair_out_batch_stride < (long long)(out_channels / 8) * 2 * pair_plane_halves(height, width))
+            return KBN_ERR_INVALID_ARGUMENT;
+        p.pair_out = static_cast<_Float16*>(pair_out); p.pair_out_bstride = pair_out_batch_stride; p.pair_out_scale = pair_out_scale;
+    }
+    if (p.pair_src && mode == 3 && !(ntf == U64_NT || uf_narrow(out_channels, cin))) return KBN_ERR_UNSUPPORTED;   // the 32-filter up-conv kernel splits its inputs itself
+    if (p.pair_src && mode == 3 && uf_narrow(out_channels, cin) && (srcs[0].channels % U16_CK)) return KBN_ERR_UNSUPPORTED;
     p.out = out; p.out_bstride = out_batch_stride;
     p.N = n; p.OC = out_channels; p.Cin = cin; p.H = height; p.W = width;
     p.tilesX = ceil_div(width, SP_TW); p.tilesY = ceil_div(height, mode == 2 ? SpGeom<2>::TH : SpGeom<0>::TH);
@@ -1947,15 +2323,22 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     static DeviceOnce o[5];
     int rc;
     if (mode == 3 && uf_narrow(out_channels, cin)) {
-        if (knob(KNOB_DEBUG) & 128) rc = launch(upconv2x_split16_kernel<8>, 2 * 2 * 4 * 18 * 34 * 16, o[4]);   // A/B: 16-row tiles, one workgroup per CU
-        else {               // 8 x 32 low-resolution pixels per workgroup of 4 waves, two workgroups per CU
+        if (knob(KNOB_DEBUG) & 128) {   // A/B: 16-row tiles, one workgroup per CU
+            static DeviceOnce o8p;
+            rc = p.pair_src ? launch(upconv2x_split16_kernel<8, true>, 2 * 2 * 4 * 18 * 34 * 16, o8p)
+                            : launch(upconv2x_split16_kernel<8, false>, 2 * 2 * 4 * 18 * 34 * 16, o[4]);
+        } else {             // 8 x 32 low-resolution pixels per workgroup of 4 waves, two workgroups per CU
             p.tilesY = ceil_div(p.sH, 8);
             const long long blocks8 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
             if (blocks8 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
             p.nblocks = (int)blocks8;
-            static DeviceOnce o16;
-            if ((rc = set_max_dynamic_lds(o16, reinterpret_cast<const void*>(upconv2x_split16_kernel<4>), 160 * 1024))) return rc;
-            hipLaunchKernelGGL(upconv2x_split16_kernel<4>, dim3(p.nblocks), dim3(256), 2 * 4 * 10 * 34 * 16, (hipStream_t)stream, p);
+            static DeviceOnce o16, o16p;
+            auto launch4 = [&](auto kern, DeviceOnce& once) -> int {
+                if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
+                hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), 2 * 4 * 10 * 34 * 16, (hipStream_t)stream, p);
+                return KBN_OK;
+            };
+            rc = p.pair_src ? launch4(upconv2x_split16_kernel<4, true>, o16p) : launch4(upconv2x_split16_kernel<4, false>, o16);
         }
         if (rc != KBN_OK) return rc;
         KBN_CHECK_LAUNCH();
@@ -1966,8 +2349,10 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         const long long blocks64 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
         if (blocks64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
         p.nblocks = (int)blocks64;
-        static DeviceOnce o64;
-        rc = launch(upconv2x_split64_kernel, 2 * (2 * 2 * 10 * 34 * 16) + 2 * (8 * 2 * 2 * 64 * 16), o64);
+        static DeviceOnce o64[4];
+        constexpr size_t lds64 = 2 * (2 * 2 * 10 * 34 * 16) + 2 * (8 * 2 * 2 * 64 * 16);
+        if (p.pair_src) rc = p.pair_out ? launch(upconv2x_split64_kernel<true, true>, lds64, o64[3]) : launch(upconv2x_split64_kernel<true, false>, lds64, o64[2]);
+        else rc = p.pair_out ? launch(upconv2x_split64_kernel<false, true>, lds64, o64[1]) : launch(upconv2x_split64_kernel<false, false>, lds64, o64[0]);
         if (rc != KBN_OK) return rc;
         KBN_CHECK_LAUNCH();
         return KBN_OK;
@@ -1982,7 +2367,12 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
                 static DeviceOnce ok32;
                 rc = launch(conv3x3_split_k32_kernel, SpGeom<0>::LDS + 2 * 10 * 2 * 2 * 64 * 16, ok32);
             } else {
-                rc = launch(conv3x3_split_kernel<0, 8, true, true>, SpGeom<0>::LDS + 2 * 9 * 2 * 2 * 64 * 16, o[0]);
+                static DeviceOnce o0p[3];
+                constexpr size_t lds0 = SpGeom<0>::LDS + 2 * 9 * 2 * 2 * 64 * 16;
+                if (p.pair_src) rc = p.pair_out ? launch(conv3x3_split_kernel<0, 8, true, true, 2, true, true>, lds0, o0p[2])
+                                                : launch(conv3x3_split_kernel<0, 8, true, true, 2, true, false>, lds0, o0p[1]);
+                else rc = p.pair_out ? launch(conv3x3_split_kernel<0, 8, true, true, 2, false, true>, lds0, o0p[0])
+                                     : launch(conv3x3_split_kernel<0, 8, true, true>, lds0, o[0]);
             }
             break;
         case 1: rc = launch(conv3x3_split_kernel<1, 8, true, false>, SpGeom<1>::LDS, o[1]); break;

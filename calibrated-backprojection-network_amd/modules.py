@@ -195,11 +195,15 @@ class Conv2d(torch.nn.Module):
                 s._keep = (s._keep[0], slot)
         return srcs
 
-    def run_split(self, srcs, n, h, w, out=None, up2x=False, out_absmax=None, stats=None):
+    def run_split(self, srcs, n, h, w, out=None, up2x=False, out_absmax=None, stats=None, pair_out=False):
         """3x3 stride-1 conv with two-term fp16 splits of both operands (ops.conv3x3_split, fp32-grade results); `h` x `w`
-        is the OUTPUT size.  None when the layer or the shape does not qualify."""
-        if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2
-                or (up2x and self.stride != 1) or any(s.kind != _lib.KBN_SRC_TENSOR or s.channels % 16 for s in srcs)):
+        is the OUTPUT size.  None when the layer or the shape does not qualify.  `pair_out`: the result as an
+        ops.PairTensor (for a split-operand consumer; its absmax slot is `out_absmax` when given); source 0 may be one
+        (ops.pair_src).  A shape the pair kernels decline returns None like any other: the caller retries in fp32."""
+        kinds_ok = all((s.kind == _lib.KBN_SRC_TENSOR or (i == 0 and s.kind == _lib.KBN_SRC_PAIR)) and s.channels % 16 == 0
+                       for i, s in enumerate(srcs))
+        if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2 or (up2x and self.stride != 1)
+                or not kinds_ok):
             return None
         # narrow layers stay on the fp32 kernels (a 64-filter tile would be mostly padding) -- except the folded up-conv,
         # which has 16-filter tiles for them (deconv0's 64 -> 12 at full resolution)
@@ -207,9 +211,15 @@ class Conv2d(torch.nn.Module):
         if self.out_channels < 48 and not narrow_up:
             return None
         dev = self.conv.weight.device
-        if out is None:
-            out = torch.empty((n, self.out_channels, h, w), device=dev, dtype=torch.float32)
         srcs = self._with_slots(srcs, n, dev, stats)
+        if pair_out:
+            if stats is None or self.out_channels % 8 or self.stride != 1:
+                return None
+            out = ops.PairTensor(n, self.out_channels, h, w, dev, stats)
+            if out_absmax is not None:
+                out.absmax = out_absmax
+        elif out is None:
+            out = torch.empty((n, self.out_channels, h, w), device=dev, dtype=torch.float32)
         packed = (self._packed_split_up.get(self.conv.weight, 1, up2x="split_up") if up2x
                   else self._packed_split.get(self.conv.weight, self.stride, up2x="split"))
         return ops.conv3x3_split(srcs, packed, n, self.out_channels, h, w, out, up2x=up2x, negative_slope=self._slope,
@@ -333,11 +343,23 @@ class UpConv2d(torch.nn.Module):
         self._packed_up2x = _PackedWeight()
         self.split_up = True    # folded 16-product form on split operands (ops.conv3x3_split(folded_up2x=True))
 
-    def forward(self, x, shape, amax=None, out_absmax=None, stats=None):
+    def forward(self, x, shape, amax=None, out_absmax=None, stats=None, pair_out=False):
         """`amax` / `out_absmax` / `stats` (extensions): the per-frame max |a| slot of `x`, the slot to fill for the result,
-        the slot pool of the forward (ops.ActStats)."""
+        the slot pool of the forward (ops.ActStats).  `x` may be an ops.PairTensor (the previous concat conv's output in
+        the producer-written split format): the folded split kernels stage it by DMA.  `pair_out`: the result as an
+        ops.PairTensor.  Either way None if the pair kernels decline the layer or the shape."""
         if x.shape[1] != self.conv.in_channels:
             raise KbnError(f"expected {self.conv.in_channels} input channels, got {x.shape[1]}")
+        if isinstance(x, ops.PairTensor) or pair_out:
+            pair_in = isinstance(x, ops.PairTensor)
+            if not pair_in:
+                x = x if _dense(x) else x.contiguous()
+            n, _, h, w = x.shape
+            oh, ow = int(shape[0]), int(shape[1])
+            if (oh, ow) != (2 * h, 2 * w) or self.conv.kernel_size != 3 or self.conv.bf16 or not self.split_up:
+                return None
+            src = ops.pair_src(x, "x") if pair_in else ops.tensor_src(x, "x", amax)
+            return self.conv.run_split([src], n, oh, ow, up2x=True, out_absmax=out_absmax, stats=stats, pair_out=pair_out)
         x = x if _dense(x) else x.contiguous()
         n, _, h, w = x.shape
         oh, ow = int(shape[0]), int(shape[1])
@@ -501,26 +523,42 @@ class DecoderBlock(torch.nn.Module):
             raise ValueError("only deconv_type='up' (KBNet's setting) is implemented")
         self.skip_channels = skip_channels
         self.deconv_type = deconv_type
+        self.pair_mid = os.environ.get("KBN_NO_PAIR_MID", "0") in ("", "0")   # A/B switch: the up-conv -> concat-conv tensor as a PairTensor
         self.deconv = UpConv2d(in_channels, out_channels, 3, weight_initializer, activation_func,
                                use_batch_norm, use_instance_norm)
         self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer,
                            activation_func, use_batch_norm, use_instance_norm)
 
-    def forward(self, x, skip=None, shape=None, amax_x=None, amax_skip=None, out_absmax=None, stats=None):
+    def forward(self, x, skip=None, shape=None, amax_x=None, amax_skip=None, out_absmax=None, stats=None, pair_out=False):
         """amax_x / amax_skip / out_absmax / stats (extensions): per-frame max |a| slots of the inputs, the slot to fill
-        for the result and the slot pool of the forward (ops.ActStats); missing input slots are measured."""
+        for the result and the slot pool of the forward (ops.ActStats); missing input slots are measured.  `x` may be an
+        ops.PairTensor and `pair_out` asks for one (the decoder's chain of split-operand kernels, MultiScaleDecoder);
+        None when the pair kernels decline a shape (the caller repeats the block in fp32)."""
         if skip is not None:
             shape = skip.shape[2:4]
         elif shape is None:
             shape = (2 * x.shape[2], 2 * x.shape[3])
         if stats is None:
-            stats = ops.ActStats(x.shape[0], x.device, capacity=4)
+            stats = ops.ActStats(x.shape[0], x.data.device if isinstance(x, ops.PairTensor) else x.device, capacity=4)
         amax_deconv = stats.new()
-        deconv = self.deconv(x, shape=shape, amax=amax_x, out_absmax=amax_deconv, stats=stats)
-        srcs = [ops.tensor_src(deconv, "deconv", amax_deconv)]
+        # inside the pair chain the up-conv's output goes to the concat conv as a PairTensor too (that kernel wants at least
+        # two 16-channel chunks from each of its two sources)
+        deconv = None
+        if (pair_out and self.pair_mid and skip is not None and self.skip_channels >= 32 and self.deconv.conv.out_channels >= 32
+                and not self.conv.bf16):
+            deconv = self.deconv(x, shape=shape, amax=amax_x, out_absmax=amax_deconv, stats=stats, pair_out=True)
+        if deconv is None:
+            deconv = self.deconv(x, shape=shape, amax=amax_x, out_absmax=amax_deconv, stats=stats)
+        if deconv is None:
+            return None
+        srcs = [ops.pair_src(deconv, "deconv") if isinstance(deconv, ops.PairTensor) else ops.tensor_src(deconv, "deconv", amax_deconv)]
         if self.skip_channels > 0:
             skip = skip if _dense(skip) else skip.contiguous()
             srcs.append(ops.tensor_src(skip, "skip", amax_skip))  # torch.cat([deconv, skip]) fused into the K loop
+        if pair_out:
+            if self.conv.bf16:
+                return None
+            return self.conv.run_split(srcs, x.shape[0], int(shape[0]), int(shape[1]), out_absmax=out_absmax, stats=stats, pair_out=True)
         return self.conv.run(srcs, x.shape[0], int(shape[0]), int(shape[1]), out_absmax=out_absmax, stats=stats)
 
 
@@ -753,6 +791,8 @@ class MultiScaleDecoder(torch.nn.Module):
             cin = n_filters[i]
         self.output0 = Conv2d(n_filters[4], output_channels, 3, 1, weight_initializer, None)
         self._packed_tail = _PackedTail()
+        # deconv4 .. deconv1 hand their concat-conv outputs to the next up-conv as ops.PairTensor (KBN_NO_PAIR=1: fp32 tensors)
+        self.pair_chain = os.environ.get("KBN_NO_PAIR", "0") in ("", "0")
 
     def set_bf16(self, enabled: bool = True):
         """THROUGHPUT-ONLY switch (BASELINE configs[2]'s bf16 figure): the decoder's 3x3 stride-1 convs with at least 16
@@ -769,16 +809,26 @@ class MultiScaleDecoder(torch.nn.Module):
         x, amax = self.features_level1(x, skips, stats=stats)
         return self.deconv0(x, None, shape=tuple(shape)[-2:], amax_x=amax, stats=stats)
 
-    def features_level1(self, x, skips, amax_x=None, amax_skips=None, stats=None):
+    def features_level1(self, x, skips, amax_x=None, amax_skips=None, stats=None, allow_pair=False):
         """deconv4 .. deconv1: the half-resolution features deconv0 starts from, and their per-frame max |a| slot.
-        amax_x / amax_skips: the slots of the latent / the skip tensors (KBNetEncoder.encode); missing ones are measured."""
+        amax_x / amax_skips: the slots of the latent / the skip tensors (KBNetEncoder.encode); missing ones are measured.
+        `allow_pair`: the result may be an ops.PairTensor (depth() hands it to deconv0's up-conv)."""
         if stats is None:
             stats = ops.ActStats(x.shape[0], x.device)
         amax_skips = amax_skips if amax_skips is not None else [None] * 4
         amax = amax_x
         for blk, i in ((self.deconv4, 3), (self.deconv3, 2), (self.deconv2, 1), (self.deconv1, 0)):
             a_out = stats.new()
-            x = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats)
+            # the concat conv's output is read by the next block's up-conv only: as a PairTensor when that kernel takes one
+            y = None
+            if self.pair_chain and (allow_pair or i > 0):
+                y = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats, pair_out=True)
+            if y is None:
+                if isinstance(x, ops.PairTensor):
+                    x = x.float()   # a shape the pair kernels declined after one of them produced x: rare, not fast
+                    amax = None
+                y = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats)
+            x = y
             amax = a_out
         return x, amax
 
@@ -789,10 +839,12 @@ class MultiScaleDecoder(torch.nn.Module):
         multiple of 4 channels (KBNet: 12); otherwise conv, then the fused output0 + mapping head."""
         if stats is None:
             stats = ops.ActStats(x.shape[0], x.device)
-        x, amax = self.features_level1(x, skips, amax_x, amax_skips, stats)
         d0 = self.deconv0
+        x, amax = self.features_level1(x, skips, amax_x, amax_skips, stats, allow_pair=d0.skip_channels == 0)
         if d0.skip_channels == 0:
             up = d0.deconv(x, shape=tuple(shape)[-2:], amax=amax, stats=stats)
+            if up is None:   # deconv0's up-conv declined the pair tensor
+                up = d0.deconv(x.float(), shape=tuple(shape)[-2:], amax=None, stats=stats)
             if d0.conv.split:   # the 12 -> 12 conv of the tail on split fp16 operands (csrc/tail.hip)
                 packed = self._packed_tail.get(d0.conv.conv.weight)
                 res = None if packed is None else ops.conv_tail(up, packed, self.output0.conv.weight, min_predict_depth,

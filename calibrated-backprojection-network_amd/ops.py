@@ -305,6 +305,43 @@ def tensor_src(t: torch.Tensor, name="src", absmax: Optional[torch.Tensor] = Non
     return s
 
 
+class PairTensor:
+    """An activation tensor in the producer-written split format (include/kbnet_hip.h, "PAIR tensors"): per frame
+    [channels / 8][h1 | h2][H * W + 1 pixels][8 channels] fp16 with a 2^k = h1 + 2^-11 h2, the per-frame 2^k in `scale`
+    (written by the producing kernel) and the true max |a| per frame in the `absmax` slot.  Only tensors that split-operand
+    kernels alone read are kept this way: the decoder's concat-conv outputs (conv3x3_split(out=PairTensor), read by the
+    next up-conv through pair_src).  Same bytes as fp32; the consumers stage it by LDS-DMA instead of splitting it."""
+
+    def __init__(self, n: int, channels: int, height: int, width: int, device, stats: "ActStats"):
+        if channels % 8:
+            raise KbnError("PairTensor: channels must be a multiple of 8")
+        self.shape = (n, channels, height, width)
+        self.data = torch.empty((n, channels // 8, 2, height * width + 1, 8), device=device, dtype=torch.float16)
+        self.scale = torch.empty(n, device=device, dtype=torch.float32)
+        self.absmax = stats.new()
+
+    def float(self) -> torch.Tensor:
+        """The tensor as N x C x H x W fp32 (tests, diagnostics)."""
+        n, c, h, w = self.shape
+        v = self.data[:, :, 0, :h * w].double() + self.data[:, :, 1, :h * w].double() / 2048.0   # n, c/8, hw, 8
+        v = v / self.scale.double().view(n, 1, 1, 1)
+        return v.permute(0, 1, 3, 2).reshape(n, c, h, w).float()
+
+
+def pair_src(t: PairTensor, name="src") -> ConvSrc:
+    n, c, h, w = t.shape
+    s = ConvSrc()
+    s.kind = _lib.KBN_SRC_PAIR
+    s.channels = c
+    s.data = t.data.data_ptr()
+    s.batch_stride = t.data.stride(0)
+    s.src_height, s.src_width = h, w
+    s.absmax = _slot_ptr(t.absmax, n)
+    s.scale = t.scale.data_ptr()
+    s._keep = (t,)
+    return s
+
+
 def coords_src(kinv: torch.Tensor) -> ConvSrc:
     _require(kinv, "kinv", 3)
     s = ConvSrc()
@@ -637,7 +674,13 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
         raise KbnError("conv3x3_split: up2x and stride 2 are mutually exclusive")
     lib = _lib.load()
     arr = (ConvSrc * len(srcs))(*srcs)
-    optr, obs = _planes(out, "out")
+    pair = isinstance(out, PairTensor)   # the output in the producer-written split format (its slot doubles as out_absmax)
+    if pair:
+        optr, obs = None, 0
+        if out_absmax is None:
+            out_absmax = out.absmax
+    else:
+        optr, obs = _planes(out, "out")
     if tuple(out.shape) != (n, out_channels, height, width):
         raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, height, width)}")
     cin = sum(s.channels for s in srcs)
@@ -649,7 +692,10 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
                                                            mode, max(-60, min(60, int(act_exponent))),
                                                            0 if negative_slope is None else 1,
                                                            0.0 if negative_slope is None else float(negative_slope),
-                                                           _slot_ptr(out_absmax, n), _stream()),
+                                                           _slot_ptr(out_absmax, n),
+                                                           out.data.data_ptr() if pair else None,
+                                                           out.data.stride(0) if pair else 0,
+                                                           out.scale.data_ptr() if pair else None, _stream()),
                      executed=conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride, up2x and folded_up2x))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:

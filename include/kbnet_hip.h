@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KBN_ABI_VERSION 2
+#define KBN_ABI_VERSION 3
 
 typedef void* kbn_stream_t; /* hipStream_t */
 
@@ -110,10 +110,12 @@ int kbn_camera_coordinates(const float* kinv, float* coordinates, int n, int hei
 typedef enum kbn_src_kind {
     KBN_SRC_TENSOR = 0, /* data: N x channels x src_height x src_width                     */
     KBN_SRC_COORDS = 1, /* 3 channels kinv.[x y 1]^T, kinv: N x 3 x 3 (data unused)        */
-    KBN_SRC_XYZ = 2     /* 3 channels coords * z, z = act(proj_weight . depth[:, y, x]);   */
+    KBN_SRC_XYZ = 2,    /* 3 channels coords * z, z = act(proj_weight . depth[:, y, x]);   */
                         /* data = depth N x aux_channels x H x W, proj_weight = aux_channels */
                         /* floats, coords from `coordinates` (N x 3 x H x W) if non-null,  */
                         /* else from kinv                                                  */
+    KBN_SRC_PAIR = 3    /* a PAIR tensor (below): activations already split into two fp16 terms by  */
+                        /* their producer; kbn_conv3x3_split_forward only, source 0 only            */
 } kbn_src_kind;
 
 typedef struct kbn_conv_src {
@@ -127,9 +129,26 @@ typedef struct kbn_conv_src {
     const float* coordinates;  /* KBN_SRC_XYZ, optional                           */
     long long coordinates_batch_stride;
     const float* kinv;      /* KBN_SRC_COORDS / KBN_SRC_XYZ without coordinates    */
-    const unsigned* absmax; /* KBN_SRC_TENSOR, optional: the per-frame max |a| slots of this tensor (see
-                             * "activation statistics" below); read by the split-operand convs only   */
+    const unsigned* absmax; /* KBN_SRC_TENSOR / KBN_SRC_PAIR, optional: the per-frame max |a| slots of this tensor
+                             * (see "activation statistics" below); read by the split-operand convs only  */
+    const float* scale;     /* KBN_SRC_PAIR: the per-frame 2^k its producer wrote (pair_out_scale)         */
 } kbn_conv_src;
+
+/* ------------------------------------------------ PAIR tensors (producer-written split operands) --
+ * The reference passes fp32 tensors between its convs (src/net_utils.py:1483-1487: conv over cat[deconv, skip]).  Where a
+ * tensor is read ONLY by split-operand convs -- the decoder's up-conv outputs and concat-conv outputs -- the producer
+ * can write the two fp16 terms itself, once, instead of every consumer splitting every value it stages (2.4-4.8 times
+ * per value: halos x filter tiles).  Layout per frame, C channels (C % 8 == 0), H x W pixels:
+ *     [k-group = channel / 8][term: h1 | h2][H * W + 1 pixels][8 channels] fp16      (4 bytes per value, like fp32)
+ * a 2^k = h1 + 2^-11 h2; the extra pixel that ends every plane is ZERO (written by the producer; a consumer's halo pixels
+ * outside the map read it).  Frames are batch_stride fp16 elements apart (>= (C / 8) * 2 * (H * W + 1) * 8, a multiple
+ * of 8; base 16-byte aligned).  k is chosen per frame by the producer from a bound of its output -- (max |a| of each
+ * input, from the inputs' absmax slots) x (a table of weight norms kept behind the packed weights) -- and written to
+ * `pair_out_scale[frame]` as the float 2^k; the consumer receives that array as kbn_conv_src.scale.  The producer still
+ * folds the true max |out| into out_absmax.  kbn_conv3x3_split_forward: `pair_out` for mode 0 and for mode 3 with whole
+ * 64-filter tiles (needs absmax slots on every source and out_channels % 8 == 0); a KBN_SRC_PAIR source 0 for mode 0
+ * and for mode 3 (64-filter tiles, or at most 16 filters and channels % 32 == 0); KBN_ERR_UNSUPPORTED otherwise -- the
+ * caller then keeps the tensor in fp32. */
 
 /* ----------------------------------------------- activation statistics ("absmax slots") --
  * The split-operand convs further down represent an activation as two fp16 terms under a per-frame
@@ -217,7 +236,9 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
  *   mode      0: 3x3 stride 1 over height x width sources; 1: nearest-2x up-conv (ONE source with
  *             (height/2) x (width/2) planes); 2: 3x3 stride 2 (source planes h x w with ceil(h/2) = height,
  *             ceil(w/2) = width: the image convs of the KB blocks, reference src/net_utils.py:1348)
- *   srcs      1 or 2 KBN_SRC_TENSOR sources, each a multiple of 16 channels
+ *   srcs      1 or 2 KBN_SRC_TENSOR sources, each a multiple of 16 channels; source 0 may be a KBN_SRC_PAIR (above)
+ *   pair_out  NULL, or the output as a PAIR tensor (then `out` is ignored and may be NULL), with
+ *             pair_out_batch_stride (fp16 elements) and pair_out_scale (n floats)
  *   packed    from kbn_conv3x3_split_pack_weight (OIHW fp32 3x3 weight in) for the SAME mode (the
  *             filter tiling of the blob depends on it)
  *   out       N x out_channels x height x width fp32, frames out_batch_stride elements apart
@@ -229,7 +250,7 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
 int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
                               long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
                               int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
-                              kbn_stream_t stream);
+                              void* pair_out, long long pair_out_batch_stride, float* pair_out_scale, kbn_stream_t stream);
 
 /* conv_fused of the KB block on split operands -- reference src/net_utils.py:1337-1343 (Conv2d(in_channels_fused + 3,
  * n_filter_fused, kernel_size=1, stride=2)) applied to cat[image, xyz, fused] (:1352-1368).  The tensor channels

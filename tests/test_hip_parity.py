@@ -607,6 +607,139 @@ def test_conv3x3_split_kernel(dev, cins, cout, hw, kind, amag):
     assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5
 
 
+def _pair_errs(got, ref64):
+    """rms / max error in units of each (frame, filter)'s rms, over the filters within 2^-9 of their frame's maximum: a pair
+    tensor has ONE window per frame, and a channel far below the frame's largest keeps the window's absolute accuracy
+    (2^-40 of its top), not 22 bits of its own."""
+    rms = ref64.pow(2).mean(dim=(2, 3), keepdim=True).sqrt()
+    live = rms >= ref64.abs().amax(dim=(1, 2, 3), keepdim=True) * 2.0 ** -9
+    e = ((got.cpu().double() - ref64) / rms).abs() * live
+    return float((e.pow(2).sum() / (live.sum() * ref64.shape[2] * ref64.shape[3])).sqrt()), float(e.max())
+
+
+@pytest.mark.parametrize("cins,cout,hw", [((64, 64), 64, (22, 76)), ((32, 48), 128, (37, 52)), ((128, 256), 128, (12, 40)), ((16, 32), 72, (9, 33))])
+@pytest.mark.parametrize("amag", [1.0, 3e5])
+def test_pair_tensor_from_concat_conv(dev, cins, cout, hw, amag):
+    """kbn_conv3x3_split_forward(pair_out=): the concat conv writes its result as a PAIR tensor (include/kbnet_hip.h) -- two
+    fp16 terms per value under a per-frame 2^k fixed from a BOUND of the output (input maxima x weight norms), k-group-major
+    granules, a zero granule behind every plane.  Decoded, it is the fp32 kernel's result to fp32 rounding; the window holds
+    the true maximum with room to spare; the absmax slot holds the true maximum."""
+    h, w = hw
+    g = torch.Generator().manual_seed(sum(cins) + cout + h)
+    n = 2
+    xs = [amag * torch.nn.functional.leaky_relu(torch.randn(n, c, h, w, generator=g), 0.2) for c in cins]
+    for x in xs:
+        x[1] *= 0.0123
+    cin = sum(cins)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    wt[1] *= 1e-3
+    wt[2] *= 50.0
+    ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.cat(xs, 1).double(), wt.double(), padding=1), 0.2)
+    xd = [x.to(dev) for x in xs]
+    stats = kb.ops.ActStats(n, dev)
+    srcs = [kb.ops.tensor_src(x, "x", stats.measure(x)) for x in xd]
+    packed = kb.ops.pack_conv3x3_split_weight(wt.to(dev))
+    out32 = torch.empty(n, cout, h, w, device=dev)
+    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, out32, negative_slope=0.2) is not None
+    pt = kb.ops.PairTensor(n, cout, h, w, dev, stats)
+    pt.data.fill_(float("nan"))                  # whatever the kernel does not write shows
+    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, pt, negative_slope=0.2) is not None
+    got = pt.float()
+    assert torch.isfinite(pt.data).all(), "every granule, the zero granules included, is written"
+    assert float(pt.data[:, :, :, h * w].abs().max()) == 0.0
+    assert torch.equal(kb.ops.slot_values(pt.absmax), out32.abs().amax(dim=(1, 2, 3)))
+    top = out32.abs().amax(dim=(1, 2, 3)) * pt.scale
+    assert float(top.max()) < 2.0 ** 15 and float(top.min()) > 2.0 ** 2, "the bound's window: above the data, within 2^13 of it"
+    # absolute accuracy of the format: 2^-25 of a window unit (flushed fp16 subnormals), whatever the channel's own size
+    win = (got.double() - out32.double()).abs() * pt.scale.double().view(n, 1, 1, 1)
+    assert float((win - out32.double().abs() * pt.scale.double().view(n, 1, 1, 1) * 2.0 ** -21).max()) <= 2.0 ** -24
+    r_pair, m_pair = _pair_errs(got, ref64)
+    r_f32, m_f32 = _pair_errs(out32, ref64)
+    print(f"pair out vs fp64: rms {r_pair:.2e} max {m_pair:.2e}; fp32 out: rms {r_f32:.2e} max {m_f32:.2e}")
+    assert r_pair < max(1.5 * r_f32, 2e-7) and m_pair < max(2.0 * m_f32, 2e-6)
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 128, (22, 76)), (128, 64, (16, 64)), (32, 192, (18, 132)), (64, 12, (36, 76)), (32, 16, (70, 8)),
+                                         (64, 12, (18, 140))])
+def test_pair_tensor_into_folded_upconv(dev, cin, cout, hw):
+    """A KBN_SRC_PAIR source of the folded up-convs (64-filter tiles and the 16-filter tiles of deconv0's up-conv): staged by
+    LDS-DMA, halo pixels from the zero granule.  The pair tensor comes from a concat conv (its own kernel); the up-conv of
+    its DECODED values on the fp32-input path is the comparison, both against fp64."""
+    h, w = hw                                   # output size of the up-conv
+    sh, sw = h // 2, w // 2
+    g = torch.Generator().manual_seed(cin + cout + h)
+    n = 2
+    x0 = torch.nn.functional.leaky_relu(torch.randn(n, 32, sh, sw, generator=g), 0.2)
+    x0[1] *= 0.05
+    w0 = torch.randn(cin, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    stats = kb.ops.ActStats(n, dev)
+    x0d = x0.to(dev)
+    pt = kb.ops.PairTensor(n, cin, sh, sw, dev, stats)
+    assert kb.ops.conv3x3_split([kb.ops.tensor_src(x0d, "x", stats.measure(x0d))], kb.ops.pack_conv3x3_split_weight(w0.to(dev)),
+                                n, cin, sh, sw, pt, negative_slope=0.2) is not None
+    xin = pt.float()                             # what the pair tensor holds, exactly
+    up = torch.nn.functional.interpolate(xin.cpu().double(), size=(h, w), mode="nearest")
+    ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(up, wt.double(), padding=1), 0.2)
+    packed = kb.ops.pack_conv3x3_split_weight(wt.to(dev), folded_up2x=True)
+    out_f32 = torch.empty(n, cout, h, w, device=dev)
+    assert kb.ops.conv3x3_split([kb.ops.tensor_src(xin, "x", pt.absmax)], packed, n, cout, h, w, out_f32, up2x=True, negative_slope=0.2,
+                                folded_up2x=True) is not None
+    out_pair = torch.full((n, cout, h, w), float("nan"), device=dev)
+    slot = stats.new()
+    assert kb.ops.conv3x3_split([kb.ops.pair_src(pt, "x")], packed, n, cout, h, w, out_pair, up2x=True, negative_slope=0.2,
+                                folded_up2x=True, out_absmax=slot) is not None
+    assert torch.equal(kb.ops.slot_values(slot), out_pair.abs().amax(dim=(1, 2, 3)))
+    r_pair, m_pair = _pair_errs(out_pair, ref64)
+    r_f32, m_f32 = _pair_errs(out_f32, ref64)
+    print(f"up-conv of a pair tensor vs fp64: rms {r_pair:.2e} max {m_pair:.2e}; of its fp32 decode: rms {r_f32:.2e} max {m_f32:.2e}")
+    assert r_pair < max(1.5 * r_f32, 3e-7) and m_pair < max(2.0 * m_f32, 3e-6)
+
+
+@pytest.mark.parametrize("cup,cskip,cout,hw", [(64, 64, 64, (22, 76)), (128, 256, 128, (12, 40)), (64, 32, 96, (16, 60))])
+def test_pair_tensor_chain_upconv_to_concat(dev, cup, cskip, cout, hw):
+    """The other direction: a 64-filter folded up-conv writes a PAIR tensor, the concat conv reads it as source 0 beside an
+    fp32 skip (its accumulators change window between the two sources)."""
+    h, w = hw
+    sh, sw = h // 2, w // 2
+    g = torch.Generator().manual_seed(cup + cskip + cout + h)
+    n = 2
+    x0 = torch.nn.functional.leaky_relu(torch.randn(n, 32, sh, sw, generator=g), 0.2)
+    x0[1] *= 0.05
+    skip = 40.0 * torch.nn.functional.leaky_relu(torch.randn(n, cskip, h, w, generator=g), 0.2)   # another magnitude than the up-conv's output
+    wu = torch.randn(cup, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
+    wc = torch.randn(cout, cup + cskip, 3, 3, generator=g) / ((cup + cskip) * 9) ** 0.5
+    stats = kb.ops.ActStats(n, dev)
+    x0d, skipd = x0.to(dev), skip.to(dev)
+    pu = kb.ops.pack_conv3x3_split_weight(wu.to(dev), folded_up2x=True)
+    pt = kb.ops.PairTensor(n, cup, h, w, dev, stats)
+    pt.data.fill_(float("nan"))
+    res = kb.ops.conv3x3_split([kb.ops.tensor_src(x0d, "x", stats.measure(x0d))], pu, n, cup, h, w, pt, up2x=True, negative_slope=0.2,
+                               folded_up2x=True)
+    assert res is not None and torch.isfinite(pt.data).all() and float(pt.data[:, :, :, h * w].abs().max()) == 0.0
+    up32 = torch.empty(n, cup, h, w, device=dev)
+    assert kb.ops.conv3x3_split([kb.ops.tensor_src(x0d, "x", stats.measure(x0d))], pu, n, cup, h, w, up32, up2x=True, negative_slope=0.2,
+                                folded_up2x=True) is not None
+    assert rel_err(pt.float(), up32) < 1e-6
+    assert torch.equal(kb.ops.slot_values(pt.absmax), up32.abs().amax(dim=(1, 2, 3)))
+    xin = pt.float()
+    ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.cat([xin.cpu(), skip], 1).double(), wc.double(), padding=1), 0.2)
+    pc = kb.ops.pack_conv3x3_split_weight(wc.to(dev))
+    sslot = stats.measure(skipd)
+    out_f32 = torch.empty(n, cout, h, w, device=dev)
+    assert kb.ops.conv3x3_split([kb.ops.tensor_src(xin, "up", pt.absmax), kb.ops.tensor_src(skipd, "skip", sslot)], pc, n, cout, h, w,
+                                out_f32, negative_slope=0.2) is not None
+    out_pair = torch.full((n, cout, h, w), float("nan"), device=dev)
+    res = kb.ops.conv3x3_split([kb.ops.pair_src(pt, "up"), kb.ops.tensor_src(skipd, "skip", sslot)], pc, n, cout, h, w, out_pair,
+                               negative_slope=0.2)
+    if res is None:
+        pytest.skip("the concat kernel takes a pair source only with at least two chunks per source")
+    r_pair, m_pair = _pair_errs(out_pair, ref64)
+    r_f32, m_f32 = _pair_errs(out_f32, ref64)
+    print(f"concat conv with a pair source vs fp64: rms {r_pair:.2e} max {m_pair:.2e}; all fp32 sources: rms {r_f32:.2e} max {m_f32:.2e}")
+    assert r_pair < max(1.5 * r_f32, 3e-7) and m_pair < max(2.0 * m_f32, 3e-6)
+
+
 @pytest.mark.parametrize("cins,cout,hw", [((64, 64), 64, (22, 76)), ((32,), 48, (16, 64)), ((16, 32), 130, (9, 40)), ((128, 128), 128, (37, 52))])
 def test_conv3x3_split_k32_form(dev, kenv, cins, cout, hw):
     """The 16x16x32 form of the concat-conv kernel (conv3x3_split_k32_kernel, KBN_DEBUG=64; off by default: slower on the
