@@ -359,6 +359,33 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
             del os.environ["KBN_NO_SPLIT"]
             kb.ops.reload_env()
 
+    # Side figure, NOT the headline: the reference's graph computes one conv whose result nothing reads -- conv_image of the
+    # last KB level (src/networks.py:475-523: conv5_image takes conv4_fused) -- and so does the timed forward above.
+    # KBNetEncoder.skip_unused_image leaves that launch out; the depth maps are the same bits.
+    dead_conv_fps = None
+    if not args.no_fp32_mfma and not args.eager and hasattr(model.encoder, "skip_unused_image"):
+        model.encoder.skip_unused_image = True
+        try:
+            dreplay = model.capture(*frames, branches=args.branches or None)
+            dout = dreplay(*dreplay.static_in)
+            same_bits = bool(torch.equal(dout, forward(*frames)))
+            for _ in range(3):
+                dreplay(*dreplay.static_in)
+            torch.cuda.synchronize()
+            kb.dist.barrier()
+            t7 = time.perf_counter()
+            for _ in range(10):
+                dreplay(*dreplay.static_in)
+            torch.cuda.synchronize()
+            kb.dist.barrier()
+            dead_conv_fps = {"frames_per_s": round(per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t7, dev), 1),
+                             "same_bits_as_timed_forward": same_bits,
+                             "what": "conv_image of KB level 3 not launched (its output feeds nothing: reference src/networks.py:475-523); "
+                                     "KBNetEncoder.skip_unused_image, off by default and in `value`"}
+            del dreplay, dout
+        finally:
+            model.encoder.skip_unused_image = False
+
     ms_per_step = 1e3 * elapsed / args.steps
     fps = per * world * args.steps / elapsed
     gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
@@ -447,6 +474,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    "void_480x640_frames_per_s": None if void_fps is None else round(void_fps, 1),
                    # side measurement: BASELINE configs[1] (batch 8 per GPU), forward only
                    "batch8_frames_per_s": None if side_fps is None else round(side_fps, 1),
+                   # side measurement: the forward without the one conv of the reference's graph whose result nothing reads
+                   "unused_image_conv_skipped": dead_conv_fps,
                    # side measurement: the same batch with every conv on the fp32 MFMAs (KBN_NO_SPLIT=1), graph replay
                    "fp32_mfma_only_frames_per_s": None if fp32_only_fps is None else round(fp32_only_fps, 1),
                    # side measurement: BASELINE configs[2]'s bf16 leg -- throughput only, never `value` (see above)

@@ -430,7 +430,7 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             raise ValueError("the fused KB block needs a (leaky) ReLU activation")
 
     def run(self, image, depth, coordinates, fused, out_image=None, out_depth=None, out_fused=None,
-            amax_image=None, amax_fused=None, out_amax_image=None, out_amax_skip=None, stats=None):
+            amax_image=None, amax_fused=None, out_amax_image=None, out_amax_skip=None, stats=None, need_image=True):
         """amax_image / amax_fused: per-frame max |a| slots of `image` / `fused` (ops.ActStats; measured here when a
         split-operand conv needs one that is missing); out_amax_image: slot to fill for conv_image's output;
         out_amax_skip: ONE slot for conv_fused's and conv_depth's outputs (the encoder keeps them in one skip tensor)."""
@@ -473,8 +473,10 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
                 stats = stats if stats is not None else ops.ActStats(n, dev, capacity=3)
                 amax_image = stats.measure(image)   # conv_image and conv_fused both read `image`: measured once
             branch = _SideBranch(dev)   # forks HERE: conv_depth and conv_fused read nothing that conv_image writes
-            res = ci_conv.run_split([ops.tensor_src(image, "image", amax_image)], n, oh, ow, out=out_image,
-                                    out_absmax=out_amax_image, stats=stats)
+            # need_image=False (KBNetEncoder.skip_unused_image): the caller never reads conv_image's output -- the reference's
+            # last KB level, whose image branch feeds nothing (src/networks.py:475-523: conv5_image takes conv4_fused)
+            res = True if not need_image else ci_conv.run_split([ops.tensor_src(image, "image", amax_image)], n, oh, ow, out=out_image,
+                                                                out_absmax=out_amax_image, stats=stats)
             if res is not None:
                 with branch:
                     self._depth_and_fused(image, depth, fused, kinv, n, h, w, oh, ow, out_depth, out_fused, ci, cf,
@@ -637,6 +639,8 @@ class KBNetEncoder(torch.nn.Module):
         # (ops.kb1_front, csrc/front.hip): KBNet's level 0 (48 / 48 filters) in all presets; other widths keep the
         # separate kernels
         self.front = True
+        # OFF by default (the reference computes it): do not launch conv_image of KB level 3, whose output nothing reads
+        self.skip_unused_image = False
         self._packed_front = _PackedFront()
         self._packed_depth_front = _PackedFront(ops.pack_kb1_depth_front_weight)
 
@@ -731,10 +735,13 @@ class KBNetEncoder(torch.nn.Module):
                     kinv = kinv1
                 skip = torch.empty((n, ff[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
                 out_fused, out_depth = skip[:, :ff[level]], skip[:, ff[level]:]
+                # the image branch of the last KB level in front of a plain level 4 feeds nothing (reference
+                # src/networks.py:475-523: conv5_image reads conv4_fused, conv4_image only lends its shape)
+                unused = self.skip_unused_image and level == 3 and 4 not in self.resolutions_backprojection
                 conv_image, conv_depth, conv_fused = blk.run(
                     conv_image, conv_depth, kinv, conv_fused, None, out_depth, out_fused,
                     amax_image=amax_image if level > 0 else None, amax_fused=amax_skip if conv_fused is not None else None,
-                    out_amax_image=a_img, out_amax_skip=a_skip, stats=stats)
+                    out_amax_image=a_img, out_amax_skip=a_skip, stats=stats, need_image=not unused)
                 amax_image = a_img
             else:
                 # plain level: conv_image lives in the skip tensor, whose slot (a superset: a safe bound) serves it too
@@ -821,7 +828,8 @@ class MultiScaleDecoder(torch.nn.Module):
             a_out = stats.new()
             # the concat conv's output is read by the next block's up-conv only: as a PairTensor when that kernel takes one
             y = None
-            if self.pair_chain and (allow_pair or i > 0):
+            # (not with KBN_NO_SPLIT=1: every split-operand launch would decline, after the block's up-conv had already run in fp32)
+            if self.pair_chain and (allow_pair or i > 0) and os.environ.get("KBN_NO_SPLIT", "0") in ("", "0"):
                 y = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats, pair_out=True)
             if y is None:
                 if isinstance(x, ops.PairTensor):

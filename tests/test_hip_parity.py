@@ -1320,6 +1320,30 @@ def test_graph_replay_with_concurrent_branches(dev):
         m.forward(*a, out=torch.zeros(4, 1, 64, 90, device=dev))
 
 
+def test_unused_image_conv_of_last_kb_level_changes_nothing(dev):
+    """KBNetEncoder.skip_unused_image (off by default): conv_image of KB level 3 feeds nothing in the reference's graph
+    (src/networks.py:475-523: conv5_image takes conv4_fused; conv4_image only lends its shape) -- not launching it leaves
+    the latent, every skip and the depth map bit-identical."""
+    cfg = kb.kitti_config()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=3, gain=1.3))
+    a = to(dev, *kb.synthetic.make_frames(2, 96, 160, "kitti", seed=9))
+    full = m.forward(*a).clone()
+    kb.ops.PROFILE = names_hook = []   # ops records one entry per kernel launch while a list hangs here
+    try:
+        m.forward(*a)
+        n_full = len(names_hook)
+        m.encoder.skip_unused_image = True
+        del names_hook[:]
+        out = m.forward(*a)
+        n_skip = len(names_hook)
+    finally:
+        kb.ops.PROFILE = None
+        m.encoder.skip_unused_image = False
+    assert torch.equal(out, full)
+    assert n_skip == n_full - 1, "exactly one launch less"
+
+
 def test_graph_replay_with_level_side_branches(dev):
     """A single-branch graph (batches below 4 frames) forks the independent convs of an encoder level -- conv_depth and
     conv_fused beside conv_image, conv5_depth beside conv5_image -- onto a side stream inside the capture
