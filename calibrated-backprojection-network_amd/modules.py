@@ -536,6 +536,9 @@ class DecoderBlock(torch.nn.Module):
         for the result and the slot pool of the forward (ops.ActStats); missing input slots are measured.  `x` may be an
         ops.PairTensor and `pair_out` asks for one (the decoder's chain of split-operand kernels, MultiScaleDecoder);
         None when the pair kernels decline a shape (the caller repeats the block in fp32)."""
+        if pair_out and (self.conv.bf16 or self.deconv.conv.bf16 or not self.conv.split or self.conv.out_channels < 48
+                         or self.conv.out_channels % 8 or self.conv.kernel_size != 3):
+            return None   # declined before anything is launched
         if skip is not None:
             shape = skip.shape[2:4]
         elif shape is None:
