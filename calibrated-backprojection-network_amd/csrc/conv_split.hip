@@ -107,6 +107,7 @@ struct SplitConvParams {
     long long pair_out_bstride;
     float* pair_out_scale;      // per frame: the 2^k applied here (every workgroup of a frame writes the same value)
     const float* l1;            // per 16-channel chunk: max over filters of sum |w| (the table behind the packed weights)
+    int sub0;                   // conv1x1s2_split_kernel: source 0 holds only the pixels the conv reads (H x W planes, stride 1)
     // conv1x1s2_split_kernel: three more input channels taken in fp32 in the epilogue (the KB block's backprojection)
     const float* xyz;           // N x 3 x H x W (output size), or null
     long long xyz_bstride;
@@ -340,7 +341,7 @@ __device__ __forceinline__ void sp_wait_b(f32x4 (&b)[NBX][2]) {   // vmcnt(N), t
 template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2, bool PIN0 = false, bool POUT = false>   // NBW: 32-filter blocks per wave
 __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
     static_assert(APART, "the two small terms share the scale 2^11 and an accumulator of their own");
-    static_assert(!(PIN0 || POUT) || (MODE == 0 && BLDS), "pair tensors: the concat kernel");
+    static_assert(!(PIN0 || POUT) || (MODE == 0 && BLDS) || (MODE == 2 && !BLDS), "pair tensors: the concat kernel and the stride-2 kernel");
     using G = SpGeom<MODE>;
     constexpr bool UP = G::UP, S2 = G::S2;
     constexpr int NB = NBW, FG = 8 / RG;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     if constexpr (PIN0) {
         const float unscale0 = 1.f / p.pair_src_scale[n];
         prescale = 0.f; unscale = unscale0;
-        if (p.nsrc > 1) {
+        if (MODE == 0 && p.nsrc > 1) {
             sp_act_scale_of(p, 1, n, prescale, unscale);
             acc_rescale = prescale * unscale0;
         }
@@ -629,9 +630,38 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
     // behind the fetch of tap 2) have taps 0-2 to arrive -- one tap more than with a single set in flight -- and the ring
     // of three closes over the nine taps (no register copy, no drained queue at the end of a chunk); they are written
     // (split) into the other A buffer from tap 4 on; ONE barrier per chunk
+    // pair source (stride 2: KB image convs fed by the previous level's conv_image): a staged chunk is 4 planes (term, k-group) x
+    // NPIX granules; LDS granule q of a plane is staged pixel (r, s) = (q / COLS, q % COLS) of the DE-INTERLEAVED row -- input
+    // column 2 s for s < (COLS + 1) / 2, else 2 (s - (COLS + 1) / 2) + 1 -- so the de-interleave is only a per-lane offset
+    constexpr int NR2 = (NPIX + 63) / 64, NDMA2 = 4 * NR2, DPW2 = NDMA2 / 8;
+    static_assert(!PIN0 || NDMA2 % 8 == 0, "the same number of DMAs in every wave (the vmcnt arithmetic counts them)");
+    const unsigned lds0s = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+    unsigned dvoff2[PIN0 ? DPW2 : 1];
+    if constexpr (PIN0) {
+#pragma unroll
+        for (int i = 0; i < DPW2; ++i) {
+            const int q = ((wave + 8 * i) % NR2) * 64 + lane;
+            const int r = q / COLS, sc = q - r * COLS;
+            const int cc = S2 ? (sc < (COLS + 1) / 2 ? 2 * sc : 2 * (sc - (COLS + 1) / 2) + 1) : sc;
+            const int Y = (S2 ? 2 * oy0 : oy0) - 1 + r, X = (S2 ? 2 * ox0 : ox0) - 1 + cc;
+            dvoff2[i] = (q < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (unsigned)(Y * sW + X) * 16u : (unsigned)(sH * sW) * 16u;
+        }
+    }
+    const long long pplane2 = pair_plane_halves(sH, sW);
+    auto dma_chunk2 = [&](int buf, int chunk) __attribute__((always_inline)) {
+        const _Float16* pn = p.pair_src + (long long)n * p.pair_src_bstride + (long long)(2 * chunk) * 2 * pplane2;
+#pragma unroll
+        for (int i = 0; i < DPW2; ++i) {
+            const int id = wave + 8 * i, plane = id / NR2, j = id - plane * NR2;
+            const int t = plane >> 1, kgl = plane & 1;
+            const unsigned long long mask = (j == NR2 - 1 && (NPIX & 63)) ? ((1ull << (NPIX & 63)) - 1) : ~0ull;
+            lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kgl * 2 + t) * pplane2), dvoff2[i],
+                         lds0s + (unsigned)(buf * G::A_BYTES + t * G::A_PART + (kgl * NPIX + j * 64) * 16), mask);
+        }
+    };
     auto chunk_body = [&](int c, auto more_tag, auto chk_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
-        constexpr int NA = MORE ? G::NLOADA : 0, NBL = 2 * NB;
+        constexpr int NA = MORE ? (PIN0 ? DPW2 : G::NLOADA) : 0, NBL = 2 * NB;
         const int abuf = (c & 1) * G::A_BYTES;
 #pragma unroll
         for (int d = 0; d < AD; ++d) load_a(aq[d], abuf, d);
@@ -646,7 +676,10 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             if (gi == 0) {
                 if (tap + 2 < 9) load_b(bn, c, tap + 2);
                 else if (MORE) load_b(bn, c + 1, tap + 2 - 9);
-                if (tap == 0 && MORE) load_chunk(c + 1);
+                if (tap == 0 && MORE) {
+                    if constexpr (PIN0) dma_chunk2((c & 1) ^ 1, c + 1);   // the other buffer was last read a chunk (a barrier) ago
+                    else load_chunk(c + 1);
+                }
                 // outstanding, oldest first: [b(tap)] b(tap+1) b(tap+2) with the inputs behind b(2); b(tap) is what the MFMAs below need
                 if (tap <= 2) sp_wait_b<2 * NBL + NA>(bc);
                 else if (tap < 7 || MORE) sp_wait_b<2 * NBL>(bc);
@@ -662,7 +695,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
             mfma_group(chk_tag, ac, bw, grp);
             __builtin_amdgcn_sched_barrier(0);
             static_assert(5 * GPT >= PR, "taps 4-8 hold the staging rounds");
-            if (MORE && tap >= 4) {   // the wait of tap 3 covered the input loads; one staging round per group
+            if (!PIN0 && MORE && tap >= 4) {   // the wait of tap 3 covered the input loads; one staging round per group
                 const int u = (tap - 4) * GPT + gi;
                 if (u < PR) store_round((c & 1) ^ 1, u);
             }
@@ -670,12 +703,15 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
         __syncthreads();
     };
 
-    load_chunk(0);
+    if constexpr (PIN0) dma_chunk2(0, 0);
+    else load_chunk(0);
     load_b(bq[0], 0, 0);
     load_b(bq[1], 0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!PIN0) {
 #pragma unroll
-    for (int u = 0; u < PR; ++u) store_round(0, u);
+        for (int u = 0; u < PR; ++u) store_round(0, u);
+    }
     __syncthreads();
     auto k_loop = [&](auto chk_tag) {
         for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{}, chk_tag);
@@ -723,6 +759,18 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
                         vb[j] = tb > 0.f ? tb : tb * slope;
                     }
                     if (X < W) amax = sp_amax4(sp_amax4(amax, va), vb);
+                    if (S2 && p.out && !((Y | X) & 1) && X < W) {
+                        // the next level's conv_fused (1x1, stride 2) reads this tensor at even pixels only: they also go out
+                        // in fp32, as a dense (H + 1) / 2 x (W + 1) / 2 tensor of their own (a sixteenth of the pair tensor's stores)
+                        const int sw2 = (W + 1) >> 1;
+                        float* so = p.out + (long long)n * p.out_bstride + ((long long)(kg0 * 8 + 4 * g) * ((H + 1) >> 1) + (Y >> 1)) * sw2 + (X >> 1);
+                        const long long cs = (long long)((H + 1) >> 1) * sw2;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (kg0 * 8 + 4 * g + j < p.OC) so[j * cs] = va[j];
+                            if (kg0 * 8 + 8 + 4 * g + j < p.OC) so[(8 + j) * cs] = vb[j];
+                        }
+                    }
                     sph4 a1, a2, b1, b2;
                     sp_split4(va * ps_out, a1, a2);
                     sp_split4(vb * ps_out, b1, b2);
@@ -2002,17 +2050,23 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const Sp
     const int kg_st = wave >> 2, t256 = tid & 255;
     const int sy = 2 * (oy0 + (t256 >> 5)), sx = 2 * (ox0 + (t256 & 31));
     const int goff = (sy < sH && sx < sW) ? (sy * sW + sx) * 4 : -1;
+    // a source that was written at the even pixels only (p.sub0: the stride-2 split conv's fp32 side output): same validity
+    const int goff_sub = goff >= 0 ? ((sy >> 1) * W + (sx >> 1)) * 4 : -1;
+    const long long plane_sub = (long long)H * W;
     const unsigned char* wp_nt = reinterpret_cast<const unsigned char*>(p.wp) + (long long)nt * nchunks * B_CHUNK;
 
     float va[2][8];
     auto load_chunk = [&](float (&v)[8], int chunk) {
         int c = chunk * SP_CK, s = 0;
         if (p.nsrc > 1 && c >= p.srcC[0]) { c -= p.srcC[0]; s = 1; }
-        const float* base = p.src[s] + (long long)n * p.src_bstride[s] + (long long)(c + kg_st * 8) * plane;
-        const unsigned voff = goff < 0 ? 0u : (unsigned)goff;
+        const bool sub = p.sub0 && s == 0;                 // launch- / wave-uniform
+        const long long pl = sub ? plane_sub : plane;
+        const float* base = p.src[s] + (long long)n * p.src_bstride[s] + (long long)(c + kg_st * 8) * pl;
+        const int go = sub ? goff_sub : goff;
+        const unsigned voff = go < 0 ? 0u : (unsigned)go;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float* sb = base + (long long)k * plane;   // wave-uniform
+            const float* sb = base + (long long)k * pl;   // wave-uniform
             asm volatile("global_load_dword %0, %1, %2" : "=v"(v[k]) : "v"(voff), "s"(sb) : "memory");
         }
     };
@@ -2262,7 +2316,8 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         if (s == 0) { p.sH = a.src_height; p.sW = a.src_width; }
         if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
         if (pair) {   // source 0 of the concat conv / the input of a folded up-conv, written by a split-operand producer
-            if (s != 0 || (mode != 0 && mode != 3) || (knob(KNOB_DEBUG) & (16 | 64))) return KBN_ERR_UNSUPPORTED;
+            if (s != 0 || mode == 1 || (knob(KNOB_DEBUG) & (16 | 64))) return KBN_ERR_UNSUPPORTED;
+            if (mode == 2 && n_src != 1) return KBN_ERR_UNSUPPORTED;
             // the concat kernel's K loop: a pair source beside an fp32 one, at least two 16-channel chunks each
             if (mode == 0 && (n_src != 2 || a.channels < 2 * SP_CK || srcs[1].kind != KBN_SRC_TENSOR || srcs[1].channels < 2 * SP_CK))
                 return KBN_ERR_UNSUPPORTED;
@@ -2296,7 +2351,8 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     p.l1 = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed_weight) +
                                           kbn_conv3x3_split_packed_weight_bytes(out_channels, cin, mode) - (size_t)(cin / SP_CK) * 4);
     if (pair_out) {   // the output as a pair tensor: concat convs and the 64-filter folded up-convs; its 2^k needs every source's slot
-        const bool kernel_ok = (mode == 0 && !(knob(KNOB_DEBUG) & 64)) || (mode == 3 && ntf == U64_NT && !uf_narrow(out_channels, cin));
+        const bool kernel_ok = (mode == 0 && !(knob(KNOB_DEBUG) & 64)) || (mode == 3 && ntf == U64_NT && !uf_narrow(out_channels, cin)) ||
+                               (mode == 2 && n_src == 1);
         if (!kernel_ok || (out_channels & 7)) return KBN_ERR_UNSUPPORTED;
         if (!p.amax[0] || (n_src > 1 && !p.amax[1]) || !pair_out_scale || (reinterpret_cast<uintptr_t>(pair_out) & 15) ||
             (pair_out_batch_stride & 7) || pair_out_batch_stride < (long long)(out_channels / 8) * 2 * pair_plane_halves(height, width))
@@ -2381,7 +2437,13 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
             // L2 by two waves instead of four -- half the vector-memory traffic of a chunk -- for twice the A fragment reads
             // from LDS.  Inside the forward (KB2 / KB3 / KB4 / conv5 image / conv5 depth, 32 KITTI frames): 397 / 337 / 314 /
             // 247 / 60 us against 414 / 360 / 322 / 281 / 69 with 4 x 2 waves of 2 rows x two blocks
-            rc = launch(conv3x3_split_kernel<2, 2, true, false, 1>, SpGeom<2>::LDS, o[2]);
+            {
+                static DeviceOnce o2p[3];
+                if (p.pair_src) rc = p.pair_out ? launch(conv3x3_split_kernel<2, 2, true, false, 1, true, true>, SpGeom<2>::LDS, o2p[2])
+                                                : launch(conv3x3_split_kernel<2, 2, true, false, 1, true, false>, SpGeom<2>::LDS, o2p[1]);
+                else rc = p.pair_out ? launch(conv3x3_split_kernel<2, 2, true, false, 1, false, true>, SpGeom<2>::LDS, o2p[0])
+                                     : launch(conv3x3_split_kernel<2, 2, true, false, 1>, SpGeom<2>::LDS, o[2]);
+            }
             break;
         default:
             if (knob(KNOB_DEBUG) & 16) {   // weights fetched per set into registers (the form before the LDS stage), for A/B runs
@@ -2447,8 +2509,15 @@ int kbn_conv1x1s2_split_forward(const kbn_conv_src* srcs, int n_src, const void*
     for (int s = 0; s < n_src; ++s) {
         const kbn_conv_src& a = srcs[s];
         if (a.kind != KBN_SRC_TENSOR || !a.data || a.channels < 1 || (a.channels % SP_CK) != 0) return KBN_ERR_UNSUPPORTED;
-        if (s == 0) { p.sH = a.src_height; p.sW = a.src_width; }
-        if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
+        // with two sources, source 0 may come pre-subsampled: height x width planes holding the pixels (2y, 2x) of the tensor
+        // the reference's conv reads (the fp32 side output of kbn_conv3x3_split_forward(mode 2, pair_out))
+        const bool sub = s == 0 && n_src == 2 && a.src_height == height && a.src_width == width &&
+                         (srcs[1].src_height != height || srcs[1].src_width != width);
+        if (sub) p.sub0 = 1;
+        else {
+            if (!p.sH) { p.sH = a.src_height; p.sW = a.src_width; }
+            if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
+        }
         p.src[s] = a.data; p.src_bstride[s] = a.batch_stride; p.srcC[s] = a.channels;
         cin += a.channels;
     }

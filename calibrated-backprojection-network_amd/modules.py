@@ -213,9 +213,11 @@ class Conv2d(torch.nn.Module):
         dev = self.conv.weight.device
         srcs = self._with_slots(srcs, n, dev, stats)
         if pair_out:
-            if stats is None or self.out_channels % 8 or self.stride != 1:
+            if stats is None or self.out_channels % 8 or (self.stride != 1 and up2x):
                 return None
             out = ops.PairTensor(n, self.out_channels, h, w, dev, stats)
+            if self.stride == 2:
+                out.with_sub()   # the even pixels in fp32 too: the next level's 1x1 stride-2 conv_fused reads those
             if out_absmax is not None:
                 out.absmax = out_absmax
         elif out is None:
@@ -236,6 +238,10 @@ class Conv2d(torch.nn.Module):
         ci, cf = image.shape[1], (0 if fused is None else fused.shape[1])
         if not self.split_fused_qualifies(ci, cf):
             return None
+        if isinstance(image, ops.PairTensor):   # the previous level's conv_image as a pair tensor: its fp32 even-pixel side output
+            if image.sub is None or fused is None:
+                return None
+            image, amax_image = image.sub, image.absmax
         srcs = [ops.tensor_src(image, "image", amax_image)] + ([] if fused is None else [ops.tensor_src(fused, "fused", amax_fused)])
         srcs = self._with_slots(srcs, n, image.device, stats)
         packed = self._packed_split_1x1.get(self.conv.weight, 2, up2x=("split_1x1s2", ci))
@@ -430,10 +436,17 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             raise ValueError("the fused KB block needs a (leaky) ReLU activation")
 
     def run(self, image, depth, coordinates, fused, out_image=None, out_depth=None, out_fused=None,
-            amax_image=None, amax_fused=None, out_amax_image=None, out_amax_skip=None, stats=None, need_image=True):
+            amax_image=None, amax_fused=None, out_amax_image=None, out_amax_skip=None, stats=None, need_image=True,
+            pair_image_out=False):
         """amax_image / amax_fused: per-frame max |a| slots of `image` / `fused` (ops.ActStats; measured here when a
         split-operand conv needs one that is missing); out_amax_image: slot to fill for conv_image's output;
         out_amax_skip: ONE slot for conv_fused's and conv_depth's outputs (the encoder keeps them in one skip tensor)."""
+        # `image` may be an ops.PairTensor (with its fp32 even-pixel side output) and `pair_image_out` asks for conv_image's result
+        # as one: the encoder's chain of stride-2 split convs (KBNetEncoder.encode); None when the pair kernels decline
+        pair_in = isinstance(image, ops.PairTensor)
+        if (pair_in or pair_image_out) and not (self.conv_image.conv_block[0].split and self.split_image and self.split_fused
+                                                and coordinates.dim() == 3 and not self.conv_image.conv_block[0].bf16 and stats is not None):
+            return None
         n, ci, h, w = image.shape
         cd, cf = depth.shape[1], (0 if fused is None else fused.shape[1])
         want = (self.conv_image.conv_block[0].in_channels, self.conv_depth.conv_block[0].in_channels - 3,
@@ -443,7 +456,7 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         oh, ow = (h + 1) // 2, (w + 1) // 2
         dev = image.device
         mk = lambda c: torch.empty((n, c, oh, ow), device=dev, dtype=torch.float32)
-        out_image = mk(self.n_filter_image) if out_image is None else out_image
+        out_image = mk(self.n_filter_image) if (out_image is None and not pair_image_out) else out_image
         out_depth = mk(self.n_filter_depth) if out_depth is None else out_depth
         out_fused = mk(self.n_filter_fused) if out_fused is None else out_fused
         kinv = coords = None
@@ -469,14 +482,21 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         if ci_conv.split and self.split_image and kinv is not None:
             # conv_image (most of the block's FLOPs) on the 16-bit matrix core (fp32-grade split operands); conv_depth and
             # conv_fused -- their inputs are synthesized in-kernel (K^-1 [x y 1]^T, backprojection) -- on the fp32 kernels
-            if amax_image is None or (stats is not None and not stats.usable(amax_image.data_ptr())):
+            if pair_in:
+                amax_image = image.absmax
+            elif amax_image is None or (stats is not None and not stats.usable(amax_image.data_ptr())):
                 stats = stats if stats is not None else ops.ActStats(n, dev, capacity=3)
                 amax_image = stats.measure(image)   # conv_image and conv_fused both read `image`: measured once
             branch = _SideBranch(dev)   # forks HERE: conv_depth and conv_fused read nothing that conv_image writes
             # need_image=False (KBNetEncoder.skip_unused_image): the caller never reads conv_image's output -- the reference's
             # last KB level, whose image branch feeds nothing (src/networks.py:475-523: conv5_image takes conv4_fused)
-            res = True if not need_image else ci_conv.run_split([ops.tensor_src(image, "image", amax_image)], n, oh, ow, out=out_image,
-                                                                out_absmax=out_amax_image, stats=stats)
+            isrc = ops.pair_src(image, "image") if pair_in else ops.tensor_src(image, "image", amax_image)
+            res = True if not need_image else ci_conv.run_split([isrc], n, oh, ow, out=out_image, out_absmax=out_amax_image, stats=stats,
+                                                                pair_out=pair_image_out)
+            if res is None and (pair_in or pair_image_out):
+                return None
+            if pair_image_out and need_image:
+                out_image = res
             if res is not None:
                 with branch:
                     self._depth_and_fused(image, depth, fused, kinv, n, h, w, oh, ow, out_depth, out_fused, ci, cf,
@@ -502,6 +522,8 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             if self.conv_fused.run_split_fused(image, fused, xyz, n, oh, ow, out_fused, amax_image, amax_fused,
                                                out_absmax=out_amax_skip, stats=stats) is not None:
                 return
+        if isinstance(image, ops.PairTensor):
+            image = image.float()   # the split conv_fused declined a pair tensor's side output: decode it (rare, not fast)
         srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
         if fused is not None:
             srcs.append(ops.tensor_src(fused, "fused"))
@@ -644,6 +666,8 @@ class KBNetEncoder(torch.nn.Module):
         self.front = True
         # OFF by default (the reference computes it): do not launch conv_image of KB level 3, whose output nothing reads
         self.skip_unused_image = False
+        # conv_image of KB levels 1 and 2 as ops.PairTensor for the next level's split convs (KBN_NO_PAIR=1: fp32 tensors)
+        self.pair_chain = os.environ.get("KBN_NO_PAIR", "0") in ("", "0") and os.environ.get("KBN_NO_PAIR_ENC", "0") in ("", "0")
         self._packed_front = _PackedFront()
         self._packed_depth_front = _PackedFront(ops.pack_kb1_depth_front_weight)
 
@@ -741,10 +765,23 @@ class KBNetEncoder(torch.nn.Module):
                 # the image branch of the last KB level in front of a plain level 4 feeds nothing (reference
                 # src/networks.py:475-523: conv5_image reads conv4_fused, conv4_image only lends its shape)
                 unused = self.skip_unused_image and level == 3 and 4 not in self.resolutions_backprojection
-                conv_image, conv_depth, conv_fused = blk.run(
-                    conv_image, conv_depth, kinv, conv_fused, None, out_depth, out_fused,
-                    amax_image=amax_image if level > 0 else None, amax_fused=amax_skip if conv_fused is not None else None,
-                    out_amax_image=a_img, out_amax_skip=a_skip, stats=stats, need_image=not unused)
+                # conv_image of a KB level is read by the next KB level only -- its stride-2 split conv_image and, at the even
+                # pixels, its conv_fused: it travels as an ops.PairTensor (+ the fp32 even-pixel side output) from level 1 on
+                want_pair = self.pair_chain and 1 <= level < 3 and (level + 1) in self.resolutions_backprojection
+                res = None
+                if want_pair or isinstance(conv_image, ops.PairTensor):
+                    res = blk.run(conv_image, conv_depth, kinv, conv_fused, None, out_depth, out_fused,
+                                  amax_image=amax_image, amax_fused=amax_skip if conv_fused is not None else None,
+                                  out_amax_image=a_img, out_amax_skip=a_skip, stats=stats, need_image=not unused,
+                                  pair_image_out=want_pair)
+                if res is None:
+                    if isinstance(conv_image, ops.PairTensor):   # a pair tensor the next level declined: decode it (rare, not fast)
+                        conv_image, amax_image = conv_image.float(), None
+                    res = blk.run(
+                        conv_image, conv_depth, kinv, conv_fused, None, out_depth, out_fused,
+                        amax_image=amax_image if level > 0 else None, amax_fused=amax_skip if conv_fused is not None else None,
+                        out_amax_image=a_img, out_amax_skip=a_skip, stats=stats, need_image=not unused)
+                conv_image, conv_depth, conv_fused = res
                 amax_image = a_img
             else:
                 # plain level: conv_image lives in the skip tensor, whose slot (a superset: a safe bound) serves it too

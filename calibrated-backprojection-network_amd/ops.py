@@ -319,6 +319,18 @@ class PairTensor:
         self.data = torch.empty((n, channels // 8, 2, height * width + 1, 8), device=device, dtype=torch.float16)
         self.scale = torch.empty(n, device=device, dtype=torch.float32)
         self.absmax = stats.new()
+        # stride-2 producers (conv3x3_split(stride=2, out=PairTensor)) can also write the pixels (2y, 2x) in fp32, as a dense
+        # N x C x ceil(H/2) x ceil(W/2) tensor: what the next KB level's 1x1 stride-2 conv_fused reads of this tensor
+        self.sub: Optional[torch.Tensor] = None
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def with_sub(self) -> "PairTensor":
+        n, c, h, w = self.shape
+        self.sub = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), device=self.data.device, dtype=torch.float32)
+        return self
 
     def float(self) -> torch.Tensor:
         """The tensor as N x C x H x W fp32 (tests, diagnostics)."""
@@ -676,7 +688,7 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     arr = (ConvSrc * len(srcs))(*srcs)
     pair = isinstance(out, PairTensor)   # the output in the producer-written split format (its slot doubles as out_absmax)
     if pair:
-        optr, obs = None, 0
+        optr, obs = (None, 0) if (out.sub is None or stride != 2) else _planes(out.sub, "out.sub")
         if out_absmax is None:
             out_absmax = out.absmax
     else:

@@ -145,9 +145,9 @@ typedef struct kbn_conv_src {
  * of 8; base 16-byte aligned).  k is chosen per frame by the producer from a bound of its output -- (max |a| of each
  * input, from the inputs' absmax slots) x (a table of weight norms kept behind the packed weights) -- and written to
  * `pair_out_scale[frame]` as the float 2^k; the consumer receives that array as kbn_conv_src.scale.  The producer still
- * folds the true max |out| into out_absmax.  kbn_conv3x3_split_forward: `pair_out` for mode 0 and for mode 3 with whole
+ * folds the true max |out| into out_absmax.  kbn_conv3x3_split_forward: `pair_out` for modes 0 and 2 and for mode 3 with whole
  * 64-filter tiles (needs absmax slots on every source and out_channels % 8 == 0); a KBN_SRC_PAIR source 0 for mode 0
- * and for mode 3 (64-filter tiles, or at most 16 filters and channels % 32 == 0); KBN_ERR_UNSUPPORTED otherwise -- the
+ * (beside an fp32 source 1), mode 2 (one source) and mode 3 (64-filter tiles, or at most 16 filters and channels % 32 == 0); KBN_ERR_UNSUPPORTED otherwise -- the
  * caller then keeps the tensor in fp32. */
 
 /* ----------------------------------------------- activation statistics ("absmax slots") --
@@ -238,7 +238,10 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
  *             ceil(w/2) = width: the image convs of the KB blocks, reference src/net_utils.py:1348)
  *   srcs      1 or 2 KBN_SRC_TENSOR sources, each a multiple of 16 channels; source 0 may be a KBN_SRC_PAIR (above)
  *   pair_out  NULL, or the output as a PAIR tensor (then `out` is ignored and may be NULL), with
- *             pair_out_batch_stride (fp16 elements) and pair_out_scale (n floats)
+ *             pair_out_batch_stride (fp16 elements) and pair_out_scale (n floats).  Mode 2 with pair_out (one source): a
+ *             non-NULL `out` receives, in fp32, the output pixels (2y, 2x) only, as N x out_channels x ceil(height / 2) x
+ *             ceil(width / 2) -- what the next KB level's 1x1 stride-2 conv_fused reads of this tensor
+ *             (kbn_conv1x1s2_split_forward takes it as a pre-subsampled source 0)
  *   packed    from kbn_conv3x3_split_pack_weight (OIHW fp32 3x3 weight in) for the SAME mode (the
  *             filter tiling of the blob depends on it)
  *   out       N x out_channels x height x width fp32, frames out_batch_stride elements apart
@@ -254,7 +257,8 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
 
 /* conv_fused of the KB block on split operands -- reference src/net_utils.py:1337-1343 (Conv2d(in_channels_fused + 3,
  * n_filter_fused, kernel_size=1, stride=2)) applied to cat[image, xyz, fused] (:1352-1368).  The tensor channels
- * (image, fused: one or two KBN_SRC_TENSOR sources of H x W planes, channels % 16 == 0) are taken through the 16-bit
+ * (image, fused: one or two KBN_SRC_TENSOR sources of H x W planes, channels % 16 == 0; with two sources, source 0 may
+ * instead hold only the pixels the conv reads: src_height x src_width = the OUTPUT size) are taken through the 16-bit
  * matrix core like the 3x3 convs above; the three backprojection channels xyz = K^-1 [x y 1]^T z, z =
  * act(proj_depth . depth) (:1352-1359), are computed once per block at the positions a stride-2 1x1 conv reads
  * (kbn_kb_xyz_s2_forward: xyz[:, :, y, x] belongs to input pixel (2y, 2x)) and enter in fp32.

@@ -740,6 +740,62 @@ def test_pair_tensor_chain_upconv_to_concat(dev, cup, cskip, cout, hw):
     assert r_pair < max(1.5 * r_f32, 3e-7) and m_pair < max(2.0 * m_f32, 3e-6)
 
 
+@pytest.mark.parametrize("c0,c1,c2,hw", [(48, 96, 192, (23, 44)), (96, 192, 384, (22, 76)), (16, 64, 72, (9, 21)), (32, 128, 96, (17, 33))])
+def test_pair_tensor_chain_of_stride2_convs(dev, c0, c1, c2, hw):
+    """The encoder's chain: a stride-2 split conv writes a PAIR tensor plus the fp32 side output of its even pixels, the next
+    stride-2 split conv stages the pair tensor (de-interleaved columns by per-lane DMA offsets) and the 1x1 stride-2
+    conv_fused takes the side output as a pre-subsampled source 0 beside a full-size fp32 source."""
+    h, w = hw                                   # size of the tensor between the two stride-2 convs
+    g = torch.Generator().manual_seed(c0 + c1 + c2 + h)
+    n = 2
+    x0 = torch.nn.functional.leaky_relu(torch.randn(n, c0, 2 * h - 1, 2 * w, generator=g), 0.2)
+    x0[1] *= 0.05
+    w1 = torch.randn(c1, c0, 3, 3, generator=g) / (c0 * 9) ** 0.5
+    w2 = torch.randn(c2, c1, 3, 3, generator=g) / (c1 * 9) ** 0.5
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    stats = kb.ops.ActStats(n, dev)
+    x0d = x0.to(dev)
+    src0 = [kb.ops.tensor_src(x0d, "x", stats.measure(x0d))]
+    p1 = kb.ops.pack_conv3x3_split_weight(w1.to(dev), stride=2)
+    mid32 = torch.empty(n, c1, h, w, device=dev)
+    assert kb.ops.conv3x3_split(src0, p1, n, c1, h, w, mid32, negative_slope=0.2, stride=2) is not None
+    pt = kb.ops.PairTensor(n, c1, h, w, dev, stats).with_sub()
+    pt.data.fill_(float("nan"))
+    pt.sub.fill_(float("nan"))
+    assert kb.ops.conv3x3_split(src0, p1, n, c1, h, w, pt, negative_slope=0.2, stride=2) is not None
+    assert torch.isfinite(pt.data).all() and float(pt.data[:, :, :, h * w].abs().max()) == 0.0
+    assert rel_err(pt.float(), mid32) < 1e-6
+    assert torch.equal(pt.sub, mid32[:, :, ::2, ::2]), "the side output: the fp32 result at the even pixels, bit for bit"
+    assert torch.equal(kb.ops.slot_values(pt.absmax), mid32.abs().amax(dim=(1, 2, 3)))
+    # consumer 1: the next stride-2 conv
+    xin = pt.float()
+    ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xin.cpu().double(), w2.double(), stride=2, padding=1), 0.2)
+    p2 = kb.ops.pack_conv3x3_split_weight(w2.to(dev), stride=2)
+    out_f32 = torch.empty(n, c2, oh, ow, device=dev)
+    assert kb.ops.conv3x3_split([kb.ops.tensor_src(xin, "x", pt.absmax)], p2, n, c2, oh, ow, out_f32, negative_slope=0.2, stride=2) is not None
+    out_pair = torch.full((n, c2, oh, ow), float("nan"), device=dev)
+    assert kb.ops.conv3x3_split([kb.ops.pair_src(pt, "x")], p2, n, c2, oh, ow, out_pair, negative_slope=0.2, stride=2) is not None
+    r_pair, m_pair = _pair_errs(out_pair, ref64)
+    r_f32, m_f32 = _pair_errs(out_f32, ref64)
+    print(f"stride-2 conv of a pair tensor vs fp64: rms {r_pair:.2e} max {m_pair:.2e}; of its fp32 decode: rms {r_f32:.2e} max {m_f32:.2e}")
+    assert r_pair < max(1.5 * r_f32, 3e-7) and m_pair < max(2.0 * m_f32, 3e-6)
+    if c1 % 16 == 0 and c2 >= 64:
+        # consumer 2: conv_fused over cat[image, xyz, fused] with image = the pre-subsampled side output
+        cf = 32
+        fused = torch.nn.functional.leaky_relu(torch.randn(n, cf, h, w, generator=g), 0.2).to(dev)
+        xyz = torch.randn(n, 3, oh, ow, generator=g).to(dev)
+        wf = torch.randn(c2, c1 + 3 + cf, 1, 1, generator=g) / (c1 + 3 + cf) ** 0.5
+        pf = kb.ops.pack_conv1x1s2_split_weight(wf.to(dev), xyz_offset=c1)
+        fslot = stats.measure(fused)
+        full = torch.empty(n, c2, oh, ow, device=dev)
+        assert kb.ops.conv1x1s2_split([kb.ops.tensor_src(mid32, "image", pt.absmax), kb.ops.tensor_src(fused, "fused", fslot)], pf, xyz,
+                                      n, c2, oh, ow, full, negative_slope=0.2) is not None
+        sub = torch.full_like(full, float("nan"))
+        assert kb.ops.conv1x1s2_split([kb.ops.tensor_src(pt.sub, "image", pt.absmax), kb.ops.tensor_src(fused, "fused", fslot)], pf, xyz,
+                                      n, c2, oh, ow, sub, negative_slope=0.2) is not None
+        assert torch.equal(sub, full), "same values fetched from the side output: same bits"
+
+
 @pytest.mark.parametrize("cins,cout,hw", [((64, 64), 64, (22, 76)), ((32,), 48, (16, 64)), ((16, 32), 130, (9, 40)), ((128, 128), 128, (37, 52))])
 def test_conv3x3_split_k32_form(dev, kenv, cins, cout, hw):
     """The 16x16x32 form of the concat-conv kernel (conv3x3_split_k32_kernel, KBN_DEBUG=64; off by default: slower on the
