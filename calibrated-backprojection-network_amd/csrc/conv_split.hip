@@ -210,10 +210,13 @@ __device__ __forceinline__ spu4 sp_pair_exchange(const sph4& a, const sph4& b) {
 // two-term split of 4 floats already in window units (t = a 2^k)
 __device__ __forceinline__ void sp_split4(const f32x4& t, sph4& h1, sph4& h2) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const _Float16 c1 = (_Float16)t[j];
-        h1[j] = c1;
-        h2[j] = (_Float16)((t[j] - (float)c1) * 2048.f);
+    for (int k = 0; k < 4; k += 2) {   // two at a time: packed conversions and packed fp32 arithmetic
+        const f32x2 a = {t[k], t[k + 1]};
+        const sph2 c1 = __builtin_convertvector(a, sph2);
+        const f32x2 f = {(float)c1[0], (float)c1[1]};
+        const sph2 c2 = __builtin_convertvector((a - f) * 2048.f, sph2);   // a - f and the scaling are exact
+        h1[k] = c1[0]; h1[k + 1] = c1[1];
+        h2[k] = c2[0]; h2[k + 1] = c2[1];
     }
 }
 
