@@ -279,6 +279,9 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
     return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
 }
 
+// fp16 elements of one (k-group, term) plane of a PAIR tensor (include/kbnet_hip.h): H * W pixels + the zero granule
+__host__ __device__ constexpr long long pair_plane_halves(int h, int w) { return ((long long)h * w + 1) * 8; }
+
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }

@@ -168,7 +168,7 @@ __device__ __forceinline__ float sp_amax4(float m, const f32x4& v) {
 // 22 bits down to 2^-29 of the window, tests/test_split_math_cpu.py).  Every workgroup of a frame computes the same k
 // and writes it to the tensor's per-frame scale slot; consumers read it there.  With two sources in different formats
 // the accumulators are rescaled by the exact power of two between the two windows when the K loop changes source.
-__host__ __device__ constexpr long long pair_plane_halves(int h, int w) { return ((long long)h * w + 1) * 8; }
+// (pair_plane_halves: conv_common.h)
 
 __device__ __forceinline__ float sp_scale_of_bound(float bound) {   // 2^k with bound 2^k in [2^14, 2^15); finite for 0 / Inf / NaN
     int k = 14 + 127 - (int)(__float_as_uint(bound) >> 23 & 255u);
@@ -205,6 +205,16 @@ __device__ __forceinline__ spu4 sp_pair_exchange(const sph4& a, const sph4& b) {
     const spu2 A = __builtin_bit_cast(spu2, a), B = __builtin_bit_cast(spu2, b);
     const auto r0 = __builtin_amdgcn_permlane32_swap(A[0], B[0], false, false);   // {A.lo | B.lo , A.hi | B.hi} by lane half
     const auto r1 = __builtin_amdgcn_permlane32_swap(A[1], B[1], false, false);
+    return (spu4){r0[0], r1[0], r0[1], r1[1]};
+}
+// The same between 16-lane rows r and r + 1 (the 16x16x32 epilogue: lane (pixel lp, kq) holds channels 4 (kq & 1) .. of k-group
+// kq >> 1): `a` is the lane's half granule of output pixel px = 0, `b` of px = 1; rows with even kq end up with the whole
+// granule of px = 0, rows with odd kq with that of px = 1 (v_permlane16_swap: odd rows of the first operand <-> even rows of
+// the second).
+__device__ __forceinline__ spu4 sp_pair_exchange16(const sph4& a, const sph4& b) {
+    const spu2 A = __builtin_bit_cast(spu2, a), B = __builtin_bit_cast(spu2, b);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(A[0], B[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(A[1], B[1], false, false);
     return (spu4){r0[0], r1[0], r0[1], r1[1]};
 }
 // two-term split of 4 floats already in window units (t = a 2^k)
@@ -1434,7 +1444,9 @@ __global__ void uf16_pack_kernel(const float* __restrict__ w, const float* __res
 // two barriers, two workgroups per CU -- with only Cin / 32 = 2 chunks per tile the first fetch and the stores are most
 // of a workgroup's life, and a second resident workgroup multiplies meanwhile: 700 -> 616 us for deconv0's up-conv.
 // (Measured and not kept, DESIGN.md round 3: persistent workgroups, with the weights from L2 as here or resident in LDS.)
-template <int NW, bool PIN>   // PIN: the input is a pair tensor, staged by LDS-DMA (see upconv2x_split64_kernel)
+// PIN: the input is a pair tensor, staged by LDS-DMA (see upconv2x_split64_kernel); POUT: the output is written as one with
+// 16 channels (two k-groups; channels past OC are zero) -- the decoder tail (csrc/tail.hip) stages it by DMA
+template <int NW, bool PIN, bool POUT = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_kernel(const SplitConvParams p) {
     static_assert(NW == 8 || NW == 4, "8 waves (16-row tiles) or 4 waves (8-row tiles)");
     constexpr bool DB = NW == 8;
@@ -1600,8 +1612,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     if (CHK && oy0 + 4 * rg + mb >= sH) continue;      // low-resolution row below the map: no MFMAs (wave-uniform)
-                    acc[mb][t.py][t.px] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot(mb + t.s, t.ox)][TA[k]], bw[k],
-                                                                                  acc[mb][t.py][t.px], 0, 0, 0);
+                    acc[mb][t.py][t.px] = POUT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[k], af[slot(mb + t.s, t.ox)][TA[k]],
+                                                                                         acc[mb][t.py][t.px], 0, 0, 0)
+                                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot(mb + t.s, t.ox)][TA[k]], bw[k],
+                                                                                         acc[mb][t.py][t.px], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
             if (!PIN && DB && MORE && it > D + 1 && it - D - 2 < PR) store_round((c & 1) ^ 1, it - D - 2);   // the wait of set D+1 covered the inputs
@@ -1639,12 +1653,56 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
     if (!KBN_SPLIT_STRAIGHT || oy0 + ROWS > sH) k_loop(std::true_type{});   // tile with rows below the map (workgroup-uniform)
     else k_loop(std::false_type{});
 
+    const float slope = p.act ? p.slope : 1.f;
+    if constexpr (POUT) {
+        // ---- pair epilogue: acc[mb][py][px][i]: low-resolution x = 16 mblk + lp, filter 4 kq + i: a lane holds half a granule
+        // (channels 4 (kq & 1) ..) of k-group kq >> 1 of the outputs (2 Y + py, 2 x + px); 8-byte stores, two lanes per granule
+        const float ps_out = sp_pair_out_scale(p, n);
+        const long long oph = pair_plane_halves(H, W);
+        _Float16* const pn = p.pair_out + (long long)n * p.pair_out_bstride;
+        if (tid == 0) p.pair_out_scale[n] = ps_out;
+        if (tx == 0 && ty == 0 && wave == 0 && lane < 4)    // the zero granules of the two k-groups x two terms
+            *reinterpret_cast<f32x4*>(pn + (long long)lane * oph + (long long)H * W * 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 inv4 = *reinterpret_cast<const f32x4*>(p.inv_scale + 4 * kq) * unscale;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * kq + i >= p.OC) inv4[i] = 0.f;          // channels past the last filter: zeros
+        const int x = ox0 + 16 * mblk + lp;
+        _Float16* const k0 = pn + (long long)((kq >> 1) * 2) * oph;
+        float amax = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int Y = oy0 + 4 * rg + mb;
+            if (Y >= sH) continue;                          // wave-uniform
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                f32x4 v0, v1;                               // this lane's four channels of outputs (2 x, 2 x + 1)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float a = acc[mb][py][0][i] * inv4[i], b = acc[mb][py][1][i] * inv4[i];
+                    v0[i] = a > 0.f ? a : a * slope;
+                    v1[i] = b > 0.f ? b : b * slope;
+                }
+                if (x < sW) amax = sp_amax4(sp_amax4(amax, v0), v1);
+                sph4 a1, a2, b1, b2;
+                sp_split4(v0 * ps_out, a1, a2);
+                sp_split4(v1 * ps_out, b1, b2);
+                const spu4 g1 = sp_pair_exchange16(a1, b1), g2 = sp_pair_exchange16(a2, b2);   // every lane takes part
+                if (x < sW) {                               // even kq: the whole granule of pixel 2 x, odd kq: of pixel 2 x + 1
+                    const long long o = ((long long)(2 * Y + py) * W + 2 * x + (kq & 1)) * 8;
+                    *reinterpret_cast<spu4*>(k0 + o) = g1;
+                    *reinterpret_cast<spu4*>(k0 + oph + o) = g2;
+                }
+            }
+        }
+        if (p.out_amax) absmax_commit(p.out_amax + n, amax);
+        return;
+    }
     // ---- epilogue: acc[mb][py][px][i]: low-resolution x = 16 mblk + 4 kq + i, filter lp; outputs (2 Y + py, 2 x + px)
     const long long oplane = (long long)H * W;
     const int oc = nt * U16_NT + lp;
     const float inv = p.inv_scale[oc] * unscale;                    // the table is padded to whole n-tiles
     float* outc = p.out + (long long)n * p.out_bstride + (long long)oc * oplane;
-    const float slope = p.act ? p.slope : 1.f;
     const int X = 2 * (ox0 + 16 * mblk + 4 * kq);                      // first of this lane's 8 output columns
     float amax = 0.f;
 #pragma unroll
@@ -2354,11 +2412,14 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     p.l1 = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed_weight) +
                                           kbn_conv3x3_split_packed_weight_bytes(out_channels, cin, mode) - (size_t)(cin / SP_CK) * 4);
     if (pair_out) {   // the output as a pair tensor: concat convs and the 64-filter folded up-convs; its 2^k needs every source's slot
+        // the narrow up-conv writes 16 channels (two k-groups, zeros past out_channels): its pair tensor feeds the decoder tail
+        const bool narrow = mode == 3 && uf_narrow(out_channels, cin) && !(knob(KNOB_DEBUG) & 128);
         const bool kernel_ok = (mode == 0 && !(knob(KNOB_DEBUG) & 64)) || (mode == 3 && ntf == U64_NT && !uf_narrow(out_channels, cin)) ||
-                               (mode == 2 && n_src == 1);
-        if (!kernel_ok || (out_channels & 7)) return KBN_ERR_UNSUPPORTED;
+                               (mode == 2 && n_src == 1) || narrow;
+        if (!kernel_ok || (!narrow && (out_channels & 7))) return KBN_ERR_UNSUPPORTED;
+        const int pair_channels = narrow ? U16_NT : out_channels;
         if (!p.amax[0] || (n_src > 1 && !p.amax[1]) || !pair_out_scale || (reinterpret_cast<uintptr_t>(pair_out) & 15) ||
-            (pair_out_batch_stride & 7) || pair_out_batch_stride < (long long)(out_channels / 8) * 2 * pair_plane_halves(height, width))
+            (pair_out_batch_stride & 7) || pair_out_batch_stride < (long long)(pair_channels / 8) * 2 * pair_plane_halves(height, width))
             return KBN_ERR_INVALID_ARGUMENT;
         p.pair_out = static_cast<_Float16*>(pair_out); p.pair_out_bstride = pair_out_batch_stride; p.pair_out_scale = pair_out_scale;
     }
@@ -2391,13 +2452,14 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
             const long long blocks8 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
             if (blocks8 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
             p.nblocks = (int)blocks8;
-            static DeviceOnce o16, o16p;
+            static DeviceOnce o16, o16p, o16o, o16po;
             auto launch4 = [&](auto kern, DeviceOnce& once) -> int {
                 if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
                 hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), 2 * 4 * 10 * 34 * 16, (hipStream_t)stream, p);
                 return KBN_OK;
             };
-            rc = p.pair_src ? launch4(upconv2x_split16_kernel<4, true>, o16p) : launch4(upconv2x_split16_kernel<4, false>, o16);
+            if (p.pair_out) rc = p.pair_src ? launch4(upconv2x_split16_kernel<4, true, true>, o16po) : launch4(upconv2x_split16_kernel<4, false, true>, o16o);
+            else rc = p.pair_src ? launch4(upconv2x_split16_kernel<4, true>, o16p) : launch4(upconv2x_split16_kernel<4, false>, o16);
         }
         if (rc != KBN_OK) return rc;
         KBN_CHECK_LAUNCH();

@@ -36,6 +36,9 @@ constexpr int TL_TAB = 16;                                                      
 struct TailParams {
     const float* x;
     long long x_bstride;
+    const _Float16* xp;      // the input as a PAIR tensor of 16 channels (include/kbnet_hip.h), or null (then `x`)
+    long long xp_bstride;    // fp16 elements per frame
+    const float* xscale;     // its per-frame 2^k
     const float* tab;        // TL_TAB floats
     const _Float16* wp;      // [5 k-steps][term][4 k-groups][16 filters][8]: k-group g = 4 ks + kq = (tap g >> 1, channels 8 (g & 1) + j)
     const float* wout;       // 1 x C x 3 x 3 (raw)
@@ -59,6 +62,9 @@ __device__ __forceinline__ void tl_split8(const float (&v)[8], float pre, th8& h
     }
 }
 
+// PIN: the input is the up-conv's PAIR tensor (16 channels: two k-groups): stage A is 6 LDS-DMAs per wave -- no loads into
+// registers, no tile maximum, no splitting; the window is the producer's
+template <bool PIN>
 __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailParams p) {
     constexpr int IN_KG = TL_NP0 * 16, IN_PART = 2 * IN_KG, IN_BYTES = 2 * IN_PART;   // [term][k-group][pixel][8 ch] fp16
     constexpr int OFF_F = IN_BYTES;                                                    // [C][TL_FP] fp32
@@ -80,7 +86,27 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
 
     // ---- A: input tile -> split granules; the fp16 window is the tile's own (max |x| over the pixels loaded here)
     float un_in;
-    {
+    if constexpr (PIN) {
+        constexpr int NR = (TL_NP0 + 63) / 64, NDMA = 4 * NR, DPW = NDMA / 8;   // 4 planes (term, k-group) x 12 rounds of 64 pixels
+        static_assert(NDMA % 8 == 0, "whole rounds of the eight waves");
+        un_in = 1.f / p.xscale[n];
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
+        const long long pplane = pair_plane_halves(H, W);
+        const _Float16* pn = p.xp + (long long)n * p.xp_bstride;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int id = wave + 8 * i, pl = id / NR, j = id - pl * NR;
+            const int t = pl >> 1, kg = pl & 1;
+            const int pix = j * 64 + lane;
+            const int r = pix / TL_R0W, c = pix - r * TL_R0W;
+            const int Y = oy0 - 2 + r, X = ox0 - 2 + c;
+            const unsigned voff = (pix < TL_NP0 && Y >= 0 && Y < H && X >= 0 && X < W) ? (unsigned)(Y * W + X) * 16u : (unsigned)(H * W) * 16u;
+            const unsigned long long mask = (j == NR - 1 && (TL_NP0 & 63)) ? ((1ull << (TL_NP0 & 63)) - 1) : ~0ull;
+            lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kg * 2 + t) * pplane), voff,
+                         lds0 + (unsigned)(t * IN_PART + kg * IN_KG + j * 64 * 16), mask);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         const float* xn = p.x + (long long)n * p.x_bstride;
         float raw[2][16];
         float tm = 0.f;
@@ -284,16 +310,21 @@ int kbn_conv_tail_pack_weight(const float* w_conv, void* packed, int channels, k
     return KBN_OK;
 }
 
-int kbn_conv_tail_forward(const float* x, long long x_batch_stride, const void* packed_w_conv, const float* w_out, float* depth,
-                          float* logits, int n, int channels, int height, int width, int apply_activation, float negative_slope,
-                          float min_predict_depth, float max_predict_depth, kbn_stream_t stream) {
+static int conv_tail_launch(const float* x, long long x_batch_stride, const void* x_pair, long long x_pair_batch_stride,
+                            const float* x_pair_scale, const void* packed_w_conv, const float* w_out, float* depth,
+                            float* logits, int n, int channels, int height, int width, int apply_activation, float negative_slope,
+                            float min_predict_depth, float max_predict_depth, kbn_stream_t stream) {
     using namespace kbn;
-    if (!x || !packed_w_conv || !w_out || !depth || n < 1 || channels < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if ((!x && !x_pair) || !packed_w_conv || !w_out || !depth || n < 1 || channels < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if (x_pair && (!x_pair_scale || (reinterpret_cast<uintptr_t>(x_pair) & 15) || (x_pair_batch_stride & 7) ||
+                   x_pair_batch_stride < 2 * 2 * pair_plane_halves(height, width)))
+        return KBN_ERR_INVALID_ARGUMENT;
     if (channels > 12 || knob(KNOB_NO_SPLIT) || knob(KNOB_NO_HEAD_FUSION)) return KBN_ERR_UNSUPPORTED;   // LDS: 12 feature planes beside the input tile
     if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
     if (apply_activation && !(negative_slope >= 0.f && negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;   // max(v, slope v) form
     TailParams p{};
     p.x = x; p.x_bstride = x_batch_stride;
+    p.xp = static_cast<const _Float16*>(x_pair); p.xp_bstride = x_pair_batch_stride; p.xscale = x_pair_scale;
     p.tab = static_cast<const float*>(packed_w_conv);
     p.wp = reinterpret_cast<const _Float16*>(p.tab + TL_TAB);
     p.wout = w_out; p.depth = depth; p.logits = logits;
@@ -306,11 +337,33 @@ int kbn_conv_tail_forward(const float* x, long long x_batch_stride, const void* 
     p.dmin = min_predict_depth;
     p.ratio = (float)((double)min_predict_depth / (double)max_predict_depth);   // evaluated in double like the reference's scalar
     const size_t lds = (size_t)2 * 2 * TL_NP0 * 16 + (size_t)channels * TL_FP * 4;
-    static DeviceOnce once;
-    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv_tail_kernel), 80 * 1024)) return rc;
-    hipLaunchKernelGGL(conv_tail_kernel, dim3(p.ntiles), dim3(TL_THREADS), lds, (hipStream_t)stream, p);
+    static DeviceOnce once, oncep;
+    if (x_pair) {
+        if (int rc = set_max_dynamic_lds(oncep, reinterpret_cast<const void*>(conv_tail_kernel<true>), 80 * 1024)) return rc;
+        hipLaunchKernelGGL(conv_tail_kernel<true>, dim3(p.ntiles), dim3(TL_THREADS), lds, (hipStream_t)stream, p);
+    } else {
+        if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv_tail_kernel<false>), 80 * 1024)) return rc;
+        hipLaunchKernelGGL(conv_tail_kernel<false>, dim3(p.ntiles), dim3(TL_THREADS), lds, (hipStream_t)stream, p);
+    }
     KBN_CHECK_LAUNCH();
     return KBN_OK;
+}
+
+int kbn_conv_tail_forward(const float* x, long long x_batch_stride, const void* packed_w_conv, const float* w_out, float* depth,
+                          float* logits, int n, int channels, int height, int width, int apply_activation, float negative_slope,
+                          float min_predict_depth, float max_predict_depth, kbn_stream_t stream) {
+    if (!x) return KBN_ERR_INVALID_ARGUMENT;
+    return conv_tail_launch(x, x_batch_stride, nullptr, 0, nullptr, packed_w_conv, w_out, depth, logits, n, channels, height, width,
+                            apply_activation, negative_slope, min_predict_depth, max_predict_depth, stream);
+}
+
+int kbn_conv_tail_forward_pair(const void* x_pair, long long x_pair_batch_stride, const float* x_pair_scale, const void* packed_w_conv,
+                               const float* w_out, float* depth, float* logits, int n, int channels, int height, int width,
+                               int apply_activation, float negative_slope, float min_predict_depth, float max_predict_depth,
+                               kbn_stream_t stream) {
+    if (!x_pair) return KBN_ERR_INVALID_ARGUMENT;
+    return conv_tail_launch(nullptr, 0, x_pair, x_pair_batch_stride, x_pair_scale, packed_w_conv, w_out, depth, logits, n, channels,
+                            height, width, apply_activation, negative_slope, min_predict_depth, max_predict_depth, stream);
 }
 
 }  // extern "C"

@@ -213,9 +213,10 @@ class Conv2d(torch.nn.Module):
         dev = self.conv.weight.device
         srcs = self._with_slots(srcs, n, dev, stats)
         if pair_out:
-            if stats is None or self.out_channels % 8 or (self.stride != 1 and up2x):
+            if stats is None or (self.out_channels % 8 and not narrow_up) or (self.stride != 1 and up2x):
                 return None
-            out = ops.PairTensor(n, self.out_channels, h, w, dev, stats)
+            # (the narrow folded up-conv writes 16 channels, zeros past its filters: the decoder tail's input)
+            out = ops.PairTensor(n, 16 if narrow_up else self.out_channels, h, w, dev, stats)
             if self.stride == 2:
                 out.with_sub()   # the even pixels in fp32 too: the next level's 1x1 stride-2 conv_fused reads those
             if out_absmax is not None:
@@ -840,6 +841,7 @@ class MultiScaleDecoder(torch.nn.Module):
         self._packed_tail = _PackedTail()
         # deconv4 .. deconv1 hand their concat-conv outputs to the next up-conv as ops.PairTensor (KBN_NO_PAIR=1: fp32 tensors)
         self.pair_chain = os.environ.get("KBN_NO_PAIR", "0") in ("", "0")
+        self.pair_tail = os.environ.get("KBN_NO_PAIR_TAIL", "0") in ("", "0")   # A/B: deconv0's up-conv -> tail tensor as a PairTensor
 
     def set_bf16(self, enabled: bool = True):
         """THROUGHPUT-ONLY switch (BASELINE configs[2]'s bf16 figure): the decoder's 3x3 stride-1 convs with at least 16
@@ -890,13 +892,24 @@ class MultiScaleDecoder(torch.nn.Module):
         d0 = self.deconv0
         x, amax = self.features_level1(x, skips, amax_x, amax_skips, stats, allow_pair=d0.skip_channels == 0)
         if d0.skip_channels == 0:
-            up = d0.deconv(x, shape=tuple(shape)[-2:], amax=amax, stats=stats)
+            packed = self._packed_tail.get(d0.conv.conv.weight) if d0.conv.split else None
+            up = None
+            if packed is not None and self.pair_tail and self.pair_chain and d0.conv.out_channels <= 12 and not d0.conv.bf16:
+                # deconv0's up-conv hands the tail a PairTensor too (16 channels for KBNet's 12)
+                up = d0.deconv(x, shape=tuple(shape)[-2:], amax=amax, stats=stats, pair_out=True)
+                if up is not None:
+                    res = ops.conv_tail(up, packed, self.output0.conv.weight, min_predict_depth, max_predict_depth, d0.conv._slope,
+                                        return_logits=return_logits, out=out)
+                    if res is not None:
+                        return res
+                    up = up.float()[:, :d0.conv.out_channels].contiguous()   # the tail declined it: decode (rare, not fast)
+            if up is None:
+                up = d0.deconv(x, shape=tuple(shape)[-2:], amax=amax, stats=stats)
             if up is None:   # deconv0's up-conv declined the pair tensor
                 up = d0.deconv(x.float(), shape=tuple(shape)[-2:], amax=None, stats=stats)
-            if d0.conv.split:   # the 12 -> 12 conv of the tail on split fp16 operands (csrc/tail.hip)
-                packed = self._packed_tail.get(d0.conv.conv.weight)
-                res = None if packed is None else ops.conv_tail(up, packed, self.output0.conv.weight, min_predict_depth,
-                                                                  max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
+            if packed is not None:   # the 12 -> 12 conv of the tail on split fp16 operands (csrc/tail.hip)
+                res = ops.conv_tail(up, packed, self.output0.conv.weight, min_predict_depth,
+                                    max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
                 if res is not None:
                     return res
             res = ops.conv_head(up, d0.conv.conv.weight, self.output0.conv.weight, min_predict_depth,

@@ -592,12 +592,20 @@ def pack_conv_tail_weight(w_conv: torch.Tensor, out: Optional[torch.Tensor] = No
 def conv_tail(x, packed_w_conv, w_out, min_predict_depth: float, max_predict_depth: float,
               negative_slope: Optional[float] = 0.2, return_logits=False, out=None):
     """deconv0's second conv (on split fp16 operands) + output0 + depth mapping in one launch (kbn_conv_tail_forward).
+    `x`: N x C x H x W fp32, or the up-conv's PairTensor of 16 channels (kbn_conv_tail_forward_pair; C = w_out's channels).
     Returns None when the shape does not qualify: the caller runs conv_head / the two-launch path."""
     lib = _lib.load()
-    xptr, xbs = _planes(x, "x")
-    n, c, h, wd = x.shape
     wo = w_out.detach().contiguous()
     _require(wo, "w_out", 4)
+    pair = isinstance(x, PairTensor)
+    if pair:
+        n, cp, h, wd = x.shape
+        c = wo.shape[1]
+        if cp != 16 or c > 16:
+            return None
+    else:
+        xptr, xbs = _planes(x, "x")
+        n, c, h, wd = x.shape
     if tuple(wo.shape) != (1, c, 3, 3):
         raise KbnError(f"conv_tail: w_out must be 1 x {c} x 3 x 3")
     if out is None:
@@ -610,12 +618,12 @@ def conv_tail(x, packed_w_conv, w_out, min_predict_depth: float, max_predict_dep
     logits = torch.empty_like(depth) if return_logits else None
     flops = 2.0 * n * h * wd * c * 9 * c
     tiles = n * (-(-h // 16)) * (-(-wd // 32))
+    tail_args = (packed_w_conv.data_ptr(), wo.data_ptr(), depth.data_ptr(), logits.data_ptr() if return_logits else None, n, c, h, wd,
+                 0 if negative_slope is None else 1, 0.0 if negative_slope is None else float(negative_slope),
+                 float(min_predict_depth), float(max_predict_depth))
     status = _launch("conv_tail", flops,
-                     lambda: lib.kbn_conv_tail_forward(xptr, xbs, packed_w_conv.data_ptr(), wo.data_ptr(), depth.data_ptr(),
-                                                       logits.data_ptr() if return_logits else None, n, c, h, wd,
-                                                       0 if negative_slope is None else 1,
-                                                       0.0 if negative_slope is None else float(negative_slope),
-                                                       float(min_predict_depth), float(max_predict_depth), _stream()),
+                     (lambda: lib.kbn_conv_tail_forward_pair(x.data.data_ptr(), x.data.stride(0), x.scale.data_ptr(), *tail_args, _stream()))
+                     if pair else (lambda: lib.kbn_conv_tail_forward(xptr, xbs, *tail_args, _stream())),
                      executed=tiles * 39 * 15 * 2.0 * 16 * 16 * 32)   # 39 pixel blocks x 15 MFMAs of 16 x 16 x 32 per tile
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
@@ -693,8 +701,9 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
             out_absmax = out.absmax
     else:
         optr, obs = _planes(out, "out")
-    if tuple(out.shape) != (n, out_channels, height, width):
-        raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, height, width)}")
+    want = (n, 16 if (pair and up2x and folded_up2x and out_channels <= 16) else out_channels, height, width)   # the narrow up-conv writes 16
+    if tuple(out.shape) != want:
+        raise KbnError(f"out has shape {tuple(out.shape)}, expected {want}")
     cin = sum(s.channels for s in srcs)
     flops = 2.0 * n * height * width * cin * 9 * out_channels
     mode = (3 if folded_up2x else 1) if up2x else (2 if stride == 2 else 0)

@@ -146,7 +146,7 @@ typedef struct kbn_conv_src {
  * input, from the inputs' absmax slots) x (a table of weight norms kept behind the packed weights) -- and written to
  * `pair_out_scale[frame]` as the float 2^k; the consumer receives that array as kbn_conv_src.scale.  The producer still
  * folds the true max |out| into out_absmax.  kbn_conv3x3_split_forward: `pair_out` for modes 0 and 2 and for mode 3 with whole
- * 64-filter tiles (needs absmax slots on every source and out_channels % 8 == 0); a KBN_SRC_PAIR source 0 for mode 0
+ * 64-filter tiles (needs absmax slots on every source and out_channels % 8 == 0; mode 3 with at most 16 filters writes 16 channels, zeros past out_channels); a KBN_SRC_PAIR source 0 for mode 0
  * (beside an fp32 source 1), mode 2 (one source) and mode 3 (64-filter tiles, or at most 16 filters and channels % 32 == 0); KBN_ERR_UNSUPPORTED otherwise -- the
  * caller then keeps the tensor in fp32. */
 
@@ -420,6 +420,14 @@ int kbn_conv_tail_pack_weight(const float* w_conv, void* packed, int channels, k
 int kbn_conv_tail_forward(const float* x, long long x_batch_stride, const void* packed_w_conv, const float* w_out, float* depth,
                           float* logits, int n, int channels, int height, int width, int apply_activation, float negative_slope,
                           float min_predict_depth, float max_predict_depth, kbn_stream_t stream);
+/* The same launch with the input as a PAIR tensor of 16 channels (two k-groups; channels past `channels` zero): what
+ * kbn_conv3x3_split_forward(mode 3, pair_out) writes for a layer of at most 16 filters -- deconv0's up-conv, reference
+ * src/net_utils.py:484-499 -- so that the 12-channel full-resolution tensor between the up-conv and the tail is staged by
+ * LDS-DMA instead of being loaded, measured and split per tile. */
+int kbn_conv_tail_forward_pair(const void* x_pair, long long x_pair_batch_stride, const float* x_pair_scale, const void* packed_w_conv,
+                               const float* w_out, float* depth, float* logits, int n, int channels, int height, int width,
+                               int apply_activation, float negative_slope, float min_predict_depth, float max_predict_depth,
+                               kbn_stream_t stream);
 
 /* ------------------------------------------------- pre-model stage --
  * What the reference's run loop does between the host->device copy and the model call:

@@ -740,6 +740,50 @@ def test_pair_tensor_chain_upconv_to_concat(dev, cup, cskip, cout, hw):
     assert r_pair < max(1.5 * r_f32, 3e-7) and m_pair < max(2.0 * m_f32, 3e-6)
 
 
+@pytest.mark.parametrize("cin,c,hw", [(64, 12, (36, 76)), (32, 12, (70, 40)), (64, 8, (18, 140)), (64, 12, (36, 68))])
+def test_pair_tensor_from_narrow_upconv_into_tail(dev, cin, c, hw):
+    """deconv0: the 16-filter-tile folded up-conv writes a PAIR tensor of 16 channels (zeros past its `c` filters) and the
+    decoder tail stages it by LDS-DMA (kbn_conv_tail_forward_pair) -- against the tail on the DECODED tensor (its own
+    per-tile window instead of the producer's per-frame one) and against fp64."""
+    h, w = hw
+    sh, sw = h // 2, w // 2
+    g = torch.Generator().manual_seed(cin + c + h)
+    n = 2
+    x0 = torch.nn.functional.leaky_relu(torch.randn(n, cin, sh, sw, generator=g), 0.2)
+    x0[1] *= 0.05
+    wu = torch.randn(c, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    wc = torch.randn(c, c, 3, 3, generator=g) * (1.3 / (c * 9) ** 0.5)
+    wo = torch.randn(1, c, 3, 3, generator=g) * 0.5
+    stats = kb.ops.ActStats(n, dev)
+    x0d = x0.to(dev)
+    src = [kb.ops.tensor_src(x0d, "x", stats.measure(x0d))]
+    pu = kb.ops.pack_conv3x3_split_weight(wu.to(dev), folded_up2x=True)
+    up32 = torch.empty(n, c, h, w, device=dev)
+    assert kb.ops.conv3x3_split(src, pu, n, c, h, w, up32, up2x=True, negative_slope=0.2, folded_up2x=True) is not None
+    pt = kb.ops.PairTensor(n, 16, h, w, dev, stats)
+    pt.data.fill_(float("nan"))
+    assert kb.ops.conv3x3_split(src, pu, n, c, h, w, pt, up2x=True, negative_slope=0.2, folded_up2x=True) is not None
+    assert torch.isfinite(pt.data).all() and float(pt.data[:, :, :, h * w].abs().max()) == 0.0
+    dec = pt.float()
+    assert float(dec[:, c:].abs().max()) == 0.0, "channels past the last filter are zero"
+    assert rel_err(dec[:, :c], up32) < 1e-6
+    assert torch.equal(kb.ops.slot_values(pt.absmax), up32.abs().amax(dim=(1, 2, 3)))
+    xin = dec[:, :c].contiguous()
+    lrelu = torch.nn.functional.leaky_relu
+    l64 = torch.nn.functional.conv2d(lrelu(torch.nn.functional.conv2d(xin.cpu().double(), wc.double(), padding=1), 0.2), wo.double(), padding=1)
+    packed = kb.ops.pack_conv_tail_weight(wc.to(dev))
+    d_f32, lg_f32 = kb.ops.conv_tail(xin, packed, wo.to(dev), 1.5, 100.0, 0.2, return_logits=True)
+    res = kb.ops.conv_tail(pt, packed, wo.to(dev), 1.5, 100.0, 0.2, return_logits=True)
+    assert res is not None
+    d_pair, lg_pair = res
+    rms = l64.pow(2).mean(dim=(1, 2, 3), keepdim=True).sqrt()
+    e_pair = float((((lg_pair.cpu().double() - l64) / rms).pow(2).mean()).sqrt())
+    e_f32 = float((((lg_f32.cpu().double() - l64) / rms).pow(2).mean()).sqrt())
+    print(f"tail of a pair tensor, logits vs fp64: rms {e_pair:.2e}; tail of its fp32 decode: rms {e_f32:.2e}")
+    assert e_pair < max(2.0 * e_f32, 4e-7)
+    assert float(((d_pair - d_f32).abs() / d_f32).max()) < 2e-6
+
+
 @pytest.mark.parametrize("c0,c1,c2,hw", [(48, 96, 192, (23, 44)), (96, 192, 384, (22, 76)), (16, 64, 72, (9, 21)), (32, 128, 96, (17, 33))])
 def test_pair_tensor_chain_of_stride2_convs(dev, c0, c1, c2, hw):
     """The encoder's chain: a stride-2 split conv writes a PAIR tensor plus the fp32 side output of its even pixels, the next
