@@ -80,6 +80,40 @@ def test_window_slack_costs_nothing():
     assert err <= 2.0 ** -25 and err / np.abs(ap).max() < 2.0 ** -19
 
 
+def _bound_scale(bound):
+    """sp_scale_of_bound (csrc/conv_split.hip): 2^k with bound 2^k in [2^14, 2^15), finite for 0 / Inf / NaN."""
+    bits = int(np.float32(bound).view(np.uint32))
+    k = 14 + 127 - ((bits >> 23) & 255)
+    return 2.0 ** max(-100, min(100, k))
+
+
+def test_pair_tensor_window_from_a_bound():
+    """The producer-written split format (include/kbnet_hip.h, "PAIR tensors") fixes its per-frame 2^k from a BOUND of the
+    output -- input maxima x weight norms -- not from the output: the window never overflows whatever the overshoot, and
+    an overshoot of up to 2^13 (KITTI layers: 2^5-2^7) leaves every value within 2^-22 of itself plus 2^-25 of a window
+    unit (the flushed fp16 subnormals): what the consumers multiply is the fp32 value to fp32 accuracy."""
+    rng = np.random.default_rng(11)
+    w = rng.standard_normal((64, 288)).astype(np.float32) / 17.0
+    x = np.abs(rng.standard_normal((288, 500))).astype(np.float32) * 3.0
+    out = w.astype(np.float64) @ x.astype(np.float64)
+    bound = float(np.abs(x).max()) * float(np.abs(w).sum(axis=1).max())
+    assert np.abs(out).max() <= bound
+    for slack in (1.0, 2.0 ** 7, 2.0 ** 13):
+        scale = _bound_scale(bound * slack)
+        t = (out * scale).astype(np.float32)
+        assert np.abs(t).max() < 2.0 ** 15 / slack * 1.0001
+        h1 = t.astype(np.float16)
+        h1 = np.where(np.abs(h1.astype(np.float32)) < 2.0 ** -14, np.float16(0), h1)
+        h2 = ((t - h1.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        h2 = np.where(np.abs(h2.astype(np.float32)) < 2.0 ** -14, np.float16(0), h2)
+        back = h1.astype(np.float64) + h2.astype(np.float64) / 2048.0
+        err = np.abs(back - t.astype(np.float64))
+        assert (err <= np.abs(t) * 2.0 ** -22 + 2.0 ** -25).all()
+        # relative to the frame's maximum: 2^-25 window units / (2^14 / slack): 2^-26 at the largest overshoot tested
+        assert err.max() / np.abs(t).max() <= 2.0 ** -22
+    assert _bound_scale(0.0) == 2.0 ** 100 and _bound_scale(float("inf")) == 2.0 ** -100 and _bound_scale(float("nan")) == 2.0 ** -100
+
+
 def test_default_window_limits():
     """What the ABI default exponent (-6) covers: full precision from 2^-8 to fp16's maximum x 64."""
     for a in (2.0 ** -8, 1.0, 4.0e6):
