@@ -101,14 +101,19 @@ def lookup_traffic(kernel, launches, frames_per_gpu):
         if not m:
             return None, None
         want = m.group(1) + "_kernel<" + m.group(2).replace(",", ", ")
-    for name, e in table.items():
-        if want in name:
-            detail = {"source": os.path.relpath(files[-1], ROOT), "fetch_bytes": e.get("fetch_bytes"),
-                      "write_bytes": e.get("write_bytes"), "launches": e.get("launches")}
-            if "mfma_busy_frac" in e:   # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)
-                detail["mfma_busy_frac_pmc"] = round(e["mfma_busy_frac"], 4)
-            return e["hbm_bytes_per_launch"], detail
-    return None, None
+    # a host-level launch runs ONE kernel of the family -- which instantiation depends on the layer (with / without the
+    # transposed tiles of a narrow last column, pair / fp32 sources): the launch-weighted mean over the instantiations
+    hits = [e for name, e in table.items() if want in name and e.get("launches")]
+    if not hits:
+        return None, None
+    total = sum(e["launches"] for e in hits)
+    per = lambda key: sum(e.get(key, 0.0) * e["launches"] for e in hits) / total
+    detail = {"source": os.path.relpath(files[-1], ROOT), "fetch_bytes": per("fetch_bytes"), "write_bytes": per("write_bytes"),
+              "launches": total, "instantiations": len(hits)}
+    if all("mfma_busy_frac" in e for e in hits):   # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs), time-weighted
+        w = [e["launches"] * e.get("avg_us_under_pmc", 1.0) for e in hits]
+        detail["mfma_busy_frac_pmc"] = round(sum(e["mfma_busy_frac"] * wi for e, wi in zip(hits, w)) / sum(w), 4)
+    return per("hbm_bytes_per_launch"), detail
 
 
 def cpu_baseline(cfg, sds, frames, budget_s=15.0, max_frames=6):

@@ -107,6 +107,7 @@ struct SplitConvParams {
     long long pair_out_bstride;
     float* pair_out_scale;      // per frame: the 2^k applied here (every workgroup of a frame writes the same value)
     const float* l1;            // per 16-channel chunk: max over filters of sum |w| (the table behind the packed weights)
+    int tp_x0, tp_tilesY, tp_nblocks;   // conv3x3_split_mixed_kernel: first column, tile rows and workgroups of the transposed tiles
     int sub0;                   // conv1x1s2_split_kernel: source 0 holds only the pixels the conv reads (H x W planes, stride 1)
     // conv1x1s2_split_kernel: three more input channels taken in fp32 in the epilogue (the KB block's backprojection)
     const float* xyz;           // N x 3 x H x W (output size), or null
@@ -351,489 +352,27 @@ __device__ __forceinline__ void sp_wait_b(f32x4 (&b)[NBX][2]) {   // vmcnt(N), t
 // PIN0: source 0 is a pair tensor (its chunks are staged by LDS-DMA; a second, fp32 source is split here as before and the
 // accumulators change window between the two); POUT: the output is written as a pair tensor (MFMA operands swapped: a
 // lane's accumulator registers run over the FILTERS of one pixel).  Both: MODE 0 with the weights through LDS.
-template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2, bool PIN0 = false, bool POUT = false>   // NBW: 32-filter blocks per wave
+// TP (MODE 0): TRANSPOSED tiles for the last, narrow column of a map whose width leaves 1-16 columns behind the whole 32-column
+// tiles (KITTI: 76 = 2 x 32 + 12, 304 = 9 x 32 + 16): 32 rows x 16 columns per workgroup, a 32-pixel MFMA block = two rows of 16
+// pixels, the staged region 34 rows x 18 columns (the same 612 granules).  Half the MFMAs of the column tiles it replaces
+// (22 x 76: 55 instead of 66 blocks per frame).  The transposed tiles are the LAST workgroups of the same launch
+// (conv3x3_split_mixed_kernel): as a launch of their own -- 128 workgroups for deconv4's conv -- they would cost the round of
+// workgroups they save.
+// MIXED: the grid is p.nblocks whole tiles followed by p.tp_nblocks transposed ones: the body (conv_split_body.inc) is compiled
+// twice into the kernel, once per tile form, and a workgroup takes the one its block index selects.
+template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2, bool PIN0 = false, bool POUT = false, bool MIXED = false>   // NBW: 32-filter blocks per wave
 __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
-    static_assert(APART, "the two small terms share the scale 2^11 and an accumulator of their own");
-    static_assert(!(PIN0 || POUT) || (MODE == 0 && BLDS) || (MODE == 2 && !BLDS), "pair tensors: the concat kernel and the stride-2 kernel");
-    using G = SpGeom<MODE>;
-    constexpr bool UP = G::UP, S2 = G::S2;
-    constexpr int NB = NBW, FG = 8 / RG;
-    constexpr int NT = 32 * NB * FG, NPIX = G::NPIX, PR = G::PR, COLS = G::COLS;
-    constexpr int MB = G::TH / RG;
-    static_assert(MB == 2 || MB == 4, "groups per chunk must be even (ping-pong A fragments)");
-    constexpr int B_TAP = 2 * 2 * NT * 16;                               // bytes: [part][k-group][filter][8 fp16]
+    static_assert(!MIXED || (MODE == 0 && BLDS), "transposed tiles: the concat kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // fp16 results of the vector ALU flush subnormals (MODE register bits 6-7 = 0): h1 of a tiny activation becomes 0 and
-    // its scaled residual carries the value; the matrix core would drop a subnormal h1 anyway
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave % RG, fg = wave / RG;
-    const int lm = lane & 31, g = lane >> 5;
-    int bid = xcd_remap(blockIdx.x, p.nblocks);
-    const int nt = bid % p.nTilesN;
-    bid /= p.nTilesN;
-    const int tx = bid % p.tilesX;
-    bid /= p.tilesX;
-    const int ty = bid % p.tilesY;
-    const int n = bid / p.tilesY;
-    const int oy0 = ty * G::TH, ox0 = tx * SP_TW;
-    const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
-    const long long plane = (long long)sH * sW;
-    const int nchunks = p.Cin / SP_CK;
-    float prescale, unscale;      // window of the source(s) split here, and what undoes the window the accumulators end in
-    float acc_rescale = 1.f;      // PIN0 with a second source: 2^(k1 - k0), applied when the K loop changes source
-    if constexpr (PIN0) {
-        const float unscale0 = 1.f / p.pair_src_scale[n];
-        prescale = 0.f; unscale = unscale0;
-        if (MODE == 0 && p.nsrc > 1) {
-            sp_act_scale_of(p, 1, n, prescale, unscale);
-            acc_rescale = prescale * unscale0;
-        }
-    } else sp_act_scale(p, n, prescale, unscale);
-
-    // ---- input staging: waves 0-3 take k-group 0 (channels 0-7 of the chunk), waves 4-7 k-group 1; a thread owns <= PR pixels
-    const int kg_st = wave >> 2, t256 = tid & 255;
-    // Stride 2: the columns of a staged row are stored de-interleaved (even columns, then odd ones), so that the 32
-    // lanes of a fragment read (columns 2 lm + kx) touch consecutive 16-byte words.
-    int goff[PR], slot[PR];
-#pragma unroll
-    for (int u = 0; u < PR; ++u) {
-        const int pix = u * 256 + t256;
-        const int r = pix / COLS, c = pix - r * COLS;
-        const int Y = (UP ? (oy0 >> 1) : (S2 ? 2 * oy0 : oy0)) - 1 + r, X = (UP ? (ox0 >> 1) : (S2 ? 2 * ox0 : ox0)) - 1 + c;
-        goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
-        slot[u] = S2 ? r * COLS + ((c & 1) ? (COLS + 1) / 2 + (c >> 1) : (c >> 1)) : pix;
+    if (!MIXED || (int)blockIdx.x < p.nblocks) {
+        constexpr bool TP = false;
+        const int block = blockIdx.x, nblocks = p.nblocks, tilesX = p.tilesX, tilesY = p.tilesY;
+#include "conv_split_body.inc"
+    } else if constexpr (MIXED) {
+        constexpr bool TP = true;
+        const int block = (int)blockIdx.x - p.nblocks, nblocks = p.tp_nblocks, tilesX = 1, tilesY = p.tp_tilesY;
+#include "conv_split_body.inc"
     }
-    const _Float16* wp_nt = p.wp + (long long)nt * nchunks * (9 * B_TAP / 2);
-
-    float va[PR][8];
-    auto load_chunk = [&](int chunk) {
-        int c = chunk * SP_CK, s = 0;
-        if (p.nsrc > 1 && c >= p.srcC[0]) { c -= p.srcC[0]; s = 1; }
-        const float* base = p.src[s] + (long long)n * p.src_bstride[s] + (long long)(c + kg_st * 8) * plane;
-#pragma unroll
-        for (int u = 0; u < PR; ++u) {
-            const unsigned voff = goff[u] < 0 ? 0u : (unsigned)goff[u];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float* sb = base + (long long)k * plane;   // wave-uniform
-                asm volatile("global_load_dword %0, %1, %2" : "=v"(va[u][k]) : "v"(voff), "s"(sb) : "memory");
-            }
-        }
-    };
-    auto store_round = [&](int buf, int u) {   // split + write of one staging round (its loads have landed: caller)
-        unsigned char* A = smem + buf * G::A_BYTES + kg_st * NPIX * 16;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));   // keeps the uses behind the caller's vmcnt wait
-        const int pix = u * 256 + t256;
-        if (pix < NPIX) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
-            sph8 h1, h2;
-            sp_split8(v, prescale, h1, h2);
-            *reinterpret_cast<sph8*>(A + slot[u] * 16) = h1;
-            *reinterpret_cast<sph8*>(A + G::A_PART + slot[u] * 16) = h2;
-        }
-    };
-    // weights: straight from L2 / L1 into the B fragments
-    const unsigned boff = (unsigned)((g * NT + fg * 32 * NB + lm) * 16);
-    auto load_b = [&](f32x4 (&b)[NB][2], int chunk, int tap) {
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(wp_nt + ((long long)chunk * 9 + tap) * (B_TAP / 2));
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const unsigned char* sb = base + (t * 2 * NT + nb * 32) * 16;   // wave-uniform
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[nb][t]) : "v"(boff), "s"(sb) : "memory");
-            }
-    };
-
-    spf16 acc[MB][NB], lo[APART ? MB : 1][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc[mb][nb][i] = 0.f;
-                if (APART) lo[mb][nb][i] = 0.f;
-            }
-
-    // A fragments are fetched one GROUP (GM m-blocks) ahead of the MFMAs that use them, ping-pong registers;
-    // sched_barriers pin that order.  Fragment of (row MB rg + mb, pixel lm, tap (ky, kx)): staged pixel
-    // (MB rg + mb + ky, lm + kx); up-conv: the low-resolution pixel ((MB rg + mb + ky + 1) >> 1, (lm + kx + 1) >> 1);
-    // stride 2: (2 (MB rg + mb) + ky, 2 lm + kx) = slot lm (kx 0), 33 + lm (kx 1), lm + 1 (kx 2) of the de-interleaved row.
-    constexpr int GM = 1, GPT = MB / GM, NGROUP = 9 * GPT;
-    const unsigned char* aptr[3];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-        aptr[kx] = smem + (g * NPIX + (UP ? MB / 2 : (S2 ? 2 * MB : MB)) * rg * COLS +
-                           (UP ? ((lm + kx + 1) >> 1) : (S2 ? (kx == 1 ? (COLS + 1) / 2 + lm : lm + (kx >> 1)) : lm + kx))) * 16;
-    auto load_a = [&](sph8 (&a)[GM][2], int abuf_off, int grp) {
-        const int tap = grp / GPT, mb0 = (grp % GPT) * GM;
-        const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-        for (int m = 0; m < GM; ++m) {
-            const int r = UP ? ((mb0 + m + ky + 1) >> 1) : (S2 ? 2 * (mb0 + m) + ky : mb0 + m + ky);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                a[m][t] = *reinterpret_cast<const sph8*>(aptr[kx] + abuf_off + t * G::A_PART + r * COLS * 16);
-        }
-    };
-    // CHK (a tag type): MFMAs of output rows below the map (22 rows in 16-row tiles) and of 32-filter blocks past the last
-    // filter (96 or 192 filters in 128-wide tiles) are skipped under wave-uniform branches
-    auto mfma_group = [&](auto chk_tag, const sph8 (&a)[GM][2], const sph8 (&b)[NB][2], int grp) {
-        constexpr bool CHK = decltype(chk_tag)::value;
-        const bool nb0_live = nt * NT + fg * 32 * NB < p.OC, nb1_live = nt * NT + fg * 32 * NB + 32 < p.OC;   // wave-uniform
-        const int mb0 = (grp % GPT) * GM;
-        constexpr int TA[3] = {0, 0, 1}, TBP[3] = {0, 1, 0};   // h1 w1 | h1 (w2 2^11), h2 w1: both 2^11 x their term of the product
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int m = 0; m < GM; ++m)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    if (CHK && oy0 + MB * rg + mb0 + m >= H) continue;
-                    if (CHK && !(nb == 0 ? nb0_live : nb1_live)) continue;
-                    spf16& c = (APART && t > 0) ? lo[mb0 + m][nb] : acc[mb0 + m][nb];
-                    c = POUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[nb][TBP[t]], a[m][TA[t]], c, 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][TA[t]], b[nb][TBP[t]], c, 0, 0, 0);
-                }
-    };
-    const bool padded_tile = !KBN_SPLIT_STRAIGHT || oy0 + G::TH > H || (nt + 1) * NT - 32 >= p.OC;   // workgroup-uniform
-
-    f32x4 bq[3][NB][2];             // fetched weights (w1, w2): tap t lives in bq[t % 3] (nine taps: the ring closes over a chunk)
-    constexpr int AD = 1;           // A fragments fetched AD groups ahead (2 measured the same)
-    static_assert(NGROUP % (AD + 1) == 0, "the fragment rotation must close over a chunk");
-    sph8 aq[AD + 1][GM][2];
-    if constexpr (BLDS) {
-        constexpr int B_CHUNK = 9 * B_TAP;
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
-        auto stage_b = [&](int bbuf, int chunk) {
-            const float* src = reinterpret_cast<const float*>(wp_nt + (long long)chunk * (B_CHUNK / 2));
-            const unsigned dst = lds0 + (unsigned)(2 * G::A_BYTES + bbuf * B_CHUNK);
-            constexpr int n4 = B_CHUNK / 16;
-#pragma unroll
-            for (int e0 = 0; e0 < n4; e0 += SP_THREADS) {
-                const int eb = e0 + wave * 64;
-                if (eb + lane < n4) lds_dma16_s(src + eb * 4, (unsigned)(lane * 16), dst + eb * 16);
-            }
-        };
-        const unsigned char* const bptr = smem + 2 * G::A_BYTES + boff;
-        // pair source: a staged chunk is 4 planes (term, k-group) x NPIX granules; wave-wide DMA id = plane * NR + round, wave w
-        // issues ids w, w + 8, ..; a halo pixel outside the map reads the plane's zero granule
-        constexpr int NR = (NPIX + 63) / 64, NDMA = 4 * NR, DPW = NDMA / 8;
-        static_assert(NDMA % 8 == 0, "the same number of DMAs in every wave");
-        unsigned dvoff[PIN0 ? DPW : 1];
-        if constexpr (PIN0) {
-#pragma unroll
-            for (int i = 0; i < DPW; ++i) {
-                const int pix = ((wave + 8 * i) % NR) * 64 + lane;
-                const int r = pix / COLS, cc = pix - r * COLS;
-                const int Y = oy0 - 1 + r, X = ox0 - 1 + cc;
-                dvoff[i] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (unsigned)(Y * sW + X) * 16u : (unsigned)(sH * sW) * 16u;
-            }
-        }
-        const long long pplane = pair_plane_halves(sH, sW);
-        auto dma_chunk = [&](int buf, int chunk) __attribute__((always_inline)) {
-            const _Float16* pn = p.pair_src + (long long)n * p.pair_src_bstride + (long long)(2 * chunk) * 2 * pplane;
-#pragma unroll
-            for (int i = 0; i < DPW; ++i) {
-                const int id = wave + 8 * i, plane = id / NR, j = id - plane * NR;
-                const int t = plane >> 1, kgl = plane & 1;
-                const unsigned long long mask = (j == NR - 1 && (NPIX & 63)) ? ((1ull << (NPIX & 63)) - 1) : ~0ull;
-                lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kgl * 2 + t) * pplane), dvoff[i],
-                             lds0 + (unsigned)(buf * G::A_BYTES + t * G::A_PART + (kgl * NPIX + j * 64) * 16), mask);
-            }
-        };
-        // next_tag: what follows chunk c -- 0 nothing, 1 a chunk of an fp32 source (fetched, then split), 2 a chunk of the
-        // pair source (LDS-DMA).  One body per kind: an asm fetch and its wait stay in straight-line code.
-        auto body = [&](int c_in, auto next_tag, auto chk_tag) __attribute__((always_inline)) {
-            const int c = PIN0 ? __builtin_amdgcn_readfirstlane(c_in) : c_in;   // the chunk index is workgroup-uniform: keep its pointers in SGPRs
-            constexpr int NEXT = decltype(next_tag)::value;
-            constexpr bool MORE = NEXT != 0;
-            const int abuf = (c & 1) * G::A_BYTES;
-            const unsigned char* B = bptr + (c & 1) * B_CHUNK;
-            if (MORE) {
-                stage_b((c & 1) ^ 1, c + 1);
-                if constexpr (NEXT == 2) dma_chunk((c & 1) ^ 1, c + 1);
-                else load_chunk(c + 1);
-            }
-            load_a(aq[0], abuf, 0);
-            sph8 bw[NB][2];
-#pragma unroll
-            for (int grp = 0; grp < NGROUP; ++grp) {
-                const int tap = grp / GPT, gi = grp % GPT;
-                sph8 (&ac)[GM][2] = aq[grp % (AD + 1)];
-                if (grp + AD < NGROUP) load_a(aq[(grp + AD) % (AD + 1)], abuf, grp + AD);
-                if (gi == 0) {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        bw[nb][0] = *reinterpret_cast<const sph8*>(B + tap * B_TAP + nb * 32 * 16);
-                        bw[nb][1] = *reinterpret_cast<const sph8*>(B + tap * B_TAP + (2 * NT + nb * 32) * 16);
-                    }
-                }
-                if (MORE && grp == 5 * GPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's weights (DMA) and inputs: issued five taps ago
-                // the fences keep the fragment reads and the staging code of a group where they are written, but let the
-                // MFMAs themselves move (mask 0x8): with full fences (0) the six MFMAs of a group issue as one dense
-                // burst; spread between the reads that feed the next ones the concat convs run 3.5 % faster
-                // (tools/probe/mfma_power_probe: a dense 32x32x16 stream is held at 1.22 PFLOP/s, one interleaved with
-                // its LDS reads runs at 1.70)
-                __builtin_amdgcn_sched_barrier(0x8);
-#if KBN_SPLIT_PRIO == 1
-                __builtin_amdgcn_s_setprio(1);
-#endif
-                mfma_group(chk_tag, ac, bw, grp);
-#if KBN_SPLIT_PRIO == 1
-                __builtin_amdgcn_s_setprio(0);
-#endif
-                __builtin_amdgcn_sched_barrier(0x8);
-                if (NEXT == 1 && tap >= 5) {   // split + write one staging round per group: the vector ALU works beside the MFMAs
-                    const int u = (tap - 5) * GPT + gi;   // (staggering the two waves of a SIMD -- taps 2-4 / 5-7 -- measured slower)
-                    if (u < PR) store_round((c & 1) ^ 1, u);
-                }
-            }
-            __syncthreads();
-        };
-        if constexpr (PIN0) dma_chunk(0, 0);
-        else load_chunk(0);
-        stage_b(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (!PIN0) {
-#pragma unroll
-            for (int u = 0; u < PR; ++u) store_round(0, u);
-        }
-        __syncthreads();
-#if KBN_SPLIT_PRIO == 2
-        if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the younger half of the workgroup (cdna_hip_programming.md T5, static form)
-#endif
-        using Next0 = std::integral_constant<int, 0>;
-        using Next1 = std::integral_constant<int, 1>;
-        using Next2 = std::integral_constant<int, 2>;
-        auto k_loop = [&](auto chk_tag) {
-            if constexpr (PIN0) {
-                // two sources, at least two chunks each (the launcher checks): loops that always run keep the 128 accumulator
-                // registers out of bypass edges (with zero-trip loops the allocator spilled 460 registers)
-                const int n0 = p.srcC[0] / SP_CK;   // chunks of the pair source
-                int c = 0;
-                do body(c, Next2{}, chk_tag); while (++c < n0 - 1);
-                body(n0 - 1, Next1{}, chk_tag);
-                // the accumulators hold sums in the pair source's window: move them to the window of the source split here
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) { acc[mb][nb][i] *= acc_rescale; lo[mb][nb][i] *= acc_rescale; }
-                c = n0;
-                do body(c, Next1{}, chk_tag); while (++c < nchunks - 1);
-                body(nchunks - 1, Next0{}, chk_tag);
-            } else {
-                for (int c = 0; c + 1 < nchunks; ++c) body(c, Next1{}, chk_tag);
-                body(nchunks - 1, Next0{}, chk_tag);
-            }
-        };
-        if (padded_tile) k_loop(std::true_type{});
-        else k_loop(std::false_type{});
-    } else {
-    // one chunk: nine taps, weights of taps t+1 and t+2 in flight under the MFMAs of tap t.  The vmcnt queue is in order: a
-    // weight set fetched AFTER the next chunk's inputs cannot be consumed before they land, so the inputs (issued at tap 0
-    // behind the fetch of tap 2) have taps 0-2 to arrive -- one tap more than with a single set in flight -- and the ring
-    // of three closes over the nine taps (no register copy, no drained queue at the end of a chunk); they are written
-    // (split) into the other A buffer from tap 4 on; ONE barrier per chunk
-    // pair source (stride 2: KB image convs fed by the previous level's conv_image): a staged chunk is 4 planes (term, k-group) x
-    // NPIX granules; LDS granule q of a plane is staged pixel (r, s) = (q / COLS, q % COLS) of the DE-INTERLEAVED row -- input
-    // column 2 s for s < (COLS + 1) / 2, else 2 (s - (COLS + 1) / 2) + 1 -- so the de-interleave is only a per-lane offset
-    constexpr int NR2 = (NPIX + 63) / 64, NDMA2 = 4 * NR2, DPW2 = NDMA2 / 8;
-    static_assert(!PIN0 || NDMA2 % 8 == 0, "the same number of DMAs in every wave (the vmcnt arithmetic counts them)");
-    const unsigned lds0s = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
-    unsigned dvoff2[PIN0 ? DPW2 : 1];
-    if constexpr (PIN0) {
-#pragma unroll
-        for (int i = 0; i < DPW2; ++i) {
-            const int q = ((wave + 8 * i) % NR2) * 64 + lane;
-            const int r = q / COLS, sc = q - r * COLS;
-            const int cc = S2 ? (sc < (COLS + 1) / 2 ? 2 * sc : 2 * (sc - (COLS + 1) / 2) + 1) : sc;
-            const int Y = (S2 ? 2 * oy0 : oy0) - 1 + r, X = (S2 ? 2 * ox0 : ox0) - 1 + cc;
-            dvoff2[i] = (q < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (unsigned)(Y * sW + X) * 16u : (unsigned)(sH * sW) * 16u;
-        }
-    }
-    const long long pplane2 = pair_plane_halves(sH, sW);
-    auto dma_chunk2 = [&](int buf, int chunk) __attribute__((always_inline)) {
-        const _Float16* pn = p.pair_src + (long long)n * p.pair_src_bstride + (long long)(2 * chunk) * 2 * pplane2;
-#pragma unroll
-        for (int i = 0; i < DPW2; ++i) {
-            const int id = wave + 8 * i, plane = id / NR2, j = id - plane * NR2;
-            const int t = plane >> 1, kgl = plane & 1;
-            const unsigned long long mask = (j == NR2 - 1 && (NPIX & 63)) ? ((1ull << (NPIX & 63)) - 1) : ~0ull;
-            lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kgl * 2 + t) * pplane2), dvoff2[i],
-                         lds0s + (unsigned)(buf * G::A_BYTES + t * G::A_PART + (kgl * NPIX + j * 64) * 16), mask);
-        }
-    };
-    auto chunk_body = [&](int c, auto more_tag, auto chk_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        constexpr int NA = MORE ? (PIN0 ? DPW2 : G::NLOADA) : 0, NBL = 2 * NB;
-        const int abuf = (c & 1) * G::A_BYTES;
-#pragma unroll
-        for (int d = 0; d < AD; ++d) load_a(aq[d], abuf, d);
-        sph8 bw[NB][2];
-#pragma unroll
-        for (int grp = 0; grp < NGROUP; ++grp) {
-            const int tap = grp / GPT, gi = grp % GPT;
-            f32x4 (&bc)[NB][2] = bq[tap % 3];
-            f32x4 (&bn)[NB][2] = bq[(tap + 2) % 3];
-            sph8 (&ac)[GM][2] = aq[grp % (AD + 1)];
-            if (grp + AD < NGROUP) load_a(aq[(grp + AD) % (AD + 1)], abuf, grp + AD);
-            if (gi == 0) {
-                if (tap + 2 < 9) load_b(bn, c, tap + 2);
-                else if (MORE) load_b(bn, c + 1, tap + 2 - 9);
-                if (tap == 0 && MORE) {
-                    if constexpr (PIN0) dma_chunk2((c & 1) ^ 1, c + 1);   // the other buffer was last read a chunk (a barrier) ago
-                    else load_chunk(c + 1);
-                }
-                // outstanding, oldest first: [b(tap)] b(tap+1) b(tap+2) with the inputs behind b(2); b(tap) is what the MFMAs below need
-                if (tap <= 2) sp_wait_b<2 * NBL + NA>(bc);
-                else if (tap < 7 || MORE) sp_wait_b<2 * NBL>(bc);
-                else if (tap == 7) sp_wait_b<NBL>(bc);
-                else sp_wait_b<0>(bc);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    bw[nb][0] = __builtin_bit_cast(sph8, bc[nb][0]);
-                    bw[nb][1] = __builtin_bit_cast(sph8, bc[nb][1]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_group(chk_tag, ac, bw, grp);
-            __builtin_amdgcn_sched_barrier(0);
-            static_assert(5 * GPT >= PR, "taps 4-8 hold the staging rounds");
-            if (!PIN0 && MORE && tap >= 4) {   // the wait of tap 3 covered the input loads; one staging round per group
-                const int u = (tap - 4) * GPT + gi;
-                if (u < PR) store_round((c & 1) ^ 1, u);
-            }
-        }
-        __syncthreads();
-    };
-
-    if constexpr (PIN0) dma_chunk2(0, 0);
-    else load_chunk(0);
-    load_b(bq[0], 0, 0);
-    load_b(bq[1], 0, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (!PIN0) {
-#pragma unroll
-        for (int u = 0; u < PR; ++u) store_round(0, u);
-    }
-    __syncthreads();
-    auto k_loop = [&](auto chk_tag) {
-        for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{}, chk_tag);
-        chunk_body(nchunks - 1, std::false_type{}, chk_tag);
-    };
-    if (padded_tile) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
-    }
-
-    const float slope = p.act ? p.slope : 1.f;
-    float amax = 0.f;   // max |stored value| of this thread, folded into the output's slot
-    if constexpr (POUT) {
-        // ---- pair epilogue: acc[mb][nb][i]: pixel x = lm of row MB rg + mb, filter fg * 32 NB + nb * 32 + 8 (i / 4) + 4 g + (i % 4):
-        // a lane holds channels 4 g .. 4 g + 3 of k-group (filter block) / 8 + i / 4 -- half a granule
-        const float ps_out = sp_pair_out_scale(p, n);
-        const long long oph = pair_plane_halves(H, W);
-        _Float16* const pn = p.pair_out + (long long)n * p.pair_out_bstride;
-        if (tid == 0) p.pair_out_scale[n] = ps_out;
-        if (tx == 0 && ty == 0 && wave == 0 && lane < NT / 4) {   // the zero granules of this filter tile's NT / 8 k-groups x 2 terms
-            const int kgz = nt * (NT / 8) + (lane >> 1);
-            if (kgz * 8 < p.OC)
-                *reinterpret_cast<f32x4*>(pn + (long long)(kgz * 2 + (lane & 1)) * oph + (long long)H * W * 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        const int X = ox0 + lm;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {     // k-groups 2 qp, 2 qp + 1 of the block: after the exchange this lane stores k-group 2 qp + g whole
-                const int kg0 = (nt * NT + fg * 32 * NB + nb * 32) / 8 + 2 * qp;
-                if (kg0 * 8 >= p.OC) continue;   // wave-uniform; pair outputs have whole k-groups (OC % 8 == 0)
-                const f32x4 invA = *reinterpret_cast<const f32x4*>(p.inv_scale + kg0 * 8 + 4 * g) * unscale;
-                const f32x4 invB = *reinterpret_cast<const f32x4*>(p.inv_scale + kg0 * 8 + 8 + 4 * g) * unscale;   // the table is padded to whole tiles
-                const bool mine = (kg0 + g) * 8 < p.OC;
-                _Float16* const k0 = pn + (long long)((kg0 + g) * 2) * oph;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const int Y = oy0 + MB * rg + mb;
-                    if (Y >= H) continue;        // wave-uniform
-                    f32x4 va, vb;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float ta = __builtin_fmaf(lo[mb][nb][qp * 8 + j], 0.00048828125f, acc[mb][nb][qp * 8 + j]) * invA[j];
-                        const float tb = __builtin_fmaf(lo[mb][nb][qp * 8 + 4 + j], 0.00048828125f, acc[mb][nb][qp * 8 + 4 + j]) * invB[j];
-                        va[j] = ta > 0.f ? ta : ta * slope;
-                        vb[j] = tb > 0.f ? tb : tb * slope;
-                    }
-                    if (X < W) amax = sp_amax4(sp_amax4(amax, va), vb);
-                    if (S2 && p.out && !((Y | X) & 1) && X < W) {
-                        // the next level's conv_fused (1x1, stride 2) reads this tensor at even pixels only: they also go out
-                        // in fp32, as a dense (H + 1) / 2 x (W + 1) / 2 tensor of their own (a sixteenth of the pair tensor's stores)
-                        const int sw2 = (W + 1) >> 1;
-                        float* so = p.out + (long long)n * p.out_bstride + ((long long)(kg0 * 8 + 4 * g) * ((H + 1) >> 1) + (Y >> 1)) * sw2 + (X >> 1);
-                        const long long cs = (long long)((H + 1) >> 1) * sw2;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (kg0 * 8 + 4 * g + j < p.OC) so[j * cs] = va[j];
-                            if (kg0 * 8 + 8 + 4 * g + j < p.OC) so[(8 + j) * cs] = vb[j];
-                        }
-                    }
-                    sph4 a1, a2, b1, b2;
-                    sp_split4(va * ps_out, a1, a2);
-                    sp_split4(vb * ps_out, b1, b2);
-                    const spu4 g1 = sp_pair_exchange(a1, b1), g2 = sp_pair_exchange(a2, b2);   // every lane takes part
-                    if (X < W && mine) {
-                        const long long o = ((long long)Y * W + X) * 8;
-                        *reinterpret_cast<spu4*>(k0 + o) = g1;
-                        *reinterpret_cast<spu4*>(k0 + oph + o) = g2;
-                    }
-                }
-            }
-        if (p.out_amax) absmax_commit(p.out_amax + n, amax);
-        return;
-    }
-    // ---- epilogue: acc[mb][nb][i]: pixel x = 8 (i / 4) + 4 g + (i % 4) of row 4 rg + mb, filter fg * 32 NB + nb * 32 + lm
-    const long long oplane = (long long)H * W;
-    float* outn = p.out + (long long)n * p.out_bstride;
-    const bool vec4 = p.vec4 != 0;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int oc = nt * NT + fg * 32 * NB + nb * 32 + lm;
-        const float inv = p.inv_scale[oc] * unscale;               // 2^-e 2^-k; the table is padded to whole n-tiles
-        if (oc >= p.OC) continue;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int Y = oy0 + MB * rg + mb;
-            if (Y >= H) continue;
-            float* o = outn + (long long)oc * oplane + (long long)Y * W + ox0 + 4 * g;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int X = ox0 + 8 * q4 + 4 * g;
-                if (X >= W) continue;
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float t = __builtin_fmaf(lo[mb][nb][q4 * 4 + j], 0.00048828125f, acc[mb][nb][q4 * 4 + j]) * inv;   // main + 2^-11 small
-                    v[j] = t > 0.f ? t : t * slope;
-                }
-                if (vec4) {                                             // W % 4 == 0: a quad is in or out as a whole, rows 16-byte aligned
-                    *reinterpret_cast<f32x4*>(o + 8 * q4) = v;
-                    amax = sp_amax4(amax, v);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (X + j < W) { o[8 * q4 + j] = v[j]; amax = fmaxf(amax, fabsf(v[j])); }
-                }
-            }
-        }
-    }
-    if (p.out_amax) absmax_commit(p.out_amax + n, amax);   // launch-uniform; the loops above only `continue`
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2488,10 +2027,29 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
                 static DeviceOnce ok32;
                 rc = launch(conv3x3_split_k32_kernel, SpGeom<0>::LDS + 2 * 10 * 2 * 2 * 64 * 16, ok32);
             } else {
-                static DeviceOnce o0p[3];
+                static DeviceOnce o0p[3], o0t[4];
                 constexpr size_t lds0 = SpGeom<0>::LDS + 2 * 9 * 2 * 2 * 64 * 16;
-                if (p.pair_src) rc = p.pair_out ? launch(conv3x3_split_kernel<0, 8, true, true, 2, true, true>, lds0, o0p[2])
-                                                : launch(conv3x3_split_kernel<0, 8, true, true, 2, true, false>, lds0, o0p[1]);
+                // a map whose width leaves 1-16 columns behind the whole 32-column tiles: that column goes to a launch of
+                // transposed tiles (32 rows x 16 columns), half the MFMAs of the tiles it replaces (KBN_DEBUG & 512: off)
+                const int wrem = width % SP_TW;
+                const bool tp = width >= SP_TW && wrem >= 1 && wrem <= 16 && !(knob(KNOB_DEBUG) & 512);
+                if (tp) {
+                    p.tilesX = width / SP_TW;
+                    p.nblocks = p.tilesX * p.tilesY * n * p.nTilesN;
+                    p.tp_x0 = SP_TW * p.tilesX;
+                    p.tp_tilesY = ceil_div(height, 2 * SpGeom<0>::TH);
+                    p.tp_nblocks = p.tp_tilesY * n * p.nTilesN;
+                    auto launch_mixed = [&](auto kern, DeviceOnce& once) -> int {
+                        if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
+                        hipLaunchKernelGGL(kern, dim3(p.nblocks + p.tp_nblocks), dim3(SP_THREADS), lds0, (hipStream_t)stream, p);
+                        return KBN_OK;
+                    };
+                    if (p.pair_src) rc = p.pair_out ? launch_mixed(conv3x3_split_kernel<0, 8, true, true, 2, true, true, true>, o0t[3])
+                                                    : launch_mixed(conv3x3_split_kernel<0, 8, true, true, 2, true, false, true>, o0t[2]);
+                    else rc = p.pair_out ? launch_mixed(conv3x3_split_kernel<0, 8, true, true, 2, false, true, true>, o0t[1])
+                                         : launch_mixed(conv3x3_split_kernel<0, 8, true, true, 2, false, false, true>, o0t[0]);
+                } else if (p.pair_src) rc = p.pair_out ? launch(conv3x3_split_kernel<0, 8, true, true, 2, true, true>, lds0, o0p[2])
+                                                       : launch(conv3x3_split_kernel<0, 8, true, true, 2, true, false>, lds0, o0p[1]);
                 else rc = p.pair_out ? launch(conv3x3_split_kernel<0, 8, true, true, 2, false, true>, lds0, o0p[0])
                                      : launch(conv3x3_split_kernel<0, 8, true, true>, lds0, o[0]);
             }

@@ -674,7 +674,12 @@ def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1, 
         nblk = 16 if (out_channels <= 16 and cin % 32 == 0) else 32   # narrow layers: v_mfma_f32_16x16x32_f16, 16-pixel segments
         seg = 16 if nblk == 16 else 32
         return 3 * 2.0 * n * (height // 2) * (-(-(width // 2) // seg) * seg) * cin * 16 * (-(-out_channels // nblk) * nblk)
-    return 3 * 2.0 * n * height * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // 32) * 32)
+    if stride == 1 and width >= 32 and 1 <= width % 32 <= 16:
+        # the narrow last column runs on transposed tiles (32 rows x 16 columns; csrc/conv_split.hip, TP): blocks of two rows
+        px = height * 32 * (width // 32) + -(-height // 2) * 32
+    else:
+        px = height * (-(-width // 32) * 32)
+    return 3 * 2.0 * n * px * cin * 9 * (-(-out_channels // 32) * 32)
 
 
 @_on_tensor_device
