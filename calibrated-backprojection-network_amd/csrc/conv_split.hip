@@ -1309,291 +1309,20 @@ __global__ void uf64_pack_kernel(const float* __restrict__ w, const float* __res
 // PIN: the input is a pair tensor (staged by LDS-DMA, nothing to split); POUT: the output is written as one (the MFMA
 // operands swap roles, so that a lane's accumulator registers run over FILTERS of one pixel: four consecutive channels
 // = half a granule per store).
-template <bool PIN, bool POUT>
+template <bool PIN, bool POUT, bool MIXED = false>   // MIXED: p.nblocks whole tiles, then p.tp_nblocks transposed ones (see conv3x3_split_kernel)
 __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const SplitConvParams p) {
-    constexpr int TH = 8, ROWS = TH + 2, COLS = 34, NPIX = ROWS * COLS, NB = 2;
-    constexpr int A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART, PR = (NPIX + 255) / 256;
-    constexpr int B_ITEM = 2 * 2 * U64_NT * 16, HALF = UF_ITEMS / 2, B_HALF = HALF * B_ITEM;   // bytes per weight set / half chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals (see conv3x3_split_kernel)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = low-resolution row oy0 + rg
-    const int lm = lane & 31, g = lane >> 5;
-    int bid = xcd_remap(blockIdx.x, p.nblocks);
-    const int nt = bid % p.nTilesN;
-    bid /= p.nTilesN;
-    const int tx = bid % p.tilesX;
-    bid /= p.tilesX;
-    const int ty = bid % p.tilesY;
-    const int n = bid / p.tilesY;
-    const int oy0 = ty * TH, ox0 = tx * 32;                            // low-resolution tile origin
-    const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
-    const long long plane = (long long)sH * sW;
-    const int nchunks = p.Cin / SP_CK;
-    float prescale, unscale;
-    if constexpr (PIN) { prescale = 0.f; unscale = 1.f / p.pair_src_scale[n]; }
-    else sp_act_scale(p, n, prescale, unscale);
-
-    const int kg_st = rg >> 2, t256 = tid & 255;
-    int goff[PR];
-#pragma unroll
-    for (int u = 0; u < PR; ++u) {
-        const int pix = u * 256 + t256;
-        const int r = pix / COLS, c = pix - r * COLS;
-        const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
-        goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
+    if (!MIXED || (int)blockIdx.x < p.nblocks) {
+        constexpr bool TP = false;
+        const int block = blockIdx.x, nblocks = p.nblocks, tilesX = p.tilesX, tilesY = p.tilesY;
+#include "upconv64_split_body.inc"
+    } else if constexpr (MIXED) {
+        constexpr bool TP = true;
+        const int block = (int)blockIdx.x - p.nblocks, nblocks = p.tp_nblocks, tilesX = 1, tilesY = p.tp_tilesY;
+#include "upconv64_split_body.inc"
     }
-    const unsigned char* wp_nt = reinterpret_cast<const unsigned char*>(p.wp) + (long long)nt * nchunks * (UF_ITEMS * B_ITEM);
-
-    float va[PR][8];
-    auto load_chunk = [&](int chunk) {
-        const float* base = p.src[0] + (long long)n * p.src_bstride[0] + (long long)(chunk * SP_CK + kg_st * 8) * plane;
-#pragma unroll
-        for (int u = 0; u < PR; ++u) {
-            const unsigned voff = goff[u] < 0 ? 0u : (unsigned)goff[u];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float* sb = base + (long long)k * plane;
-                asm volatile("global_load_dword %0, %1, %2" : "=v"(va[u][k]) : "v"(voff), "s"(sb) : "memory");
-            }
-        }
-    };
-    auto store_round = [&](int buf, int u) {
-        unsigned char* A = smem + buf * A_BYTES + kg_st * NPIX * 16;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));
-        const int pix = u * 256 + t256;
-        if (pix < NPIX) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
-            sph8 h1, h2;
-            sp_split8(v, prescale, h1, h2);
-            *reinterpret_cast<sph8*>(A + pix * 16) = h1;
-            *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
-        }
-    };
-    // weights: half chunks (eight sets, 32 KiB) by LDS-DMA into two buffers behind the A buffers
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
-    // pair input: a staged chunk is 4 planes (term, k-group) x NPIX granules; wave-wide DMA id = plane * NR + round, wave rg
-    // issues ids rg, rg + 8, ..; a halo pixel outside the map reads the plane's zero granule
-    constexpr int NR = (NPIX + 63) / 64, NDMA = 4 * NR, DPW = NDMA / 8;
-    static_assert(NDMA % 8 == 0, "the same number of DMAs in every wave");
-    unsigned dvoff[DPW];
-    if constexpr (PIN) {
-#pragma unroll
-        for (int i = 0; i < DPW; ++i) {
-            const int pix = ((rg + 8 * i) % NR) * 64 + lane;
-            const int r = pix / COLS, c = pix - r * COLS;
-            const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
-            dvoff[i] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (unsigned)(Y * sW + X) * 16u : (unsigned)(sH * sW) * 16u;
-        }
-    }
-    const long long pplane = pair_plane_halves(sH, sW);
-    auto dma_chunk = [&](int buf, int chunk) {
-        const _Float16* pn = p.pair_src + (long long)n * p.pair_src_bstride + (long long)(2 * chunk) * 2 * pplane;
-#pragma unroll
-        for (int i = 0; i < DPW; ++i) {
-            const int id = rg + 8 * i, plane = id / NR, j = id - plane * NR;
-            const int t = plane >> 1, kgl = plane & 1;
-            const unsigned long long mask = (j == NR - 1 && (NPIX & 63)) ? ((1ull << (NPIX & 63)) - 1) : ~0ull;
-            lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kgl * 2 + t) * pplane), dvoff[i],
-                         lds0 + (unsigned)(buf * A_BYTES + t * A_PART + (kgl * NPIX + j * 64) * 16), mask);
-        }
-    };
-    auto stage_half = [&](int hbuf, int chunk, int half) {
-        const float* src = reinterpret_cast<const float*>(wp_nt + ((long long)chunk * UF_ITEMS + half * HALF) * B_ITEM);
-        const unsigned dst = lds0 + (unsigned)(2 * A_BYTES + hbuf * B_HALF);
-        constexpr int n4 = B_HALF / 16;
-        static_assert(n4 % SP_THREADS == 0, "whole rounds of the workgroup");
-#pragma unroll
-        for (int e0 = 0; e0 < n4; e0 += SP_THREADS) {
-            const int eb = e0 + rg * 64;
-            lds_dma16_s(src + eb * 4, (unsigned)(lane * 16), dst + eb * 16);
-        }
-    };
-
-    spf16 acc[2][2][NB];   // [py][px][32-filter block]
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[a >> 2][(a >> 1) & 1][a & 1][i] = 0.f;
-
-    const unsigned char* const aptr = smem + (g * NPIX + rg * COLS + lm) * 16;
-    sph8 af[3][2];        // A fragments of staged rows rg + 0..2 at the column offset of their group (two split terms each)
-    auto load_arow = [&](int abuf, int ry, int ox) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            af[ry][t] = *reinterpret_cast<const sph8*>(aptr + abuf + t * A_PART + (ry * COLS + ox) * 16);
-    };
-    const unsigned char* const bptr = smem + 2 * A_BYTES + (g * U64_NT + lm) * 16;   // + part * 2 NT 16 + nb * 32 * 16
-    const bool row_live = oy0 + rg < sH;                                            // wave-uniform
-    constexpr int WAIT_IT = 4;   // set of the first half whose MFMAs follow the wait for the next chunk's inputs (and the second half's weights)
-    static_assert(WAIT_IT + PR <= HALF, "the staging rounds sit in the first half");
-
-    auto half_body = [&](int c, auto half_tag, auto more_tag) {
-        constexpr int HF = decltype(half_tag)::value;
-        constexpr bool MORE = decltype(more_tag)::value;   // a chunk c+1 exists
-        const int abuf = (c & 1) * A_BYTES;
-        const unsigned char* B = bptr + HF * B_HALF;
-        // the other weight buffer was last read in the previous half (a barrier ago): refill it
-        if (HF == 0) {
-            stage_half(1, c, 1);
-            if (MORE) {
-                if constexpr (PIN) dma_chunk((c & 1) ^ 1, c + 1);   // the other buffer was last read a chunk (two barriers) ago
-                else load_chunk(c + 1);
-            }
-            load_arow(abuf, 0, 0);
-        } else if (MORE) {
-            stage_half(0, c + 1, 0);
-        }
-        sph8 bwq[2][NB][2];   // (w1, w2) of the current / next set, per 32-filter block
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) bwq[0][nb][t] = *reinterpret_cast<const sph8*>(B + (t * 2 * U64_NT + nb * 32) * 16);
-#pragma unroll
-        for (int ih = 0; ih < HALF; ++ih) {
-            constexpr int dummy = 0; (void)dummy;
-            const int it = HF * HALF + ih;
-            const UfItem t = uf_item(it);
-            const bool first_of_group = it == 0 || uf_item(it - 1).s != t.s || uf_item(it - 1).ox != t.ox;
-            if (first_of_group) {   // fetch the row the NEXT group reads
-                if (t.s < 2) load_arow(abuf, t.s + 1, t.ox);
-                else if (t.ox < 2) load_arow(abuf, 0, t.ox + 1);
-            }
-            if (ih + 1 < HALF) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
-                        bwq[(ih + 1) & 1][nb][tt] = *reinterpret_cast<const sph8*>(B + (ih + 1) * B_ITEM + (tt * 2 * U64_NT + nb * 32) * 16);
-            }
-            sph8 bw[NB][3];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                bw[nb][0] = bwq[ih & 1][nb][0];
-                bw[nb][1] = bwq[ih & 1][nb][1];
-                bw[nb][2] = bw[nb][0] * (_Float16)0.00048828125f;   // w1 2^-11
-            }
-            if (!PIN && HF == 0 && MORE && ih == WAIT_IT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's inputs (and this chunk's second half of weights)
-            __builtin_amdgcn_sched_barrier(0);
-            if (row_live) {
-                constexpr int TA[3] = {0, 0, 1};
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[t.py][t.px][nb] = POUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[nb][k], af[t.s][TA[k]], acc[t.py][t.px][nb], 0, 0, 0)
-                                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t.s][TA[k]], bw[nb][k], acc[t.py][t.px][nb], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!PIN && HF == 0 && MORE && ih >= WAIT_IT && ih - WAIT_IT < PR) store_round((c & 1) ^ 1, ih - WAIT_IT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight DMA issued at the top of the half
-        __syncthreads();
-    };
-
-    if constexpr (PIN) dma_chunk(0, 0);
-    else load_chunk(0);
-    stage_half(0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (!PIN) {
-#pragma unroll
-        for (int u = 0; u < PR; ++u) store_round(0, u);
-    }
-    __syncthreads();
-    for (int c = 0; c + 1 < nchunks; ++c) {
-        half_body(c, std::integral_constant<int, 0>{}, std::true_type{});
-        half_body(c, std::integral_constant<int, 1>{}, std::true_type{});
-    }
-    half_body(nchunks - 1, std::integral_constant<int, 0>{}, std::false_type{});
-    half_body(nchunks - 1, std::integral_constant<int, 1>{}, std::false_type{});
-
-    const float slope = p.act ? p.slope : 1.f;
-    float amax = 0.f;
-    if constexpr (POUT) {
-        // ---- pair epilogue: acc[py][px][nb][i]: low-resolution x = lm, filter nb * 32 + 8 (i / 4) + 4 g + (i % 4): a lane holds
-        // channels 4 g .. 4 g + 3 of k-group (nt 64 + nb 32) / 8 + i / 4 -- half a granule -- of outputs (2 Y + py, 2 x + px)
-        const float ps_out = sp_pair_out_scale(p, n);
-        const long long oph = pair_plane_halves(H, W);
-        _Float16* const pn = p.pair_out + (long long)n * p.pair_out_bstride;
-        if (tid == 0) p.pair_out_scale[n] = ps_out;
-        if (tx == 0 && ty == 0 && rg == 0 && lane < 16) {   // the zero granules of this filter tile's 8 k-groups x 2 terms
-            const int kgz = nt * (U64_NT / 8) + (lane >> 1);
-            if (kgz * 8 < p.OC)
-                *reinterpret_cast<f32x4*>(pn + (long long)(kgz * 2 + (lane & 1)) * oph + (long long)H * W * 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        const int Y = oy0 + rg, x = ox0 + lm;
-        if (Y >= sH) return;   // wave-uniform
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {     // k-groups 2 qp, 2 qp + 1 of the block: after the exchange this lane stores k-group 2 qp + g whole
-                const int kg0 = nt * (U64_NT / 8) + nb * 4 + 2 * qp;
-                if (kg0 * 8 >= p.OC) continue;   // wave-uniform; pair outputs have whole k-groups (OC % 8 == 0)
-                const f32x4 invA = *reinterpret_cast<const f32x4*>(p.inv_scale + kg0 * 8 + 4 * g) * unscale;
-                const f32x4 invB = *reinterpret_cast<const f32x4*>(p.inv_scale + kg0 * 8 + 8 + 4 * g) * unscale;   // the table is padded to whole tiles
-                const bool mine = (kg0 + g) * 8 < p.OC;
-                _Float16* const k0 = pn + (long long)((kg0 + g) * 2) * oph;
-#pragma unroll
-                for (int py = 0; py < 2; ++py)
-#pragma unroll
-                    for (int px = 0; px < 2; ++px) {
-                        f32x4 va, vb;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float ta = acc[py][px][nb][qp * 8 + j] * invA[j];
-                            const float tb = acc[py][px][nb][qp * 8 + 4 + j] * invB[j];
-                            va[j] = ta > 0.f ? ta : ta * slope;
-                            vb[j] = tb > 0.f ? tb : tb * slope;
-                        }
-                        if (x < sW) amax = sp_amax4(sp_amax4(amax, va), vb);
-                        sph4 a1, a2, b1, b2;
-                        sp_split4(va * ps_out, a1, a2);
-                        sp_split4(vb * ps_out, b1, b2);
-                        const spu4 g1 = sp_pair_exchange(a1, b1), g2 = sp_pair_exchange(a2, b2);   // every lane takes part
-                        if (x < sW && mine) {
-                            const long long o = ((long long)(2 * Y + py) * W + 2 * x + px) * 8;
-                            *reinterpret_cast<spu4*>(k0 + o) = g1;
-                            *reinterpret_cast<spu4*>(k0 + oph + o) = g2;
-                        }
-                    }
-            }
-        if (p.out_amax) absmax_commit(p.out_amax + n, amax);
-        return;
-    }
-    // ---- epilogue: acc[py][px][nb][i]: low-resolution x = 8 (i / 4) + 4 g + (i % 4), filter nb * 32 + lm; outputs (2 Y + py, 2 x + px)
-    const long long oplane = (long long)H * W;
-    const int Y = oy0 + rg;
-    if (Y >= sH) return;   // wave-uniform: a wave whose row lies below the map stores nothing
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int oc = nt * U64_NT + nb * 32 + lm;
-        const float inv = p.inv_scale[oc] * unscale;
-        if (oc >= p.OC) continue;
-        float* outc = p.out + (long long)n * p.out_bstride + (long long)oc * oplane;
-#pragma unroll
-        for (int py = 0; py < 2; ++py) {
-            float* orow = outc + (long long)(2 * Y + py) * W;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int X = 2 * (ox0 + 8 * q4 + 4 * g);              // first output column of this lane's 8
-                f32x4 v0, v1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = acc[py][j & 1][nb][q4 * 4 + (j >> 1)] * inv;
-                    const float b = acc[py][j & 1][nb][q4 * 4 + 2 + (j >> 1)] * inv;
-                    v0[j] = a > 0.f ? a : a * slope;
-                    v1[j] = b > 0.f ? b : b * slope;
-                }
-                if (X < W) { *reinterpret_cast<f32x4*>(orow + X) = v0; amax = sp_amax4(amax, v0); }
-                if (X + 4 < W) { *reinterpret_cast<f32x4*>(orow + X + 4) = v1; amax = sp_amax4(amax, v1); }
-            }
-        }
-    }
-    if (p.out_amax) absmax_commit(p.out_amax + n, amax);
 }
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // 1x1 stride-2 conv (+ LeakyReLU) on split operands: conv_fused of the KB block, reference src/net_utils.py:1337-1343 and
@@ -2009,9 +1738,25 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         const long long blocks64 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
         if (blocks64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
         p.nblocks = (int)blocks64;
-        static DeviceOnce o64[4];
+        static DeviceOnce o64[4], o64t[4];
         constexpr size_t lds64 = 2 * (2 * 2 * 10 * 34 * 16) + 2 * (8 * 2 * 2 * 64 * 16);
-        if (p.pair_src) rc = p.pair_out ? launch(upconv2x_split64_kernel<true, true>, lds64, o64[3]) : launch(upconv2x_split64_kernel<true, false>, lds64, o64[2]);
+        // a low-resolution map whose width leaves 1-16 columns behind the whole 32-column tiles: transposed tiles (16 rows x 16
+        // columns) for that column, in the same launch (KBN_DEBUG & 512: off)
+        const int wrem = p.sW % 32;
+        if (p.sW >= 32 && wrem >= 1 && wrem <= 16 && !(knob(KNOB_DEBUG) & 512)) {
+            p.tilesX = p.sW / 32;
+            p.nblocks = p.tilesX * p.tilesY * n * p.nTilesN;
+            p.tp_x0 = 32 * p.tilesX;
+            p.tp_tilesY = ceil_div(p.sH, 16);
+            p.tp_nblocks = p.tp_tilesY * n * p.nTilesN;
+            auto launch_mixed = [&](auto kern, DeviceOnce& once) -> int {
+                if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
+                hipLaunchKernelGGL(kern, dim3(p.nblocks + p.tp_nblocks), dim3(SP_THREADS), lds64, (hipStream_t)stream, p);
+                return KBN_OK;
+            };
+            if (p.pair_src) rc = p.pair_out ? launch_mixed(upconv2x_split64_kernel<true, true, true>, o64t[3]) : launch_mixed(upconv2x_split64_kernel<true, false, true>, o64t[2]);
+            else rc = p.pair_out ? launch_mixed(upconv2x_split64_kernel<false, true, true>, o64t[1]) : launch_mixed(upconv2x_split64_kernel<false, false, true>, o64t[0]);
+        } else if (p.pair_src) rc = p.pair_out ? launch(upconv2x_split64_kernel<true, true>, lds64, o64[3]) : launch(upconv2x_split64_kernel<true, false>, lds64, o64[2]);
         else rc = p.pair_out ? launch(upconv2x_split64_kernel<false, true>, lds64, o64[1]) : launch(upconv2x_split64_kernel<false, false>, lds64, o64[0]);
         if (rc != KBN_OK) return rc;
         KBN_CHECK_LAUNCH();

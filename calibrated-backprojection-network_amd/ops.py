@@ -673,7 +673,13 @@ def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1, 
     if folded_up2x:
         nblk = 16 if (out_channels <= 16 and cin % 32 == 0) else 32   # narrow layers: v_mfma_f32_16x16x32_f16, 16-pixel segments
         seg = 16 if nblk == 16 else 32
-        return 3 * 2.0 * n * (height // 2) * (-(-(width // 2) // seg) * seg) * cin * 16 * (-(-out_channels // nblk) * nblk)
+        sh, sw = height // 2, width // 2
+        wide = out_channels >= 64 and (-(-out_channels // 32)) % 2 == 0     # the 64-filter tiles (csrc/conv_split.hip, uf_wide)
+        if nblk == 32 and wide and sw >= 32 and 1 <= sw % 32 <= 16:
+            px = sh * 32 * (sw // 32) + -(-sh // 2) * 32                     # the narrow last column on transposed tiles: blocks of two rows
+        else:
+            px = sh * (-(-sw // seg) * seg)
+        return 3 * 2.0 * n * px * cin * 16 * (-(-out_channels // nblk) * nblk)
     if stride == 1 and width >= 32 and 1 <= width % 32 <= 16:
         # the narrow last column runs on transposed tiles (32 rows x 16 columns; csrc/conv_split.hip, TP): blocks of two rows
         px = height * 32 * (width // 32) + -(-height // 2) * 32
