@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for any N: started WITHOUT torchrun's environment (no WORLD_SIZE) and with --gpus N > 1, the script
+re-launches itself as N ranks under `torch.distributed.run --standalone`-style arguments on 127.0.0.1 (`self_spawn`),
+passes the ranks' output through and exits with their exit code.
+
 A step = one `KBNetModel.forward` over this rank's batch of synthetic KITTI-shaped
 frames (352 x 1216, fp32, inputs resident in HBM), followed -- for N > 1 -- by the RCCL
 all-gather of the depth maps.  Frames shard across ranks (weak scaling: 32 frames per GPU =
@@ -24,6 +28,9 @@ this box's host cores over a bounded sample.
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -38,17 +45,65 @@ import kbnet_amd as kb  # noqa: E402
 HEIGHT, WIDTH = 352, 1216
 FRAMES_PER_GPU = 32      # configs[2] (fp32 leg) / configs[3] per-GPU share; --frames-per-gpu 8 = configs[1]
 SIDE_BATCH = 8           # configs[1]
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32, dense (the fp32 vector datapath)
-FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/fp16 MFMA (the matrix core proper)
+FP32_MFMA_PEAK_TFLOPS = kb.ops.PIPE_PEAK_TFLOPS["fp32"]  # MI355X_MICROARCH.md: v_mfma_f32_*_f32, dense (the fp32 vector datapath)
+FP16_MFMA_PEAK_TFLOPS = kb.ops.PIPE_PEAK_TFLOPS["fp16"]  # MI355X_MICROARCH.md: dense bf16/fp16 MFMA (the matrix core proper)
+# host-level launch name -> the rocprofv3 kernel-name prefix of its instantiations (PMC lookup)
 SPLIT_KERNELS = {"conv_split": "conv3x3_split_kernel<0, 8,", "conv_split_up": "conv3x3_split_kernel<1, 8,",
                  "conv_split_s2": "conv3x3_split_kernel<2, 2,", "conv_split_upfold": "upconv2x_split_kernel"}
-
-
-def pipe_peak(name):
-    """Dense peak of the pipe a kernel group's MFMAs run on: the split-operand convs issue fp16 MFMAs (three per fp32
-    product), everything else v_mfma_f32_*_f32."""
-    return FP16_MFMA_PEAK_TFLOPS if name in SPLIT_KERNELS else FP32_MFMA_PEAK_TFLOPS
 HBM_PEAK_GBS = 8000.0
+
+
+def summarise_profile(prof, steps):
+    """Per-kernel-group sums of an ops.PROFILE list: {name: dict(work, seconds, launches, executed, pipe, nbytes)}.
+    The PIPE each launch's MFMAs run on travels with the record (ops._launch), so every group is priced at the peak of
+    its own pipe -- the split-operand kernels (conv_split*, conv_split_1x1s2, kb1_front, kb1_depth_front, conv_tail) at
+    the fp16 matrix core's 2.5 PFLOP/s, the fp32-MFMA kernels at 157.3 TFLOP/s."""
+    groups = {}
+    for name, work, executed, pipe, nbytes, s, e in prof:
+        g = groups.setdefault(name, {"work": 0.0, "seconds": 0.0, "launches": 0, "executed": 0.0, "has_executed": True,
+                                     "pipe": pipe, "nbytes": 0.0, "has_bytes": True})
+        g["work"] += work
+        g["seconds"] += s.elapsed_time(e) * 1e-3
+        g["launches"] += 1
+        if executed is None:
+            g["has_executed"] = False
+        else:
+            g["executed"] += executed
+        if nbytes is None:
+            g["has_bytes"] = False
+        else:
+            g["nbytes"] += nbytes
+        if pipe != g["pipe"]:
+            raise ValueError(f"launch group {name} mixes pipes {g['pipe']} and {pipe}")
+    return groups
+
+
+def per_kernel_table(groups, steps):
+    """roofline.per_kernel: for every launch group of a step its time and the fraction of each roof it reaches --
+    `issued_frac` = FLOPs of the MFMAs it issues / time / peak of ITS pipe, `useful_frac` = the reference's
+    multiply-adds (x the products its pipe needs per fp32 product) / time / the same peak, `hbm_frac` = algorithmic
+    bytes (inputs once + outputs once) / time / 8 TB/s.  None where a roof does not apply.  No fraction can exceed 1
+    unless a launch executes fewer FLOPs than the reference formulation (`useful_frac` of Winograd / folded up-convs on
+    the fp32 pipe): those are capped by `issued_frac`, which counts what runs."""
+    table = {}
+    for name, g in groups.items():
+        t = g["seconds"]
+        row = {"us_per_step": round(t / steps * 1e6, 1), "launches_per_step": round(g["launches"] / steps, 2), "pipe": g["pipe"],
+               "useful_frac": None, "issued_frac": None, "hbm_frac": None}
+        if g["pipe"] is not None and g["has_executed"] and g["executed"] > 0 and t > 0:
+            peak = kb.ops.PIPE_PEAK_TFLOPS[g["pipe"]] * 1e12
+            row["issued_frac"] = round(g["executed"] / t / peak, 4)
+            row["useful_frac"] = round(min(kb.ops.PIPE_PRODUCTS[g["pipe"]] * g["work"], g["executed"]) / t / peak, 4)
+        if g["has_bytes"] and g["nbytes"] > 0 and t > 0:
+            row["hbm_frac"] = round(g["nbytes"] / t / (HBM_PEAK_GBS * 1e9), 4)
+        table[name] = row
+    return table
+
+
+def pipe_seconds(groups):
+    """Seconds the issued MFMA FLOPs of every group would take at the dense peak of the pipe they run on."""
+    return sum(g["executed"] / (kb.ops.PIPE_PEAK_TFLOPS[g["pipe"]] * 1e12) for g in groups.values()
+               if g["pipe"] is not None and g["has_executed"] and g["executed"] > 0)
 WEIGHT_GAIN = 1.3  # keeps random-weight logits O(1) so the sigmoid head is off saturation
 
 
@@ -116,46 +171,116 @@ def lookup_traffic(kernel, launches, frames_per_gpu):
     return per("hbm_bytes_per_launch"), detail
 
 
-def cpu_baseline(cfg, sds, frames, budget_s=15.0, max_frames=6):
-    """Oracle (CPU port of the reference) on this box's host cores, one frame at a time
-    like the reference's own loop (reference src/kbnet.py:887).  Thread count: the
-    reference's single-channel MaxPool2d / strided 1x1 conv do not scale past a few
-    dozen threads (measured on the 256-core GPU box: 16 threads 0.98 s/frame, 64: 1.19, 128: 1.71,
-    256: 33), so use
-    min(cores, KBNET_CPU_THREADS or 16) and report that number as `cores`."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(cfg, sds, frames, batch_frames=None, runs=3):
+    """Oracle (CPU port of the reference, bit-identical to it) on this box's host cores, as SURVEY.md 8(d) asks: CPU
+    model and host core count stated, N = 1 (one frame at a time like the reference's own loop, src/kbnet.py:887-921)
+    and N = 8 (one batch-8 forward), MEDIAN of `runs` >= 3 runs each.  `value` is the better of the two rates (the
+    reference's loader may batch).  Thread count: the reference's single-channel MaxPool2d / strided 1x1 conv do not
+    scale past a few dozen threads (measured on the 256-core GPU box: 16 threads 0.98 s/frame, 64: 1.19, 128: 1.71,
+    256: 33), so min(cores, KBNET_CPU_THREADS or 16) threads run and that number is reported as `cores` / `threads`.
+    Returns (dict, oracle output of frame 0)."""
     from oracle import kbnet_oracle as orc
-    threads = min(os.cpu_count() or 1, int(os.environ.get("KBNET_CPU_THREADS", "16")))
+    host_cores = os.cpu_count() or 1
+    threads = min(host_cores, int(os.environ.get("KBNET_CPU_THREADS", "16")))
     torch.set_num_threads(threads)
-    run = lambda: orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools,
-                                    cfg.min_predict_depth, cfg.max_predict_depth)
-    ref = run()  # warm-up (also the parity reference for frame 0 of rank 0)
-    t0 = time.perf_counter()
-    done = 0
-    while done < max_frames and (time.perf_counter() - t0 < budget_s or done == 0):
-        run()
-        done += 1
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} KITTI 352x1216 frames, batch 1, fp32, oracle/kbnet_oracle.py (torch CPU)"}, ref
+    run = lambda fr: orc.kbnet_forward(*fr, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+    one = [f[0:1] for f in frames]
+    ref = run(one)  # warm-up (also the parity reference for frame 0 of rank 0)
+
+    def median_seconds(fr):
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            run(fr)
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), ts
+
+    s1, t1 = median_seconds(one)
+    res = {"value": 1.0 / s1, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "cpu_model": cpu_model_name(), "host_cores": host_cores, "threads": torch.get_num_threads(),
+           "n1_frames_per_s": round(1.0 / s1, 4), "n1_seconds_per_run": [round(t, 3) for t in t1], "n8_frames_per_s": None,
+           "statistic": f"median of {runs} runs",
+           "sample": f"{runs} runs of 1 KITTI 352x1216 frame (batch 1)"}
+    if batch_frames is not None and batch_frames[0].shape[0] > 1:
+        nb = batch_frames[0].shape[0]
+        sb, tb = median_seconds(batch_frames)
+        res["n8_frames_per_s"] = round(nb / sb, 4)
+        res["n8_seconds_per_run"] = [round(t, 3) for t in tb]
+        res["value"] = max(res["value"], nb / sb)
+        res["sample"] += f" + {runs} runs of one batch of {nb} frames"
+    res["sample"] += ", fp32, oracle/kbnet_oracle.py (torch CPU)"
+    return res, ref
+
+
+def rccl_version():
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:   # no GPU build / no RCCL: the line still prints
+        return None
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_spawn(argv, gpus: int, backend: str):
+    """`python bench.py --gpus N` started without torchrun's environment: run the same command line as N ranks (one
+    process per GPU) under torch.distributed.run on 127.0.0.1, pass their stdout / stderr through (rank 0 prints the ONE
+    JSON line) and return their exit code.  Replaces the three DataParallel wrappers of reference
+    src/kbnet_model.py:408-415 as the way more than one GPU is driven."""
+    if backend == "nccl":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        have = torch.cuda.device_count()
+        if have < gpus:
+            raise SystemExit(f"--gpus {gpus} but only {have} GPU(s) are visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["KBN_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def setup_ranks(gpus: int, backend: str):
     """One process per GPU, launched as the contract says: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
-    environment (torch.distributed.run sets them), `--gpus N` must equal WORLD_SIZE.  backend "nccl" = RCCL: the rank's
-    device is cuda:LOCAL_RANK; "gloo": CPU (tests/test_dist_cpu.py runs this very code at world size 2)."""
+    environment (torch.distributed.run sets them; `main` re-launches itself under it when they are missing), `--gpus N`
+    must equal WORLD_SIZE.  backend "nccl" = RCCL: the rank's device is cuda:LOCAL_RANK; "gloo": CPU
+    (tests/test_dist_cpu.py runs this very code at world size 2)."""
     rank, local_rank, world = kb.dist.env_world()
     if world != gpus:
-        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run "
-                         f"--nproc-per-node {gpus} bench.py --gpus {gpus} ...`")
+        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {gpus}` (it spawns its "
+                         f"ranks) or `python -m torch.distributed.run --nproc-per-node {gpus} bench.py --gpus {gpus} ...`")
     if backend == "nccl":
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
         dev = torch.device("cpu")
     kb.dist.init(backend)
     return rank, local_rank, world, dev
+
+
+def standin_forward(image, sparse, valid, k):
+    """Frame-independent stand-in for the HIP forward (plumbing tests: KBN_BENCH_TEST_BACKEND=gloo)."""
+    return image.mean(1, keepdim=True) + sparse + valid * k[:, 0, 0].view(-1, 1, 1, 1)
 
 
 def device_sync(dev):
@@ -200,7 +325,14 @@ def emit(result, rank: int):
 def main(argv=None, backend: str = "nccl", forward_factory=None):
     """`backend` / `forward_factory` are test hooks (tests/test_dist_cpu.py): with gloo and a stand-in forward --
     forward_factory(rank, dev, frames) -> callable -- the rank logic above runs end to end on CPU processes; the GPU-only
-    measurements (roofline, side figures, cpu_baseline) are skipped then."""
+    measurements (roofline, side figures, cpu_baseline) are skipped then.  The same hook from the command line (so that
+    the self-spawn path can be tested on CPU): KBN_BENCH_TEST_BACKEND=gloo runs `standin_forward` on tiny frames."""
+    global HEIGHT, WIDTH
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if os.environ.get("KBN_BENCH_TEST_BACKEND") and forward_factory is None:
+        backend = os.environ["KBN_BENCH_TEST_BACKEND"]
+        forward_factory = lambda rank, dev, frames: standin_forward
+        HEIGHT, WIDTH = 16, 24
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -214,9 +346,21 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     ap.add_argument("--branches", type=int, default=0,
                     help="concurrent sub-batches inside the captured graph (0 = default: 2 for even batches >= 4)")
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of HIP-graph replay")
+    ap.add_argument("--side", action="store_true",
+                    help="with --gpus N > 1: also run the side measurements (VOID, batch 8, bf16 / fp16 legs, fp32-MFMA-only, "
+                         "unused conv); by default an N-rank run is the timed region plus rank 0's roofline pass")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the throughput-only one-term fp16 leg (configs[2])")
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (never reached by a rank: torchrun sets WORLD_SIZE)
+        if os.environ.get("KBN_BENCH_SPAWNED"):
+            raise SystemExit("bench.py: spawned rank without WORLD_SIZE in its environment")
+        raise SystemExit(self_spawn(argv, args.gpus, backend))
+
     rank, local_rank, world, dev = setup_ranks(args.gpus, backend)
+    if world > 1 and not args.side:
+        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = True
     per = args.frames_per_gpu
     # rank r holds frames [r*per, (r+1)*per) of the global batch (seed 1+rank; frame 0 of
     # rank 0 is the frame the CPU oracle sees)
@@ -227,7 +371,9 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         elapsed, out = timed_steps(runner, frames, args.steps, args.warmup, dev)
         result = base_result(per * world * args.steps / elapsed, world, args.steps, args.warmup, 1e3 * elapsed / args.steps)
         result["config"] = {"workload": "stand-in forward (plumbing test)", "frames_per_gpu": per, "global_batch": per * world,
-                            "gathered_frames": int(out.shape[0]), "rank_seeds": [1 + r for r in range(world)]}
+                            "gathered_frames": int(out.shape[0]), "rank_seeds": [1 + r for r in range(world)],
+                            "n_ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                            "backend": backend}
         result["roofline"] = None
         result["cpu_baseline"] = None
         emit(result, rank)
@@ -395,50 +541,43 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     fps = per * world * args.steps / elapsed
     gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
 
-    # ---- roofline of the dominant kernel (rank 0's launches) ----
-    groups = {}
-    for name, work, executed, s, e in prof:
-        g = groups.setdefault(name, [0.0, 0.0, 0, 0.0, True])
-        g[0] += work
-        g[1] += s.elapsed_time(e) * 1e-3
-        g[2] += 1
-        if executed is None:
-            g[4] = False
-        else:
-            g[3] += executed
-    breakdown = {k: {"launches": v[2], "ms_total": round(v[1] * 1e3, 3),
-                     "avg_us": round(v[1] / v[2] * 1e6, 2)} for k, v in groups.items()}
-    conv_groups = {k: v for k, v in groups.items() if k.startswith("conv_")}
-    dom = max(conv_groups, key=lambda k: conv_groups[k][1])
-    dwork, dtime, dlaunch, dexec, _ = conv_groups[dom]
+    # ---- roofline of the dominant kernel (this rank's launches; rank 0 prints) ----
+    groups = summarise_profile(prof, args.steps)
+    breakdown = {k: {"launches": g["launches"], "ms_total": round(g["seconds"] * 1e3, 3),
+                     "avg_us": round(g["seconds"] / g["launches"] * 1e6, 2)} for k, g in groups.items()}
+    conv_groups = {k: g for k, g in groups.items() if k.startswith("conv_")}
+    dom = max(conv_groups, key=lambda k: conv_groups[k]["seconds"])
+    d = conv_groups[dom]
+    dwork, dtime, dlaunch, dexec = d["work"], d["seconds"], d["launches"], d["executed"]
     # `achieved`: FLOPs of the MFMA instructions the dominant kernel ISSUES (its launch plan minus the padding the kernel
     # skips: ops.conv3x3_split_executed_flops agrees with SQ_INSTS_MFMA x 32768 of the PMC collection) per second;
-    # `frac` = achieved / peak is the matrix-pipe fraction and cannot exceed 1.  `useful_frac`: only the reference's
-    # multiply-adds, at the three fp16 products each costs on this pipe.  `algorithmic`: the same launches priced at the
-    # reference's direct-conv FLOPs (2 * N * Hout * Wout * Cin * 9 * Cout) -- fp32 work, which may exceed the fp32 peak.
+    # `frac` = achieved / peak of the pipe those MFMAs run on (carried by the launch record) and cannot exceed 1.
+    # `useful_frac`: only the reference's multiply-adds, at the three fp16 products each costs on this pipe.
+    # `algorithmic`: the same launches priced at the reference's direct-conv FLOPs (2 * N * Hout * Wout * Cin * 9 * Cout)
+    # -- fp32 work, which may exceed the fp32 peak.
     achieved = dexec / dtime / 1e12
-    peak = pipe_peak(dom)
-    products = 3.0 if dom in SPLIT_KERNELS else 1.0
-    mfma_flops = [v[3] for k, v in groups.items() if v[4] and v[3] > 0]
-    mfma_time = [v[1] for k, v in groups.items() if v[4] and v[3] > 0]
-    # seconds the executed FLOPs of every MFMA kernel would take at the dense peak of the pipe they run on
-    pipe_seconds = sum(v[3] / (pipe_peak(k) * 1e12) for k, v in groups.items() if v[4] and v[3] > 0)
+    peak = kb.ops.PIPE_PEAK_TFLOPS[d["pipe"]]
+    products = kb.ops.PIPE_PRODUCTS[d["pipe"]]
+    mfma_groups = [g for g in groups.values() if g["pipe"] is not None and g["has_executed"] and g["executed"] > 0]
+    psec = pipe_seconds(groups)
     roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "useful_frac": round(products * dwork / dtime / 1e12 / peak, 4), "traffic": None,
+                "useful_frac": round(min(products * dwork, dexec) / dtime / 1e12 / peak, 4), "traffic": None,
                 "launches": dlaunch, "avg_launch_us": round(dtime / dlaunch * 1e6, 2),
                 "flop_per_launch": dexec / dlaunch,
                 "algorithmic": {"flop_per_launch": dwork / dlaunch, "tflops": round(dwork / dtime / 1e12, 3),
                                 "multiple_of_peak": round(dwork / dtime / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                 "executed_over_algorithmic": round(dexec / dwork, 4)},
-                # whole forward: time the executed FLOPs of every MFMA launch of a step need at the dense peak of their
-                # pipe (fp16 MFMA for the split-operand convs, fp32 MFMA for the rest) / the timed step
-                "whole_forward_frac": round(pipe_seconds / args.steps / (ms_per_step * 1e-3), 4),
-                "whole_forward_executed_gflop_per_frame": round(sum(mfma_flops) / args.steps / per / 1e9, 3),
+                # whole forward: time the issued FLOPs of every MFMA launch of a step need at the dense peak of THEIR pipe
+                # (fp16 matrix core for the split-operand kernels incl. the front / tail / 1x1 stride-2 kernels, fp32 MFMA
+                # for the rest) / the timed step -- a fraction, <= 1
+                "whole_forward_frac": round(psec / args.steps / (ms_per_step * 1e-3), 4),
+                "whole_forward_executed_gflop_per_frame": round(sum(g["executed"] for g in mfma_groups) / args.steps / per / 1e9, 3),
                 "whole_forward_algorithmic_multiple_of_peak":
                     round(fps / world * gflop_frame / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
-                "mfma_kernels_eager_frac": round(pipe_seconds / sum(mfma_time), 4)}
-    if dom in SPLIT_KERNELS:
+                "mfma_kernels_eager_frac": round(psec / sum(g["seconds"] for g in mfma_groups), 4),
+                "per_kernel": per_kernel_table(groups, args.steps)}
+    if d["pipe"] == "fp16":
         roofline["pipe"] = ("fp16 MFMA (matrix core): every fp32 product is taken as three fp16 products over two-term "
                             "splits of both operands, fp32 accumulation (csrc/conv_split.hip); `achieved` counts the "
                             "fp16 MFMA FLOPs issued, 3x the fp32 products incl. the tile padding that is not skipped; "
@@ -451,11 +590,14 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                                "(the timed graph may run the batch as concurrent sub-batch branches; "
                                "`rocprofv3 --stats -- bench.py --branches 1` shows the same launches)")
     roofline["traffic"], roofline["pmc"] = lookup_traffic(dom, dlaunch, per)
-    s2d = groups.get("s2d")
-    if s2d:
-        gbs = s2d[0] / s2d[1] / 1e9
-        roofline["s2d_hbm"] = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_us": round(s2d[1] / s2d[2] * 1e6, 2)}
+    # the two north-star kernels that are bounded by bytes: S2D and the KB layer's fused front (HBM GB/s against 8 TB/s)
+    for key, names in (("s2d_hbm", ("s2d",)), ("kb_front_hbm", ("kb1_front", "kb1_depth_front", "s2d_depth_front"))):
+        hit = [groups[nm] for nm in names if nm in groups and groups[nm]["has_bytes"]]
+        if hit:
+            nb, sec, ln = sum(g["nbytes"] for g in hit), sum(g["seconds"] for g in hit), sum(g["launches"] for g in hit)
+            roofline[key] = {"achieved": round(nb / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(nb / sec / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": round(sec / ln * 1e6, 2),
+                             "kernels": [nm for nm in names if nm in groups]}
 
     result = base_result(fps, world, args.steps, args.warmup, ms_per_step)
     result.update({
@@ -471,6 +613,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    "frames_per_gpu": per, "global_batch": per * world, "height": HEIGHT, "width": WIDTH,
                    "gflop_per_frame": round(gflop_frame, 3),
                    "parallelism": f"frames sharded over {world} rank(s), RCCL all-gather of outputs",
+                   "n_ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   "rccl_version": rccl_version(),
                    "launch": "eager" if args.eager else
                              f"HIP graph replay, {getattr(forward, 'branches', 1)} concurrent sub-batch branch(es)",
                    "eager_ms_per_step_with_event_timing": round(eager_ms, 4),
@@ -489,7 +633,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     })
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, ref = cpu_baseline(cfg, sds, [f[0:1].cpu() for f in frames])
+        base, ref = cpu_baseline(cfg, sds, [f[0:1].cpu() for f in frames], [f[:SIDE_BATCH].cpu() for f in frames])
         result["cpu_baseline"] = base
         got = out[0:1].cpu()  # frame 0 of rank 0
         result["parity"] = {"max_rel_err_vs_oracle": float(((got - ref).abs() / ref.abs()).max()),

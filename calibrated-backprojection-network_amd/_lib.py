@@ -54,6 +54,7 @@ SIGNATURES = {
     "kbn_version": (_I, []),
     "kbn_status_string": (C.c_char_p, [_I]),
     "kbn_reload_env": (None, []),
+    "kbn_knob": (_I, [C.c_char_p]),
     "kbn_set_autotune": (_I, [_I]),
     "kbn_get_autotune": (_I, []),
     "kbn_s2d_forward": (_I, [_P, C.POINTER(_P), _P, _P, _I, _I, _I, _I, C.POINTER(_I), _I,
@@ -74,6 +75,8 @@ SIGNATURES = {
                                   _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "kbn_kb1_front_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_kb1_front_pack_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "kbn_kb1_front_query": (_I, [_I, _I, _I, _I, _I, _F]),
+    "kbn_kb1_depth_front_query": (_I, [_I, _I, _I, _I, _I, _F]),
     "kbn_kb1_front_forward": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "kbn_kb1_depth_front_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_kb1_depth_front_pack_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -1,6 +1,7 @@
 // abi.hip -- version / status entry points of the C ABI (include/kbnet_hip.h), the debug-knob table
 // (environment read once at load) and small per-device caches shared by the launch code.
 #include <stdlib.h>
+#include <string.h>
 
 #include "kbn_common.h"
 
@@ -12,7 +13,8 @@ static const char* const kKnobNames[KNOB_COUNT] = {
     "KBN_DEBUG", "KBN_FORCE_MW", "KBN_FORCE_TWB", "KBN_FORCE_CK", "KBN_EPI_LDS", "KBN_NO_WINO", "KBN_NO_DMA",
     "KBN_NO_UP2X_DMA", "KBN_NO_UP2X9", "KBN_NO_UP2X3", "KBN_UP_MW", "KBN_WINO_RT", "KBN_WINO_GRID", "KBN_NO_HEAD_DMA",
     "KBN_NO_KB_PAIR", "KBN_NO_KB_DEPTH_FUSION", "KBN_PAIR_CAND", "KBN_S2D_DEBUG", "KBN_AUTOTUNE",
-    "KBN_NO_HEAD_FUSION", "KBN_NO_SPLIT"};
+    "KBN_NO_HEAD_FUSION", "KBN_NO_SPLIT", "KBN_NO_OVERLAP", "KBN_NO_PAIR", "KBN_NO_PAIR_MID", "KBN_NO_PAIR_ENC",
+    "KBN_NO_PAIR_TAIL", "KBN_NO_DEPTH_FRONT_FUSION", "KBN_NO_TAIL_FUSION", "KBN_FP16_ONE_TERM"};
 
 void tune_reload_env();   // tune.hip
 
@@ -57,6 +59,13 @@ const char* kbn_status_string(int status) {
         case KBN_ERR_LAUNCH: return "HIP launch error";
         default: return "unknown status";
     }
+}
+
+int kbn_knob(const char* name) {
+    if (!name) return 0;
+    for (int k = 0; k < kbn::KNOB_COUNT; ++k)
+        if (!strcmp(name, kbn::kKnobNames[k])) return kbn::g_knobs[k].value;
+    return 0;
 }
 
 void kbn_reload_env(void) {

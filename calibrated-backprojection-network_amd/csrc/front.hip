@@ -801,6 +801,15 @@ int kbn_kb1_front_pack_weight(const float* w_conv0, const float* w_conv_image, c
     return KBN_OK;
 }
 
+int kbn_kb1_front_query(int image_channels, int conv0_filters, int kb_filters, int height, int width, float conv0_negative_slope) {
+    using namespace kbn;
+    if (height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if (!front_shape_ok(image_channels, conv0_filters, kb_filters) || knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
+    if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
+    if (!(conv0_negative_slope >= 0.f && conv0_negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;   // LeakyReLU as max(t, slope t)
+    return KBN_OK;
+}
+
 int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const void* packed_weight,
                           const float* xyz, long long xyz_batch_stride, float* out_image, long long out_image_batch_stride,
                           float* out_fused, long long out_fused_batch_stride, int n, int image_channels, int conv0_filters,
@@ -809,8 +818,7 @@ int kbn_kb1_front_forward(const float* image, long long image_batch_stride, cons
     using namespace kbn;
     if (!image || !packed_weight || !out_image || !out_fused || n < 1 || height < 1 || width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
-    if (!front_shape_ok(image_channels, conv0_filters, kb_filters) || knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
-    if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
+    if (int rc = kbn_kb1_front_query(image_channels, conv0_filters, kb_filters, height, width, conv0_negative_slope)) return rc;
     FrontParams p{};
     p.image = image; p.image_bstride = image_batch_stride;
     p.tab = static_cast<const float*>(packed_weight);
@@ -827,7 +835,6 @@ int kbn_kb1_front_forward(const float* image, long long image_batch_stride, cons
     if (tiles > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
     p.ntiles = (int)tiles;
     p.slope0 = conv0_negative_slope; p.slope1 = kb_negative_slope;
-    if (!(conv0_negative_slope >= 0.f && conv0_negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;   // LeakyReLU as max(t, slope t)
     p.vec4 = !((p.w & 3) || (reinterpret_cast<uintptr_t>(out_image) & 15) || (reinterpret_cast<uintptr_t>(out_fused) & 15) ||
                (out_image_batch_stride & 3) || (out_fused_batch_stride & 3) || (reinterpret_cast<uintptr_t>(xyz) & 15) ||
                (xyz_batch_stride & 3)) ? 1 : 0;
@@ -863,6 +870,15 @@ int kbn_kb1_depth_front_pack_weight(const float* w_conv0, const float* w_conv_de
     return KBN_OK;
 }
 
+int kbn_kb1_depth_front_query(int depth_channels, int conv0_filters, int kb_filters, int height, int width, float conv0_negative_slope) {
+    using namespace kbn;
+    if (height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if (!depth_front_shape_ok(depth_channels, conv0_filters, kb_filters) || knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
+    if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
+    if (!(conv0_negative_slope >= 0.f && conv0_negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;
+    return KBN_OK;
+}
+
 int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride, const float* kinv, const void* packed_weight,
                                 float* out_depth, long long out_depth_batch_stride, float* xyz, long long xyz_batch_stride, int n,
                                 int depth_channels, int conv0_filters, int kb_filters, int height, int width,
@@ -870,9 +886,7 @@ int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride
                                 unsigned* out_depth_absmax, kbn_stream_t stream) {
     using namespace kbn;
     if (!depth || !kinv || !packed_weight || !out_depth || !xyz || n < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
-    if (!depth_front_shape_ok(depth_channels, conv0_filters, kb_filters) || knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
-    if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
-    if (!(conv0_negative_slope >= 0.f && conv0_negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;
+    if (int rc = kbn_kb1_depth_front_query(depth_channels, conv0_filters, kb_filters, height, width, conv0_negative_slope)) return rc;
     DepthFrontParams p{};
     p.depth = depth; p.depth_bstride = depth_batch_stride; p.kinv = kinv;
     p.tab = static_cast<const float*>(packed_weight);

@@ -71,7 +71,10 @@ enum Knob {
     KNOB_DEBUG, KNOB_FORCE_MW, KNOB_FORCE_TWB, KNOB_FORCE_CK, KNOB_EPI_LDS, KNOB_NO_WINO, KNOB_NO_DMA,
     KNOB_NO_UP2X_DMA, KNOB_NO_UP2X9, KNOB_NO_UP2X3, KNOB_UP_MW, KNOB_WINO_RT, KNOB_WINO_GRID, KNOB_NO_HEAD_DMA,
     KNOB_NO_KB_PAIR, KNOB_NO_KB_DEPTH_FUSION, KNOB_PAIR_CAND, KNOB_S2D_DEBUG, KNOB_AUTOTUNE,
-    KNOB_NO_HEAD_FUSION, KNOB_NO_SPLIT, KNOB_COUNT
+    KNOB_NO_HEAD_FUSION, KNOB_NO_SPLIT,
+    // switches of the host mirror (modules.py asks kbn_knob(): one reading of the environment for both sides)
+    KNOB_NO_OVERLAP, KNOB_NO_PAIR, KNOB_NO_PAIR_MID, KNOB_NO_PAIR_ENC, KNOB_NO_PAIR_TAIL, KNOB_NO_DEPTH_FRONT_FUSION,
+    KNOB_NO_TAIL_FUSION, KNOB_FP16_ONE_TERM, KNOB_COUNT
 };
 struct KnobValue { int set, value; };
 extern KnobValue g_knobs[KNOB_COUNT];

@@ -321,6 +321,7 @@ static int conv_tail_launch(const float* x, long long x_batch_stride, const void
         return KBN_ERR_INVALID_ARGUMENT;
     if (channels > 12 || knob(KNOB_NO_SPLIT) || knob(KNOB_NO_HEAD_FUSION)) return KBN_ERR_UNSUPPORTED;   // LDS: 12 feature planes beside the input tile
     if ((long long)height * width > 0x1fffffffLL) return KBN_ERR_UNSUPPORTED;
+    if (x_pair && (long long)height * width >= 0x0fffffffLL) return KBN_ERR_UNSUPPORTED;   // 32-bit DMA offsets of 16-byte granules (as kbn_conv3x3_split_forward)
     if (apply_activation && !(negative_slope >= 0.f && negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;   // max(v, slope v) form
     TailParams p{};
     p.x = x; p.x_bstride = x_batch_stride;

@@ -21,6 +21,7 @@
 // that does not exist.
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/file.h>
 
 #include <map>
 #include <mutex>
@@ -36,7 +37,7 @@ static std::map<DevKey, int> g_cache;
 static std::mutex g_mutex;
 static std::string g_path;
 static std::atomic<int> g_autotune{0};
-constexpr int kTuneTables = 3;   // candidate tables of round 3 (ABI 2)
+constexpr int kTuneTables = 3;   // candidate tables of round 3 (KBN_ABI_VERSION is checked beside it)
 static const char kHeaderFmt[] = "kbn-tune-cache abi %d tables %d\n";
 
 static void load_file_locked() {   // g_mutex held
@@ -62,9 +63,14 @@ static void append_file_locked(const TuneKey& k, int cand) {
     if (g_path.empty()) return;
     FILE* f = fopen(g_path.c_str(), "a");
     if (!f) return;
+    // several ranks of one job may share the file (bench.py --gpus N: one process per GPU): the "new file -> header"
+    // test and the entry go out under an exclusive lock, as ONE write each (the stream is flushed before the unlock)
+    const bool locked = flock(fileno(f), LOCK_EX) == 0;
     fseek(f, 0, SEEK_END);
     if (ftell(f) == 0) fprintf(f, kHeaderFmt, KBN_ABI_VERSION, kTuneTables);   // new file
     fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], cand);
+    fflush(f);
+    if (locked) (void)flock(fileno(f), LOCK_UN);
     fclose(f);
 }
 

@@ -301,12 +301,13 @@ class _SideBranch:
     current stream); what is allocated inside must also die inside.  KBN_NO_OVERLAP=1 keeps everything on one stream."""
 
     _streams = {}
-    enabled = os.environ.get("KBN_NO_OVERLAP", "0") in ("", "0")
+    enabled = None        # None: follow KBN_NO_OVERLAP as the library read it (ops.knob; ops.reload_env() refreshes); True / False force
     only_from = None      # raw handle of the one stream that may fork (set while a multi-branch graph is captured), or None
 
     def __init__(self, device):
         # under capture only: eagerly the extra events cost more host time than the overlap returns (batch 1: 1.59 -> 1.68 ms)
-        self.on = bool(_SideBranch.enabled and device.type == "cuda" and torch.cuda.is_current_stream_capturing())
+        self.on = bool(device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+                       and (_SideBranch.enabled if _SideBranch.enabled is not None else ops.knob("KBN_NO_OVERLAP") == 0))
         if self.on:
             self.cur = torch.cuda.current_stream(device)
             if _SideBranch.only_from is not None and self.cur.cuda_stream != _SideBranch.only_from:
@@ -330,6 +331,27 @@ class _SideBranch:
             self._ctx.__exit__(*exc)
             self.cur.wait_stream(self.side)
         return False
+
+
+class _KnobSwitch:
+    """A boolean A/B switch of the host mirror that is ON unless its KBN_NO_* variable is set -- as the LIBRARY read the
+    environment (ops.knob: at load time and on ops.reload_env(), like the C side's own switches) -- or unless the attribute
+    was assigned on the instance (tests, tools)."""
+
+    def __init__(self, *names):
+        self.names = names
+
+    def __set_name__(self, owner, name):
+        self.attr = "_force_" + name
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        forced = obj.__dict__.get(self.attr)
+        return forced if forced is not None else all(ops.knob(n) == 0 for n in self.names)
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.attr] = None if value is None else bool(value)
 
 
 def _dense(t):
@@ -539,6 +561,8 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
 
 
 class DecoderBlock(torch.nn.Module):
+    pair_mid = _KnobSwitch("KBN_NO_PAIR_MID")   # A/B switch: the up-conv -> concat-conv tensor as a PairTensor
+
     def __init__(self, in_channels, skip_channels, out_channels, weight_initializer="kaiming_uniform",
                  activation_func=torch.nn.LeakyReLU(negative_slope=0.10, inplace=True),
                  use_batch_norm=False, use_instance_norm=False, deconv_type="up",
@@ -548,7 +572,6 @@ class DecoderBlock(torch.nn.Module):
             raise ValueError("only deconv_type='up' (KBNet's setting) is implemented")
         self.skip_channels = skip_channels
         self.deconv_type = deconv_type
-        self.pair_mid = os.environ.get("KBN_NO_PAIR_MID", "0") in ("", "0")   # A/B switch: the up-conv -> concat-conv tensor as a PairTensor
         self.deconv = UpConv2d(in_channels, out_channels, 3, weight_initializer, activation_func,
                                use_batch_norm, use_instance_norm)
         self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer,
@@ -625,6 +648,9 @@ class KBNetEncoder(torch.nn.Module):
     block's conv_fused / conv_depth land in the two channel slices of one buffer, which
     is both the skip connection and the next block's `fused` / `depth` inputs."""
 
+    # conv_image of KB levels 1 and 2 as ops.PairTensor for the next level's split convs (KBN_NO_PAIR=1 / KBN_NO_PAIR_ENC=1: fp32 tensors)
+    pair_chain = _KnobSwitch("KBN_NO_PAIR", "KBN_NO_PAIR_ENC")
+
     def __init__(self, input_channels_image=3, input_channels_depth=1,
                  n_filters_image=[48, 96, 192, 384, 384], n_filters_depth=[16, 32, 64, 128, 128],
                  n_filters_fused=[48, 96, 192, 384, 384], n_convolutions_image=[1, 1, 1, 1, 1],
@@ -667,8 +693,6 @@ class KBNetEncoder(torch.nn.Module):
         self.front = True
         # OFF by default (the reference computes it): do not launch conv_image of KB level 3, whose output nothing reads
         self.skip_unused_image = False
-        # conv_image of KB levels 1 and 2 as ops.PairTensor for the next level's split convs (KBN_NO_PAIR=1: fp32 tensors)
-        self.pair_chain = os.environ.get("KBN_NO_PAIR", "0") in ("", "0") and os.environ.get("KBN_NO_PAIR_ENC", "0") in ("", "0")
         self._packed_front = _PackedFront()
         self._packed_depth_front = _PackedFront(ops.pack_kb1_depth_front_weight)
 
@@ -682,11 +706,15 @@ class KBNetEncoder(torch.nn.Module):
         if (not self.front or not c0.split or not ci.split or ci.bf16 or c0._slope is None or blk.proj_depth._slope is None
                 or cf.in_channels != c0.out_channels + 3 or not _dense(image)):
             return None
+        n, _, h, w = image.shape
+        # decided BEFORE anything is launched: a late decline (KBN_NO_SPLIT=1, a slope outside [0, 1], an oversized map) would
+        # leave the depth branch's launches below to be repeated by the caller's three-launch path
+        if not ops.kb1_front_supported(image.shape[1], c0.out_channels, ci.out_channels, h, w, c0._slope):
+            return None
         packed = self._packed_front.get(c0.conv.weight, ci.conv.weight, cf.conv.weight)
         if packed is None:
             return None
         fi, fd, ff = self._f
-        n, _, h, w = image.shape
         oh, ow = (h + 1) // 2, (w + 1) // 2
         dev = image.device
         skip = torch.empty((n, ff[0] + fd[0], oh, ow), device=dev, dtype=torch.float32)
@@ -697,7 +725,9 @@ class KBNetEncoder(torch.nn.Module):
         c0d = self.conv0_depth
         xyz = None
         packed_d = (self._packed_depth_front.get(c0d.conv.weight, cd.conv.weight, blk.proj_depth.conv.weight)
-                    if (c0d.split and cd.split and c0d._slope is not None and _dense(depth)) else None)
+                    if (c0d.split and cd.split and c0d._slope is not None and _dense(depth)
+                        and ops.kb1_front_supported(depth.shape[1], c0d.out_channels, cd.out_channels, h, w, c0d._slope, depth_branch=True))
+                    else None)
         if packed_d is not None:
             res = ops.kb1_depth_front(depth, kinv, packed_d, c0d.out_channels, cd.out_channels, out_depth, c0d._slope, blk._slope,
                                       blk.proj_depth._slope, out_depth_absmax=a_skip)
@@ -708,7 +738,7 @@ class KBNetEncoder(torch.nn.Module):
             cd.run([ops.tensor_src(conv_depth0, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth, out_absmax=a_skip)
         if ops.kb1_front(image, packed, xyz, c0.out_channels, ci.out_channels, out_image, out_fused,
                          c0._slope, blk._slope, a_img, a_skip) is None:
-            return None
+            raise KbnError("kb1_front declined a problem kbn_kb1_front_query accepted")
         return skip, out_image, out_depth, out_fused, a_img, a_skip
 
     def set_bf16(self, enabled: bool = True):
@@ -820,6 +850,10 @@ class MultiScaleDecoder(torch.nn.Module):
     """The decoder as KBNet builds it: five 'up' DecoderBlocks, n_resolution=1, linear
     output0.  `forward` returns `[logits]` like the reference (the caller takes [-1])."""
 
+    # deconv4 .. deconv1 hand their concat-conv outputs to the next up-conv as ops.PairTensor (KBN_NO_PAIR=1: fp32 tensors)
+    pair_chain = _KnobSwitch("KBN_NO_PAIR")
+    pair_tail = _KnobSwitch("KBN_NO_PAIR_TAIL")   # A/B: deconv0's up-conv -> tail tensor as a PairTensor
+
     def __init__(self, input_channels=256, output_channels=1, n_resolution=1,
                  n_filters=[256, 128, 64, 32, 16], n_skips=[256, 128, 64, 32, 0],
                  weight_initializer="kaiming_uniform", activation_func="leaky_relu",
@@ -839,9 +873,6 @@ class MultiScaleDecoder(torch.nn.Module):
             cin = n_filters[i]
         self.output0 = Conv2d(n_filters[4], output_channels, 3, 1, weight_initializer, None)
         self._packed_tail = _PackedTail()
-        # deconv4 .. deconv1 hand their concat-conv outputs to the next up-conv as ops.PairTensor (KBN_NO_PAIR=1: fp32 tensors)
-        self.pair_chain = os.environ.get("KBN_NO_PAIR", "0") in ("", "0")
-        self.pair_tail = os.environ.get("KBN_NO_PAIR_TAIL", "0") in ("", "0")   # A/B: deconv0's up-conv -> tail tensor as a PairTensor
 
     def set_bf16(self, enabled: bool = True):
         """THROUGHPUT-ONLY switch (BASELINE configs[2]'s bf16 figure): the decoder's 3x3 stride-1 convs with at least 16
@@ -871,12 +902,16 @@ class MultiScaleDecoder(torch.nn.Module):
             # the concat conv's output is read by the next block's up-conv only: as a PairTensor when that kernel takes one
             y = None
             # (not with KBN_NO_SPLIT=1: every split-operand launch would decline, after the block's up-conv had already run in fp32)
-            if self.pair_chain and (allow_pair or i > 0) and os.environ.get("KBN_NO_SPLIT", "0") in ("", "0"):
+            if self.pair_chain and (allow_pair or i > 0) and ops.split_enabled():
                 y = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats, pair_out=True)
-            if y is None:
-                if isinstance(x, ops.PairTensor):
+            if y is None and isinstance(x, ops.PairTensor):
+                # a pair tensor in, an fp32 tensor out (the block's up-conv stages the pair source by DMA, mode "pair in /
+                # fp32 out"): the last block of features() / forward(), where the caller wants fp32
+                y = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats)
+                if y is None:
                     x = x.float()   # a shape the pair kernels declined after one of them produced x: rare, not fast
                     amax = None
+            if y is None:
                 y = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats)
             x = y
             amax = a_out

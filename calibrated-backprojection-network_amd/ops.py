@@ -42,8 +42,19 @@ def _on_tensor_device(fn):
 
 
 def reload_env():
-    """Re-reads the KBN_* switches from the environment (the library reads them once at load time)."""
+    """Re-reads the KBN_* switches from the environment (the library reads them once at load time).  The host mirror's
+    own A/B switches (KBN_NO_PAIR*, KBN_NO_OVERLAP, ...) are answered by the library too (`knob`), so they follow."""
     _lib.load().kbn_reload_env()
+
+
+def knob(name: str) -> int:
+    """Value of a KBN_* switch as the library read it (kbn_knob): 0 when unset."""
+    return int(_lib.load().kbn_knob(name.encode()))
+
+
+def split_enabled() -> bool:
+    """False under KBN_NO_SPLIT=1: every split-operand entry point declines (A/B against the all-fp32-MFMA path)."""
+    return knob("KBN_NO_SPLIT") == 0
 
 
 @contextlib.contextmanager
@@ -60,23 +71,37 @@ def autotune(enabled: bool = True):
 
 
 # Optional per-launch timing (bench.py): when PROFILE is a list, every ABI call is
-# bracketed by HIP events recorded on the launch stream and (name, work, executed, start, end)
-# is appended.  `work` is the launch's ALGORITHMIC FLOPs (convs: the reference's direct
-# formulation) or bytes (S2D, head); `executed` the FLOPs the launch really issues on the matrix
-# cores (Winograd / phase-decomposed up-convs execute fewer; tile and channel padding execute more),
-# None for byte-bound launches.
+# bracketed by HIP events recorded on the launch stream and
+# (name, work, executed, pipe, nbytes, start, end) is appended.  `work` is the launch's ALGORITHMIC FLOPs
+# (convs: the reference's direct formulation) or bytes (S2D, head); `executed` the FLOPs the launch really
+# issues on the matrix cores (Winograd / phase-decomposed up-convs execute fewer; tile and channel padding
+# execute more), None for byte-bound launches; `pipe` names the pipe those MFMAs run on -- "fp32"
+# (v_mfma_f32_*_f32: the vector datapath's 157.3 TFLOP/s), "fp16" (split-operand kernels: three fp16 MFMAs per fp32
+# product on the 2.5 PFLOP/s matrix core), "bf16" (the throughput-only leg) -- so that whoever prices `executed`
+# uses the right peak; `nbytes` the launch's ALGORITHMIC HBM bytes (every input read once + every output written once).
 PROFILE = None
+PIPE_PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0, "bf16": 2500.0}    # MI355X_MICROARCH.md, dense
+PIPE_PRODUCTS = {"fp32": 1.0, "fp16": 3.0, "bf16": 1.0}              # MFMA products issued per product of the reference
 
 
-def _launch(name: str, work: float, fn, executed=None):
+def _launch(name: str, work: float, fn, executed=None, pipe: Optional[str] = None, nbytes: Optional[float] = None):
     if PROFILE is None:
         return fn()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     status = fn()
     end.record()
-    PROFILE.append((name, work, executed() if callable(executed) else executed, start, end))
+    PROFILE.append((name, work, executed() if callable(executed) else executed, pipe, nbytes, start, end))
     return status
+
+
+def _src_bytes(srcs, n: int) -> float:
+    """fp32-equivalent bytes the tensor / pair sources of a conv hold (4 B per value in both formats)."""
+    total = 0
+    for s in srcs:
+        if s.kind in (_lib.KBN_SRC_TENSOR, _lib.KBN_SRC_PAIR):
+            total += s.channels * s.src_height * s.src_width
+    return 4.0 * n * total
 
 
 def conv_executed_flops(n, out_channels, in_channels, kernel_size, stride, in_height, in_width, resize=False):
@@ -186,7 +211,8 @@ def absmax_frames(t: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
     ptr, bs = _planes(t, "t")
     n, c, h, w = t.shape
     check(_launch("absmax", 4.0 * n * c * h * w,
-                  lambda: _lib.load().kbn_absmax_frames(ptr, bs, n, c * h * w, _slot_ptr(slot, n), _stream())), "kbn_absmax_frames")
+                  lambda: _lib.load().kbn_absmax_frames(ptr, bs, n, c * h * w, _slot_ptr(slot, n), _stream()),
+                  nbytes=4.0 * n * c * h * w), "kbn_absmax_frames")
     return slot
 
 
@@ -222,7 +248,10 @@ def s2d_forward(x, w_pool_convs: List[torch.Tensor], w_conv, min_pool_sizes, max
     check(_launch("s2d", 4.0 * n * h * w * (cin + nf),
                   lambda: lib.kbn_s2d_forward(x.data_ptr(), wptrs, wc.data_ptr(), out.data_ptr(), n, h, w, cin,
                                               amin, len(mins), amax, len(maxs), len(ws), nf,
-                                              float(negative_slope), _stream())), "kbn_s2d_forward")
+                                              float(negative_slope), _stream()),
+                  # both convs on v_mfma_f32_4x4x1 (the fp32 datapath): 2 x (pools x nf + (convs - 1) x nf^2 + 9 (nf + cin) nf) per pixel
+                  executed=2.0 * n * h * w * (ws[0].shape[1] * nf + (len(ws) - 1) * nf * nf + 9 * (nf + cin) * nf),
+                  pipe="fp32", nbytes=4.0 * n * h * w * (cin + nf)), "kbn_s2d_forward")
     return out
 
 
@@ -312,9 +341,13 @@ class PairTensor:
     kernels alone read are kept this way: the decoder's concat-conv outputs (conv3x3_split(out=PairTensor), read by the
     next up-conv through pair_src).  Same bytes as fp32; the consumers stage it by LDS-DMA instead of splitting it."""
 
+    LOG = None   # diagnostics (tests/analysis): when a list hangs here, every PairTensor of a forward is appended
+
     def __init__(self, n: int, channels: int, height: int, width: int, device, stats: "ActStats"):
         if channels % 8:
             raise KbnError("PairTensor: channels must be a multiple of 8")
+        if PairTensor.LOG is not None:
+            PairTensor.LOG.append(self)
         self.shape = (n, channels, height, width)
         self.data = torch.empty((n, channels // 8, 2, height * width + 1, 8), device=device, dtype=torch.float16)
         self.scale = torch.empty(n, device=device, dtype=torch.float32)
@@ -331,6 +364,13 @@ class PairTensor:
         n, c, h, w = self.shape
         self.sub = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), device=self.data.device, dtype=torch.float32)
         return self
+
+    def window_slack_log2(self) -> torch.Tensor:
+        """Per frame: binades between the top of the fp16 window the producer chose from its BOUND (2^15 / scale) and the true
+        max |a| it then measured (the absmax slot).  The two terms keep 22 bits down to 2^-29 of the window, so a slack
+        below ~16 costs nothing (tests/test_split_math_cpu.py); diagnostics only (synchronises)."""
+        amax = slot_values(self.absmax).double().clamp_min(1e-300)
+        return 15.0 - torch.log2(amax * self.scale.double())
 
     def float(self) -> torch.Tensor:
         """The tensor as N x C x H x W fp32 (tests, diagnostics)."""
@@ -410,7 +450,10 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
                                                  0.0 if negative_slope is None else float(negative_slope),
                                                  _slot_ptr(out_absmax, n), _stream()),
                   executed=lambda: conv_executed_flops(n, out_channels, cin, kernel_size, stride, in_height, in_width,
-                                                       resize)), "kbn_conv2d_forward")
+                                                       resize),
+                  pipe="fp32",
+                  nbytes=_src_bytes(srcs, n) + 4.0 * n * (oh * ow * out_channels + sum(
+                      s.aux_channels * in_height * in_width for s in srcs if s.kind == _lib.KBN_SRC_XYZ))), "kbn_conv2d_forward")
     return out
 
 
@@ -447,7 +490,8 @@ def upconv2x(x: torch.Tensor, packed_weight: torch.Tensor, out_channels: int, ou
                                                    out_channels, h, w, 0 if negative_slope is None else 1,
                                                    0.0 if negative_slope is None else float(negative_slope),
                                                    _slot_ptr(out_absmax, n), _stream()),
-                  executed=lambda: upconv2x_executed_flops(n, cin, out_channels, h, w)), "kbn_upconv2x_forward")
+                  executed=lambda: upconv2x_executed_flops(n, cin, out_channels, h, w), pipe="fp32",
+                  nbytes=4.0 * n * h * w * (cin + 4 * out_channels)), "kbn_upconv2x_forward")
     return out
 
 
@@ -498,7 +542,8 @@ def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_de
                                                    of, ofbs, n, h, w, ci, cd, cf, filters_image, filters_depth,
                                                    filters_fused, float(negative_slope), _slot_ptr(absmax_image, n),
                                                    _slot_ptr(absmax_depth, n), _slot_ptr(absmax_fused, n), _stream()),
-                  executed=flops),   # direct convs: executed = algorithmic (tile padding not counted)
+                  executed=flops,   # direct convs: executed = algorithmic (tile padding not counted)
+                  pipe="fp32", nbytes=4.0 * n * (h * w * (ci + cd + cf) + oh * ow * (filters_image + filters_depth + filters_fused))),
           "kbn_kb_block_forward")
     return out_image, out_depth, out_fused
 
@@ -527,7 +572,7 @@ def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, re
                   lambda: lib.kbn_depth_head_forward(x.data_ptr(), w.data_ptr(), depth.data_ptr(),
                                                      logits.data_ptr() if return_logits else None, n, c, h, wd,
                                                      float(min_predict_depth), float(max_predict_depth),
-                                                     _stream())), "kbn_depth_head_forward")
+                                                     _stream()), nbytes=4.0 * n * h * wd * (c + 1)), "kbn_depth_head_forward")
     return (depth, logits) if return_logits else depth
 
 
@@ -561,7 +606,8 @@ def conv_head(x, w_conv, w_out, min_predict_depth: float, max_predict_depth: flo
                                                        0.0 if negative_slope is None else float(negative_slope),
                                                        float(min_predict_depth), float(max_predict_depth), _stream()),
                      # 75 m-blocks of 16 positions per 64 x 16 tile, 16 filter columns, K = 9 c
-                     executed=2.0 * n * (-(-h // 16)) * (-(-wd // 64)) * 75 * 16 * 16 * 9 * c)
+                     executed=2.0 * n * (-(-h // 16)) * (-(-wd // 64)) * 75 * 16 * 16 * 9 * c, pipe="fp32",
+                     nbytes=4.0 * n * h * wd * (c + 1))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()
@@ -624,7 +670,8 @@ def conv_tail(x, packed_w_conv, w_out, min_predict_depth: float, max_predict_dep
     status = _launch("conv_tail", flops,
                      (lambda: lib.kbn_conv_tail_forward_pair(x.data.data_ptr(), x.data.stride(0), x.scale.data_ptr(), *tail_args, _stream()))
                      if pair else (lambda: lib.kbn_conv_tail_forward(xptr, xbs, *tail_args, _stream())),
-                     executed=tiles * 39 * 15 * 2.0 * 16 * 16 * 32)   # 39 pixel blocks x 15 MFMAs of 16 x 16 x 32 per tile
+                     executed=tiles * 39 * 15 * 2.0 * 16 * 16 * 32,   # 39 pixel blocks x 15 MFMAs of 16 x 16 x 32 per tile
+                     pipe="fp16", nbytes=4.0 * n * h * wd * ((16 if pair else c) + 1))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()
@@ -728,7 +775,9 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
                                                            out.data.data_ptr() if pair else None,
                                                            out.data.stride(0) if pair else 0,
                                                            out.scale.data_ptr() if pair else None, _stream()),
-                     executed=conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride, up2x and folded_up2x))
+                     executed=conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride, up2x and folded_up2x),
+                     pipe="fp16", nbytes=_src_bytes(srcs, n) + 4.0 * n * height * width * want[1]
+                     + (4.0 * n * out_channels * out.sub.shape[2] * out.sub.shape[3] if (pair and out.sub is not None and stride == 2) else 0.0))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()
@@ -776,7 +825,7 @@ def kb_xyz_s2(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: torch.Tensor
                   lambda: lib.kbn_kb_xyz_s2_forward(dptr, dbs, cd, h, w, pw.data_ptr(), kinv.data_ptr(),
                                                     0 if negative_slope is None else 1,
                                                     0.0 if negative_slope is None else float(negative_slope),
-                                                    optr, obs, n, _stream())), "kbn_kb_xyz_s2_forward")
+                                                    optr, obs, n, _stream()), nbytes=4.0 * n * oh * ow * (cd + 3)), "kbn_kb_xyz_s2_forward")
     return out
 
 
@@ -805,7 +854,9 @@ def conv1x1s2_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, xyz: Optio
                                                              out_channels, height, width, max(-60, min(60, int(act_exponent))),
                                                              0 if negative_slope is None else 1,
                                                              0.0 if negative_slope is None else float(negative_slope),
-                                                             _slot_ptr(out_absmax, n), _stream()), executed=executed)
+                                                             _slot_ptr(out_absmax, n), _stream()), executed=executed, pipe="fp16",
+                     # a 1x1 stride-2 conv needs the even pixels of its sources only
+                     nbytes=4.0 * n * height * width * (cin + (3 if xyz is not None else 0) + out_channels))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()
@@ -838,6 +889,14 @@ def pack_kb1_front_weight(w_conv0: torch.Tensor, w_conv_image: torch.Tensor, w_c
     return packed
 
 
+def kb1_front_supported(image_channels: int, conv0_filters: int, kb_filters: int, height: int, width: int,
+                        conv0_negative_slope: float, depth_branch: bool = False) -> bool:
+    """Would kb1_front (depth_branch: kb1_depth_front) take this problem?  (kbn_kb1_front_query / kbn_kb1_depth_front_query)"""
+    lib = _lib.load()
+    q = lib.kbn_kb1_depth_front_query if depth_branch else lib.kbn_kb1_front_query
+    return q(int(image_channels), int(conv0_filters), int(kb_filters), int(height), int(width), float(conv0_negative_slope)) == _lib.KBN_OK
+
+
 @_on_tensor_device
 def kb1_front(image: torch.Tensor, packed_weight: torch.Tensor, xyz: Optional[torch.Tensor],
               conv0_filters: int, kb_filters: int, out_image: torch.Tensor, out_fused: torch.Tensor,
@@ -867,7 +926,7 @@ def kb1_front(image: torch.Tensor, packed_weight: torch.Tensor, xyz: Optional[to
                                                        oi, oibs, of, ofbs, n, c, conv0_filters, kb_filters, h, w,
                                                        float(conv0_negative_slope), float(kb_negative_slope),
                                                        _slot_ptr(out_image_absmax, n), _slot_ptr(out_fused_absmax, n), _stream()),
-                     executed=executed)
+                     executed=executed, pipe="fp16", nbytes=4.0 * n * (h * w * c + oh * ow * (2 * kb_filters + (3 if xyz is not None else 0))))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()
@@ -926,7 +985,7 @@ def kb1_depth_front(depth: torch.Tensor, kinv: torch.Tensor, packed_weight: torc
                                                              float(kb_negative_slope), 0 if proj_negative_slope is None else 1,
                                                              0.0 if proj_negative_slope is None else float(proj_negative_slope),
                                                              _slot_ptr(out_depth_absmax, n), _stream()),
-                     executed=executed)
+                     executed=executed, pipe="fp16", nbytes=4.0 * n * (h * w * c + oh * ow * (kb_filters + 3)))
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()
@@ -972,7 +1031,10 @@ def conv3x3_bf16(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_c
                                                           out_channels, height, width, 1 if up2x else (2 if stride == 2 else 0),
                                                           0 if negative_slope is None else 1,
                                                           0.0 if negative_slope is None else float(negative_slope),
-                                                          _stream()))
+                                                          _stream()),
+                     # 16 x 32 pixels x 64 filters per workgroup (csrc/conv_bf16.hip): tile padding is issued
+                     executed=2.0 * n * (-(-height // 16) * 16) * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // 64) * 64),
+                     pipe="bf16", nbytes=_src_bytes(srcs, n) + 4.0 * n * height * width * out_channels)
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()

@@ -64,11 +64,38 @@ def _xavier_normal(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor
     return torch.from_numpy((std * g.standard_normal(shape)).astype(np.float32))
 
 
-def make_state_dicts(cfg: KBNetConfig, seed: int = 0, gain: float = 1.0):
+def _trained_like(name: str, shape: Tuple[int, ...], seed: int, spread_log2: float, dead_fraction: float) -> torch.Tensor:
+    """A weight tensor with the statistics trained conv nets show and xavier noise does not: heavy-tailed entries
+    (Student-t, 3 degrees of freedom), a per-filter scale drawn log-uniformly over 2^spread_log2 (a few filters dominate
+    a layer's output range, most sit binades below it), and `dead_fraction` of the filters exactly zero (dead channels:
+    all-zero activation planes downstream).  The layer keeps xavier's Frobenius norm, so the network's activations stay
+    O(1) and the sigmoid head off saturation.  Single-filter layers (proj_depth, output0) keep their filter alive."""
+    fan_in = shape[1] * shape[2] * shape[3]
+    fan_out = shape[0] * shape[2] * shape[3]
+    std = (2.0 / (fan_in + fan_out)) ** 0.5
+    g = _rng((seed << 32) ^ zlib.crc32(("trained/" + name).encode()))
+    w = g.standard_t(3.0, shape) / np.sqrt(3.0)
+    f = shape[0]
+    w *= np.exp2(spread_log2 * (g.random((f, 1, 1, 1)) - 0.5))
+    if f > 1:
+        dead = g.random(f) < dead_fraction
+        dead[int(g.integers(f))] = False            # never all of them
+        w[dead] = 0.0
+    w *= std * np.sqrt(w.size) / max(float(np.sqrt((w * w).sum())), 1e-30)
+    return torch.from_numpy(w.astype(np.float32))
+
+
+def make_state_dicts(cfg: KBNetConfig, seed: int = 0, gain: float = 1.0, trained_like: bool = False,
+                     spread_log2: float = 7.0, dead_fraction: float = 0.10):
     """Three dicts (S2D, encoder, decoder) keyed like the reference's state_dicts
-    (without the DataParallel `module.` prefix)."""
+    (without the DataParallel `module.` prefix).  `trained_like`: the stress statistics of `_trained_like` instead of
+    xavier noise (the pretrained checkpoints of reference README.md:205-217 are external files; this is the stand-in
+    that drives the fp16 windows of the split-operand kernels the way trained weights would)."""
     out = []
     for part, shapes in (("s2d", s2d_param_shapes(cfg)), ("enc", encoder_param_shapes(cfg)),
                          ("dec", decoder_param_shapes(cfg))):
-        out.append({k: gain * _xavier_normal(part + "/" + k, s, seed) for k, s in shapes.items()})
+        if trained_like:
+            out.append({k: gain * _trained_like(part + "/" + k, s, seed, spread_log2, dead_fraction) for k, s in shapes.items()})
+        else:
+            out.append({k: gain * _xavier_normal(part + "/" + k, s, seed) for k, s in shapes.items()})
     return tuple(out)

@@ -46,6 +46,12 @@ const char* kbn_status_string(int status);
  * (they are otherwise read once, when the library is loaded; no launch path calls getenv). */
 void kbn_reload_env(void);
 
+/* Value of a KBN_* switch AS THE LIBRARY READ IT (at load time / the last kbn_reload_env()): 0 when unset or unknown.  The
+ * host mirror asks here instead of reading the environment itself, so its A/B switches (KBN_NO_SPLIT, KBN_NO_PAIR,
+ * KBN_NO_PAIR_MID, KBN_NO_PAIR_ENC, KBN_NO_PAIR_TAIL, KBN_NO_OVERLAP, KBN_NO_DEPTH_FRONT_FUSION, KBN_NO_TAIL_FUSION,
+ * KBN_FP16_ONE_TERM) change together with the library's. */
+int kbn_knob(const char* name);
+
 /* First-use tuning of launch geometry (tile / region shapes; csrc/tune.hip).  OFF by default:
  * calls launch the analytic choice or a cached one.  While ON, the first call of a problem
  * shape on a device times every candidate geometry on `stream` and waits for its own events --
@@ -360,6 +366,9 @@ int kbn_kb_block_forward(const float* image, long long image_batch_stride, const
  * KBN_ERR_UNSUPPORTED unless conv0_filters == kb_filters == 48 (KBNet's level 0 in all three presets) -- the caller then
  * runs kbn_conv2d_forward + kbn_kb_block_forward. */
 size_t kbn_kb1_front_packed_weight_bytes(int image_channels, int conv0_filters, int kb_filters);
+/* KBN_OK when kbn_kb1_front_forward would take this problem, KBN_ERR_UNSUPPORTED otherwise (widths, map size, slope outside
+ * [0, 1], KBN_NO_SPLIT): lets a caller decide BEFORE it launches the depth branch whose xyz output the kernel consumes. */
+int kbn_kb1_front_query(int image_channels, int conv0_filters, int kb_filters, int height, int width, float conv0_negative_slope);
 int kbn_kb1_front_pack_weight(const float* w_conv0, const float* w_conv_image, const float* w_conv_fused, void* packed,
                               int image_channels, int conv0_filters, int kb_filters, kbn_stream_t stream);
 int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const void* packed_weight, const float* xyz, long long xyz_batch_stride, float* out_image,
@@ -381,6 +390,7 @@ int kbn_kb1_front_forward(const float* image, long long image_batch_stride, cons
  *   xyz             N x 3 x ceil(H/2) x ceil(W/2): what kbn_kb1_front_forward / kbn_conv1x1s2_split_forward take
  * KBN_ERR_UNSUPPORTED unless conv0_filters == kb_filters == 16. */
 size_t kbn_kb1_depth_front_packed_weight_bytes(int depth_channels, int conv0_filters, int kb_filters);
+int kbn_kb1_depth_front_query(int depth_channels, int conv0_filters, int kb_filters, int height, int width, float conv0_negative_slope);
 int kbn_kb1_depth_front_pack_weight(const float* w_conv0, const float* w_conv_depth, const float* w_proj, void* packed,
                                     int depth_channels, int conv0_filters, int kb_filters, kbn_stream_t stream);
 int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride, const float* kinv, const void* packed_weight,

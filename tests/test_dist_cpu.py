@@ -175,16 +175,92 @@ def test_bench_rank_logic_world2_gloo(tmp_path):
     assert firsts[0] != firsts[1], "ranks draw different frames (seed 1 + rank)"
 
 
-def test_bench_refuses_gpus_without_matching_world(monkeypatch):
+def _load_bench():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
-        monkeypatch.delenv(k, raising=False)
-    with pytest.raises(SystemExit, match="WORLD_SIZE=1"):
+    return bench
+
+
+def test_bench_refuses_gpus_that_contradict_world(monkeypatch):
+    """Inside a torchrun environment `--gpus N` must equal WORLD_SIZE (a rank never re-spawns)."""
+    bench = _load_bench()
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    with pytest.raises(SystemExit, match="WORLD_SIZE=3"):
         bench.main(["--gpus", "2"], backend="gloo", forward_factory=lambda *a: _fake_forward)
+
+
+def test_bench_plain_python_launch_spawns_its_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT torchrun's environment -- the form the driver uses --
+    must not die on WORLD_SIZE: it re-launches itself as 2 ranks (bench.self_spawn), rank 0 prints ONE JSON line with
+    n_gpus 2 and the exit code is the ranks'.  KBN_BENCH_TEST_BACKEND=gloo swaps the HIP forward for a stand-in on CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["KBN_BENCH_TEST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--frames-per-gpu", "4"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["n_ranks_seen"] == 2 and line["config"]["gathered_frames"] == 8
+    assert line["cpu_baseline"] is None
+    # failing ranks' exit code comes back (here: zero timed steps cannot be averaged)
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "0", "--warmup", "0",
+                          "--frames-per-gpu", "2"], env=env, capture_output=True, text=True, timeout=240)
+    assert bad.returncode != 0
+
+
+class _FakeEvent:
+    def __init__(self, t):
+        self.t = t
+
+    def elapsed_time(self, other):
+        return other.t - self.t   # ms
+
+
+def test_bench_roofline_fractions_never_exceed_one():
+    """every launch group is priced at the peak of the pipe ITS MFMAs run on (the record carries it),
+    so no fraction of the bench line can exceed 1 -- round 3 priced kb1_front / kb1_depth_front / conv_tail /
+    conv_split_1x1s2 (fp16 MFMAs) at the fp32 peak and reported whole_forward_frac 1.24."""
+    bench = _load_bench()
+    ev = lambda ms: (_FakeEvent(0.0), _FakeEvent(ms))
+    steps = 2
+    prof = []
+    for _ in range(steps):
+        # (name, work, executed, pipe, nbytes, start, end): fp16 kernels issue 3 x work (+ padding)
+        prof.append(("conv_split", 347e9, 1056e9, "fp16", 1.15e9) + ev(0.96))
+        prof.append(("kb1_front", 245e9, 850e9, "fp16", 1.5e9) + ev(1.04))
+        prof.append(("kb1_depth_front", 60e9, 180e9, "fp16", 0.7e9) + ev(0.53))
+        prof.append(("conv_tail", 35e9, 125e9, "fp16", 0.9e9) + ev(0.47))
+        prof.append(("conv_split_1x1s2", 20e9, 70e9, "fp16", 0.3e9) + ev(0.18))
+        prof.append(("conv_split_upfold", 300e9, 400e9, "fp16", 0.5e9) + ev(0.40))   # folded: executes < 3 x work
+        prof.append(("conv_wino", 100e9, 44.4e9, "fp32", 0.4e9) + ev(0.40))            # Winograd: executes 4/9 of work
+        prof.append(("conv_dma<3,2,4,2,4>", 5e9, 6e9, "fp32", 0.2e9) + ev(0.17))
+        prof.append(("s2d", 0.55e9, 24.8e9, "fp32", 0.55e9) + ev(0.58))
+        prof.append(("kb_xyz", 4e7, None, None, 4e7) + ev(0.012))
+    groups = bench.summarise_profile(prof, steps)
+    table = bench.per_kernel_table(groups, steps)
+    assert set(table) == {r[0] for r in prof}
+    for name, row in table.items():
+        for key in ("useful_frac", "issued_frac", "hbm_frac"):
+            assert row[key] is None or 0.0 < row[key] <= 1.0, (name, key, row[key])
+        assert row["useful_frac"] is None or row["useful_frac"] <= row["issued_frac"]
+    assert table["kb1_front"]["pipe"] == "fp16" and abs(table["kb1_front"]["issued_frac"] - 850e9 / 1.04e-3 / 2.5e15) < 1e-3
+    assert table["kb_xyz"]["issued_frac"] is None and table["kb_xyz"]["hbm_frac"] is not None
+    step_seconds = sum(s.elapsed_time(e) for *_, s, e in prof) * 1e-3 / steps
+    whole = bench.pipe_seconds(groups) / steps / step_seconds
+    assert 0.0 < whole <= 1.0
+    with pytest.raises(ValueError):   # one name on two pipes would be priced wrongly: refused
+        bench.summarise_profile(prof + [("conv_split", 1e9, 3e9, "fp32", 1e6) + ev(0.1)], steps)
 
 
 # ---- evaluation metrics over a sharded run (reference src/kbnet.py:932-984 averages over ALL samples) ----------------

@@ -1300,6 +1300,82 @@ def test_forward_full_size_seed_sweep(dev, preset, shape):
         assert hip64 < TOL and hip64 <= 2.0 * orc64, f"{preset} seed {seed}: HIP {hip64:.3e} vs fp64, fp32 oracle {orc64:.3e}"
 
 
+def _fp64_forward(cfg, sds, frames):
+    torch.set_default_dtype(torch.float64)      # the oracle's pixel grid follows the default dtype (reference quirk Q8)
+    try:
+        return orc.kbnet_forward(*[f.double() for f in frames], *[{k: v.double() for k, v in sd.items()} for sd in sds],
+                                 cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("preset,shape,seeds", [("kitti", (352, 1216), (0, 1, 2)), ("void", (480, 640), (0, 5))])
+def test_forward_full_size_trained_like_weights(dev, preset, shape, seeds):
+    """the pretrained checkpoints are external files, and xavier noise has none of what trained weights do to
+    an fp16 window -- so the full-size forward is stressed with TRAINED-LIKE statistics (synthetic.make_state_dicts(
+    trained_like=True): Student-t entries, per-filter scales spread log-uniformly over 2^7, 10 % of the filters exactly zero =
+    dead channels).  A few filters then own a layer's output range: the pair tensors' window "from a bound" (max |a| of the
+    sources x the widest filter's L1 norm, csrc/conv_split.hip sp_pair_out_scale) overshoots the true maximum by more binades
+    than on xavier weights, and most channels sit far below the window's top.  Asserted per seed: the 1e-4 gate against the
+    fp32 oracle; against an fp64 evaluation the HIP path is at most 2x as far from the exact result as the fp32 oracle is
+    (or within 2e-5: the resolution of a max over 4e5 pixels); every pair tensor's window slack stays below the 16 binades
+    the two-term format tolerates at no cost (tests/test_split_math_cpu.py::test_window_slack_costs_nothing)."""
+    cfg = kb.PRESETS[preset]()
+    lines = []
+    for seed in seeds:
+        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3, trained_like=True)
+        frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
+        m = kb.modules.KBNetModel.from_config(cfg, dev)
+        m.load_state_dicts(*sds)
+        kb.ops.PairTensor.LOG = log = []
+        try:
+            out = m.forward(*to(dev, *frames))
+        finally:
+            kb.ops.PairTensor.LOG = None
+        assert len(log) >= 8, "the decoder / encoder pair chains ran"
+        slack = max(float(t.window_slack_log2().max()) for t in log)
+        ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+        ref64 = _fp64_forward(cfg, sds, frames)
+        vs_orc = _worst_rel(out, ref)
+        hip64 = float(((out.cpu().double() - ref64).abs() / ref64.abs()).max())
+        orc64 = float(((ref.double() - ref64).abs() / ref64.abs()).max())
+        lines.append(f"{preset} seed {seed}: vs oracle {vs_orc:.2e}, vs fp64 HIP {hip64:.2e} / oracle {orc64:.2e}, max window slack {slack:.1f} binades")
+        print(lines[-1])
+        assert vs_orc < TOL, lines[-1]
+        assert hip64 <= max(2.0 * orc64, 2e-5), lines[-1]
+        assert 0.0 <= slack < 16.0, lines[-1]
+
+
+def test_no_split_forward_launches_nothing_twice(dev, kenv):
+    """with KBN_NO_SPLIT=1 (bench.py's fp32-MFMA-only side figure) KBNetEncoder._front used to launch the
+    depth branch's fallback (conv0_depth, kb_xyz, conv_depth), learn from kb1_front's decline that the front is off, and leave
+    encode() to run conv0_depth and the whole KB block again.  Eligibility is now decided before anything is launched: a
+    KBN_NO_SPLIT forward has exactly the launches of the three-launch path, none of them twice."""
+    cfg = kb.kitti_config()   # full widths: the front kernels only take KBNet's 48 / 16 filters
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=3, gain=1.3))
+    a = to(dev, *kb.synthetic.make_frames(2, 64, 96, "kitti", seed=9))
+    ref = m.forward(*a).clone()
+    kenv.setenv("KBN_NO_SPLIT", "1")
+
+    def launches():
+        kb.ops.PROFILE = names = []
+        try:
+            out = m.forward(*a).clone()
+        finally:
+            kb.ops.PROFILE = None
+        return [r[0] for r in names], out
+
+    got, out = launches()
+    m.encoder.front = False            # the plain three-launch level 0: the reference for "nothing twice"
+    want, out_plain = launches()
+    assert got == want, (got, want)
+    assert not any(n.startswith(("conv_split", "kb1_")) or n in ("conv_tail", "kb_xyz") for n in got), got
+    assert got.count("kb_block") == len(cfg.resolutions_backprojection) and got.count("s2d") == 1, got
+    assert torch.equal(out, out_plain)
+    assert rel_err(out, ref) < TIGHT
+
+
 def test_intermediate_tensors_elementwise_full_size(dev):
     """Single-op tests use a max-norm metric (conftest.rel_err: max|a-b| / max|b|) because conv outputs cross zero.
     This is the element-wise check of every intermediate tensor of ONE full-size KITTI forward: |a-b| <= 1e-4 |b| +

@@ -20,7 +20,8 @@ torch.cuda.synchronize()
 prof, kb.ops.PROFILE = kb.ops.PROFILE, None
 per = len(prof) // 5
 tot = 0.0
-for name, work, s, e in prof[-per:]:
+for rec in prof[-per:]:
+    name, work, s, e = rec[0], rec[1], rec[-2], rec[-1]
     us = s.elapsed_time(e) * 1e3
     tot += us
     print(f"{us:8.1f} us  {work / us / 1e6:7.1f} TF-equiv  {name}")
