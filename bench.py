@@ -487,6 +487,39 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         model.set_bf16(False)
         del breplay, bout
 
+    # The one-term leg: the SAME tuned split / pair kernels issuing h1 w1 alone -- plain fp16 operands, fp32
+    # accumulation, one MFMA instead of three, the h2 halves of the pair tensors not fetched (KBN_FP16_ONE_TERM=1: concat convs,
+    # 64-filter folded up-convs, stride-2 image convs; the front, tail, 16-filter up-conv and 1x1 stride-2 kernels keep three
+    # terms).  Two readings: (a) how MFMA-bound the three-product kernels are (same skeleton, a third of the MFMAs), (b) BASELINE
+    # configs[2]'s 16-bit figure on the tuned kernels.  THROUGHPUT-ONLY: reported with its measured error, never `value`.
+    fp16_leg = None
+    if not args.no_fp16 and not args.eager:
+        os.environ["KBN_FP16_ONE_TERM"] = "1"
+        kb.ops.reload_env()
+        try:
+            hreplay = model.capture(*frames, branches=args.branches or None)
+            for _ in range(3):
+                hreplay(*hreplay.static_in)
+            torch.cuda.synchronize()
+            kb.dist.barrier()
+            t8 = time.perf_counter()
+            for _ in range(10):
+                hout = hreplay(*hreplay.static_in)
+            torch.cuda.synchronize()
+            kb.dist.barrier()
+            hfps = per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t8, dev)
+            ref_out = out[rank * per:(rank + 1) * per]
+            hrel = (hout - ref_out).abs() / ref_out.abs()
+            fp16_leg = {"frames_per_s": round(hfps, 1),
+                        "scope": "concat convs, 64-filter folded up-convs and stride-2 image convs (72 % of the step) with ONE fp16 MFMA per "
+                                 "product (h1 w1: fp16 operands, fp32 accumulation), pair tensors read at 2 B / value; everything else as in `value`",
+                        "max_rel_err_vs_fp32_path": float(hrel.max()), "mean_rel_err_vs_fp32_path": float(hrel.mean()),
+                        "parity_gated": False}
+            del hreplay, hout
+        finally:
+            del os.environ["KBN_FP16_ONE_TERM"]
+            kb.ops.reload_env()
+
     # The same forward with every conv on the fp32 MFMAs (KBN_NO_SPLIT=1: Winograd / 9-product up-convs / fused KB kernels,
     # round 2's v20 path): what the split-operand arithmetic buys, measured by the same driver run.
     fp32_only_fps = None
@@ -628,7 +661,9 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    # side measurement: the same batch with every conv on the fp32 MFMAs (KBN_NO_SPLIT=1), graph replay
                    "fp32_mfma_only_frames_per_s": None if fp32_only_fps is None else round(fp32_only_fps, 1),
                    # side measurement: BASELINE configs[2]'s bf16 leg -- throughput only, never `value` (see above)
-                   "bf16_leg": bf16_leg},
+                   "bf16_leg": bf16_leg,
+                   # side measurement: the tuned split kernels in one-term mode (fp16 h1 w1 alone) -- throughput only
+                   "fp16_one_term_leg": fp16_leg},
         "roofline": roofline, "kernels": breakdown,
     })
 

@@ -360,7 +360,10 @@ __device__ __forceinline__ void sp_wait_b(f32x4 (&b)[NBX][2]) {   // vmcnt(N), t
 // workgroups they save.
 // MIXED: the grid is p.nblocks whole tiles followed by p.tp_nblocks transposed ones: the body (conv_split_body.inc) is compiled
 // twice into the kernel, once per tile form, and a workgroup takes the one its block index selects.
-template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2, bool PIN0 = false, bool POUT = false, bool MIXED = false>   // NBW: 32-filter blocks per wave
+// ONE: the THROUGHPUT-ONLY one-term mode (KBN_FP16_ONE_TERM=1; BASELINE configs[2]'s 16-bit leg and the ablation "same skeleton, a
+// third of the MFMAs"): only h1 w1 is issued -- plain fp16 operands, fp32 accumulation -- and the h2 halves of the staged tiles
+// are neither fetched (pair sources, weights through LDS) nor read.  Never on the parity-gated path.
+template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2, bool PIN0 = false, bool POUT = false, bool MIXED = false, bool ONE = false>   // NBW: 32-filter blocks per wave
 __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
     static_assert(!MIXED || (MODE == 0 && BLDS), "transposed tiles: the concat kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1309,7 +1312,7 @@ __global__ void uf64_pack_kernel(const float* __restrict__ w, const float* __res
 // PIN: the input is a pair tensor (staged by LDS-DMA, nothing to split); POUT: the output is written as one (the MFMA
 // operands swap roles, so that a lane's accumulator registers run over FILTERS of one pixel: four consecutive channels
 // = half a granule per store).
-template <bool PIN, bool POUT, bool MIXED = false>   // MIXED: p.nblocks whole tiles, then p.tp_nblocks transposed ones (see conv3x3_split_kernel)
+template <bool PIN, bool POUT, bool MIXED = false, bool ONE = false>   // MIXED: p.nblocks whole tiles, then p.tp_nblocks transposed ones; ONE: see conv3x3_split_kernel
 __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const SplitConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!MIXED || (int)blockIdx.x < p.nblocks) {
@@ -1703,6 +1706,8 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.prescale = ldexpf(1.f, act_exponent); p.unscale = ldexpf(1.f, -act_exponent);
     p.vec4 = vec4 ? 1 : 0;
+    // THROUGHPUT-ONLY (KBN_FP16_ONE_TERM=1): the concat convs, the 64-filter folded up-convs and the stride-2 convs issue h1 w1 alone
+    const bool one_term = knob(KNOB_FP16_ONE_TERM) != 0;
     auto launch = [&](auto kern, size_t lds, DeviceOnce& once) -> int {
         if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
         hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(SP_THREADS), lds, (hipStream_t)stream, p);
@@ -1738,26 +1743,34 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         const long long blocks64 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
         if (blocks64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
         p.nblocks = (int)blocks64;
-        static DeviceOnce o64[4], o64t[4];
         constexpr size_t lds64 = 2 * (2 * 2 * 10 * 34 * 16) + 2 * (8 * 2 * 2 * 64 * 16);
         // a low-resolution map whose width leaves 1-16 columns behind the whole 32-column tiles: transposed tiles (16 rows x 16
         // columns) for that column, in the same launch (KBN_DEBUG & 512: off)
         const int wrem = p.sW % 32;
-        if (p.sW >= 32 && wrem >= 1 && wrem <= 16 && !(knob(KNOB_DEBUG) & 512)) {
+        const bool tp64 = p.sW >= 32 && wrem >= 1 && wrem <= 16 && !(knob(KNOB_DEBUG) & 512);
+        if (tp64) {
             p.tilesX = p.sW / 32;
             p.nblocks = p.tilesX * p.tilesY * n * p.nTilesN;
             p.tp_x0 = 32 * p.tilesX;
             p.tp_tilesY = ceil_div(p.sH, 16);
             p.tp_nblocks = p.tp_tilesY * n * p.nTilesN;
-            auto launch_mixed = [&](auto kern, DeviceOnce& once) -> int {
-                if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
-                hipLaunchKernelGGL(kern, dim3(p.nblocks + p.tp_nblocks), dim3(SP_THREADS), lds64, (hipStream_t)stream, p);
-                return KBN_OK;
-            };
-            if (p.pair_src) rc = p.pair_out ? launch_mixed(upconv2x_split64_kernel<true, true, true>, o64t[3]) : launch_mixed(upconv2x_split64_kernel<true, false, true>, o64t[2]);
-            else rc = p.pair_out ? launch_mixed(upconv2x_split64_kernel<false, true, true>, o64t[1]) : launch_mixed(upconv2x_split64_kernel<false, false, true>, o64t[0]);
-        } else if (p.pair_src) rc = p.pair_out ? launch(upconv2x_split64_kernel<true, true>, lds64, o64[3]) : launch(upconv2x_split64_kernel<true, false>, lds64, o64[2]);
-        else rc = p.pair_out ? launch(upconv2x_split64_kernel<false, true>, lds64, o64[1]) : launch(upconv2x_split64_kernel<false, false>, lds64, o64[0]);
+        }
+        auto launch64 = [&](auto kern, DeviceOnce& once) -> int {
+            if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
+            hipLaunchKernelGGL(kern, dim3(p.nblocks + (tp64 ? p.tp_nblocks : 0)), dim3(SP_THREADS), lds64, (hipStream_t)stream, p);
+            return KBN_OK;
+        };
+        auto pick64 = [&](auto one_tag) -> int {   // (static locals of a generic lambda: one set per instantiation)
+            constexpr bool ONE = decltype(one_tag)::value;
+            static DeviceOnce o64[4], o64t[4];
+            if (tp64) {
+                if (p.pair_src) return p.pair_out ? launch64(upconv2x_split64_kernel<true, true, true, ONE>, o64t[3]) : launch64(upconv2x_split64_kernel<true, false, true, ONE>, o64t[2]);
+                return p.pair_out ? launch64(upconv2x_split64_kernel<false, true, true, ONE>, o64t[1]) : launch64(upconv2x_split64_kernel<false, false, true, ONE>, o64t[0]);
+            }
+            if (p.pair_src) return p.pair_out ? launch64(upconv2x_split64_kernel<true, true, false, ONE>, o64[3]) : launch64(upconv2x_split64_kernel<true, false, false, ONE>, o64[2]);
+            return p.pair_out ? launch64(upconv2x_split64_kernel<false, true, false, ONE>, o64[1]) : launch64(upconv2x_split64_kernel<false, false, false, ONE>, o64[0]);
+        };
+        rc = one_term ? pick64(std::true_type{}) : pick64(std::false_type{});
         if (rc != KBN_OK) return rc;
         KBN_CHECK_LAUNCH();
         return KBN_OK;
@@ -1772,7 +1785,6 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
                 static DeviceOnce ok32;
                 rc = launch(conv3x3_split_k32_kernel, SpGeom<0>::LDS + 2 * 10 * 2 * 2 * 64 * 16, ok32);
             } else {
-                static DeviceOnce o0p[3], o0t[4];
                 constexpr size_t lds0 = SpGeom<0>::LDS + 2 * 9 * 2 * 2 * 64 * 16;
                 // a map whose width leaves 1-16 columns behind the whole 32-column tiles: that column goes to a launch of
                 // transposed tiles (32 rows x 16 columns), half the MFMAs of the tiles it replaces (KBN_DEBUG & 512: off)
@@ -1784,19 +1796,27 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
                     p.tp_x0 = SP_TW * p.tilesX;
                     p.tp_tilesY = ceil_div(height, 2 * SpGeom<0>::TH);
                     p.tp_nblocks = p.tp_tilesY * n * p.nTilesN;
-                    auto launch_mixed = [&](auto kern, DeviceOnce& once) -> int {
-                        if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
-                        hipLaunchKernelGGL(kern, dim3(p.nblocks + p.tp_nblocks), dim3(SP_THREADS), lds0, (hipStream_t)stream, p);
-                        return KBN_OK;
-                    };
-                    if (p.pair_src) rc = p.pair_out ? launch_mixed(conv3x3_split_kernel<0, 8, true, true, 2, true, true, true>, o0t[3])
-                                                    : launch_mixed(conv3x3_split_kernel<0, 8, true, true, 2, true, false, true>, o0t[2]);
-                    else rc = p.pair_out ? launch_mixed(conv3x3_split_kernel<0, 8, true, true, 2, false, true, true>, o0t[1])
-                                         : launch_mixed(conv3x3_split_kernel<0, 8, true, true, 2, false, false, true>, o0t[0]);
-                } else if (p.pair_src) rc = p.pair_out ? launch(conv3x3_split_kernel<0, 8, true, true, 2, true, true>, lds0, o0p[2])
-                                                       : launch(conv3x3_split_kernel<0, 8, true, true, 2, true, false>, lds0, o0p[1]);
-                else rc = p.pair_out ? launch(conv3x3_split_kernel<0, 8, true, true, 2, false, true>, lds0, o0p[0])
-                                     : launch(conv3x3_split_kernel<0, 8, true, true>, lds0, o[0]);
+                }
+                auto launch0 = [&](auto kern, DeviceOnce& once) -> int {
+                    if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
+                    hipLaunchKernelGGL(kern, dim3(p.nblocks + (tp ? p.tp_nblocks : 0)), dim3(SP_THREADS), lds0, (hipStream_t)stream, p);
+                    return KBN_OK;
+                };
+                auto pick0 = [&](auto one_tag) -> int {
+                    constexpr bool ONE = decltype(one_tag)::value;
+                    static DeviceOnce o0p[4], o0t[4];
+                    if (tp) {
+                        if (p.pair_src) return p.pair_out ? launch0(conv3x3_split_kernel<0, 8, true, true, 2, true, true, true, ONE>, o0t[3])
+                                                          : launch0(conv3x3_split_kernel<0, 8, true, true, 2, true, false, true, ONE>, o0t[2]);
+                        return p.pair_out ? launch0(conv3x3_split_kernel<0, 8, true, true, 2, false, true, true, ONE>, o0t[1])
+                                          : launch0(conv3x3_split_kernel<0, 8, true, true, 2, false, false, true, ONE>, o0t[0]);
+                    }
+                    if (p.pair_src) return p.pair_out ? launch0(conv3x3_split_kernel<0, 8, true, true, 2, true, true, false, ONE>, o0p[3])
+                                                      : launch0(conv3x3_split_kernel<0, 8, true, true, 2, true, false, false, ONE>, o0p[2]);
+                    return p.pair_out ? launch0(conv3x3_split_kernel<0, 8, true, true, 2, false, true, false, ONE>, o0p[1])
+                                      : launch0(conv3x3_split_kernel<0, 8, true, true, 2, false, false, false, ONE>, o0p[0]);
+                };
+                rc = one_term ? pick0(std::true_type{}) : pick0(std::false_type{});
             }
             break;
         case 1: rc = launch(conv3x3_split_kernel<1, 8, true, false>, SpGeom<1>::LDS, o[1]); break;
@@ -1806,11 +1826,15 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
             // from LDS.  Inside the forward (KB2 / KB3 / KB4 / conv5 image / conv5 depth, 32 KITTI frames): 397 / 337 / 314 /
             // 247 / 60 us against 414 / 360 / 322 / 281 / 69 with 4 x 2 waves of 2 rows x two blocks
             {
-                static DeviceOnce o2p[3];
-                if (p.pair_src) rc = p.pair_out ? launch(conv3x3_split_kernel<2, 2, true, false, 1, true, true>, SpGeom<2>::LDS, o2p[2])
-                                                : launch(conv3x3_split_kernel<2, 2, true, false, 1, true, false>, SpGeom<2>::LDS, o2p[1]);
-                else rc = p.pair_out ? launch(conv3x3_split_kernel<2, 2, true, false, 1, false, true>, SpGeom<2>::LDS, o2p[0])
-                                     : launch(conv3x3_split_kernel<2, 2, true, false, 1>, SpGeom<2>::LDS, o[2]);
+                auto pick2 = [&](auto one_tag) -> int {
+                    constexpr bool ONE = decltype(one_tag)::value;
+                    static DeviceOnce o2p[4];
+                    if (p.pair_src) return p.pair_out ? launch(conv3x3_split_kernel<2, 2, true, false, 1, true, true, false, ONE>, SpGeom<2>::LDS, o2p[3])
+                                                      : launch(conv3x3_split_kernel<2, 2, true, false, 1, true, false, false, ONE>, SpGeom<2>::LDS, o2p[2]);
+                    return p.pair_out ? launch(conv3x3_split_kernel<2, 2, true, false, 1, false, true, false, ONE>, SpGeom<2>::LDS, o2p[1])
+                                      : launch(conv3x3_split_kernel<2, 2, true, false, 1, false, false, false, ONE>, SpGeom<2>::LDS, o2p[0]);
+                };
+                rc = one_term ? pick2(std::true_type{}) : pick2(std::false_type{});
             }
             break;
         default:

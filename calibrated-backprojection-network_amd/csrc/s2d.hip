@@ -34,6 +34,7 @@
 #include <initializer_list>
 
 #include "kbn_common.h"
+#include "s2d_pools.h"
 
 namespace kbn {
 
@@ -72,43 +73,11 @@ __host__ __device__ constexpr int s2d_zw(int R) { return S2D_FW + 2 * R; }
 __host__ __device__ constexpr int s2d_zh(int R) { return S2D_FH + 2 * R; }
 __host__ __device__ constexpr int s2d_vp(int R) { return (S2D_FWP + 2 * R + 3) / 4 * 4; }
 
-// Pool configuration: compile-time lists for the reference's shipped presets (the register-blocked passes
-// unroll to straight-line code), a run-time list for anything else (same phases, plain loops).
-template <int NMIN, int... KS>
-struct StaticPools {
-    static constexpr bool is_static = true;
-    static constexpr int NP = sizeof...(KS);
-    static constexpr int K[NP] = {KS...};
-    static constexpr int cmax(int lo, int hi) {
-        int m = 0;
-        for (int i = lo; i < hi; ++i) m = (K[i] / 2 > m) ? K[i] / 2 : m;
-        return m;
-    }
-    static constexpr int NMINP = NMIN;
-    static constexpr int RMIN = cmax(0, NMIN), RMAX = cmax(NMIN, NP);
-    static constexpr int RR = RMIN > RMAX ? RMIN : RMAX;
-    static constexpr int RMAXZ = RR;          // radius the depth-tile register prefetch is sized for
-    static constexpr int radius(int pi) { return K[pi] / 2; }
-    __device__ static constexpr int R(const S2DParams&) { return RR; }
-};
 struct DynamicPools {
     static constexpr bool is_static = false;
     static constexpr int RMAXZ = S2D_MAXR;
     __device__ static int R(const S2DParams& p) { return p.R; }
 };
-using KittiPools = StaticPools<5, 5, 7, 9, 11, 13, 15, 17>;   // bash/kitti/run_kbnet_kitti_validation.sh:15-16
-using VoidPools = StaticPools<2, 15, 17, 23, 27, 29>;         // bash/void/run_kbnet_void1500.sh:15-16
-using VoidTrainPools = StaticPools<3, 15, 17, 19, 23, 27>;    // bash/void/train_kbnet_void1500.sh:21-22
-
-template <int N>
-struct IntC { static constexpr int value = N; };
-template <int I, int N, typename F>
-__device__ __forceinline__ void s2d_for(F&& f) {
-    if constexpr (I < N) {
-        f(IntC<I>{});
-        s2d_for<I + 1, N>(static_cast<F&&>(f));
-    }
-}
 
 // LeakyReLU as max(v, slope v): 2 vector instructions instead of 3 (0 <= slope <= 1, checked by the launcher)
 __device__ __forceinline__ float s2d_lrelu(float v, float slope) {

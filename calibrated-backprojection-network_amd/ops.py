@@ -245,7 +245,8 @@ def s2d_forward(x, w_pool_convs: List[torch.Tensor], w_conv, min_pool_sizes, max
         raise KbnError("s2d_forward: `out` must be a contiguous N x n_filter x H x W tensor")
     wptrs = (C.c_void_p * len(ws))(*[wt.data_ptr() for wt in ws])
     amin, amax = _int_array(mins), _int_array(maxs)
-    check(_launch("s2d", 4.0 * n * h * w * (cin + nf),
+    # (work = the layer's multiply-adds x 2: nothing is skipped or padded, so executed = algorithmic; its bytes travel as `nbytes`)
+    check(_launch("s2d", 2.0 * n * h * w * (ws[0].shape[1] * nf + (len(ws) - 1) * nf * nf + 9 * (nf + cin) * nf),
                   lambda: lib.kbn_s2d_forward(x.data_ptr(), wptrs, wc.data_ptr(), out.data_ptr(), n, h, w, cin,
                                               amin, len(mins), amax, len(maxs), len(ws), nf,
                                               float(negative_slope), _stream()),

@@ -1376,6 +1376,35 @@ def test_no_split_forward_launches_nothing_twice(dev, kenv):
     assert rel_err(out, ref) < TIGHT
 
 
+def test_fp16_one_term_leg_is_throughput_only(dev, kenv):
+    """KBN_FP16_ONE_TERM=1 (bench.py's `fp16_one_term_leg`, BASELINE configs[2]'s 16-bit figure): the tuned split / pair kernels
+    issue h1 w1 alone.  The result is a 16-bit-grade depth map (mean relative error around 1e-3, far off the 1e-4 gate: never
+    the parity-gated path), the same launches run (no fallback to another kernel), and switching it off restores the bits."""
+    cfg = kb.kitti_config()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    a = to(dev, *kb.synthetic.make_frames(2, 128, 320, "kitti", seed=4))
+
+    def run():
+        kb.ops.PROFILE = names = []
+        try:
+            out = m.forward(*a).clone()
+        finally:
+            kb.ops.PROFILE = None
+        return out, [r[0] for r in names]
+
+    full, launches = run()
+    kenv.setenv("KBN_FP16_ONE_TERM", "1")
+    one, launches_one = run()
+    kenv.delenv("KBN_FP16_ONE_TERM")
+    again, _ = run()
+    assert launches_one == launches and "conv_split" in launches and "conv_split_upfold" in launches and "conv_split_s2" in launches
+    assert torch.equal(again, full)
+    rel = ((one - full).abs() / full.abs())
+    print(f"one-term fp16 leg vs the fp32-grade path: max rel {float(rel.max()):.3e}, mean {float(rel.mean()):.3e}")
+    assert torch.isfinite(one).all() and 1e-6 < float(rel.mean()) < 2e-2 and float(rel.max()) < 0.5
+
+
 def test_intermediate_tensors_elementwise_full_size(dev):
     """Single-op tests use a max-norm metric (conftest.rel_err: max|a-b| / max|b|) because conv outputs cross zero.
     This is the element-wise check of every intermediate tensor of ONE full-size KITTI forward: |a-b| <= 1e-4 |b| +
