@@ -81,6 +81,11 @@ SIGNATURES = {
     "kbn_kb1_depth_front_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_kb1_depth_front_pack_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "kbn_kb1_depth_front_forward": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P, _P]),
+    "kbn_s2d_depth_front_packed_weight_bytes": (C.c_size_t, [_I]),
+    "kbn_s2d_depth_front_pack_weight": (_I, [_P, _P, _P, _P, _P, _I, _P]),
+    "kbn_s2d_depth_front_query": (_I, [_I, C.POINTER(_I), _I, C.POINTER(_I), _I, _I, _I, _I, _I, _I, _I, _F, _F]),
+    "kbn_s2d_depth_front_forward": (_I, [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, C.POINTER(_I), _I, C.POINTER(_I), _I, _I, _I, _I, _I,
+                                        _I, _I, _F, _F, _F, _I, _F, _P, _P]),
     "kbn_preprocess_forward": (_I, [_P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _P]),
     "kbn_eval_accumulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "kbn_depth_head_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),

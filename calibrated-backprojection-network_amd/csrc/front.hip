@@ -25,7 +25,11 @@
 //      consecutive granules thanks to the de-interleave), B operand = weights from LDS (double buffered, LDS-DMA).
 //   D  after the last chunk: scales, xyz channels of conv_fused in fp32 (kbn_kb_xyz_s2_forward computes them once per block),
 //      LeakyReLU, 16-byte NCHW stores (a lane holds 4 consecutive pixels of a filter), absmax.
+#include <initializer_list>
+#include <type_traits>
+
 #include "front_common.h"
+#include "s2d_stage.h"
 
 namespace kbn {
 
@@ -357,17 +361,47 @@ struct DepthFrontParams {
     int N, Cin, H, W, h, w, tilesX, tilesY, ntiles;
     float slope0, slope1, slope_proj;
     int act_proj, vec4;
+    S2DStageParams s2d;           // kb1_depth_front_kernel<pool preset>: S2D evaluated on chip from the raw [sparse depth, validity] planes
+};
+// Stage A of the depth front: NoS2D = `depth` is the S2D tensor in HBM (loaded and split); a pool preset (s2d_pools.h) = the tile
+// of that tensor is computed on chip by s2d_stage_run from p.s2d.x (S2D -> conv0_depth -> KB1's depth branch
+// as ONE launch; the 8-channel full-resolution S2D tensor never reaches HBM).
+struct NoS2D {};
+template <typename C>
+struct DepthFrontLayout {
+    static constexpr bool FUSED = true;
+    static constexpr int STAGE = S2DStage<C>::BYTES;
+};
+template <>
+struct DepthFrontLayout<NoS2D> {
+    static constexpr bool FUSED = false;
+    static constexpr int STAGE = 0;
 };
 // table (floats): [0] L1max of conv0_depth, [4..19] inv0, [20..35] invC, [36..51] proj, [52..) per filter f (16): S0[3], Sx[3],
 // Sy[3] (9), then [196..) the raw coordinate weights wc[f][j][tap] (16 x 27)
 constexpr int DF_TAB = 640, DF_SUM = 52, DF_RAW = DF_SUM + 16 * 9;
 
+template <typename S2DCFG>
+struct DepthFrontLds {
+    using L = DepthFrontLayout<S2DCFG>;
+    static constexpr int IN_PART = FR_NIN * 16, IN_BYTES = 2 * IN_PART;            // [term][pixel][8 channels] fp16
+    static constexpr int X_KG = FR_NP1 * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
+    static constexpr int WC_KQ = 16 * 16, WC_PART = 4 * WC_KQ, WC_KS = 2 * WC_PART, WC_BYTES = 5 * WC_KS;   // 10 KB
+    // NoS2D: [IN][X][WC].  On-chip S2D: X and WC overlay the stage's bytes (dead once IN is complete), IN and the reduction scratch behind them
+    static constexpr int OFF_X = L::FUSED ? 0 : IN_BYTES, OFF_WC = OFF_X + X_BYTES;
+    static constexpr int OFF_IN = L::FUSED ? L::STAGE : 0, OFF_RED = L::FUSED ? OFF_IN + IN_BYTES : OFF_X;
+    static constexpr int BYTES = L::FUSED ? OFF_RED + 64 : OFF_WC + WC_BYTES;
+    static_assert(!L::FUSED || OFF_WC + WC_BYTES <= OFF_IN, "X and the conv_depth weights fit in front of IN");
+    static_assert(BYTES <= 80 * 1024, "two workgroups per CU");
+};
+
+template <typename S2DCFG>
 __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const DepthFrontParams p) {
-    constexpr int IN_PART = FR_NIN * 16, IN_BYTES = 2 * IN_PART;            // [term][pixel][8 channels] fp16
-    constexpr int X_KG = FR_NP1 * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
-    constexpr int WC_KQ = 16 * 16, WC_PART = 4 * WC_KQ, WC_KS = 2 * WC_PART, WC_BYTES = 5 * WC_KS;   // 10 KB
-    constexpr int OFF_X = IN_BYTES, OFF_WC = OFF_X + X_BYTES;
-    static_assert(OFF_WC + WC_BYTES <= 80 * 1024, "two workgroups per CU");
+    using LD = DepthFrontLds<S2DCFG>;
+    constexpr bool FUSED = LD::L::FUSED;
+    constexpr int IN_PART = LD::IN_PART, X_KG = LD::X_KG, X_PART = LD::X_PART;
+    constexpr int WC_KQ = LD::WC_KQ, WC_PART = LD::WC_PART, WC_KS = LD::WC_KS, WC_BYTES = LD::WC_BYTES;
+    constexpr int OFF_X = LD::OFF_X, OFF_WC = LD::OFF_WC, OFF_IN = LD::OFF_IN;
     constexpr int NBLK = (FR_NB0 + 7) / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals
@@ -384,18 +418,24 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
     const long long plane = (long long)H * W;
 
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
-    {   // conv_depth's weights: 10 KB by LDS-DMA, awaited in front of the second barrier
+    auto stage_wc = [&]() {   // conv_depth's weights: 10 KB by LDS-DMA, awaited in front of the barrier that ends phase B
         constexpr int n4 = WC_BYTES / 16;
 #pragma unroll
         for (int e0 = 0; e0 < n4; e0 += FR_THREADS) {
             const int eb = e0 + wave * 64;
             if (eb + lane < n4) lds_dma16_s(reinterpret_cast<const float*>(p.wc) + eb * 4, (unsigned)(lane * 16), lds0 + (unsigned)(OFF_WC + eb * 16));
         }
-    }
+    };
+    if constexpr (!FUSED) stage_wc();
 
     // ---- A: depth-feature tile -> split granules [8 channels] per pixel; windows from the tile's own maximum (see kb1_front_kernel)
     float pre_in, un_in, pre0, un0;
-    {
+    if constexpr (FUSED) {
+        // the S2D layer for this tile, on chip (s2d_stage.h): IN is written from the raw sparse depth / validity planes
+        float bound_in;
+        s2d_stage_run<S2DCFG>(p.s2d, smem, OFF_IN, reinterpret_cast<float*>(smem + LD::OFF_RED), n, 2 * oy0 - 2, 2 * ox0 - 2, H, W, pre_in, un_in, bound_in);
+        fr_scales(__float_as_uint(p.tab[0] * bound_in), pre0, un0);
+    } else {
         const float* src0 = p.depth + (long long)n * p.depth_bstride;
         float raw[2][8];
         float tm = 0.f;
@@ -414,7 +454,7 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
-        float* red = reinterpret_cast<float*>(smem + OFF_X);
+        float* red = reinterpret_cast<float*>(smem + LD::OFF_RED);
         if (lane == 0) red[wave] = tm;
         __syncthreads();
         tm = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
@@ -428,8 +468,8 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
                 fh4 a1, a2, b1, b2;
                 fr_split4((ff4){raw[u][0], raw[u][1], raw[u][2], raw[u][3]} * pre_in, a1, a2);
                 fr_split4((ff4){raw[u][4], raw[u][5], raw[u][6], raw[u][7]} * pre_in, b1, b2);
-                *reinterpret_cast<fh8*>(smem + pix * 16) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                *reinterpret_cast<fh8*>(smem + IN_PART + pix * 16) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<fh8*>(smem + OFF_IN + pix * 16) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<fh8*>(smem + OFF_IN + IN_PART + pix * 16) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
     }
@@ -451,7 +491,7 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
         const bool ok = r1 < FR_R1H;
         const int r1c = ok ? r1 : FR_R1H - 1;
         const int Y = 2 * oy0 - 1 + r1c, X = 2 * ox0 - 1 + c1;
-        inoff[i] = (r1c * FR_R0W + c1) * 16;
+        inoff[i] = OFF_IN + (r1c * FR_R0W + c1) * 16;
         const int xi = r1c * FR_R1W + ((c1 & 1) ? (FR_R1W + 1) / 2 + (c1 >> 1) : (c1 >> 1));
         xoff[i] = OFF_X + (kq >> 1) * X_KG + xi * 16 + (kq & 1) * 8;
         if (ok) valid |= 1u << i;
@@ -474,6 +514,7 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
     const bool row_live = oy0 + yrow < p.h;
     const int nblk = wave + 8 * (NBLK - 1) < FR_NB0 ? NBLK : NBLK - 1;
     __syncthreads();   // IN complete
+    if constexpr (FUSED) stage_wc();   // its bytes (and X's) were the S2D stage's until this barrier
 
     // ---- B: conv0_depth over the 561 pixels of the halo region
     {
@@ -679,6 +720,68 @@ __global__ void depth_front_pack_kernel(const float* __restrict__ w0, const floa
     }
 }
 
+// blob of the on-chip S2D stage (s2d_stage.h): tables, then the A operands of its MFMAs lane by lane.  ONE workgroup.
+//   chain layer i (cin = n_pools for i = 0, else 8 input channels): lane (m = lane & 15, kq = lane >> 4), row m = filter m (rows 8-15 zero):
+//       kq 0: w1 = fp16(w 2^e)   kq 1: w2 = fp16(w 2^e - w1)   kq 2: fp16(w1 2^-11) (pairs with the scaled residual h2)   kq 3: 0
+//   3x3 conv, K-steps s = 0..2 (window row): rows 0-7 = filter m at the pair's first pixel (window column kq = kx, kq 3: zero), rows 8-15 =
+//       filter m - 8 at its second pixel (kx = kq - 1, kq 0: zero), k-group entry j = feature channel j; terms (w1, (w 2^e - w1) 2^11)
+//       K-step 3 (raw channels): k-group kq = window row (kq 3: zero), entry j = (window column j >> 1, channel 8 + (j & 1))
+__global__ __launch_bounds__(256) void s2d_stage_pack_kernel(const float* __restrict__ wp0, const float* __restrict__ wp1,
+                                                             const float* __restrict__ wp2, const float* __restrict__ wc, float* __restrict__ tab,
+                                                             _Float16* __restrict__ wchain, _Float16* __restrict__ wconv, int n_pools) {
+    __shared__ float inv[4][8], l1[4][8];
+    const int t = threadIdx.x;
+    for (int e = t; e < SF_TAB; e += 256) tab[e] = 0.f;
+    if (t < 32) {
+        const int layer = t >> 3, f = t & 7;
+        const int per = layer == 0 ? n_pools : (layer == 3 ? 90 : 8);
+        const float* w = (layer == 0 ? wp0 : layer == 1 ? wp1 : layer == 2 ? wp2 : wc) + (long long)f * per;
+        float m = 0.f, s1 = 0.f;
+        for (int i = 0; i < per; ++i) { m = fmaxf(m, fabsf(w[i])); s1 += fabsf(w[i]); }
+        int ex = FR_WEXP;
+        if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &ex);
+        int e = FR_WEXP - ex;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        inv[layer][f] = ldexpf(1.f, -e);
+        l1[layer][f] = s1;
+    }
+    __syncthreads();
+    if (t < 32) tab[8 + t] = inv[t >> 3][t & 7];
+    if (t < 4) {
+        float m = 0.f;
+        for (int f = 0; f < 8; ++f) m = fmaxf(m, l1[t][f]);
+        tab[t] = m;
+    }
+    for (int e = t; e < SF_CHAIN_HALVES; e += 256) {
+        const int j = e & 7, lane = (e >> 3) & 63, layer = e >> 9;
+        const int m = lane & 15, kq = lane >> 4;
+        const int cin = layer == 0 ? n_pools : 8;
+        float v = 0.f;
+        if (m < 8 && j < cin && kq < 3) {
+            const float* w = layer == 0 ? wp0 : (layer == 1 ? wp1 : wp2);
+            const float ws = w[m * cin + j] / inv[layer][m];
+            const _Float16 w1 = (_Float16)ws;
+            v = kq == 0 ? (float)w1 : (kq == 1 ? ws - (float)w1 : (float)w1 * 0.00048828125f);
+        }
+        wchain[e] = (_Float16)v;
+    }
+    for (int e = t; e < SF_CONV_HALVES; e += 256) {
+        const int j = e & 7, lane = (e >> 3) & 63, term = (e >> 9) & 1, s = e >> 10;
+        const int m = lane & 15, kq = lane >> 4;
+        const int f = m & 7, second = m >> 3;
+        float ws = 0.f;
+        bool live = false;
+        if (s < 3) {              // features: window row s, window column kq
+            const int kx = kq - second;
+            if (kx >= 0 && kx < 3) { live = true; ws = wc[((f * 10 + j) * 3 + s) * 3 + kx]; }
+        } else if (kq < 3) {      // raw channels: window row kq, window column j >> 1
+            const int kx = (j >> 1) - second;
+            if (kx >= 0 && kx < 3) { live = true; ws = wc[((f * 10 + 8 + (j & 1)) * 3 + kq) * 3 + kx]; }
+        }
+        wconv[e] = live ? fr_term(ws / inv[3][f], term) : (_Float16)0.f;
+    }
+}
+
 // ---- weight packing ---------------------------------------------------------------------------------------------
 // table: per-filter 2^-e (largest |w 2^e| in [2^12, 2^13)), the bound factor L1max0 = max_f sum |w0_f|, the fp32 xyz weights
 __global__ void front_table_kernel(const float* __restrict__ w0, const float* __restrict__ wi, const float* __restrict__ wf,
@@ -879,16 +982,15 @@ int kbn_kb1_depth_front_query(int depth_channels, int conv0_filters, int kb_filt
     return KBN_OK;
 }
 
-int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride, const float* kinv, const void* packed_weight,
-                                float* out_depth, long long out_depth_batch_stride, float* xyz, long long xyz_batch_stride, int n,
-                                int depth_channels, int conv0_filters, int kb_filters, int height, int width,
-                                float conv0_negative_slope, float kb_negative_slope, int proj_activation, float proj_negative_slope,
-                                unsigned* out_depth_absmax, kbn_stream_t stream) {
+}  // extern "C"
+
+// fills the part of the parameters both forms of the depth front share; KBN_OK or a status
+static int depth_front_params(kbn::DepthFrontParams& p, const float* kinv, const void* packed_weight, float* out_depth,
+                              long long out_depth_batch_stride, float* xyz, long long xyz_batch_stride, int n, int depth_channels, int height,
+                              int width, float conv0_negative_slope, float kb_negative_slope, int proj_activation, float proj_negative_slope,
+                              unsigned* out_depth_absmax) {
     using namespace kbn;
-    if (!depth || !kinv || !packed_weight || !out_depth || !xyz || n < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
-    if (int rc = kbn_kb1_depth_front_query(depth_channels, conv0_filters, kb_filters, height, width, conv0_negative_slope)) return rc;
-    DepthFrontParams p{};
-    p.depth = depth; p.depth_bstride = depth_batch_stride; p.kinv = kinv;
+    p.kinv = kinv;
     p.tab = static_cast<const float*>(packed_weight);
     p.w0 = reinterpret_cast<const _Float16*>(p.tab + DF_TAB);
     p.wc = p.w0 + 3 * 2 * 64 * 8;
@@ -904,12 +1006,113 @@ int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride
     p.slope0 = conv0_negative_slope; p.slope1 = kb_negative_slope;
     p.act_proj = proj_activation ? 1 : 0; p.slope_proj = proj_negative_slope;
     p.vec4 = !((p.w & 3) || (reinterpret_cast<uintptr_t>(out_depth) & 15) || (out_depth_batch_stride & 3)) ? 1 : 0;
-    constexpr size_t lds = 2 * FR_NIN * 16 + 2 * 2 * FR_NP1 * 16 + 5 * 2 * 4 * 16 * 16;
-    static DeviceOnce once;
-    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kb1_depth_front_kernel), 80 * 1024)) return rc;
-    hipLaunchKernelGGL(kb1_depth_front_kernel, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
+    return KBN_OK;
+}
+
+template <typename S2DCFG>
+static int depth_front_launch(const kbn::DepthFrontParams& p, hipStream_t stream) {
+    using namespace kbn;
+    static DeviceOnce once;   // one per instantiation
+    auto kern = kb1_depth_front_kernel<S2DCFG>;
+    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
+    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), DepthFrontLds<S2DCFG>::BYTES, stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
+}
+
+extern "C" {
+
+int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride, const float* kinv, const void* packed_weight,
+                                float* out_depth, long long out_depth_batch_stride, float* xyz, long long xyz_batch_stride, int n,
+                                int depth_channels, int conv0_filters, int kb_filters, int height, int width,
+                                float conv0_negative_slope, float kb_negative_slope, int proj_activation, float proj_negative_slope,
+                                unsigned* out_depth_absmax, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!depth || !kinv || !packed_weight || !out_depth || !xyz || n < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if (int rc = kbn_kb1_depth_front_query(depth_channels, conv0_filters, kb_filters, height, width, conv0_negative_slope)) return rc;
+    DepthFrontParams p{};
+    p.depth = depth; p.depth_bstride = depth_batch_stride;
+    if (int rc = depth_front_params(p, kinv, packed_weight, out_depth, out_depth_batch_stride, xyz, xyz_batch_stride, n, depth_channels, height,
+                                    width, conv0_negative_slope, kb_negative_slope, proj_activation, proj_negative_slope, out_depth_absmax))
+        return rc;
+    return depth_front_launch<NoS2D>(p, (hipStream_t)stream);
+}
+
+// ---- S2D -> conv0_depth -> KB1's depth branch in ONE launch (kb1_depth_front_kernel<pool preset>, s2d_stage.h) --------------
+// which compiled pool preset (csrc/s2d_pools.h) the lists are: 0 KITTI, 1 VOID / NYUv2, 2 VOID training, -1 none
+static int s2d_front_preset(const int* min_pool_sizes, int n_min, const int* max_pool_sizes, int n_max) {
+    if (n_min < 0 || n_max < 0 || n_min + n_max > 8 || (n_min && !min_pool_sizes) || (n_max && !max_pool_sizes)) return -1;
+    int k[8], np = 0;
+    for (int i = 0; i < n_min; ++i) k[np++] = min_pool_sizes[i];
+    for (int i = 0; i < n_max; ++i) k[np++] = max_pool_sizes[i];
+    auto is = [&](int nm, std::initializer_list<int> ks) {
+        if (n_min != nm || np != (int)ks.size()) return false;
+        int i = 0;
+        for (int v : ks)
+            if (k[i++] != v) return false;
+        return true;
+    };
+    if (is(5, {5, 7, 9, 11, 13, 15, 17})) return 0;
+    if (is(2, {15, 17, 23, 27, 29})) return 1;
+    if (is(3, {15, 17, 19, 23, 27})) return 2;
+    return -1;
+}
+
+size_t kbn_s2d_depth_front_packed_weight_bytes(int n_pools) {
+    if (n_pools < 1 || n_pools > 8) return 0;
+    return (size_t)kbn::SF_TAB * 4 + 2 * (size_t)(kbn::SF_CHAIN_HALVES + kbn::SF_CONV_HALVES);
+}
+
+int kbn_s2d_depth_front_pack_weight(const float* w_pool_conv0, const float* w_pool_conv1, const float* w_pool_conv2, const float* w_conv,
+                                    void* packed, int n_pools, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!w_pool_conv0 || !w_pool_conv1 || !w_pool_conv2 || !w_conv || !packed) return KBN_ERR_INVALID_ARGUMENT;
+    if (n_pools < 1 || n_pools > 8) return KBN_ERR_UNSUPPORTED;
+    float* tab = static_cast<float*>(packed);
+    _Float16* wchain = reinterpret_cast<_Float16*>(tab + SF_TAB);
+    hipLaunchKernelGGL(s2d_stage_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w_pool_conv0, w_pool_conv1, w_pool_conv2, w_conv, tab,
+                       wchain, wchain + SF_CHAIN_HALVES, n_pools);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_s2d_depth_front_query(int input_channels, const int* min_pool_sizes, int n_min, const int* max_pool_sizes, int n_max,
+                              int n_convolution, int n_filter, int conv0_filters, int kb_filters, int height, int width,
+                              float s2d_negative_slope, float conv0_negative_slope) {
+    using namespace kbn;
+    if (height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if (knob(KNOB_NO_DEPTH_FRONT_FUSION)) return KBN_ERR_UNSUPPORTED;
+    if (input_channels != 2 || n_convolution != 3 || n_filter != 8) return KBN_ERR_UNSUPPORTED;   // [sparse depth, validity] -> KBNet's S2D
+    if (s2d_front_preset(min_pool_sizes, n_min, max_pool_sizes, n_max) < 0) return KBN_ERR_UNSUPPORTED;
+    if (!(s2d_negative_slope >= 0.f && s2d_negative_slope <= 1.f)) return KBN_ERR_UNSUPPORTED;
+    return kbn_kb1_depth_front_query(n_filter, conv0_filters, kb_filters, height, width, conv0_negative_slope);
+}
+
+int kbn_s2d_depth_front_forward(const float* x, long long x_batch_stride, const float* kinv, const void* packed_s2d, const void* packed_weight,
+                                float* out_depth, long long out_depth_batch_stride, float* xyz, long long xyz_batch_stride, int n,
+                                int input_channels, const int* min_pool_sizes, int n_min, const int* max_pool_sizes, int n_max,
+                                int n_convolution, int n_filter, int conv0_filters, int kb_filters, int height, int width,
+                                float s2d_negative_slope, float conv0_negative_slope, float kb_negative_slope, int proj_activation,
+                                float proj_negative_slope, unsigned* out_depth_absmax, kbn_stream_t stream) {
+    using namespace kbn;
+    if (!x || !kinv || !packed_s2d || !packed_weight || !out_depth || !xyz || n < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
+    if (int rc = kbn_s2d_depth_front_query(input_channels, min_pool_sizes, n_min, max_pool_sizes, n_max, n_convolution, n_filter, conv0_filters,
+                                           kb_filters, height, width, s2d_negative_slope, conv0_negative_slope))
+        return rc;
+    DepthFrontParams p{};
+    if (int rc = depth_front_params(p, kinv, packed_weight, out_depth, out_depth_batch_stride, xyz, xyz_batch_stride, n, n_filter, height, width,
+                                    conv0_negative_slope, kb_negative_slope, proj_activation, proj_negative_slope, out_depth_absmax))
+        return rc;
+    p.s2d.x = x; p.s2d.x_bstride = x_batch_stride;
+    p.s2d.tab = static_cast<const float*>(packed_s2d);
+    p.s2d.wchain = reinterpret_cast<const _Float16*>(p.s2d.tab + SF_TAB);
+    p.s2d.wconv = p.s2d.wchain + SF_CHAIN_HALVES;
+    p.s2d.slope = s2d_negative_slope;
+    switch (s2d_front_preset(min_pool_sizes, n_min, max_pool_sizes, n_max)) {
+        case 0: return depth_front_launch<KittiPools>(p, (hipStream_t)stream);
+        case 1: return depth_front_launch<VoidPools>(p, (hipStream_t)stream);
+        default: return depth_front_launch<VoidTrainPools>(p, (hipStream_t)stream);
+    }
 }
 
 }  // extern "C"

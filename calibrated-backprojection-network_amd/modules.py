@@ -124,8 +124,8 @@ class _PackedTail:
 
 
 class _PackedFront:
-    """The blob of ops.kb1_front / ops.kb1_depth_front (`pack`), rebuilt (in place when possible) when one of its three
-    weights changes."""
+    """The blob of ops.kb1_front / ops.kb1_depth_front / ops.s2d_depth_front (`pack`), rebuilt (in place when possible) when one
+    of its weights changes."""
 
     def __init__(self, pack=None):
         self._key = None
@@ -133,12 +133,12 @@ class _PackedFront:
         self._args = None
         self._pack = pack or ops.pack_kb1_front_weight
 
-    def get(self, w0, wi, wf):
-        key = tuple((w.data_ptr(), w._version, w.device) for w in (w0, wi, wf))
+    def get(self, *ws):
+        key = tuple((w.data_ptr(), w._version, w.device) for w in ws)
         if key != self._key:
-            self._packed = self._pack(w0, wi, wf, out=self._packed)
+            self._packed = self._pack(*ws, out=self._packed)
             self._key = key
-            self._args = (w0, wi, wf)
+            self._args = ws
         return self._packed
 
     def refresh(self):
@@ -695,11 +695,16 @@ class KBNetEncoder(torch.nn.Module):
         self.skip_unused_image = False
         self._packed_front = _PackedFront()
         self._packed_depth_front = _PackedFront(ops.pack_kb1_depth_front_weight)
+        # S2D -> conv0_depth -> level-0 conv_depth (+ xyz) as ONE launch (ops.s2d_depth_front, csrc/s2d_stage.h): KBNetModel.forward
+        # hands encode() the S2D module and its input instead of the S2D tensor (KBN_NO_DEPTH_FRONT_FUSION=1: two launches)
+        self._packed_s2d_front = _PackedFront(lambda a, b, c, d, out=None: ops.pack_s2d_depth_front_weight([a, b, c], d, out=out))
 
-    def _front(self, image, depth, kinv, stats):
+    def _front(self, image, depth, kinv, stats, s2d=None):
         """Level 0 with conv0_image / conv0_depth fused in (their outputs stay on the CU): (skip, conv_image, conv_depth,
         conv_fused, amax_image, amax_skip), or None when the shapes are outside ops.kb1_front's (the caller runs the conv0s
-        and the block on their own).  `depth`: the S2D output."""
+        and the block on their own; nothing has been launched then).  `depth`: the S2D output, or None with `s2d` =
+        (SparseToDensePool module, its N x 2 x H x W input): the S2D layer then runs inside the depth branch's launch
+        (ops.s2d_depth_front) or, where that declines, on its own in front of it."""
         blk = self.calibrated_backprojection1
         ci, cf, cd = blk.conv_image.conv_block[0], blk.conv_fused, blk.conv_depth.conv_block[0]
         c0 = self.conv0_image
@@ -724,11 +729,25 @@ class KBNetEncoder(torch.nn.Module):
         # depth branch: conv0_depth -> conv_depth (+ xyz) in one launch too, or the separate kernels
         c0d = self.conv0_depth
         xyz = None
-        packed_d = (self._packed_depth_front.get(c0d.conv.weight, cd.conv.weight, blk.proj_depth.conv.weight)
-                    if (c0d.split and cd.split and c0d._slope is not None and _dense(depth)
-                        and ops.kb1_front_supported(depth.shape[1], c0d.out_channels, cd.out_channels, h, w, c0d._slope, depth_branch=True))
-                    else None)
-        if packed_d is not None:
+        depth_front_ok = (c0d.split and cd.split and c0d._slope is not None and (depth is None or _dense(depth))
+                          and ops.kb1_front_supported(c0d.in_channels, c0d.out_channels, cd.out_channels, h, w, c0d._slope, depth_branch=True))
+        packed_d = self._packed_depth_front.get(c0d.conv.weight, cd.conv.weight, blk.proj_depth.conv.weight) if depth_front_ok else None
+        if depth is None:
+            s2d_mod, s2d_x = s2d
+            if (packed_d is not None and s2d_x.shape[1] == 2 and _dense(s2d_x) and len(s2d_mod.pool_convs) == 3
+                    and ops.s2d_depth_front_supported(s2d_x.shape[1], s2d_mod.min_pool_sizes, s2d_mod.max_pool_sizes, len(s2d_mod.pool_convs),
+                                                      s2d_mod.conv.out_channels, c0d.out_channels, cd.out_channels, h, w, s2d_mod._slope, c0d._slope)):
+                packed_s = self._packed_s2d_front.get(*[c.conv.weight for c in s2d_mod.pool_convs], s2d_mod.conv.conv.weight)
+                if packed_s is not None:
+                    res = ops.s2d_depth_front(s2d_x, kinv, packed_s, packed_d, s2d_mod.min_pool_sizes, s2d_mod.max_pool_sizes, c0d.out_channels,
+                                              cd.out_channels, out_depth, s2d_mod._slope, c0d._slope, blk._slope, blk.proj_depth._slope,
+                                              out_depth_absmax=a_skip)
+                    if res is None:
+                        raise KbnError("s2d_depth_front declined a problem kbn_s2d_depth_front_query accepted")
+                    xyz = res[1]
+            if xyz is None:
+                depth = s2d_mod(s2d_x)   # the S2D tensor after all: its own launch
+        if xyz is None and packed_d is not None:
             res = ops.kb1_depth_front(depth, kinv, packed_d, c0d.out_channels, cd.out_channels, out_depth, c0d._slope, blk._slope,
                                       blk.proj_depth._slope, out_depth_absmax=a_skip)
             xyz = res[1] if res is not None else None
@@ -754,22 +773,26 @@ class KBNetEncoder(torch.nn.Module):
         latent, skips, _, _ = self.encode(image, depth, intrinsics)
         return latent, skips
 
-    def encode(self, image, depth, intrinsics, stats=None):
+    def encode(self, image, depth, intrinsics, stats=None, s2d=None):
         """forward() plus the per-frame max |a| slots of what it returns: (latent, skips, amax_latent, amax_skips).  Every
         conv of the encoder folds max |out| into the slot of its output tensor (ops.ActStats); the split-operand convs
-        downstream -- here and in the decoder -- place their fp16 windows on them."""
+        downstream -- here and in the decoder -- place their fp16 windows on them.  `depth` may be None with `s2d` =
+        (SparseToDensePool module, its input): the S2D layer is then evaluated here, inside level 0's depth launch where it fits."""
         fi, fd, ff = self._f
         n, _, h0, w0 = image.shape
         if stats is None:
             stats = ops.ActStats(n, image.device)
         dev = image.device
         image = image if _dense(image) else image.contiguous()
-        depth = depth if _dense(depth) else depth.contiguous()
+        if depth is not None:
+            depth = depth if _dense(depth) else depth.contiguous()
         intrinsics = intrinsics.contiguous()
 
         kinv = ops.intrinsics_inverse(intrinsics, 1.0, 1.0)
-        front = self._front(image, depth, kinv, stats) if 0 in self.resolutions_backprojection else None
+        front = self._front(image, depth, kinv, stats, s2d) if 0 in self.resolutions_backprojection else None
         if front is None:
+            if depth is None:
+                depth = s2d[0](s2d[1])
             conv_image = self.conv0_image(image)
             conv_depth = self.conv0_depth(depth)
         h, w = h0, w0
@@ -1126,12 +1149,14 @@ class KBNetModel(object):
         input_depth = paired_planes(sparse_depth, validity_map_depth)   # the two planes of one N x 2 x H x W buffer: no copy
         if input_depth is None:
             input_depth = torch.cat([sparse_depth, validity_map_depth], dim=1)   # reference src/kbnet_model.py:161
-        input_depth = self.sparse_to_dense_pool(input_depth)
         shape = input_depth.shape[-2:]
         # per-frame max |a| of every activation tensor, kept on the device: the split-operand convs place their fp16
         # windows on the data of THIS call (no calibration state, no host round trip; ops.ActStats)
         stats = ops.ActStats(image.shape[0], image.device)
-        latent, skips, amax_latent, amax_skips = self.encoder.encode(image, input_depth, intrinsics, stats)
+        # the S2D layer (reference src/kbnet_model.py:163) runs inside the encoder's first depth launch where the shapes fit
+        # (KBNetEncoder._front: S2D -> conv0_depth -> level-0 conv_depth in one kernel), otherwise as its own launch in front of it
+        latent, skips, amax_latent, amax_skips = self.encoder.encode(image, None, intrinsics, stats,
+                                                                     s2d=(self.sparse_to_dense_pool, input_depth.contiguous()))
         # decoder; its tail (deconv0's second conv + output0 + sigmoid + d_min / (s + d_min/d_max)) is one kernel
         return self.decoder.depth(latent, skips, shape, self.min_predict_depth, self.max_predict_depth,
                                   return_logits=return_logits, out=out, amax_x=amax_latent, amax_skips=amax_skips, stats=stats)
@@ -1173,6 +1198,7 @@ class KBNetModel(object):
                 elif isinstance(sub, KBNetEncoder):
                     sub._packed_front.refresh()
                     sub._packed_depth_front.refresh()
+                    sub._packed_s2d_front.refresh()
 
     # -- nn.Module-like plumbing the reference driver uses ------------------------
     def modules(self):

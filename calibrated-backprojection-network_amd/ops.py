@@ -995,6 +995,89 @@ def kb1_depth_front(depth: torch.Tensor, kinv: torch.Tensor, packed_weight: torc
     return out_depth, xyz
 
 
+# ----------------------------------------------------- S2D -> conv0_depth -> KB1's depth branch in one launch
+@_on_tensor_device
+def pack_s2d_depth_front_weight(w_pool_convs: List[torch.Tensor], w_conv: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Blob of the on-chip S2D stage of `s2d_depth_front` (kbn_s2d_depth_front_pack_weight) from SparseToDensePool's weights:
+    pool_convs.{0,1,2}.conv.weight and conv.conv.weight.  None when the shapes are outside the kernel's (three 1x1 layers of 8
+    filters, a 3x3 conv over 8 + 2 channels)."""
+    lib = _lib.load()
+    if len(w_pool_convs) != 3:
+        return None
+    ws = [w.detach().contiguous() for w in w_pool_convs]
+    wc = w_conv.detach().contiguous()
+    for w in ws + [wc]:
+        _require(w, "weight", 4)
+    npool = ws[0].shape[1]
+    if (tuple(ws[0].shape) != (8, npool, 1, 1) or tuple(ws[1].shape) != (8, 8, 1, 1) or tuple(ws[2].shape) != (8, 8, 1, 1)
+            or tuple(wc.shape) != (8, 10, 3, 3)):
+        return None
+    nbytes = lib.kbn_s2d_depth_front_packed_weight_bytes(npool)
+    if nbytes == 0:
+        return None
+    packed = out if _reusable(out, nbytes // 4, wc) else torch.empty(nbytes // 4, device=wc.device, dtype=torch.float32)
+    check(lib.kbn_s2d_depth_front_pack_weight(ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), wc.data_ptr(), packed.data_ptr(), npool,
+                                              _stream()), "kbn_s2d_depth_front_pack_weight")
+    return packed
+
+
+def s2d_depth_front_supported(input_channels: int, min_pool_sizes, max_pool_sizes, n_convolution: int, n_filter: int, conv0_filters: int,
+                              kb_filters: int, height: int, width: int, s2d_negative_slope: float, conv0_negative_slope: float) -> bool:
+    """Would `s2d_depth_front` take this problem?  (kbn_s2d_depth_front_query: pool preset, widths, slopes, switches)"""
+    mins = [int(k) for k in min_pool_sizes if k > 1]
+    maxs = [int(k) for k in max_pool_sizes if k > 1]
+    return _lib.load().kbn_s2d_depth_front_query(int(input_channels), _int_array(mins), len(mins), _int_array(maxs), len(maxs), int(n_convolution),
+                                                 int(n_filter), int(conv0_filters), int(kb_filters), int(height), int(width),
+                                                 float(s2d_negative_slope), float(conv0_negative_slope)) == _lib.KBN_OK
+
+
+@_on_tensor_device
+def s2d_depth_front(x: torch.Tensor, kinv: torch.Tensor, packed_s2d: torch.Tensor, packed_weight: torch.Tensor, min_pool_sizes, max_pool_sizes,
+                    conv0_filters: int, kb_filters: int, out_depth: torch.Tensor, s2d_negative_slope: float = 0.2,
+                    conv0_negative_slope: float = 0.2, kb_negative_slope: float = 0.2, proj_negative_slope: Optional[float] = 0.2,
+                    out_depth_absmax=None, xyz: Optional[torch.Tensor] = None):
+    """SparseToDensePool -> conv0_depth -> conv_depth of the level-0 KB block and the backprojection channels xyz in ONE launch
+    (kbn_s2d_depth_front_forward): `x` = N x 2 x H x W [sparse depth, validity]; the S2D tensor stays on the CU.  Returns
+    (out_depth, xyz) or None when the problem does not qualify (the caller runs s2d_forward + kb1_depth_front)."""
+    lib = _lib.load()
+    xptr, xbs = _planes(x, "x")
+    n, c, h, w = x.shape
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    if tuple(out_depth.shape) != (n, kb_filters, oh, ow):
+        raise KbnError(f"out_depth has shape {tuple(out_depth.shape)}, expected {(n, kb_filters, oh, ow)}")
+    if tuple(kinv.shape) != (n, 3, 3) or not kinv.is_contiguous():
+        raise KbnError("kinv must be a dense N x 3 x 3")
+    _require(kinv, "kinv", 3)
+    if xyz is None:
+        xyz = torch.empty((n, 3, oh, ow), device=x.device, dtype=torch.float32)
+    optr, obs = _planes(out_depth, "out_depth")
+    zptr, zbs = _planes(xyz, "xyz")
+    mins = [int(k) for k in min_pool_sizes if k > 1]
+    maxs = [int(k) for k in max_pool_sizes if k > 1]
+    npool = len(mins) + len(maxs)
+    nf = 8
+    # the reference's work for the three layers (S2D at full resolution, conv0_depth, conv_depth + proj at half resolution)
+    flops = 2.0 * n * (h * w * (npool * nf + 2 * nf * nf + 9 * (nf + c) * nf + nf * 9 * conv0_filters)
+                       + oh * ow * ((conv0_filters + 3) * 9 * kb_filters + conv0_filters))
+    tiles = n * (-(-oh // 8)) * (-(-ow // 16))
+    executed = tiles * (53 * 3 + 22 * 12 + 36 * 9 + 8 * 15) * 2.0 * 16 * 16 * 32   # chain, 3x3 pairs, conv0, conv_depth: MFMAs of 16 x 16 x 32 per tile
+    amin, amax = _int_array(mins), _int_array(maxs)
+    status = _launch("s2d_depth_front", flops,
+                     lambda: lib.kbn_s2d_depth_front_forward(xptr, xbs, kinv.data_ptr(), packed_s2d.data_ptr(), packed_weight.data_ptr(), optr, obs,
+                                                             zptr, zbs, n, c, amin, len(mins), amax, len(maxs), 3, nf, conv0_filters, kb_filters,
+                                                             h, w, float(s2d_negative_slope), float(conv0_negative_slope), float(kb_negative_slope),
+                                                             0 if proj_negative_slope is None else 1,
+                                                             0.0 if proj_negative_slope is None else float(proj_negative_slope),
+                                                             _slot_ptr(out_depth_absmax, n), _stream()),
+                     executed=executed, pipe="fp16", nbytes=4.0 * n * (h * w * c + oh * ow * (kb_filters + 3)))
+    if status == _lib.KBN_ERR_UNSUPPORTED:
+        if PROFILE is not None:
+            PROFILE.pop()
+        return None
+    check(status, "kbn_s2d_depth_front_forward")
+    return out_depth, xyz
+
+
 # ----------------------------------------------------- bf16 leg (throughput-only)
 @_on_tensor_device
 def pack_conv3x3_bf16_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -399,6 +399,33 @@ int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride
                                 float conv0_negative_slope, float kb_negative_slope, int proj_activation, float proj_negative_slope,
                                 unsigned* out_depth_absmax, kbn_stream_t stream);
 
+/* The same depth branch with the S2D layer in front of it, in ONE launch (csrc/s2d_stage.h, kb1_depth_front_kernel<pool preset>):
+ *     s2d         = SparseToDensePool.forward(x)                        reference src/networks.py:2168-2196, src/kbnet_model.py:161-163
+ *     conv0_depth, conv_depth, xyz as above                             reference src/networks.py:366-367, src/net_utils.py:1351-1360
+ * Per tile of 8 x 16 half-resolution pixels the workgroup evaluates S2D for the 19 x 35 full-resolution pixels conv0_depth reads
+ * (min / max pyramid bit-exact as in kbn_s2d_forward; the 1x1 chain and the 3x3 conv on split fp16 operands) and keeps the result
+ * in LDS: the N x 8 x H x W S2D tensor (13.7 MB per KITTI frame written and read back) never reaches HBM.
+ *   x               N x 2 x H x W: [sparse depth, validity map] (kbn_s2d_forward's input), frames x_batch_stride apart
+ *   packed_s2d      from kbn_s2d_depth_front_pack_weight: pool_convs.{0,1,2}.conv.weight (8 x n_pools | 8 | 8), conv.conv.weight (8 x 10 x 3 x 3)
+ *   packed_weight   from kbn_kb1_depth_front_pack_weight (depth_channels = 8)
+ *   pool lists      as kbn_s2d_forward; the kernel is compiled for the reference's shipped presets -- KITTI (min 5..13, max 15, 17), VOID / NYUv2
+ *                   (min 15, 17, max 23, 27, 29), VOID training (min 15, 17, 19, max 23, 27)
+ * KBN_ERR_UNSUPPORTED (kbn_s2d_depth_front_query says so beforehand) for any other pool list, input_channels != 2, n_convolution != 3,
+ * n_filter != 8, slopes outside [0, 1], under KBN_NO_DEPTH_FRONT_FUSION=1 or KBN_NO_SPLIT=1, and wherever kbn_kb1_depth_front_forward
+ * declines: the caller runs kbn_s2d_forward + kbn_kb1_depth_front_forward. */
+size_t kbn_s2d_depth_front_packed_weight_bytes(int n_pools);
+int kbn_s2d_depth_front_pack_weight(const float* w_pool_conv0, const float* w_pool_conv1, const float* w_pool_conv2, const float* w_conv,
+                                    void* packed, int n_pools, kbn_stream_t stream);
+int kbn_s2d_depth_front_query(int input_channels, const int* min_pool_sizes, int n_min, const int* max_pool_sizes, int n_max,
+                              int n_convolution, int n_filter, int conv0_filters, int kb_filters, int height, int width,
+                              float s2d_negative_slope, float conv0_negative_slope);
+int kbn_s2d_depth_front_forward(const float* x, long long x_batch_stride, const float* kinv, const void* packed_s2d, const void* packed_weight,
+                                float* out_depth, long long out_depth_batch_stride, float* xyz, long long xyz_batch_stride, int n,
+                                int input_channels, const int* min_pool_sizes, int n_min, const int* max_pool_sizes, int n_max,
+                                int n_convolution, int n_filter, int conv0_filters, int kb_filters, int height, int width,
+                                float s2d_negative_slope, float conv0_negative_slope, float kb_negative_slope, int proj_activation,
+                                float proj_negative_slope, unsigned* out_depth_absmax, kbn_stream_t stream);
+
 /* ------------------------------------------------------------ depth head -------
  * MultiScaleDecoder.output0 (3x3, linear)           reference src/networks.py:1842-1851, 1985
  * + KBNetModel.forward's sigmoid / depth mapping    reference src/kbnet_model.py:181-184

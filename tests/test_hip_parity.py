@@ -1045,6 +1045,114 @@ def test_kb1_depth_front_kernel(dev, hw, amag):
             assert rel_err(got[i], r32[i]) < TIGHT, (name, i)
 
 
+@pytest.mark.parametrize("preset,hw", [("kitti", (64, 96)), ("kitti", (35, 70)), ("kitti", (16, 32)), ("kitti", (52, 100)), ("kitti", (33, 47)),
+                                        ("void", (48, 80)), ("void", (37, 45)), ("void_train", (40, 64))])
+@pytest.mark.parametrize("zmag,density", [(1.0, 0.05), (1.0, 0.6), (1e-2, 0.3), (1.0, 0.0)])
+def test_s2d_depth_front_kernel(dev, preset, hw, zmag, density):
+    """kbn_s2d_depth_front_forward: SparseToDensePool -> conv0_depth -> conv_depth / xyz of the level-0 KB block
+    in ONE launch, the S2D tensor kept on the CU (csrc/s2d_stage.h).  Against the oracle's composition of the three layers and
+    against fp64, with the bars of test_kb1_depth_front_kernel; and against the two-launch path it replaces (kbn_s2d_forward +
+    kbn_kb1_depth_front_forward).  Cases: the three compiled pool presets; maps with partial tiles and odd sizes; dense and sparse
+    depth maps, centimetre-scale depths (the tile-local fp16 windows), an EMPTY sparse map (all windows take the 999 sentinel)."""
+    h, w = hw
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    cfg = kb.PRESETS["kitti" if preset == "kitti" else "void"]()
+    mins, maxs = list(cfg.min_pools), list(cfg.max_pools)
+    if preset == "void_train":
+        mins, maxs = [15, 17, 19], [23, 27]    # reference bash/void/train_kbnet_void1500.sh:21-22
+    g = torch.Generator().manual_seed(h * w + len(mins))
+    n, nf, f0, fd = 2, 8, 16, 16
+    npool = len(mins) + len(maxs)
+    lrelu = torch.nn.functional.leaky_relu
+    mask = (torch.rand(n, 1, h, w, generator=g) < density).float()
+    z = torch.round((1.0 + 79.0 * torch.rand(n, 1, h, w, generator=g)) * 256.0) / 256.0 * mask * zmag
+    z[1] *= 0.37
+    x = torch.cat([z, (z > 0).float()], 1)
+    sd = {"pool_convs.0.conv.weight": torch.randn(nf, npool, 1, 1, generator=g) / npool ** 0.5,
+          "pool_convs.1.conv.weight": torch.randn(nf, nf, 1, 1, generator=g) / nf ** 0.5,
+          "pool_convs.2.conv.weight": torch.randn(nf, nf, 1, 1, generator=g) / nf ** 0.5,
+          "conv.conv.weight": torch.randn(nf, nf + 2, 3, 3, generator=g) / ((nf + 2) * 9) ** 0.5}
+    sd["pool_convs.1.conv.weight"][3] *= 1e-2
+    sd["conv.conv.weight"][5] *= 30.0
+    w0 = torch.randn(f0, nf, 3, 3, generator=g) / (nf * 9) ** 0.5
+    wc = torch.randn(fd, f0 + 3, 3, 3, generator=g) / ((f0 + 3) * 9) ** 0.5
+    proj = torch.randn(1, f0, 1, 1, generator=g) / f0 ** 0.5
+    kmat = torch.tensor([[[60.0, 0.0, w / 2.0], [0.0, 58.0, h / 2.0], [0.0, 0.0, 1.0]]]).repeat(n, 1, 1)
+    kmat[1, 0, 0] = 71.0
+    coords = orc.camera_coordinates(kmat, h, w)
+    # references: fp32 oracle, and the same layers in fp64
+    s2d_32 = orc.sparse_to_dense_pool(x, sd, mins, maxs)
+    x0_32 = orc.conv2d(s2d_32, w0, 1, 0.2)
+    dep_32 = orc.conv2d(torch.cat([x0_32, coords], 1), wc, 2, 0.2)
+    xyz_32 = (coords * orc.conv2d(x0_32, proj, 1, 0.2))[:, :, ::2, ::2]
+    torch.set_default_dtype(torch.float64)
+    try:
+        s2d_64 = orc.sparse_to_dense_pool(x.double(), {k: v.double() for k, v in sd.items()}, mins, maxs)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    c64 = lambda t, wt, stride: lrelu(torch.nn.functional.conv2d(t.double(), wt.double(), stride=stride, padding=wt.shape[-1] // 2), 0.2)
+    x0_64 = c64(s2d_64, w0, 1)
+    dep_64 = c64(torch.cat([x0_64, coords.double()], 1), wc, 2)
+    xyz_64 = (coords.double() * c64(x0_64, proj, 1))[:, :, ::2, ::2]
+    # the fused launch
+    stats = kb.ops.ActStats(n, dev)
+    assert kb.ops.s2d_depth_front_supported(2, mins, maxs, 3, nf, f0, fd, h, w, 0.2, 0.2)
+    packed_s = kb.ops.pack_s2d_depth_front_weight([sd[f"pool_convs.{i}.conv.weight"].to(dev) for i in range(3)], sd["conv.conv.weight"].to(dev))
+    packed_d = kb.ops.pack_kb1_depth_front_weight(w0.to(dev), wc.to(dev), proj.to(dev))
+    assert packed_s is not None and packed_d is not None
+    kinv = kb.ops.intrinsics_inverse(kmat.to(dev))
+    out_d = torch.full((n, fd, oh, ow), float("nan"), device=dev)
+    slot = stats.new()
+    res = kb.ops.s2d_depth_front(x.to(dev), kinv, packed_s, packed_d, mins, maxs, f0, fd, out_d, 0.2, 0.2, 0.2, 0.2, out_depth_absmax=slot)
+    assert res is not None
+    xyz = res[1]
+    assert torch.isfinite(out_d).all() and torch.isfinite(xyz).all()
+    assert torch.equal(kb.ops.slot_values(slot), out_d.abs().amax(dim=(1, 2, 3)))
+    # the two launches it replaces
+    s2d_hip = kb.ops.s2d_forward(x.to(dev), [sd[f"pool_convs.{i}.conv.weight"].to(dev) for i in range(3)], sd["conv.conv.weight"].to(dev), mins, maxs, 0.2)
+    out_2 = torch.empty_like(out_d)
+    res2 = kb.ops.kb1_depth_front(s2d_hip, kinv, packed_d, f0, fd, out_2, 0.2, 0.2, 0.2)
+    for name, got, r64, r32, two in (("conv_depth", out_d, dep_64, dep_32, out_2), ("xyz", xyz, xyz_64, xyz_32, res2[1])):
+        rms = r64.pow(2).mean(dim=(2, 3), keepdim=True).sqrt().clamp_min(1e-30)
+        e_hip = ((got.cpu().double() - r64) / rms).abs()
+        e_orc = ((r32.double() - r64) / rms).abs()
+        e_two = ((two.cpu().double() - r64) / rms).abs()
+        print(f"s2d depth front {preset} {hw} {name} vs fp64: max {float(e_hip.max()):.2e} rms {float(e_hip.pow(2).mean().sqrt()):.2e}; two launches: "
+              f"max {float(e_two.max()):.2e} rms {float(e_two.pow(2).mean().sqrt()):.2e}; oracle fp32: max {float(e_orc.max()):.2e} rms {float(e_orc.pow(2).mean().sqrt()):.2e}")
+        assert float(e_hip.pow(2).mean().sqrt()) < max(3.5 * float(e_orc.pow(2).mean().sqrt()), 6e-7), name
+        assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 3e-5, name
+        for i in range(n):
+            assert rel_err(got[i], r32[i]) < TIGHT, (name, i)
+
+
+def test_forward_with_and_without_depth_front_fusion(dev, kenv):
+    """KBNetModel.forward runs S2D inside the depth front's launch by default; KBN_NO_DEPTH_FRONT_FUSION=1 restores the two launches.
+    Same launches otherwise, results within single-op noise of each other, both within the gate of the oracle."""
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.3)
+    frames = kb.synthetic.make_frames(2, 96, 160, "kitti", seed=5, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+
+    def run():
+        kb.ops.PROFILE = names = []
+        try:
+            out = m.forward(*to(dev, *frames)).clone()
+        finally:
+            kb.ops.PROFILE = None
+        return out, [r[0] for r in names]
+
+    fused, names_f = run()
+    kenv.setenv("KBN_NO_DEPTH_FRONT_FUSION", "1")
+    plain, names_p = run()
+    assert "s2d_depth_front" in names_f and "s2d" not in names_f and "kb1_depth_front" not in names_f
+    assert "s2d" in names_p and "kb1_depth_front" in names_p and "s2d_depth_front" not in names_p
+    assert len(names_f) == len(names_p) - 1
+    ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+    assert _worst_rel(fused, ref) < TOL and _worst_rel(plain, ref) < TOL
+    assert _worst_rel(fused, plain.cpu()) < TOL
+
+
 @pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [(48, 16, 48, 96, 32, 34, 72), (96, 32, 96, 192, 64, 19, 44), (48, 16, 0, 96, 32, 21, 37)])
 def test_kb_block_split_fused(dev, ci, cd, cf, fi, fd, h, w):
     """A KB block whose conv_image AND conv_fused run on split operands (KBNet's KB2-KB4 shapes) against the oracle, and
