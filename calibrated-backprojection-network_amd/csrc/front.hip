@@ -552,7 +552,8 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
                 *reinterpret_cast<fh4*>(smem + xoff[i] + X_PART) = h2;
             }
         };
-        if (interior) {
+        if (FUSED && (p.s2d.dbg & 32)) {
+        } else if (interior) {
 #pragma unroll
             for (int i = 0; i < NBLK - 1; ++i) block(i, std::false_type{});
             if (NBLK - 1 < nblk) block(NBLK - 1, std::true_type{});
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // conv_depth's weights
     __syncthreads();
 
-    if (!row_live) return;   // wave-uniform; no barrier follows
+    if (!row_live || (FUSED && (p.s2d.dbg & 64))) return;   // wave-uniform; no barrier follows
     // ---- C: conv_depth's tensor channels (taps in pairs)
     ff4 mD = (ff4){0.f, 0.f, 0.f, 0.f}, sD = mD;
     {
@@ -721,8 +722,9 @@ __global__ void depth_front_pack_kernel(const float* __restrict__ w0, const floa
 }
 
 // blob of the on-chip S2D stage (s2d_stage.h): tables, then the A operands of its MFMAs lane by lane.  ONE workgroup.
-//   chain layer i (cin = n_pools for i = 0, else 8 input channels): lane (m = lane & 15, kq = lane >> 4), row m = filter m (rows 8-15 zero):
-//       kq 0: w1 = fp16(w 2^e)   kq 1: w2 = fp16(w 2^e - w1)   kq 2: fp16(w1 2^-11) (pairs with the scaled residual h2)   kq 3: 0
+//   chain layer i (cin = n_pools for i = 0, else 8 input channels), two operands: lane (m = lane & 15, kq = lane >> 4), rows 0-7 = filter m at the
+//       block's first pixel (k-groups 0, 1 = its h1, h2), rows 8-15 = filter m - 8 at the second pixel (k-groups 2, 3):
+//       operand 0: [w1 = fp16(w 2^e) | fp16(w1 2^-11)] (the second pairs with the scaled residual h2), operand 1: [w2 = fp16(w 2^e - w1) | 0]
 //   3x3 conv, K-steps s = 0..2 (window row): rows 0-7 = filter m at the pair's first pixel (window column kq = kx, kq 3: zero), rows 8-15 =
 //       filter m - 8 at its second pixel (kx = kq - 1, kq 0: zero), k-group entry j = feature channel j; terms (w1, (w 2^e - w1) 2^11)
 //       K-step 3 (raw channels): k-group kq = window row (kq 3: zero), entry j = (window column j >> 1, channel 8 + (j & 1))
@@ -753,15 +755,17 @@ __global__ __launch_bounds__(256) void s2d_stage_pack_kernel(const float* __rest
         tab[t] = m;
     }
     for (int e = t; e < SF_CHAIN_HALVES; e += 256) {
-        const int j = e & 7, lane = (e >> 3) & 63, layer = e >> 9;
+        const int j = e & 7, lane = (e >> 3) & 63, op = (e >> 9) & 1, layer = e >> 10;
         const int m = lane & 15, kq = lane >> 4;
+        const int f = m & 7, second = m >> 3;       // rows 8-15: the same filters at the block's second pixel (k-groups 2, 3)
         const int cin = layer == 0 ? n_pools : 8;
         float v = 0.f;
-        if (m < 8 && j < cin && kq < 3) {
+        if (j < cin && (kq >> 1) == second) {
             const float* w = layer == 0 ? wp0 : (layer == 1 ? wp1 : wp2);
-            const float ws = w[m * cin + j] / inv[layer][m];
+            const float ws = w[f * cin + j] / inv[layer][f];
             const _Float16 w1 = (_Float16)ws;
-            v = kq == 0 ? (float)w1 : (kq == 1 ? ws - (float)w1 : (float)w1 * 0.00048828125f);
+            if (op == 0) v = (kq & 1) ? (float)w1 * 0.00048828125f : (float)w1;   // [w1 | w1 2^-11] . [h1 ; h2]
+            else v = (kq & 1) ? 0.f : ws - (float)w1;                                // [w2 | 0] . [h1 ; h2]
         }
         wchain[e] = (_Float16)v;
     }
@@ -1108,6 +1112,7 @@ int kbn_s2d_depth_front_forward(const float* x, long long x_batch_stride, const 
     p.s2d.wchain = reinterpret_cast<const _Float16*>(p.s2d.tab + SF_TAB);
     p.s2d.wconv = p.s2d.wchain + SF_CHAIN_HALVES;
     p.s2d.slope = s2d_negative_slope;
+    p.s2d.dbg = knob(KNOB_S2D_DEBUG);
     switch (s2d_front_preset(min_pool_sizes, n_min, max_pool_sizes, n_max)) {
         case 0: return depth_front_launch<KittiPools>(p, (hipStream_t)stream);
         case 1: return depth_front_launch<VoidPools>(p, (hipStream_t)stream);

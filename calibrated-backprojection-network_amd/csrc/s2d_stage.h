@@ -29,10 +29,10 @@
 
 namespace kbn {
 
-// blob of kbn_s2d_depth_front_pack_weight: SF_TAB floats, then fp16 [chain: 3 layers][64 lanes][8] [conv: 4 K-steps][2 terms][64 lanes][8]
+// blob of kbn_s2d_depth_front_pack_weight: SF_TAB floats, then fp16 [chain: 3 layers][2 operands][64 lanes][8] [conv: 4 K-steps][2 terms][64 lanes][8]
 //   tab[0..2]  L1max of the chain layers (max over filters of sum |w|), tab[3] of the 3x3 conv (all 90 weights)
 //   tab[8 + 8 i + f]  2^-e of filter f of chain layer i (i = 0..2), tab[32 + f] of the 3x3 conv
-constexpr int SF_TAB = 64, SF_CHAIN_HALVES = 3 * 64 * 8, SF_CONV_HALVES = 4 * 2 * 64 * 8;
+constexpr int SF_TAB = 64, SF_CHAIN_HALVES = 3 * 2 * 64 * 8, SF_CONV_HALVES = 4 * 2 * 64 * 8;
 
 template <typename CFG>
 struct S2DStage {
@@ -41,7 +41,7 @@ struct S2DStage {
     static constexpr int ZH = FH + 2 * R, ZW = FWP + 2 * R;                                      // staged depth tile (every feature column has its window)
     static constexpr int VP = (ZW + 3) / 4 * 4, VPLANE = FH * VP;
     static constexpr int GS = 3, NGRP = FH / GS;                                                  // vertical pass: rows per item
-    static constexpr int NG = (FH * FWP + 15) / 16 * 16 + 16, GPART = NG * 16;                    // granules of G (+ one block of slack)
+    static constexpr int NG = (FH * FWP + 31) / 32 * 32, GPART = NG * 16;                         // granules of G (whole 32-pixel blocks)
     static constexpr int NPAIR = (FR_R0W + 1) / 2, X2PART = FH * NPAIR * 16;                      // 18 pairs per row
     static constexpr int ZBYTES = (2 * ZH * ZW * 4 + 15) / 16 * 16, VBYTES = NP * VPLANE * 4;
     static constexpr int OFF_Z = 0, OFF_V = ZBYTES, OFF_G = OFF_V, OFF_X2 = 0;
@@ -49,8 +49,8 @@ struct S2DStage {
     static_assert(FH % GS == 0 && VP % 4 == 0, "tile geometry");
     static_assert(2 * GPART <= VBYTES, "G overlays V");
     static_assert(2 * X2PART <= ZBYTES, "X2 overlays the depth tile");
-    static_assert(ZW * NGRP <= FR_THREADS && FH * NQ <= FR_THREADS, "one round of items per pass");
-    static constexpr int NBLK4 = (FH * FWP + 15) / 16;                                            // 16-pixel blocks of the chain: 53
+    static_assert(ZW * NGRP <= FR_THREADS && 2 * FH * NQ + (NG - FH * FWP) <= FR_THREADS, "one round of items per pass");
+    static constexpr int NBLK4 = (FH * FWP + 31) / 32;                                            // 32-pixel blocks of the chain: 27
     static constexpr int NPAIRS = FR_R0H * NPAIR, NBLK5 = (NPAIRS + 15) / 16;                     // pixel pairs of IN: 342 -> 22 blocks
 };
 
@@ -58,9 +58,10 @@ struct S2DStageParams {
     const float* x;               // N x 2 x H x W: [sparse depth, validity]
     long long x_bstride;
     const float* tab;             // SF_TAB floats
-    const _Float16* wchain;       // [3][64][8]
+    const _Float16* wchain;       // [3][2][64][8]
     const _Float16* wconv;        // [4][2][64][8]
     float slope;                  // S2D's LeakyReLU (0 <= slope <= 1)
+    int dbg;                      // phase ablation for tools/depth_front_bench.py (KBN_S2D_DEBUG): 1 no vertical pass, 2 no horizontal pass, 4 no 1x1 chain, 8 no 3x3 conv, 16 no depth loads
 };
 
 __device__ __forceinline__ float s2d_stage_lrelu(float v, float slope) { return fmaxf(v, v * slope); }   // 0 <= slope <= 1
@@ -86,9 +87,12 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
     const int YZ = YF - R, XZ = XF - R;          // depth tile origin
     const bool f_interior = YF >= 0 && YF + S::FH <= H && XF >= 0 && XF + S::FWP <= W;   // block-uniform: no zero padding to apply
 
-    // ---- P1: depth tile (+halo) -> zmin / zmax; this thread's horizontal-pass item (row fr, columns 4 q ..) fetches its validity values
-    const int fr = tid / S::NQ, q = tid - fr * S::NQ;
-    const bool item = tid < S::FH * S::NQ;
+    // ---- P1: depth tile (+halo) -> zmin / zmax; a horizontal-pass item = (row fr, columns 4 q .., pool half): threads 0-209 take
+    // pools 0-3 (channels 0-3 of the granule) and the raw z / v values of the pixels, threads 210-419 pools 4-7
+    constexpr int NITEM = S::FH * S::NQ;
+    const int half = tid >= NITEM ? 1 : 0, tbase = tid - half * NITEM;
+    const int fr = tbase / S::NQ, q = tbase - fr * S::NQ;
+    const bool item = tid < NITEM, item2 = tid < 2 * NITEM;
     float vr[6];
     float tm = 0.f;
     {
@@ -109,7 +113,7 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
             const int r = e / ZW, c = e - r * ZW;
             const int Y2 = YZ + r, X2 = XZ + c;
             const bool ok = e < ZH * ZW && (z_inside || (Y2 >= 0 && Y2 < H && X2 >= 0 && X2 < W));
-            vz[u] = ok ? xz[(long long)Y2 * W + X2] : -INFINITY;
+            vz[u] = (ok && !(sp.dbg & 16)) ? xz[(long long)Y2 * W + X2] : -INFINITY;
         }
 #pragma unroll
         for (int u = 0; u < MAXE; ++u) {
@@ -139,7 +143,7 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
     pre_in_out = preI; un_in_out = unI; bound_in_out = bIN;
 
     // ---- P2: vertical pass -> V[pool][feature row][z column]
-    if (tid < ZW * S::NGRP) {
+    if (tid < ZW * S::NGRP && !(sp.dbg & 1)) {
         const int g = tid / ZW, c = tid - g * ZW;
         auto sweep = [&](auto is_min_c, const float* zsrc) {
             constexpr bool IS_MIN = decltype(is_min_c)::value != 0;
@@ -177,14 +181,15 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
     __syncthreads();
 
     // ---- P3: horizontal pass: the pooled values of 4 consecutive feature pixels (csrc/s2d.hip P3, same compare / select arithmetic)
-    float pooled[4][8];
+    float pooled[4][4];   // [pixel][pool 4 half + i]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int pi = 0; pi < 8; ++pi) pooled[j][pi] = 0.f;
-    if (item) {
+        for (int pi = 0; pi < 4; ++pi) pooled[j][pi] = 0.f;
+    if (item2 && !(sp.dbg & 2)) {
         s2d_for<0, NP>([&](auto pic) {
             constexpr int pi = decltype(pic)::value;
+            if ((pi >> 2) != half) return;
             constexpr int r = CFG::radius(pi);
             constexpr bool IS_MIN = pi < CFG::NMINP;
             constexpr int OFF = R - r;                    // z column of window element o of pixel j: 4q + j + OFF + o
@@ -207,7 +212,7 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
                 o0 = (o0 == 999.f) ? 0.f : o0; o1 = (o1 == 999.f) ? 0.f : o1;
                 o2 = (o2 == 999.f) ? 0.f : o2; o3 = (o3 == 999.f) ? 0.f : o3;
             }
-            pooled[0][pi] = o0; pooled[1][pi] = o1; pooled[2][pi] = o2; pooled[3][pi] = o3;
+            pooled[0][pi & 3] = o0; pooled[1][pi & 3] = o1; pooled[2][pi & 3] = o2; pooled[3][pi & 3] = o3;
         });
     }
     __syncthreads();   // every V and depth-tile read is done: G overlays V, X2 the depth tile
@@ -215,23 +220,22 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
     // ---- P3b: split granules of the chain's input (G) and of the raw channels (X2)
     unsigned char* const G = smem + S::OFF_G;
     unsigned char* const X2 = smem + S::OFF_X2;
-    if (item) {
+    if (item2) {
         const int Y = YF + fr;
         const bool rowin = Y >= 0 && Y < H;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int X = XF + 4 * q + j;
             const bool in = f_interior || (rowin && X >= 0 && X < W);
-            ff4 a = {pooled[j][0], pooled[j][1], pooled[j][2], pooled[j][3]}, b = {pooled[j][4], pooled[j][5], pooled[j][6], pooled[j][7]};
-            if (!in) { a = (ff4){0.f, 0.f, 0.f, 0.f}; b = a; }   // (windows of pixels outside the image may hold the +-inf sentinels)
-            fh4 a1, a2, b1, b2;
+            ff4 a = {pooled[j][0], pooled[j][1], pooled[j][2], pooled[j][3]};
+            if (!in) a = (ff4){0.f, 0.f, 0.f, 0.f};   // (windows of pixels outside the image may hold the +-inf sentinels)
+            fh4 a1, a2;
             fr_split4(a * pre0, a1, a2);
-            fr_split4(b * pre0, b1, b2);
-            const int e = (fr * S::FWP + 4 * q + j) * 16;
-            *reinterpret_cast<fh8*>(G + e) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-            *reinterpret_cast<fh8*>(G + S::GPART + e) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+            const int e = (fr * S::FWP + 4 * q + j) * 16 + half * 8;
+            *reinterpret_cast<fh4*>(G + e) = a1;
+            *reinterpret_cast<fh4*>(G + S::GPART + e) = a2;
         }
-        if (2 * q + 1 < S::NPAIR) {   // pairs 2q, 2q + 1 of this row: (z, v) of columns 4q .. 4q + 3 and 4q + 2 .. 4q + 5
+        if (item && 2 * q + 1 < S::NPAIR) {   // pairs 2q, 2q + 1 of this row: (z, v) of columns 4q .. 4q + 3 and 4q + 2 .. 4q + 5
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const ff4 a = {zr[2 * h], vr[2 * h], zr[2 * h + 1], vr[2 * h + 1]}, b = {zr[2 * h + 2], vr[2 * h + 2], zr[2 * h + 3], vr[2 * h + 3]};
@@ -243,47 +247,61 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
                 *reinterpret_cast<fh8*>(X2 + S::X2PART + e) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
-    } else if (tid - S::FH * S::NQ < S::NG - S::FH * S::FWP) {   // the slack behind the last feature pixel: finite values for the last block
-        const int e = (S::FH * S::FWP + tid - S::FH * S::NQ) * 16;
+    } else if (tid - 2 * NITEM < S::NG - S::FH * S::FWP) {   // the slack behind the last feature pixel: finite values for the last block
+        const int e = (S::FH * S::FWP + tid - 2 * NITEM) * 16;
         const fh8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         *reinterpret_cast<fh8*>(G + e) = zero;
         *reinterpret_cast<fh8*>(G + S::GPART + e) = zero;
     }
     __syncthreads();
 
-    // ---- P4: the 1x1 chain, in place on G
+    // ---- P4: the 1x1 chain, in place on G.  A block = 32 pixels: columns n of the MFMA carry pixels 32 b + n (k-groups 0, 1 = its h1, h2)
+    //      and 32 b + 16 + n (k-groups 2, 3); rows 0-7 are the filters at the first pixel, rows 8-15 the same filters at the second:
+    //      every lane ends up with half a granule to write.  Two instructions per layer: [w1 | w1 2^-11] . [h1 ; h2] and [w2 | 0] . [h1 ; h2].
+    //      A wave runs its (up to four) blocks layer by layer, so that four independent read -> MFMA -> split -> write chains overlap.
     {
-        fh8 A[3];
+        fh8 A[3][2];
         ff4 sc[3];
         const float us[3] = {un0 * pre1, un1 * pre2, un2 * pre3};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            A[i] = *reinterpret_cast<const fh8*>(sp.wchain + (i * 64 + lane) * 8);
+            A[i][0] = *reinterpret_cast<const fh8*>(sp.wchain + ((i * 2 + 0) * 64 + lane) * 8);
+            A[i][1] = *reinterpret_cast<const fh8*>(sp.wchain + ((i * 2 + 1) * 64 + lane) * 8);
             sc[i] = *reinterpret_cast<const ff4*>(sp.tab + 8 + 8 * i + 4 * (kq & 1)) * us[i];
         }
-        for (int b = wave; b < S::NBLK4; b += 8) {
-            const int px = 16 * b + l15;
-            unsigned char* const gp = G + px * 16;
-            const int rd = (kq == 2 ? S::GPART : 0);
-            const int pr = px / S::FWP, pc = px - pr * S::FWP;
-            const bool in = f_interior || (YF + pr >= 0 && YF + pr < H && XF + pc >= 0 && XF + pc < W);
+        constexpr int NU = (S::NBLK4 + 7) / 8;
+        unsigned char* gp[NU];
+        bool in[NU];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const fh8 bv = *reinterpret_cast<const fh8*>(gp + rd);
-                ff4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[i], bv, (ff4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                d *= sc[i];
-                ff4 v = {s2d_stage_lrelu(d[0], sp.slope), s2d_stage_lrelu(d[1], sp.slope), s2d_stage_lrelu(d[2], sp.slope), s2d_stage_lrelu(d[3], sp.slope)};
-                if (i == 2 && !in) v = (ff4){0.f, 0.f, 0.f, 0.f};   // zero padding of the 3x3 conv's input
-                fh4 h1, h2;
-                fr_split4(v, h1, h2);
-                if (kq < 2) {
-                    *reinterpret_cast<fh4*>(gp + kq * 8) = h1;
-                    *reinterpret_cast<fh4*>(gp + S::GPART + kq * 8) = h2;
+        for (int u = 0; u < NU; ++u) {
+            const int px = 32 * (wave + 8 * u) + 16 * (kq >> 1) + l15;
+            gp[u] = G + px * 16;
+            const int pr = px / S::FWP, pc = px - pr * S::FWP;
+            in[u] = f_interior || (YF + pr >= 0 && YF + pr < H && XF + pc >= 0 && XF + pc < W);
+        }
+        const int rd = (kq & 1) * S::GPART, wr = (kq & 1) * 8;
+        const int nblk = (sp.dbg & 4) ? 0 : S::NBLK4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (wave + 8 * u < nblk) {   // wave-uniform
+                    const fh8 bv = *reinterpret_cast<const fh8*>(gp[u] + rd);
+                    ff4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[i][0], bv, (ff4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[i][1], bv, d, 0, 0, 0);
+                    d *= sc[i];
+                    ff4 v = {s2d_stage_lrelu(d[0], sp.slope), s2d_stage_lrelu(d[1], sp.slope), s2d_stage_lrelu(d[2], sp.slope), s2d_stage_lrelu(d[3], sp.slope)};
+                    if (i == 2 && !in[u]) v = (ff4){0.f, 0.f, 0.f, 0.f};   // zero padding of the 3x3 conv's input
+                    fh4 h1, h2;
+                    fr_split4(v, h1, h2);
+                    *reinterpret_cast<fh4*>(gp[u] + wr) = h1;
+                    *reinterpret_cast<fh4*>(gp[u] + S::GPART + wr) = h2;
                 }
-                // the next layer's fh8 read of this granule must stay behind these fh4 writes (other lanes of the wave wrote half of
-                // it: the LDS keeps a wave's accesses in order, the compiler is told here)
-                asm volatile("" ::: "memory");
             }
+            // the next layer's fh8 reads of these granules must stay behind the fh4 writes (another lane of the wave wrote the other
+            // half: the LDS keeps a wave's accesses in order, the compiler is told here -- it may otherwise reorder accesses of
+            // different vector types)
+            asm volatile("" ::: "memory");
         }
     }
     __syncthreads();
@@ -300,7 +318,13 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
         const ff4 inv = *reinterpret_cast<const ff4*>(sp.tab + 32 + 4 * (kq & 1));
         const ff4 scF = inv * (un3 * preI), scR = inv * (un0 * preI);
         unsigned char* const IN = smem + off_in;
-        for (int b = wave; b < S::NBLK5; b += 8) {
+        // a wave's (up to three) blocks as straight-line code: their fragment reads and MFMAs interleave; a wave without a third block
+        // repeats the last one (same values to the same addresses)
+        constexpr int NU5 = (S::NBLK5 + 7) / 8;
+        if (!(sp.dbg & 8))
+#pragma unroll
+        for (int u = 0; u < NU5; ++u) {
+            const int b = min(wave + 8 * u, S::NBLK5 - 1);
             const int qq = 16 * b + l15;
             const bool valid = qq < S::NPAIRS;
             const int qc = valid ? qq : S::NPAIRS - 1;

@@ -338,8 +338,9 @@ class _KnobSwitch:
     environment (ops.knob: at load time and on ops.reload_env(), like the C side's own switches) -- or unless the attribute
     was assigned on the instance (tests, tools)."""
 
-    def __init__(self, *names):
+    def __init__(self, *names, enable=None):
         self.names = names
+        self.enable = enable      # an opt-IN variable: the switch is ON only when it is set (and no KBN_NO_* name is)
 
     def __set_name__(self, owner, name):
         self.attr = "_force_" + name
@@ -348,7 +349,9 @@ class _KnobSwitch:
         if obj is None:
             return self
         forced = obj.__dict__.get(self.attr)
-        return forced if forced is not None else all(ops.knob(n) == 0 for n in self.names)
+        if forced is not None:
+            return forced
+        return all(ops.knob(n) == 0 for n in self.names) and (self.enable is None or ops.knob(self.enable) != 0)
 
     def __set__(self, obj, value):
         obj.__dict__[self.attr] = None if value is None else bool(value)
@@ -650,6 +653,10 @@ class KBNetEncoder(torch.nn.Module):
 
     # conv_image of KB levels 1 and 2 as ops.PairTensor for the next level's split convs (KBN_NO_PAIR=1 / KBN_NO_PAIR_ENC=1: fp32 tensors)
     pair_chain = _KnobSwitch("KBN_NO_PAIR", "KBN_NO_PAIR_ENC")
+    # S2D -> conv0_depth -> level-0 conv_depth (+ xyz) as ONE launch (ops.s2d_depth_front, csrc/s2d_stage.h).  OPT-IN
+    # (KBN_DEPTH_FRONT_FUSION=1 or `encoder.fuse_s2d = True`): measured inside the forward it is level with the two launches it
+    # replaces -- it removes their 0.9 GB HBM round trip of the S2D tensor, not time
+    fuse_s2d = _KnobSwitch("KBN_NO_DEPTH_FRONT_FUSION", enable="KBN_DEPTH_FRONT_FUSION")
 
     def __init__(self, input_channels_image=3, input_channels_depth=1,
                  n_filters_image=[48, 96, 192, 384, 384], n_filters_depth=[16, 32, 64, 128, 128],
@@ -695,8 +702,8 @@ class KBNetEncoder(torch.nn.Module):
         self.skip_unused_image = False
         self._packed_front = _PackedFront()
         self._packed_depth_front = _PackedFront(ops.pack_kb1_depth_front_weight)
-        # S2D -> conv0_depth -> level-0 conv_depth (+ xyz) as ONE launch (ops.s2d_depth_front, csrc/s2d_stage.h): KBNetModel.forward
-        # hands encode() the S2D module and its input instead of the S2D tensor (KBN_NO_DEPTH_FRONT_FUSION=1: two launches)
+        # the blob of the on-chip S2D stage (`fuse_s2d`): KBNetModel.forward hands encode() the S2D module and its input instead of the
+        # S2D tensor, and _front decides where the layer runs
         self._packed_s2d_front = _PackedFront(lambda a, b, c, d, out=None: ops.pack_s2d_depth_front_weight([a, b, c], d, out=out))
 
     def _front(self, image, depth, kinv, stats, s2d=None):
@@ -734,7 +741,7 @@ class KBNetEncoder(torch.nn.Module):
         packed_d = self._packed_depth_front.get(c0d.conv.weight, cd.conv.weight, blk.proj_depth.conv.weight) if depth_front_ok else None
         if depth is None:
             s2d_mod, s2d_x = s2d
-            if (packed_d is not None and s2d_x.shape[1] == 2 and _dense(s2d_x) and len(s2d_mod.pool_convs) == 3
+            if (self.fuse_s2d and packed_d is not None and s2d_x.shape[1] == 2 and _dense(s2d_x) and len(s2d_mod.pool_convs) == 3
                     and ops.s2d_depth_front_supported(s2d_x.shape[1], s2d_mod.min_pool_sizes, s2d_mod.max_pool_sizes, len(s2d_mod.pool_convs),
                                                       s2d_mod.conv.out_channels, c0d.out_channels, cd.out_channels, h, w, s2d_mod._slope, c0d._slope)):
                 packed_s = self._packed_s2d_front.get(*[c.conv.weight for c in s2d_mod.pool_convs], s2d_mod.conv.conv.weight)

@@ -1060,7 +1060,7 @@ def s2d_depth_front(x: torch.Tensor, kinv: torch.Tensor, packed_s2d: torch.Tenso
     flops = 2.0 * n * (h * w * (npool * nf + 2 * nf * nf + 9 * (nf + c) * nf + nf * 9 * conv0_filters)
                        + oh * ow * ((conv0_filters + 3) * 9 * kb_filters + conv0_filters))
     tiles = n * (-(-oh // 8)) * (-(-ow // 16))
-    executed = tiles * (53 * 3 + 22 * 12 + 36 * 9 + 8 * 15) * 2.0 * 16 * 16 * 32   # chain, 3x3 pairs, conv0, conv_depth: MFMAs of 16 x 16 x 32 per tile
+    executed = tiles * (27 * 6 + 22 * 12 + 36 * 9 + 8 * 15) * 2.0 * 16 * 16 * 32   # chain, 3x3 pairs, conv0, conv_depth: MFMAs of 16 x 16 x 32 per tile
     amin, amax = _int_array(mins), _int_array(maxs)
     status = _launch("s2d_depth_front", flops,
                      lambda: lib.kbn_s2d_depth_front_forward(xptr, xbs, kinv.data_ptr(), packed_s2d.data_ptr(), packed_weight.data_ptr(), optr, obs,

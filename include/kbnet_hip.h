@@ -48,7 +48,7 @@ void kbn_reload_env(void);
 
 /* Value of a KBN_* switch AS THE LIBRARY READ IT (at load time / the last kbn_reload_env()): 0 when unset or unknown.  The
  * host mirror asks here instead of reading the environment itself, so its A/B switches (KBN_NO_SPLIT, KBN_NO_PAIR,
- * KBN_NO_PAIR_MID, KBN_NO_PAIR_ENC, KBN_NO_PAIR_TAIL, KBN_NO_OVERLAP, KBN_NO_DEPTH_FRONT_FUSION, KBN_NO_TAIL_FUSION,
+ * KBN_NO_PAIR_MID, KBN_NO_PAIR_ENC, KBN_NO_PAIR_TAIL, KBN_NO_OVERLAP, KBN_DEPTH_FRONT_FUSION, KBN_NO_DEPTH_FRONT_FUSION,
  * KBN_FP16_ONE_TERM) change together with the library's. */
 int kbn_knob(const char* name);
 

@@ -1126,8 +1126,8 @@ def test_s2d_depth_front_kernel(dev, preset, hw, zmag, density):
 
 
 def test_forward_with_and_without_depth_front_fusion(dev, kenv):
-    """KBNetModel.forward runs S2D inside the depth front's launch by default; KBN_NO_DEPTH_FRONT_FUSION=1 restores the two launches.
-    Same launches otherwise, results within single-op noise of each other, both within the gate of the oracle."""
+    """KBN_DEPTH_FRONT_FUSION=1 (or encoder.fuse_s2d = True) makes KBNetModel.forward run S2D inside the depth front's launch; the
+    default is the two launches.  Same launches otherwise, results within single-op noise of each other, both within the gate of the oracle."""
     cfg = kb.kitti_config()
     sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.3)
     frames = kb.synthetic.make_frames(2, 96, 160, "kitti", seed=5, jitter_intrinsics=0.1)
@@ -1142,9 +1142,12 @@ def test_forward_with_and_without_depth_front_fusion(dev, kenv):
             kb.ops.PROFILE = None
         return out, [r[0] for r in names]
 
-    fused, names_f = run()
-    kenv.setenv("KBN_NO_DEPTH_FRONT_FUSION", "1")
     plain, names_p = run()
+    kenv.setenv("KBN_DEPTH_FRONT_FUSION", "1")
+    fused, names_f = run()
+    kenv.setenv("KBN_NO_DEPTH_FRONT_FUSION", "1")     # the NO_ switch wins
+    off_again, names_o = run()
+    assert names_o == names_p and torch.equal(off_again, plain)
     assert "s2d_depth_front" in names_f and "s2d" not in names_f and "kb1_depth_front" not in names_f
     assert "s2d" in names_p and "kb1_depth_front" in names_p and "s2d_depth_front" not in names_p
     assert len(names_f) == len(names_p) - 1
