@@ -1125,12 +1125,13 @@ def test_s2d_depth_front_kernel(dev, preset, hw, zmag, density):
             assert rel_err(got[i], r32[i]) < TIGHT, (name, i)
 
 
-def test_forward_with_and_without_depth_front_fusion(dev, kenv):
+@pytest.mark.parametrize("preset,shape", [("kitti", (96, 160)), ("void", (96, 128)), ("nyu_v2", (70, 100))])
+def test_forward_with_and_without_depth_front_fusion(dev, kenv, preset, shape):
     """KBN_DEPTH_FRONT_FUSION=1 (or encoder.fuse_s2d = True) makes KBNetModel.forward run S2D inside the depth front's launch; the
     default is the two launches.  Same launches otherwise, results within single-op noise of each other, both within the gate of the oracle."""
-    cfg = kb.kitti_config()
+    cfg = kb.PRESETS[preset]()
     sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.3)
-    frames = kb.synthetic.make_frames(2, 96, 160, "kitti", seed=5, jitter_intrinsics=0.1)
+    frames = kb.synthetic.make_frames(2, *shape, preset, seed=5, jitter_intrinsics=0.1)
     m = kb.modules.KBNetModel.from_config(cfg, dev)
     m.load_state_dicts(*sds)
 
