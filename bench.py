@@ -278,6 +278,39 @@ def setup_ranks(gpus: int, backend: str):
     return rank, local_rank, world, dev
 
 
+def mixed_stream_rate(dev, rank, world, frames_per_shape=8, reps=8):
+    """BASELINE configs[4] in miniature on the ranks of this run: an interleaved stream of VOID 480x640 and NYUv2 416x576 frames (VOID
+    preset) and KITTI 352x1216 frames (KITTI preset) with per-frame intrinsics (+-10 %), two weight sets resident, one captured graph per
+    shape; every shape bucket is split over the ranks (dist.shard_bounds) and gathered by its own all-gather
+    (ShardedRunner.step_mixed).  Returns frames/s of the round-robin stream (tools/mixed_stream_bench.py is the stand-alone form)."""
+    b = frames_per_shape * world
+    models, replay = {}, {}
+    for preset in ("kitti", "void"):
+        cfg = kb.PRESETS[preset]()
+        m = kb.modules.KBNetModel.from_config(cfg, dev)
+        m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+        models[preset] = m
+    stream = [("void", "void", (480, 640)), ("void", "nyu_v2", (416, 576)), ("kitti", "kitti", (352, 1216))]
+    for preset, stats, shape in stream:
+        frames = kb.synthetic.make_frames(b, *shape, stats, seed=3, jitter_intrinsics=0.1)
+        lo, hi = kb.dist.shard_bounds(b, rank, world)
+        if hi > lo:
+            replay[shape] = models[preset].capture(*[f[lo:hi].to(dev) for f in frames])
+    runner = kb.dist.ShardedRunner(None, rank, world)
+    buckets = [(replay.get(shape), replay[shape].static_in if shape in replay else None, b, (1,) + shape) for _, _, shape in stream]
+    runner.step_mixed(buckets)
+    torch.cuda.synchronize()
+    kb.dist.barrier()
+    t = time.perf_counter()
+    for _ in range(reps):
+        outs = runner.step_mixed(buckets)
+    torch.cuda.synchronize()
+    kb.dist.barrier()
+    dt = kb.dist.max_over_ranks(time.perf_counter() - t, dev)
+    assert all(o.shape[0] == b for o in outs)
+    return reps * len(stream) * b / dt
+
+
 def standin_forward(image, sparse, valid, k):
     """Frame-independent stand-in for the HIP forward (plumbing tests: KBN_BENCH_TEST_BACKEND=gloo)."""
     return image.mean(1, keepdim=True) + sparse + valid * k[:, 0, 0].view(-1, 1, 1, 1)
@@ -350,6 +383,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                     help="with --gpus N > 1: also run the side measurements (VOID, batch 8, bf16 / fp16 legs, fp32-MFMA-only, "
                          "unused conv); by default an N-rank run is the timed region plus rank 0's roofline pass")
     ap.add_argument("--no-fp16", action="store_true", help="skip the throughput-only one-term fp16 leg (configs[2])")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-shape stream side measurement (configs[4] in miniature)")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -360,7 +394,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
 
     rank, local_rank, world, dev = setup_ranks(args.gpus, backend)
     if world > 1 and not args.side:
-        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = True
+        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = args.no_mixed = True
     per = args.frames_per_gpu
     # rank r holds frames [r*per, (r+1)*per) of the global batch (seed 1+rank; frame 0 of
     # rank 0 is the frame the CPU oracle sees)
@@ -570,6 +604,11 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         finally:
             model.encoder.skip_unused_image = False
 
+    # BASELINE configs[4] in miniature (8 frames of each of three shapes per rank and step, two weight sets, per-frame intrinsics)
+    mixed_fps = None
+    if not args.no_mixed and not args.eager:
+        mixed_fps = mixed_stream_rate(dev, rank, world)
+
     ms_per_step = 1e3 * elapsed / args.steps
     fps = per * world * args.steps / elapsed
     gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
@@ -663,7 +702,10 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    # side measurement: BASELINE configs[2]'s bf16 leg -- throughput only, never `value` (see above)
                    "bf16_leg": bf16_leg,
                    # side measurement: the tuned split kernels in one-term mode (fp16 h1 w1 alone) -- throughput only
-                   "fp16_one_term_leg": fp16_leg},
+                   "fp16_one_term_leg": fp16_leg,
+                   # side measurement: BASELINE configs[4] in miniature -- VOID 480x640 / NYUv2 416x576 / KITTI 352x1216 round robin, 8 frames of
+                   # each per rank and step, per-frame intrinsics, two weight sets resident, one graph per shape, one gather per shape bucket
+                   "mixed_shape_stream_frames_per_s": None if mixed_fps is None else round(mixed_fps, 1)},
         "roofline": roofline, "kernels": breakdown,
     })
 
