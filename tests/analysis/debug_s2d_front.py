@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Debug aid for kbn_s2d_depth_front_forward: with conv0_depth / conv_depth set to centre-tap identities the launch returns the
+"""Debug aid for kbn_s2d_depth_front_forward (lives under tests/ because it runs the oracle): with conv0_depth / conv_depth set to centre-tap identities the launch returns the
 on-chip S2D tensor at the even pixels (through two LeakyReLUs, undone here); compared channel by channel with the oracle's S2D."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import kbnet_amd as kb
 from oracle import kbnet_oracle as orc
