@@ -74,7 +74,7 @@ enum Knob {
     KNOB_NO_HEAD_FUSION, KNOB_NO_SPLIT,
     // switches of the host mirror (modules.py asks kbn_knob(): one reading of the environment for both sides)
     KNOB_NO_OVERLAP, KNOB_NO_PAIR, KNOB_NO_PAIR_MID, KNOB_NO_PAIR_ENC, KNOB_NO_PAIR_TAIL, KNOB_NO_DEPTH_FRONT_FUSION,
-    KNOB_NO_TAIL_FUSION, KNOB_FP16_ONE_TERM, KNOB_DEPTH_FRONT_FUSION, KNOB_COUNT
+    KNOB_FP16_ONE_TERM, KNOB_DEPTH_FRONT_FUSION, KNOB_COUNT
 };
 struct KnobValue { int set, value; };
 extern KnobValue g_knobs[KNOB_COUNT];

@@ -157,3 +157,60 @@ def test_paired_planes_recognises_only_the_two_planes_of_one_buffer():
     a2, b2 = two[:70].view(2, 1, 5, 7), two[70:].view(2, 1, 5, 7)
     assert modules.paired_planes(a2, b2) is None               # two frames each, back to back: not the paired layout
     assert modules.paired_planes(sd.double(), vm.double()) is None
+
+
+def test_host_switches_follow_the_library_reading_of_the_environment(monkeypatch):
+    """the host mirror's A/B switches (KBN_NO_PAIR*, KBN_NO_OVERLAP, KBN_DEPTH_FRONT_FUSION ...) used to be read from
+    os.environ at import / construction time, while the C side's switches follow kbn_reload_env().  They now ask the library
+    (kbn_knob): one reading of the environment for both sides, refreshed together; an attribute assignment still overrides."""
+    enc = kb.modules.KBNetEncoder(3, 8, resolutions_backprojection=[0, 1, 2, 3], weight_initializer="xavier_normal")
+    dec = kb.modules.MultiScaleDecoder(512, 1, 1, [256, 128, 128, 64, 12], [512, 256, 128, 64, 0], "xavier_normal")
+    for name in ("KBN_NO_PAIR", "KBN_NO_PAIR_ENC", "KBN_NO_PAIR_MID", "KBN_NO_PAIR_TAIL", "KBN_DEPTH_FRONT_FUSION", "KBN_NO_DEPTH_FRONT_FUSION",
+                 "KBN_NO_SPLIT", "KBN_FP16_ONE_TERM"):
+        monkeypatch.delenv(name, raising=False)
+    kb.ops.reload_env()
+    try:
+        assert enc.pair_chain and dec.pair_chain and dec.pair_tail and dec.deconv4.pair_mid and kb.ops.split_enabled()
+        assert not enc.fuse_s2d, "the S2D-in-the-depth-front fusion is opt-in"
+        monkeypatch.setenv("KBN_NO_PAIR", "1")
+        assert enc.pair_chain, "the environment alone changes nothing: the library read it at load time"
+        kb.ops.reload_env()
+        assert not enc.pair_chain and not dec.pair_chain and dec.pair_tail
+        monkeypatch.delenv("KBN_NO_PAIR")
+        monkeypatch.setenv("KBN_NO_PAIR_ENC", "1")
+        monkeypatch.setenv("KBN_DEPTH_FRONT_FUSION", "1")
+        kb.ops.reload_env()
+        assert not enc.pair_chain and dec.pair_chain and enc.fuse_s2d
+        monkeypatch.setenv("KBN_NO_DEPTH_FRONT_FUSION", "1")
+        kb.ops.reload_env()
+        assert not enc.fuse_s2d, "the NO_ switch wins over the opt-in"
+        enc.fuse_s2d = True
+        assert enc.fuse_s2d, "an assignment overrides the environment"
+        enc.fuse_s2d = None
+        assert not enc.fuse_s2d
+        assert kb.ops.knob("KBN_NO_SUCH_SWITCH") == 0
+    finally:
+        monkeypatch.undo()
+        kb.ops.reload_env()
+
+
+def test_front_queries_answer_without_a_gpu():
+    """The eligibility queries the host mirror asks before it launches anything of level 0 (kbn_kb1_front_query,
+    kbn_kb1_depth_front_query, kbn_s2d_depth_front_query) are pure host logic."""
+    assert kb.ops.kb1_front_supported(3, 48, 48, 352, 1216, 0.2)
+    assert not kb.ops.kb1_front_supported(3, 32, 48, 352, 1216, 0.2), "only KBNet's 48 / 48 filters"
+    assert not kb.ops.kb1_front_supported(3, 48, 48, 352, 1216, 1.5), "LeakyReLU as max(t, slope t) needs a slope in [0, 1]"
+    assert kb.ops.kb1_front_supported(8, 16, 16, 352, 1216, 0.2, depth_branch=True)
+    kitti, void = kb.kitti_config(), kb.void_config()
+    assert kb.ops.s2d_depth_front_supported(2, kitti.min_pools, kitti.max_pools, 3, 8, 16, 16, 352, 1216, 0.2, 0.2)
+    assert kb.ops.s2d_depth_front_supported(2, void.min_pools, void.max_pools, 3, 8, 16, 16, 480, 640, 0.2, 0.2)
+    assert not kb.ops.s2d_depth_front_supported(2, [3, 5], [7], 3, 8, 16, 16, 64, 64, 0.2, 0.2), "only the compiled pool presets"
+    assert not kb.ops.s2d_depth_front_supported(1, kitti.min_pools, kitti.max_pools, 3, 8, 16, 16, 352, 1216, 0.2, 0.2)
+    os.environ["KBN_NO_SPLIT"] = "1"
+    kb.ops.reload_env()
+    try:
+        assert not kb.ops.kb1_front_supported(3, 48, 48, 352, 1216, 0.2)
+        assert not kb.ops.s2d_depth_front_supported(2, kitti.min_pools, kitti.max_pools, 3, 8, 16, 16, 352, 1216, 0.2, 0.2)
+    finally:
+        del os.environ["KBN_NO_SPLIT"]
+        kb.ops.reload_env()
