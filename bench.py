@@ -719,6 +719,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         result["cpu_baseline"] = None   # rank 0 at N = 1 only (the contract): the host cores are shared by all ranks
     emit(result, rank)
     if world > 1:
+        kb.dist.barrier()   # ranks leave together (rank 0 printed its line; nobody tears the group down under a peer's collective)
         torch.distributed.destroy_process_group()
     return result
 
