@@ -16,11 +16,13 @@ BASELINE.json configs[3]'s per-GPU share of its 256 frames and configs[2]'s sing
 fp32; the batch-8 rate of configs[1] is reported as a side field); there is no other collective on
 the data path.  Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around
 every launch of the dominant kernel (the MFMA conv variant with the largest total time):
-`achieved` / `frac` are the FLOPs of the MFMA instructions the kernel ISSUES (padding that is
-issued included, skipped padding not: the figure SQ_INSTS_MFMA x 32768 of the PMC collection gives)
-over the pipe's peak -- never above 1; `useful_frac` prices only the reference's multiply-adds (x 3
-fp16 products each for the split-operand kernels) and `algorithmic` carries the reference-formulation
-FLOPs the same launches are worth;
+`achieved` / `frac` are the ALGORITHMIC FLOPs of its launches (the reference's direct-conv
+formulation, 2 * N * Hout * Wout * Cin * 9 * Cout) over their time and over the dense peak of the pipe
+its MFMAs run on; a split-operand kernel takes three fp16 products per fp32 product, so its ceiling is
+1/3 (`ceiling_frac`); `issued` carries the FLOPs of the MFMA instructions it really issues (padding that
+is issued included: the figure SQ_INSTS_MFMA x 32768 of the PMC collection gives);
+`config.sustained` repeats the timed region for >= 300 steps and >= 3 s (and replaces `value` when it is
+more than 3 % lower), `config.batch1` is the graph-replayed latency of one frame;
 `cpu_baseline` times the CPU oracle (the port of the reference, bit-identical to it) on
 this box's host cores over a bounded sample.
 """
@@ -51,6 +53,43 @@ FP16_MFMA_PEAK_TFLOPS = kb.ops.PIPE_PEAK_TFLOPS["fp16"]  # MI355X_MICROARCH.md: 
 SPLIT_KERNELS = {"conv_split": "conv3x3_split_kernel<0, 8,", "conv_split_up": "conv3x3_split_kernel<1, 8,",
                  "conv_split_s2": "conv3x3_split_kernel<2, 2,", "conv_split_upfold": "upconv2x_split_kernel"}
 HBM_PEAK_GBS = 8000.0
+# switches that take the forward off the parity-gated path (throughput-only arithmetic) or off the shipped kernels
+NON_PARITY_KNOBS = ("KBN_FP16_ONE_TERM", "KBN_NO_SPLIT")
+README_KITTI_MS_PER_FRAME = 15.19   # reference README.md:232 (batch 1, its GPU, preprocessing included, no device sync)
+
+
+class knob_env:
+    """`with knob_env("KBN_NO_SPLIT"):` sets a KBN_* switch to 1 for a side leg and puts the caller's value (or its absence) back."""
+
+    def __init__(self, name, value="1"):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = os.environ.get(self.name)
+        os.environ[self.name] = self.value
+        kb.ops.reload_env()
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.old
+        kb.ops.reload_env()
+        return False
+
+
+def replay_rate(replay, inputs, reps, warm, frames, world, dev):
+    """frames/s of `reps` graph replays between barriers + synchronises (MAX over ranks)."""
+    for _ in range(warm):
+        replay(*inputs)
+    torch.cuda.synchronize()
+    kb.dist.barrier()
+    t = time.perf_counter()
+    for _ in range(reps):
+        out = replay(*inputs)
+    torch.cuda.synchronize()
+    kb.dist.barrier()
+    return frames * world * reps / kb.dist.max_over_ranks(time.perf_counter() - t, dev), out
 
 
 def summarise_profile(prof, steps):
@@ -104,7 +143,7 @@ def pipe_seconds(groups):
     """Seconds the issued MFMA FLOPs of every group would take at the dense peak of the pipe they run on."""
     return sum(g["executed"] / (kb.ops.PIPE_PEAK_TFLOPS[g["pipe"]] * 1e12) for g in groups.values()
                if g["pipe"] is not None and g["has_executed"] and g["executed"] > 0)
-WEIGHT_GAIN = 1.3  # keeps random-weight logits O(1) so the sigmoid head is off saturation
+WEIGHT_GAIN = kb.synthetic.PARITY_GAIN["kitti"]  # logits std ~ 1: the sigmoid head is exercised over its range (synthetic.PARITY_GAIN)
 
 
 def conv_gflop_per_frame(cfg, h, w):
@@ -288,7 +327,7 @@ def mixed_stream_rate(dev, rank, world, frames_per_shape=8, reps=8):
     for preset in ("kitti", "void"):
         cfg = kb.PRESETS[preset]()
         m = kb.modules.KBNetModel.from_config(cfg, dev)
-        m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+        m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN[preset]))
         models[preset] = m
     stream = [("void", "void", (480, 640)), ("void", "nyu_v2", (416, 576)), ("kitti", "kitti", (352, 1216))]
     for preset, stats, shape in stream:
@@ -368,8 +407,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         HEIGHT, WIDTH = 16, 24
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-void", action="store_true", help="skip the VOID 480x640 side measurement")
@@ -384,6 +423,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                          "unused conv); by default an N-rank run is the timed region plus rank 0's roofline pass")
     ap.add_argument("--no-fp16", action="store_true", help="skip the throughput-only one-term fp16 leg (configs[2])")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-shape stream side measurement (configs[4] in miniature)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step / >= 3 s sustained-rate run")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the batch-1 latency side measurement")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -393,8 +434,15 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         raise SystemExit(self_spawn(argv, args.gpus, backend))
 
     rank, local_rank, world, dev = setup_ranks(args.gpus, backend)
+    if forward_factory is None:
+        # `value` is the parity-gated fp32 path: a caller's environment must not turn the timed region into one of the A/B or
+        # throughput-only modes the side legs below switch on for themselves
+        bad = [k for k in NON_PARITY_KNOBS if kb.ops.knob(k) != 0]
+        if bad:
+            raise SystemExit(f"bench.py: {', '.join(bad)} set in the environment -- the timed region would not be the parity-gated "
+                             "path; unset it (the bench runs those modes itself as side legs)")
     if world > 1 and not args.side:
-        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = args.no_mixed = True
+        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = args.no_mixed = args.no_batch1 = True
     per = args.frames_per_gpu
     # rank r holds frames [r*per, (r+1)*per) of the global batch (seed 1+rank; frame 0 of
     # rank 0 is the frame the CPU oracle sees)
@@ -422,7 +470,9 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     # The forward of this batch shape is captured once into a HIP graph; a step replays it (same
     # kernels, no per-launch host round trips).  --eager times the plain launch sequence instead.
     # --branches: concurrent sub-batches inside the graph (default: 2 for even batches >= 4, see GraphedForward)
-    forward = model.forward if args.eager else model.capture(*frames, branches=args.branches or None)
+    # outputs=2: the graph writes two alternating output tensors, so the asynchronous all-gather of step i reads the graph's own
+    # output while step i+1's forward runs -- no staging copy inside the step (dist.ShardedRunner.step_pipelined)
+    forward = model.forward if args.eager else model.capture(*frames, branches=args.branches or None, outputs=2)
     runner = kb.dist.ShardedRunner(forward, rank, world)
     # Inputs live where the graph reads them (its static input tensors, filled once here): a producer such as
     # loader.InferenceFrameLoader writes there directly, so a step has no input copy.  Eager mode: the frames.
@@ -430,6 +480,15 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
 
     elapsed, out = timed_steps(runner, step_inputs, args.steps, args.warmup, dev)
     out = out.clone()
+
+    # Sustained rate: the SAME runner and graph for at least 300 more steps and at least 3 s (the part is power-capped: clocks settle
+    # over seconds, and K = 50 steps is half a second).  Reported beside `value`; if it falls more than 3 % below, it REPLACES `value`.
+    sustained = None
+    if not args.eager and not args.no_sustained:
+        ms = 1e3 * elapsed / args.steps
+        n_sus = max(300, int(3000.0 / ms) + 1)
+        sus_elapsed, _ = timed_steps(runner, step_inputs, n_sus, 0, dev)
+        sustained = {"frames_per_s": round(per * world * n_sus / sus_elapsed, 1), "steps": n_sus, "seconds": round(sus_elapsed, 3)}
 
     # Per-kernel durations for the roofline: the same K steps launched eagerly, every ABI call
     # bracketed by HIP events on the launch stream (graph nodes cannot be timed individually).
@@ -462,64 +521,60 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     if not args.no_void:
         vcfg = kb.void_config()
         vmodel = kb.modules.KBNetModel.from_config(vcfg, dev)
-        vmodel.load_state_dicts(*kb.synthetic.make_state_dicts(vcfg, seed=0, gain=1.45))
+        vmodel.load_state_dicts(*kb.synthetic.make_state_dicts(vcfg, seed=0, gain=kb.synthetic.PARITY_GAIN["void"]))
         vframes = [f.to(dev) for f in kb.synthetic.make_frames(per, 480, 640, "void", seed=1)]
         vreplay = vmodel.capture(*vframes)
-        for _ in range(3):
-            vreplay(*vframes)
-        torch.cuda.synchronize()
-        kb.dist.barrier()
-        t3 = time.perf_counter()
-        for _ in range(10):
-            vreplay(*vframes)
-        torch.cuda.synchronize()
-        kb.dist.barrier()
-        # all ranks run their 8 frames at the same time: whole-job rate = frames of all ranks / slowest rank's time
-        void_fps = per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t3, dev)
+        # all ranks run their frames at the same time: whole-job rate = frames of all ranks / slowest rank's time
+        void_fps, _ = replay_rate(vreplay, vreplay.static_in, 10, 3, per, world, dev)
         del vreplay, vmodel, vframes
 
     # configs[1] (batch 8 per GPU, the round-1 headline) as a side measurement on the same weights
     side_fps = None
     if not args.no_side_batch and per != SIDE_BATCH:
-        sframes = [f[:SIDE_BATCH].contiguous() for f in frames]
-        sreplay = model.capture(*sframes)
-        for _ in range(3):
-            sreplay(*sreplay.static_in)
+        sreplay = model.capture(*[f[:SIDE_BATCH].contiguous() for f in frames])
+        side_fps, _ = replay_rate(sreplay, sreplay.static_in, 20, 3, SIDE_BATCH, world, dev)
+        del sreplay
+
+    # Batch-1 latency (graph replay of ONE frame, the encoder's level side branches on): the figure that sits beside the reference's
+    # README.md:232 "15.19 ms per KITTI sample" (its GPU, batch 1, its timed region src/kbnet.py:896-921 incl. the pre-model stage)
+    batch1 = None
+    if not args.no_batch1 and not args.eager:
+        one = [f[:1].contiguous() for f in frames]
+        oreplay = model.capture(*one)
+        rate1, _ = replay_rate(oreplay, oreplay.static_in, 200, 20, 1, 1, dev)
+        image255_1 = one[0] * 255.0
         torch.cuda.synchronize()
-        kb.dist.barrier()
-        t4 = time.perf_counter()
-        for _ in range(20):
-            sreplay(*sreplay.static_in)
+        t9 = time.perf_counter()
+        for _ in range(200):   # the reference's timed region: validity map + outlier removal + /255, then the forward
+            img1, valid1, _ = kb.ops.preprocess(image255_1, one[1])
+            oreplay(img1, one[1], valid1, one[3])
         torch.cuda.synchronize()
-        kb.dist.barrier()
-        side_fps = SIDE_BATCH * world * 20 / kb.dist.max_over_ranks(time.perf_counter() - t4, dev)
-        del sreplay, sframes
+        ref_region_ms = 1e3 * (time.perf_counter() - t9) / 200
+        batch1 = {"ms_per_frame": round(1e3 / rate1, 4), "reference_style_region_ms_per_frame": round(ref_region_ms, 4),
+                  "reference_readme_ms_per_frame": README_KITTI_MS_PER_FRAME,
+                  "note": "graph replay of one KITTI 352x1216 frame; the reference's 15.19 ms (README.md:232) is on its own GPU and "
+                          "includes the pre-model stage without a device sync: context, not a same-hardware comparison"}
+        del oreplay
 
     # BASELINE configs[2] asks for a bf16 figure: THROUGHPUT-ONLY leg, same weights / frames / batch, the wide 3x3 convs
     # (decoder + the encoder's stride-2 image convs: 92 % of the FLOPs) on bf16 MFMAs with fp32 accumulation
     # (csrc/conv_bf16.hip), everything else on the fp32 kernels.  Reported under its own key with its measured error; `value` / `dtype` stay the parity-gated fp32 path.
+    mine = out[rank * per:(rank + 1) * per]
     bf16_leg = None
     if not args.no_bf16 and not args.eager:
         model.set_bf16(True)
-        breplay = model.capture(*frames, branches=args.branches or None)
-        for _ in range(3):
-            breplay(*breplay.static_in)
-        torch.cuda.synchronize()
-        kb.dist.barrier()
-        t5 = time.perf_counter()
-        for _ in range(10):
-            bout = breplay(*breplay.static_in)
-        torch.cuda.synchronize()
-        kb.dist.barrier()
-        bfps = per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t5, dev)
-        rel = (bout - out[rank * per:(rank + 1) * per]).abs() / out[rank * per:(rank + 1) * per].abs()
-        bf16_leg = {"frames_per_s": round(bfps, 1), "scope": "3x3 convs with Cin % 16 == 0 per source (decoder up-convs and concat convs, stride-2 image convs "
-                                                                 "of the KB blocks, conv5) with bf16 MFMA operands, fp32 accumulation, fp32 NCHW tensors; "
-                                                                 "S2D, conv0, conv_depth / conv_fused of the KB blocks and the fused tail stay fp32",
-                    "max_rel_err_vs_fp32_path": float(rel.max()), "mean_rel_err_vs_fp32_path": float(rel.mean()),
-                    "parity_gated": False}
-        model.set_bf16(False)
-        del breplay, bout
+        try:
+            breplay = model.capture(*frames, branches=args.branches or None)
+            bfps, bout = replay_rate(breplay, breplay.static_in, 10, 3, per, world, dev)
+            rel = (bout - mine).abs() / mine.abs()
+            bf16_leg = {"frames_per_s": round(bfps, 1), "scope": "3x3 convs with Cin % 16 == 0 per source (decoder up-convs and concat convs, stride-2 image convs "
+                                                                     "of the KB blocks, conv5) with bf16 MFMA operands, fp32 accumulation, fp32 NCHW tensors; "
+                                                                     "S2D, conv0, conv_depth / conv_fused of the KB blocks and the fused tail stay fp32",
+                        "max_rel_err_vs_fp32_path": float(rel.max()), "mean_rel_err_vs_fp32_path": float(rel.mean()),
+                        "parity_gated": False}
+            del breplay, bout
+        finally:
+            model.set_bf16(False)
 
     # The one-term leg: the SAME tuned split / pair kernels issuing h1 w1 alone -- plain fp16 operands, fp32
     # accumulation, one MFMA instead of three, the h2 halves of the pair tensors not fetched (KBN_FP16_ONE_TERM=1: concat convs,
@@ -528,54 +583,25 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     # configs[2]'s 16-bit figure on the tuned kernels.  THROUGHPUT-ONLY: reported with its measured error, never `value`.
     fp16_leg = None
     if not args.no_fp16 and not args.eager:
-        os.environ["KBN_FP16_ONE_TERM"] = "1"
-        kb.ops.reload_env()
-        try:
+        with knob_env("KBN_FP16_ONE_TERM"):
             hreplay = model.capture(*frames, branches=args.branches or None)
-            for _ in range(3):
-                hreplay(*hreplay.static_in)
-            torch.cuda.synchronize()
-            kb.dist.barrier()
-            t8 = time.perf_counter()
-            for _ in range(10):
-                hout = hreplay(*hreplay.static_in)
-            torch.cuda.synchronize()
-            kb.dist.barrier()
-            hfps = per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t8, dev)
-            ref_out = out[rank * per:(rank + 1) * per]
-            hrel = (hout - ref_out).abs() / ref_out.abs()
+            hfps, hout = replay_rate(hreplay, hreplay.static_in, 10, 3, per, world, dev)
+            hrel = (hout - mine).abs() / mine.abs()
             fp16_leg = {"frames_per_s": round(hfps, 1),
                         "scope": "concat convs, 64-filter folded up-convs and stride-2 image convs (72 % of the step) with ONE fp16 MFMA per "
                                  "product (h1 w1: fp16 operands, fp32 accumulation), pair tensors read at 2 B / value; everything else as in `value`",
                         "max_rel_err_vs_fp32_path": float(hrel.max()), "mean_rel_err_vs_fp32_path": float(hrel.mean()),
                         "parity_gated": False}
             del hreplay, hout
-        finally:
-            del os.environ["KBN_FP16_ONE_TERM"]
-            kb.ops.reload_env()
 
     # The same forward with every conv on the fp32 MFMAs (KBN_NO_SPLIT=1: Winograd / 9-product up-convs / fused KB kernels,
     # round 2's v20 path): what the split-operand arithmetic buys, measured by the same driver run.
     fp32_only_fps = None
     if not args.no_fp32_mfma and not args.eager:
-        os.environ["KBN_NO_SPLIT"] = "1"
-        kb.ops.reload_env()
-        try:
+        with knob_env("KBN_NO_SPLIT"):
             freplay = model.capture(*frames, branches=args.branches or None)
-            for _ in range(3):
-                freplay(*freplay.static_in)
-            torch.cuda.synchronize()
-            kb.dist.barrier()
-            t6 = time.perf_counter()
-            for _ in range(10):
-                freplay(*freplay.static_in)
-            torch.cuda.synchronize()
-            kb.dist.barrier()
-            fp32_only_fps = per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t6, dev)
+            fp32_only_fps, _ = replay_rate(freplay, freplay.static_in, 10, 3, per, world, dev)
             del freplay
-        finally:
-            del os.environ["KBN_NO_SPLIT"]
-            kb.ops.reload_env()
 
     # Side figure, NOT the headline: the reference's graph computes one conv whose result nothing reads -- conv_image of the
     # last KB level (src/networks.py:475-523: conv5_image takes conv4_fused) -- and so does the timed forward above.
@@ -587,16 +613,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
             dreplay = model.capture(*frames, branches=args.branches or None)
             dout = dreplay(*dreplay.static_in)
             same_bits = bool(torch.equal(dout, forward(*frames)))
-            for _ in range(3):
-                dreplay(*dreplay.static_in)
-            torch.cuda.synchronize()
-            kb.dist.barrier()
-            t7 = time.perf_counter()
-            for _ in range(10):
-                dreplay(*dreplay.static_in)
-            torch.cuda.synchronize()
-            kb.dist.barrier()
-            dead_conv_fps = {"frames_per_s": round(per * world * 10 / kb.dist.max_over_ranks(time.perf_counter() - t7, dev), 1),
+            drate, _ = replay_rate(dreplay, dreplay.static_in, 10, 3, per, world, dev)
+            dead_conv_fps = {"frames_per_s": round(drate, 1),
                              "same_bits_as_timed_forward": same_bits,
                              "what": "conv_image of KB level 3 not launched (its output feeds nothing: reference src/networks.py:475-523); "
                                      "KBNetEncoder.skip_unused_image, off by default and in `value`"}
@@ -611,6 +629,13 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
 
     ms_per_step = 1e3 * elapsed / args.steps
     fps = per * world * args.steps / elapsed
+    value_source = f"{args.steps} timed steps"
+    if sustained is not None:
+        sustained["ratio_to_timed_steps"] = round(sustained["frames_per_s"] / fps, 4)
+        if sustained["frames_per_s"] < 0.97 * fps:   # the short region flattered the part: the sustained figure is the headline
+            value_source = f"sustained run of {sustained['steps']} steps (more than 3 % below the {args.steps} timed steps: {fps:.1f} frames/s)"
+            fps = sustained["frames_per_s"]
+            ms_per_step = 1e3 * per * world / fps
     gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
 
     # ---- roofline of the dominant kernel (this rank's launches; rank 0 prints) ----
@@ -621,29 +646,35 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     dom = max(conv_groups, key=lambda k: conv_groups[k]["seconds"])
     d = conv_groups[dom]
     dwork, dtime, dlaunch, dexec = d["work"], d["seconds"], d["launches"], d["executed"]
-    # `achieved`: FLOPs of the MFMA instructions the dominant kernel ISSUES (its launch plan minus the padding the kernel
-    # skips: ops.conv3x3_split_executed_flops agrees with SQ_INSTS_MFMA x 32768 of the PMC collection) per second;
-    # `frac` = achieved / peak of the pipe those MFMAs run on (carried by the launch record) and cannot exceed 1.
-    # `useful_frac`: only the reference's multiply-adds, at the three fp16 products each costs on this pipe.
-    # `algorithmic`: the same launches priced at the reference's direct-conv FLOPs (2 * N * Hout * Wout * Cin * 9 * Cout)
-    # -- fp32 work, which may exceed the fp32 peak.
-    achieved = dexec / dtime / 1e12
+    # SURVEY 8(d) / the bench contract: `achieved` = ALGORITHMIC FLOPs of the dominant kernel's launches (the reference's
+    # direct-conv formulation: 2 * N * Hout * Wout * Cin * 9 * Cout per launch) / their time, `peak` = the dense peak of the pipe its
+    # MFMAs run on, `frac` = achieved / peak.  A split-operand kernel spends `products_per_fp32_product` = 3 fp16 MFMA products on
+    # every fp32 product, so its `frac` cannot exceed `ceiling_frac` = 1/3.  What the kernel really ISSUES (3 x the products plus the
+    # tile padding it does not skip; = SQ_INSTS_MFMA x 32768 of the PMC collection) is reported beside it under `issued`.
     peak = kb.ops.PIPE_PEAK_TFLOPS[d["pipe"]]
     products = kb.ops.PIPE_PRODUCTS[d["pipe"]]
+    achieved = dwork / dtime / 1e12
+    issued = dexec / dtime / 1e12
     mfma_groups = [g for g in groups.values() if g["pipe"] is not None and g["has_executed"] and g["executed"] > 0]
     psec = pipe_seconds(groups)
+    alg_sec = sum(kb.ops.PIPE_PRODUCTS[g["pipe"]] * g["work"] / (kb.ops.PIPE_PEAK_TFLOPS[g["pipe"]] * 1e12) for g in mfma_groups)
     roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "useful_frac": round(min(products * dwork, dexec) / dtime / 1e12 / peak, 4), "traffic": None,
+                "algorithmic_frac": round(achieved / peak, 4),
+                "products_per_fp32_product": products, "ceiling_frac": round(1.0 / products, 4),
+                "frac_of_ceiling": round(achieved / peak * products, 4),
+                "traffic": None,
                 "launches": dlaunch, "avg_launch_us": round(dtime / dlaunch * 1e6, 2),
-                "flop_per_launch": dexec / dlaunch,
-                "algorithmic": {"flop_per_launch": dwork / dlaunch, "tflops": round(dwork / dtime / 1e12, 3),
-                                "multiple_of_peak": round(dwork / dtime / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                                "executed_over_algorithmic": round(dexec / dwork, 4)},
-                # whole forward: time the issued FLOPs of every MFMA launch of a step need at the dense peak of THEIR pipe
-                # (fp16 matrix core for the split-operand kernels incl. the front / tail / 1x1 stride-2 kernels, fp32 MFMA
-                # for the rest) / the timed step -- a fraction, <= 1
-                "whole_forward_frac": round(psec / args.steps / (ms_per_step * 1e-3), 4),
+                "flop_per_launch": dwork / dlaunch,
+                "issued": {"tflops": round(issued, 3), "frac": round(issued / peak, 4), "flop_per_launch": dexec / dlaunch,
+                           "over_algorithmic": round(dexec / dwork, 4),
+                           "what": "FLOPs of the MFMA instructions the kernel issues (products x algorithmic + tile padding)"},
+                "algorithmic_multiple_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                # whole forward: time the ALGORITHMIC products of every MFMA launch of a step need at the dense peak of THEIR pipe
+                # (x 3 on the fp16 matrix core for the split-operand kernels, x 1 on the fp32 MFMAs) / the timed step; and the same
+                # for the FLOPs the launches issue.  Fractions, <= 1
+                "whole_forward_frac": round(alg_sec / args.steps / (ms_per_step * 1e-3), 4),
+                "whole_forward_issued_frac": round(psec / args.steps / (ms_per_step * 1e-3), 4),
                 "whole_forward_executed_gflop_per_frame": round(sum(g["executed"] for g in mfma_groups) / args.steps / per / 1e9, 3),
                 "whole_forward_algorithmic_multiple_of_peak":
                     round(fps / world * gflop_frame / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -651,9 +682,9 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                 "per_kernel": per_kernel_table(groups, args.steps)}
     if d["pipe"] == "fp16":
         roofline["pipe"] = ("fp16 MFMA (matrix core): every fp32 product is taken as three fp16 products over two-term "
-                            "splits of both operands, fp32 accumulation (csrc/conv_split.hip); `achieved` counts the "
-                            "fp16 MFMA FLOPs issued, 3x the fp32 products incl. the tile padding that is not skipped; "
-                            "`useful_frac` = 3 x algorithmic / time / peak.  A whole-chip stream of nothing but its instruction, "
+                            "splits of both operands, fp32 accumulation (csrc/conv_split.hip); `achieved` / `frac` price the "
+                            "reference's fp32 multiply-adds against this pipe's dense peak (ceiling 1/3), `issued` counts the fp16 "
+                            "MFMA FLOPs that run.  A whole-chip stream of nothing but its instruction, "
                             "v_mfma_f32_32x32x16_f16, sustains 1.22 PFLOP/s on random operands from registers and 1.69 "
                             "interleaved with the LDS reads that feed it (profiles/r02/mfma_power_probe.txt)")
     if dom == "conv_wino":
@@ -689,6 +720,11 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    "rccl_version": rccl_version(),
                    "launch": "eager" if args.eager else
                              f"HIP graph replay, {getattr(forward, 'branches', 1)} concurrent sub-batch branch(es)",
+                   "value_source": value_source,
+                   # the same runner / graph for >= 300 more steps and >= 3 s (power-capped part: steady state, not a burst)
+                   "sustained": sustained,
+                   # graph replay of ONE frame, beside the reference's README latency
+                   "batch1": batch1,
                    "eager_ms_per_step_with_event_timing": round(eager_ms, 4),
                    "reference_style_region_ms_per_step": round(refstyle_ms, 4),
                    # side measurement: VOID preset, 480x640, same batch per GPU, forward only (no all-gather)

@@ -21,7 +21,7 @@ KBN_ERR_UNSUPPORTED = -2
 KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ, KBN_SRC_PAIR = 0, 1, 2, 3
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
 KBN_MAX_SRC = 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class KbnError(RuntimeError):
@@ -124,12 +124,22 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
             " (needs hipcc).  There is no CPU fallback for the product path.")
     lib = C.CDLL(LIB_PATH)
+    rebuild = "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`"
+    try:
+        lib.kbn_version.restype = _I
+        lib.kbn_version.argtypes = []
+        have = lib.kbn_version()
+    except AttributeError:
+        raise KbnError(f"{LIB_PATH} exports no kbn_version: not a KBNet HIP library; {rebuild}") from None
+    if have != ABI_VERSION:   # checked BEFORE the symbols are bound: a stale library names the mismatch, not a missing symbol
+        raise KbnError(f"libkbnet_hip.so ABI {have} != binding ABI {ABI_VERSION}: stale library; {rebuild}")
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise KbnError(f"libkbnet_hip.so (ABI {have}) does not export {name}: header / library mismatch; {rebuild}") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.kbn_version() != ABI_VERSION:
-        raise KbnError(f"libkbnet_hip.so ABI {lib.kbn_version()} != binding ABI {ABI_VERSION}")
     _lib = lib
     return lib
 

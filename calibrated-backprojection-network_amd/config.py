@@ -93,7 +93,7 @@ def encoder_param_shapes(cfg: KBNetConfig) -> Dict[str, Tuple[int, ...]]:
     """Keys/shapes of `networks.KBNetEncoder` (reference src/networks.py:52-299)."""
     fi, fd, ff = cfg.n_filters_encoder_image, cfg.n_filters_encoder_depth, cfg.n_filters_encoder_fused
     kb = cfg.resolutions_backprojection
-    assert 0 in kb and 4 not in kb, "supported topologies: KB at level 0, plain level 4"
+    assert 0 in kb, "resolution 0 must use calibrated backprojection (the reference is undefined otherwise)"
     s = {}
     s["conv0_image.conv.weight"] = (fi[0], cfg.input_channels_image, 3, 3)
     s["conv0_depth.conv.weight"] = (fd[0], cfg.n_filter_sparse_to_dense_pool, 3, 3)
@@ -114,8 +114,14 @@ def encoder_param_shapes(cfg: KBNetConfig) -> Dict[str, Tuple[int, ...]]:
         else:
             s[f"conv{n + 1}_image.conv_block.0.conv.weight"] = (fi[n], fi[n - 1], 3, 3)
             s[f"conv{n + 1}_depth.conv_block.0.conv.weight"] = (fd[n], fd[n - 1], 3, 3)
-    s["conv5_image.conv_block.0.conv.weight"] = (fi[4], fi[3], 3, 3)
-    s["conv5_depth.conv_block.0.conv.weight"] = (fd[4], fd[3], 3, 3)
+    if 4 in kb:
+        # the reference BUILDS calibrated_backprojection5 (src/networks.py:266-283) and then never calls it: its level-4 branch
+        # re-uses calibrated_backprojection4 (:512, quirk Q3).  The parameters still exist in its state_dict.
+        cf = fi[3] + ff[3] if 3 in kb else fi[3]
+        kb_block(5, fi[3], fd[3], cf, 4)
+    else:
+        s["conv5_image.conv_block.0.conv.weight"] = (fi[4], fi[3], 3, 3)
+        s["conv5_depth.conv_block.0.conv.weight"] = (fd[4], fd[3], 3, 3)
     return s
 
 

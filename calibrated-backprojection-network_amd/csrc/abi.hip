@@ -22,7 +22,14 @@ static void load_knobs() {
     for (int k = 0; k < KNOB_COUNT; ++k) {
         const char* v = getenv(kKnobNames[k]);
         g_knobs[k].set = (v && *v) ? 1 : 0;
-        g_knobs[k].value = (v && *v) ? atoi(v) : 0;
+        int val = 0;
+        if (v && *v) {
+            char* end = nullptr;
+            const long parsed = strtol(v, &end, 10);
+            // "true" / "yes" / "on": set, not a number -> 1 (the pre-kbn_knob host switches treated any non-empty value but "0" as set)
+            val = (end == v) ? 1 : (int)parsed;
+        }
+        g_knobs[k].value = val;
     }
 }
 

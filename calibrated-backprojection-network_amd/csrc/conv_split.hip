@@ -14,9 +14,11 @@
 // 2^11 so that it sits in fp16's normal range whenever h1 does (the matrix core flushes fp16 subnormals); e is chosen
 // per filter at pack time (largest |w 2^e| in [2^12, 2^13)); k (`act_exponent`) is the caller's: it places the fp16
 // window on the layer's activations -- |a| 2^k up to 65504 is finite, |a| 2^k >= 2^-14 has the full 22 bits, smaller
-// activations (h1 subnormal -> flushed, the mode register is set so) are carried by h2 alone with 11 bits.  The host
-// mirror measures max |a| of every layer input once (first call / graph warm-up) and puts it at 2^9: 128x of headroom
-// above, 23 binades of full precision below (modules.Conv2d.run_split); the ABI default -6 covers 0.0039 .. 4.2e6.  Measured against an fp64 evaluation (profiles/r02/bf16x_probe.txt, K = 576 .. 6912): rms error 0.28e-6 .. 0.9e-6
+// activations (h1 subnormal -> flushed, the mode register is set so) are carried by h2 alone with 11 bits.  There is
+// no calibration and no state: every producer folds max |out| per frame into a device-side slot (kbn_conv_src.absmax,
+// ops.ActStats) and the consumer derives k = 14 - floor(log2 max) per frame inside the forward (sp_act_scale below: the
+// frame's maximum lands in [2^14, 2^15) of the window); a source without a slot takes the ABI default -6, which covers
+// 0.0039 .. 4.2e6.  Measured against an fp64 evaluation (profiles/r02/bf16x_probe.txt, K = 576 .. 6912): rms error 0.28e-6 .. 0.9e-6
 // of the output's rms, the fp32 MFMA chain (== fmaf chain) 0.44e-6 .. 1.7e-6 -- the accuracy class of the fp32 path, which
 // is why this kernel sits on the parity-gated path (tests/test_hip_parity.py holds it to the same 1e-4 bar).
 //

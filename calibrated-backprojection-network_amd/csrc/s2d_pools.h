@@ -1,5 +1,5 @@
 // s2d_pools.h -- compile-time pool lists of the reference's shipped S2D presets, shared by csrc/s2d.hip (SparseToDensePool.forward)
-// and csrc/depth_front_fused.hip (S2D -> conv0_depth -> KB1 depth branch in one launch).
+// and csrc/front.hip's kb1_depth_front_kernel<pool preset> through csrc/s2d_stage.h (S2D -> conv0_depth -> KB1 depth branch in one launch).
 #pragma once
 
 namespace kbn {

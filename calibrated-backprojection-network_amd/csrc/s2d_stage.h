@@ -9,10 +9,12 @@
 //   P2  vertical min / max pass, register blocked (3 rows per item), every pool size from one outward sweep -> V
 //   P3  horizontal pass, register blocked (4 pixels per item): the pooled values, BIT-EXACT compare / select arithmetic,
 //       999-sentinel semantics (s2d.hip's P3) -> registers -> (barrier) -> split granules G [term][pixel][8 channels]
-//   P4  the 1x1 chain (7|5 -> 8 -> 8 -> 8, LeakyReLU each) on v_mfma_f32_16x16x32_f16, IN PLACE on G, a 16-pixel block per
-//       wave at a time: D[filter][pixel], ONE instruction per layer with the three products of the two-term split packed
-//       along K: [h1 | h1 | h2] . [w1 ; w2 ; w1 2^-11] (8 channels each).  A lane ends up with 4 consecutive channels of a
-//       pixel = half a granule: scale, LeakyReLU, split, ds_write_b64.
+//   P4  the 1x1 chain (7|5 -> 8 -> 8 -> 8, LeakyReLU each) on v_mfma_f32_16x16x32_f16, IN PLACE on G, 32-pixel blocks, a wave's
+//       (up to four) blocks layer by layer: D[filter | filter][pixel] -- rows 0-7 the filters at pixel 32 b + n (B k-groups 0, 1 =
+//       its h1, h2), rows 8-15 the same filters at pixel 32 b + 16 + n (k-groups 2, 3).  TWO instructions per layer carry the
+//       three products of the two-term split: A0 = [w1 | w1 2^-11] . [h1 ; h2] and A1 = [w2 | 0] . [h1 ; h2] (8 channels per
+//       k-group; s2d_stage_pack_kernel in csrc/front.hip writes exactly this operand layout).  A lane ends up with 4 consecutive
+//       channels of a pixel = half a granule: scale, LeakyReLU, split, ds_write_b64.
 //   P5  the 3x3 conv over cat[features, z, v] (10 -> 8): 8 filters fill half of a 16-row MFMA, so a block computes pixel
 //       PAIRS -- rows 0-7 the filters at pixel 2p, rows 8-15 the same filters at pixel 2p + 1 -- over the 3 x 4 window the two
 //       share: K-step = window row, k-group = window column (weights of the column a pixel does not read are zero); the two

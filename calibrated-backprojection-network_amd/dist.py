@@ -77,6 +77,16 @@ class ShardedRunner:
         next step's forward (RCCL runs on its own stream; xGMI traffic hides behind the MFMAs).
         Every rank must hold the same number of frames (checked once).  Returns the gathered
         N_total x 1 x H x W tensor of the PREVIOUS step (None on the first call); `drain()` returns the last."""
+        # A forward with `rotating_outputs` >= 2 (GraphedForward(outputs=2): the captured graph exists once per output tensor and
+        # calls alternate between them) hands back a tensor nothing overwrites before the next-but-one call: the all-gather
+        # reads it in place and the ring's staging copy (55 MB per rank and step at 32 KITTI frames) is skipped.  The gather
+        # that read the tensor this call is about to overwrite was issued two steps ago; it is awaited here, BEFORE the forward.
+        rotating = int(getattr(self.forward_fn, "rotating_outputs", 0) or 0) >= 2
+        if rotating and self._ring is not None:
+            stale = self._ring[self._step & 1]
+            if stale[2] is not None:
+                stale[2].wait()
+                stale[2] = None
         out = self.forward_fn(*local_inputs)
         if self._ring is None:
             if self.collective:   # a ragged shard would hang or fail inside the collective: check once
@@ -87,11 +97,14 @@ class ShardedRunner:
                                      f"max {int(n[0])} frames); use step() / step_mixed() for ragged batches")
             gathered = lambda: (torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]),
                                             device=out.device, dtype=out.dtype) if self.collective else None)
-            self._ring = [[torch.empty_like(out), gathered(), None] for _ in range(2)]
+            self._ring = [[None if rotating else torch.empty_like(out), gathered(), None] for _ in range(2)]
         slot = self._ring[self._step & 1]
         if slot[2] is not None:
             slot[2].wait()                      # the gather that used this slot two steps ago
-        slot[0].copy_(out)                      # `out` may be a graph's static buffer: detach it
+        if rotating:
+            slot[0] = out                       # the forward's own (rotating) output tensor: no copy
+        else:
+            slot[0].copy_(out)                  # `out` may be a graph's ONE static buffer: detach it
         if self.collective:
             slot[2] = dist.all_gather_into_tensor(slot[1], slot[0], async_op=True)
         prev = self._ring[(self._step & 1) ^ 1]

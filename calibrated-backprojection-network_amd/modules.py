@@ -430,6 +430,18 @@ class VGGNetBlock(torch.nn.Module):
                              use_batch_norm, use_instance_norm))
         self.conv_block = torch.nn.Sequential(*layers)
 
+    def run(self, srcs, n, h, w, out=None, out_absmax=None, stats=None):
+        """Every conv of the block in turn (reference src/net_utils.py:945-958): the stride-1 convs in front write fresh
+        tensors, the last one (the block's stride) writes `out` and fills `out_absmax`.  `srcs`: the sources of the FIRST conv
+        (a concatenation is just several of them); `h` x `w` is the input size."""
+        convs = list(self.conv_block)
+        x = None
+        for i, conv in enumerate(convs):
+            last = i == len(convs) - 1
+            x = conv.run(srcs if i == 0 else [ops.tensor_src(x, "x")], n, h, w, out=out if last else None,
+                         out_absmax=out_absmax if last else None, stats=stats)
+        return x
+
     def forward(self, x):
         return self.conv_block(x)
 
@@ -444,8 +456,10 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
                  n_convolution_fused=1, weight_initializer="kaiming_uniform",
                  activation_func=torch.nn.LeakyReLU(negative_slope=0.10, inplace=True)):
         super().__init__()
-        if n_convolution_image != 1 or n_convolution_depth != 1:
-            raise ValueError("the fused KB block supports one convolution per branch (KBNet's setting)")
+        # n_convolution_image / n_convolution_depth > 1 (reference src/net_utils.py:1311-1325): stride-1 convs stacked in front of
+        # a branch's stride-2 conv; such a block runs conv by conv (_run_stacked), the fused launches are KBNet's one-conv form.
+        # n_convolution_fused is accepted and unused, as in the reference (conv_fused is ONE 1x1 conv, :1335-1341)
+        self.stacked = n_convolution_image != 1 or n_convolution_depth != 1
         self.conv_image = VGGNetBlock(in_channels_image, n_filter_image, n_convolution_image, 2,
                                       weight_initializer, activation_func)
         self.conv_depth = VGGNetBlock(in_channels_depth + 3, n_filter_depth, n_convolution_depth, 2,
@@ -471,7 +485,8 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         # as one: the encoder's chain of stride-2 split convs (KBNetEncoder.encode); None when the pair kernels decline
         pair_in = isinstance(image, ops.PairTensor)
         if (pair_in or pair_image_out) and not (self.conv_image.conv_block[0].split and self.split_image and self.split_fused
-                                                and coordinates.dim() == 3 and not self.conv_image.conv_block[0].bf16 and stats is not None):
+                                                and coordinates.dim() == 3 and not self.conv_image.conv_block[0].bf16 and stats is not None
+                                                and not self.stacked):
             return None
         n, ci, h, w = image.shape
         cd, cf = depth.shape[1], (0 if fused is None else fused.shape[1])
@@ -479,6 +494,9 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
                 self.conv_fused.in_channels - 3 - self.conv_image.conv_block[0].in_channels)
         if (ci, cd, cf) != want:   # the kernels trust these counts when they walk the packed weight panels
             raise KbnError(f"KB block built for (image, depth, fused) channels {want}, got {(ci, cd, cf)}")
+        if self.stacked:
+            return self._run_stacked(image, depth, coordinates, fused, out_image, out_depth, out_fused, out_amax_image,
+                                     out_amax_skip, stats, need_image)
         oh, ow = (h + 1) // 2, (w + 1) // 2
         dev = image.device
         mk = lambda c: torch.empty((n, c, oh, ow), device=dev, dtype=torch.float32)
@@ -534,6 +552,33 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
                             self.n_filter_image, self.n_filter_depth, self.n_filter_fused,
                             out_image, out_depth, out_fused, self._slope, absmax_image=out_amax_image,
                             absmax_depth=out_amax_skip, absmax_fused=out_amax_skip)
+
+    def _run_stacked(self, image, depth, coordinates, fused, out_image, out_depth, out_fused, out_amax_image, out_amax_skip, stats,
+                     need_image=True):
+        """A block with n_convolution_image / n_convolution_depth > 1, conv by conv: image -> (stride-1 convs) -> stride-2 conv;
+        cat[depth, coordinates] -> (stride-1 convs) -> stride-2 conv; conv_fused over cat[image, xyz, fused] reads the block's
+        INPUTS (reference src/net_utils.py:1343-1371).  Coordinates / backprojection channels are synthesized in the kernels
+        (K^-1 given) or read from the dense tensor, never concatenated."""
+        n, _, h, w = image.shape
+        oh, ow = (h + 1) // 2, (w + 1) // 2
+        dev = image.device
+        mk = lambda c: torch.empty((n, c, oh, ow), device=dev, dtype=torch.float32)
+        out_image = mk(self.n_filter_image) if out_image is None else out_image
+        out_depth = mk(self.n_filter_depth) if out_depth is None else out_depth
+        out_fused = mk(self.n_filter_fused) if out_fused is None else out_fused
+        dense = coordinates.dim() == 4
+        coordinates = coordinates.contiguous()
+        if dense and tuple(coordinates.shape) != (n, 3, h, w):
+            raise KbnError(f"coordinates must be N x 3 x H x W = {(n, 3, h, w)} or the N x 3 x 3 inverse intrinsics, got {tuple(coordinates.shape)}")
+        if need_image:
+            self.conv_image.run([ops.tensor_src(image, "image")], n, h, w, out=out_image, out_absmax=out_amax_image, stats=stats)
+        csrc = ops.tensor_src(coordinates, "coordinates") if dense else ops.coords_src(coordinates)
+        self.conv_depth.run([ops.tensor_src(depth, "depth"), csrc], n, h, w, out=out_depth, out_absmax=out_amax_skip, stats=stats)
+        xyz = (ops.xyz_src(depth, self.proj_depth.conv.weight, None, coordinates=coordinates) if dense
+               else ops.xyz_src(depth, self.proj_depth.conv.weight, coordinates))
+        srcs = [ops.tensor_src(image, "image"), xyz] + ([] if fused is None else [ops.tensor_src(fused, "fused")])
+        self.conv_fused.run(srcs, n, h, w, out=out_fused, out_absmax=out_amax_skip)
+        return out_image, out_depth, out_fused
 
     def _depth_and_fused(self, image, depth, fused, kinv, n, h, w, oh, ow, out_depth, out_fused, ci, cf, amax_image, amax_fused,
                          out_amax_skip, stats):
@@ -646,8 +691,8 @@ class SparseToDensePool(torch.nn.Module):
 
 # ----------------------------------------------------------------------- encoder
 class KBNetEncoder(torch.nn.Module):
-    """KBNet encoder for the shipped topology family: KB at level 0, KB or plain VGG
-    blocks at levels 1-3, plain level 4.  Skip tensors are written in place: each KB
+    """KBNet encoder: KB at level 0, KB or plain VGG blocks at levels 1-3, level 4 plain (the shipped presets) or
+    a KB level with the reference's quirk Q3 (block 4 called twice).  Skip tensors are written in place: each KB
     block's conv_fused / conv_depth land in the two channel slices of one buffer, which
     is both the skip connection and the next block's `fused` / `depth` inputs."""
 
@@ -670,8 +715,6 @@ class KBNetEncoder(torch.nn.Module):
             assert len(lst) == 5
         if 0 not in resolutions_backprojection:
             raise ValueError("resolution 0 must use calibrated backprojection (undefined in the reference otherwise)")
-        if 4 in resolutions_backprojection:
-            raise ValueError("calibrated backprojection at resolution 4 is not supported")
         self.resolutions_backprojection = list(resolutions_backprojection)
         act = globals()["activation_func"](activation_func)
         fi, fd, ff = n_filters_image, n_filters_depth, n_filters_fused
@@ -691,8 +734,16 @@ class KBNetEncoder(torch.nn.Module):
                                                                weight_initializer, act))
                 setattr(self, f"conv{n + 1}_depth", VGGNetBlock(fd[n - 1], fd[n], n_convolutions_depth[n], 2,
                                                                weight_initializer, act))
-        self.conv5_image = VGGNetBlock(fi[3], fi[4], n_convolutions_image[4], 2, weight_initializer, act)
-        self.conv5_depth = VGGNetBlock(fd[3], fd[4], n_convolutions_depth[4], 2, weight_initializer, act)
+        if 4 in resolutions_backprojection:
+            # The reference BUILDS this block (src/networks.py:266-283) and never calls it: its level-4 branch re-uses
+            # calibrated_backprojection4 (:512, quirk Q3).  It exists here for the same state_dict; encode() reproduces the quirk.
+            cf = fi[3] + ff[3] if 3 in resolutions_backprojection else fi[3]
+            self.calibrated_backprojection5 = CalibratedBackprojectionBlock(
+                fi[3], fd[3], cf, fi[4], fd[4], ff[4], n_convolutions_image[4], n_convolutions_depth[4],
+                n_convolutions_fused[4], weight_initializer, act)
+        else:
+            self.conv5_image = VGGNetBlock(fi[3], fi[4], n_convolutions_image[4], 2, weight_initializer, act)
+            self.conv5_depth = VGGNetBlock(fd[3], fd[4], n_convolutions_depth[4], 2, weight_initializer, act)
         self._f = (list(fi), list(fd), list(ff))
         # conv0_image + the level-0 KB block's conv_image / conv_fused as ONE launch, conv0's output kept on the CU
         # (ops.kb1_front, csrc/front.hip): KBNet's level 0 (48 / 48 filters) in all presets; other widths keep the
@@ -716,7 +767,7 @@ class KBNetEncoder(torch.nn.Module):
         ci, cf, cd = blk.conv_image.conv_block[0], blk.conv_fused, blk.conv_depth.conv_block[0]
         c0 = self.conv0_image
         if (not self.front or not c0.split or not ci.split or ci.bf16 or c0._slope is None or blk.proj_depth._slope is None
-                or cf.in_channels != c0.out_channels + 3 or not _dense(image)):
+                or cf.in_channels != c0.out_channels + 3 or not _dense(image) or blk.stacked):
             return None
         n, _, h, w = image.shape
         # decided BEFORE anything is launched: a late decline (KBN_NO_SPLIT=1, a slope outside [0, 1], an oversized map) would
@@ -848,8 +899,8 @@ class KBNetEncoder(torch.nn.Module):
                 # plain level: conv_image lives in the skip tensor, whose slot (a superset: a safe bound) serves it too
                 src, a_src = (conv_fused, amax_skip) if conv_fused is not None else (conv_image, amax_image if level > 0 else None)
                 skip = torch.empty((n, fi[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
-                ci_blk = getattr(self, f"conv{level + 1}_image").conv_block[0]
-                cd_blk = getattr(self, f"conv{level + 1}_depth").conv_block[0]
+                ci_blk = getattr(self, f"conv{level + 1}_image")
+                cd_blk = getattr(self, f"conv{level + 1}_depth")
                 branch = _SideBranch(dev)
                 conv_image = ci_blk.run([ops.tensor_src(src, "image", a_src)], n, h, w, out=skip[:, :fi[level]], out_absmax=a_skip,
                                         stats=stats)
@@ -863,15 +914,33 @@ class KBNetEncoder(torch.nn.Module):
             amax_skips.append(a_skip)
             h, w = oh, ow
         oh, ow = (h + 1) // 2, (w + 1) // 2
-        latent = torch.empty((n, fi[4] + fd[4], oh, ow), device=dev, dtype=torch.float32)
         amax_latent = stats.new()
+        if 4 in self.resolutions_backprojection:
+            # Quirk Q3 (reference src/networks.py:499-517): the level-4 branch calls calibrated_backprojection4 -- level 3's block --
+            # a second time, on level 3's outputs, with the level-1-ratio intrinsics of every deeper level (Q1); the block built as
+            # calibrated_backprojection5 stays unused.  Like the reference this needs a KB layer at level 3 and levels 2 and 3 of
+            # equal width (the block's channel check raises otherwise, where the reference raises a shape error); latent =
+            # cat[conv5_fused, conv5_depth] then carries block 4's filter counts.
+            if 3 not in self.resolutions_backprojection:
+                raise AttributeError("'KBNetEncoder' object has no attribute 'calibrated_backprojection4'")   # as in the reference
+            blk = self.calibrated_backprojection4
+            if isinstance(conv_image, ops.PairTensor):
+                conv_image, amax_image = conv_image.float(), None
+            if kinv1 is None:
+                kinv1 = ops.intrinsics_inverse(intrinsics, sx, sy)
+            latent = torch.empty((n, blk.n_filter_fused + blk.n_filter_depth, oh, ow), device=dev, dtype=torch.float32)
+            blk.run(conv_image, conv_depth, kinv1, conv_fused, None, latent[:, blk.n_filter_fused:], latent[:, :blk.n_filter_fused],
+                    amax_image=amax_image, amax_fused=amax_skip if conv_fused is not None else None, out_amax_image=stats.new(),
+                    out_amax_skip=amax_latent, stats=stats, need_image=not self.skip_unused_image)
+            return latent, skips, amax_latent, amax_skips
+        latent = torch.empty((n, fi[4] + fd[4], oh, ow), device=dev, dtype=torch.float32)
         src, a_src = (conv_fused, amax_skip) if conv_fused is not None else (conv_image, amax_image)
         branch = _SideBranch(dev)   # the two convs of level 4 are independent
-        self.conv5_image.conv_block[0].run([ops.tensor_src(src, "image", a_src)], n, h, w, out=latent[:, :fi[4]],
-                                           out_absmax=amax_latent, stats=stats)
+        self.conv5_image.run([ops.tensor_src(src, "image", a_src)], n, h, w, out=latent[:, :fi[4]],
+                             out_absmax=amax_latent, stats=stats)
         with branch:
-            self.conv5_depth.conv_block[0].run([ops.tensor_src(conv_depth, "depth", amax_skip)], n, h, w, out=latent[:, fi[4]:],
-                                               out_absmax=amax_latent, stats=stats)
+            self.conv5_depth.run([ops.tensor_src(conv_depth, "depth", amax_skip)], n, h, w, out=latent[:, fi[4]:],
+                                 out_absmax=amax_latent, stats=stats)
         return latent, skips, amax_latent, amax_skips
 
 
@@ -1024,9 +1093,14 @@ class GraphedForward:
     `branches` > 1 captures the batch as that many equal sub-batches on concurrent branches of the graph
     (frames are independent): while one branch's kernel drains its last, partly filled round of
     workgroups, the other branch's kernel already runs -- +4 % at 2 x 4 KITTI frames, bit-identical
-    output.  Default: 2 branches for even batches of at least 4 frames, otherwise 1."""
+    output.  Default: 2 branches for even batches of at least 4 frames, otherwise 1.
 
-    def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True):
+    `outputs` = 2 captures the graph TWICE, each copy writing its own output tensor (one memory pool: the activations are
+    shared, only the N x 1 x H x W result exists twice), and calls alternate between them (`rotating_outputs`): the tensor a
+    call returns stays untouched until the next-but-one call, so an asynchronous consumer -- the all-gather of
+    dist.ShardedRunner.step_pipelined, in flight under the next step's forward -- reads it in place instead of from a copy."""
+
+    def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1):
         # the static sparse depth / validity inputs are the two planes of one buffer (paired_planes: no torch.cat in the graph)
         sd, vm = new_depth_input_pair(sparse_depth.shape[0], sparse_depth.shape[2], sparse_depth.shape[3], sparse_depth.device)
         sd.copy_(sparse_depth)
@@ -1037,14 +1111,18 @@ class GraphedForward:
             branches = 2 if (n >= 4 and n % 2 == 0) else 1
         if branches < 1 or n % branches != 0:
             raise KbnError(f"cannot split a batch of {n} frames into {branches} equal branches")
+        if outputs not in (1, 2):
+            raise KbnError(f"outputs must be 1 or 2, got {outputs}")
         per = n // branches
         parts = [[t[i * per:(i + 1) * per] for t in self.static_in] for i in range(branches)]
         self.model = model
+        self.rotating_outputs = outputs if outputs > 1 else 0
+        self._turn = 0
         dev = self.static_in[0].device
         with torch.cuda.device(dev):
-            self._capture(model, parts, branches, per, n, tune)
+            self._capture(model, parts, branches, per, n, tune, outputs)
 
-    def _capture(self, model, parts, branches, per, n, tune):
+    def _capture(self, model, parts, branches, per, n, tune, outputs=1):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         # warm-up on a side stream: packs weights, sets kernel attributes and -- the one place the host mirror
@@ -1057,29 +1135,40 @@ class GraphedForward:
         self._weights = model.weight_state()
         self.branches = branches
         self._streams = [torch.cuda.Stream() for _ in range(branches - 1)]
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            if branches == 1:
-                self.static_out = model.forward(*self.static_in)
-            else:
-                cur = torch.cuda.current_stream()
-                h, w = self.static_in[1].shape[-2:]
-                self.static_out = torch.empty((n, 1, h, w), device=self.static_in[0].device, dtype=torch.float32)
-                # a fork inside a forked branch (and any wait between two forked streams) crashes hipStreamEndCapture on
-                # ROCm 7.2 (tools/probe/fork_capture_bisect.py), and forking only the capturing stream's sub-batch measured no
-                # gain (2795-2812 vs 2816-2845 frames/s): the per-level side branches stay off under sub-batch branches
-                _SideBranch.only_from = 0
-                try:
-                    for s in self._streams:
-                        s.wait_stream(cur)
-                    for i, s in enumerate(self._streams):   # every branch writes its frames of the one output tensor
-                        with torch.cuda.stream(s):
-                            model.forward(*parts[i + 1], out=self.static_out[(i + 1) * per:(i + 2) * per])
-                    model.forward(*parts[0], out=self.static_out[0:per])
-                    for s in self._streams:
-                        cur.wait_stream(s)
-                finally:
-                    _SideBranch.only_from = None
+        self.graphs, self.static_outs = [], []
+        for k in range(outputs):
+            graph = torch.cuda.CUDAGraph()
+            # one memory pool for all copies: they replay one after the other on one stream, never concurrently
+            with torch.cuda.graph(graph, pool=self.graphs[0].pool() if self.graphs else None):
+                static_out = self._record(model, parts, branches, per, n)
+            self.graphs.append(graph)
+            self.static_outs.append(static_out)
+        self.graph, self.static_out = self.graphs[0], self.static_outs[0]
+
+    def _record(self, model, parts, branches, per, n):
+        """The launches of one forward, issued under capture; returns the output tensor they write."""
+        h, w = self.static_in[1].shape[-2:]
+        static_out = torch.empty((n, 1, h, w), device=self.static_in[0].device, dtype=torch.float32)
+        if branches == 1:
+            model.forward(*self.static_in, out=static_out)
+            return static_out
+        cur = torch.cuda.current_stream()
+        # a fork inside a forked branch (and any wait between two forked streams) crashes hipStreamEndCapture on
+        # ROCm 7.2 (tools/probe/fork_capture_bisect.py), and forking only the capturing stream's sub-batch measured no
+        # gain (2795-2812 vs 2816-2845 frames/s): the per-level side branches stay off under sub-batch branches
+        _SideBranch.only_from = 0
+        try:
+            for s in self._streams:
+                s.wait_stream(cur)
+            for i, s in enumerate(self._streams):   # every branch writes its frames of the one output tensor
+                with torch.cuda.stream(s):
+                    model.forward(*parts[i + 1], out=static_out[(i + 1) * per:(i + 2) * per])
+            model.forward(*parts[0], out=static_out[0:per])
+            for s in self._streams:
+                cur.wait_stream(s)
+        finally:
+            _SideBranch.only_from = None
+        return static_out
 
     def __call__(self, image, sparse_depth, validity_map_depth, intrinsics):
         with torch.cuda.device(self.static_out.device):
@@ -1099,8 +1188,10 @@ class GraphedForward:
         for dst, src in zip(self.static_in, (image, sparse_depth, validity_map_depth, intrinsics)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
-        self.graph.replay()
-        return self.static_out
+        k = self._turn
+        self._turn = (k + 1) % len(self.graphs)
+        self.graphs[k].replay()
+        return self.static_outs[k]
 
 
 class KBNetModel(object):
@@ -1176,13 +1267,14 @@ class KBNetModel(object):
         self.decoder.set_bf16(enabled)
         return self
 
-    def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True):
+    def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1):
         """Captures one forward of this batch shape into a HIP graph and returns a callable
         `replay(image, sparse_depth, validity_map_depth, intrinsics) -> depth` (inputs are copied
         into the graph's static buffers unless they ARE those buffers; the output tensor is
         re-used between replays).  Removes the ~35 per-launch host round trips of a forward.
-        `tune`: time candidate launch geometries during the warm-up (results are bit-identical either way)."""
-        return GraphedForward(self, image, sparse_depth, validity_map_depth, intrinsics, branches, tune)
+        `tune`: time candidate launch geometries during the warm-up (results are bit-identical either way).
+        `outputs` = 2: two alternating output tensors (GraphedForward: what dist.ShardedRunner.step_pipelined gathers in place)."""
+        return GraphedForward(self, image, sparse_depth, validity_map_depth, intrinsics, branches, tune, outputs)
 
     def weight_state(self):
         """(storage pointer, version) of every parameter: what a captured graph depends on."""

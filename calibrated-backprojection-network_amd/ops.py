@@ -73,7 +73,7 @@ def autotune(enabled: bool = True):
 # Optional per-launch timing (bench.py): when PROFILE is a list, every ABI call is
 # bracketed by HIP events recorded on the launch stream and
 # (name, work, executed, pipe, nbytes, start, end) is appended.  `work` is the launch's ALGORITHMIC FLOPs
-# (convs: the reference's direct formulation) or bytes (S2D, head); `executed` the FLOPs the launch really
+# (the reference's direct formulation: convs, and the conv part of S2D / the head; 0 for pure byte movers); `executed` the FLOPs the launch really
 # issues on the matrix cores (Winograd / phase-decomposed up-convs execute fewer; tile and channel padding
 # execute more), None for byte-bound launches; `pipe` names the pipe those MFMAs run on -- "fp32"
 # (v_mfma_f32_*_f32: the vector datapath's 157.3 TFLOP/s), "fp16" (split-operand kernels: three fp16 MFMAs per fp32
@@ -405,10 +405,10 @@ def coords_src(kinv: torch.Tensor) -> ConvSrc:
     return s
 
 
-def xyz_src(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: torch.Tensor) -> ConvSrc:
-    """The KB layer's backprojection channels K^-1 [x y 1]^T * act(proj . depth), computed in-kernel."""
+def xyz_src(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: Optional[torch.Tensor], coordinates: Optional[torch.Tensor] = None) -> ConvSrc:
+    """The KB layer's backprojection channels coords * act(proj . depth), computed in-kernel; coords = K^-1 [x y 1]^T from `kinv`
+    (N x 3 x 3) or read from the dense `coordinates` tensor (N x 3 x H x W, the reference's own argument)."""
     ptr, bs = _planes(depth, "depth")
-    _require(kinv, "kinv", 3)
     s = ConvSrc()
     s.kind = _lib.KBN_SRC_XYZ
     s.channels = 3
@@ -416,8 +416,16 @@ def xyz_src(depth: torch.Tensor, proj_weight: torch.Tensor, kinv: torch.Tensor) 
     s.batch_stride = bs
     s.aux_channels = depth.shape[1]
     s.proj_weight = proj_weight.data_ptr()
-    s.kinv = kinv.data_ptr()
-    s._keep = (depth, proj_weight, kinv)
+    if coordinates is not None:
+        _require(coordinates, "coordinates", 4)
+        if not coordinates.is_contiguous() or tuple(coordinates.shape) != (depth.shape[0], 3, depth.shape[2], depth.shape[3]):
+            raise KbnError("coordinates must be a contiguous N x 3 x H x W tensor of the depth features' size")
+        s.coordinates = coordinates.data_ptr()
+        s.coordinates_batch_stride = coordinates.stride(0)
+    else:
+        _require(kinv, "kinv", 3)
+        s.kinv = kinv.data_ptr()
+    s._keep = (depth, proj_weight, kinv, coordinates)
     return s
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KBN_ABI_VERSION 3
+#define KBN_ABI_VERSION 4
 
 typedef void* kbn_stream_t; /* hipStream_t */
 
@@ -49,7 +49,8 @@ void kbn_reload_env(void);
 /* Value of a KBN_* switch AS THE LIBRARY READ IT (at load time / the last kbn_reload_env()): 0 when unset or unknown.  The
  * host mirror asks here instead of reading the environment itself, so its A/B switches (KBN_NO_SPLIT, KBN_NO_PAIR,
  * KBN_NO_PAIR_MID, KBN_NO_PAIR_ENC, KBN_NO_PAIR_TAIL, KBN_NO_OVERLAP, KBN_DEPTH_FRONT_FUSION, KBN_NO_DEPTH_FRONT_FUSION,
- * KBN_FP16_ONE_TERM) change together with the library's. */
+ * KBN_FP16_ONE_TERM) change together with the library's.  Values are integers (atoi); a variable that is set to
+ * something that is not a number ("true", "yes", "on") reads as 1, so that KBN_NO_PAIR=true still switches the path off. */
 int kbn_knob(const char* name);
 
 /* First-use tuning of launch geometry (tile / region shapes; csrc/tune.hip).  OFF by default:

@@ -122,18 +122,32 @@ def scale_intrinsics(k, height0, width0, height1, width1):
     return k * scale.view(1, 3, 3)
 
 
+# -------------------------------------------------------------------- VGG block
+def vgg_block(x, sd, prefix, stride, slope=NEGATIVE_SLOPE):
+    """VGGNetBlock.forward, reference src/net_utils.py:900-958: n_convolution - 1 stride-1 3x3 convs, then one 3x3 conv
+    with `stride` (keys `<prefix>.conv_block.<i>.conv.weight`, i = 0 .. n_convolution - 1); KBNet's presets use one conv."""
+    n = 0
+    while f"{prefix}.conv_block.{n}.conv.weight" in sd:
+        n += 1
+    if n == 0:
+        raise KeyError(f"{prefix}.conv_block.0.conv.weight")
+    for i in range(n):
+        x = conv2d(x, sd[f"{prefix}.conv_block.{i}.conv.weight"], stride if i == n - 1 else 1, slope)
+    return x
+
+
 # --------------------------------------------------------------------- KB block
 def kb_block(image, depth, coordinates, fused, sd, slope=NEGATIVE_SLOPE):
     """Calibrated backprojection block.
 
     Reference: CalibratedBackprojectionBlock.forward, src/net_utils.py:1343-1371.
-    `sd` keys: conv_image.conv_block.0.conv.weight, conv_depth.conv_block.0.conv.weight,
+    `sd` keys: conv_image.conv_block.<i>.conv.weight, conv_depth.conv_block.<i>.conv.weight (one conv each in KBNet's
+    presets; n_convolution_image / n_convolution_depth > 1 stack stride-1 convs in front, :1311-1325),
     proj_depth.conv.weight, conv_fused.conv.weight.
     Returns (conv_image, conv_depth, conv_fused), all at ceil(H/2) x ceil(W/2).
     """
-    conv_image = conv2d(image, sd["conv_image.conv_block.0.conv.weight"], 2, slope)
-    conv_depth = conv2d(torch.cat([depth, coordinates], dim=1),
-                        sd["conv_depth.conv_block.0.conv.weight"], 2, slope)
+    conv_image = vgg_block(image, sd, "conv_image", 2, slope)
+    conv_depth = vgg_block(torch.cat([depth, coordinates], dim=1), sd, "conv_depth", 2, slope)
     z = conv2d(depth, sd["proj_depth.conv.weight"], 1, slope)
     xyz = coordinates * z
     layers = [image, xyz] + ([fused] if fused is not None else [])
@@ -151,16 +165,19 @@ def encoder(image, depth, intrinsics, sd, resolutions_backprojection=(0, 1, 2, 3
             slope=NEGATIVE_SLOPE, return_trace=False):
     """KBNetEncoder.forward, reference src/networks.py:301-533.
 
-    Supports the shipped topology family: level 0 must be a KB level (the
-    reference is undefined otherwise); levels 1..3 are KB levels
-    when listed, plain stride-2 VGG blocks otherwise; level 4 is always plain
-    (shipped configs; the reference's level-4 KB branch re-uses block 4, Q3).
+    Level 0 must be a KB level (the reference is undefined otherwise, SURVEY.md
+    Q4); levels 1..3 are KB levels when listed, plain stride-2 VGG blocks
+    otherwise; level 4 is plain in the shipped configs.  With 4 listed the
+    reference's level-4 branch calls `calibrated_backprojection4` AGAIN
+    (src/networks.py:499-517, quirk Q3: the block it built as
+    `calibrated_backprojection5` is never used), which only runs when level 3 is
+    a KB level too and levels 2 and 3 have the same widths -- reproduced here.
     Returns (latent, [skip1..skip4]).
     """
     if 0 not in resolutions_backprojection:
         raise ValueError("resolution 0 must use calibrated backprojection (reference Q4)")
-    if 4 in resolutions_backprojection:
-        raise ValueError("calibrated backprojection at resolution 4 is not supported")
+    if 4 in resolutions_backprojection and 3 not in resolutions_backprojection:
+        raise ValueError("resolution 4 re-uses calibrated_backprojection4 (reference Q3), which exists only with resolution 3")
     n, _, h0, w0 = image.shape
     trace = {}
 
@@ -186,15 +203,25 @@ def encoder(image, depth, intrinsics, sd, resolutions_backprojection=(0, 1, 2, 3
             skips.append(torch.cat([conv_fused, conv_depth], dim=1))
         else:
             src = conv_fused if conv_fused is not None else conv_image
-            conv_image = conv2d(src, sd[f"conv{level + 1}_image.conv_block.0.conv.weight"], 2, slope)
-            conv_depth = conv2d(conv_depth, sd[f"conv{level + 1}_depth.conv_block.0.conv.weight"], 2, slope)
+            conv_image = vgg_block(src, sd, f"conv{level + 1}_image", 2, slope)
+            conv_depth = vgg_block(conv_depth, sd, f"conv{level + 1}_depth", 2, slope)
             conv_fused = None
             skips.append(torch.cat([conv_image, conv_depth], dim=1))
 
-    src = conv_fused if conv_fused is not None else conv_image
-    conv5_image = conv2d(src, sd["conv5_image.conv_block.0.conv.weight"], 2, slope)
-    conv5_depth = conv2d(conv_depth, sd["conv5_depth.conv_block.0.conv.weight"], 2, slope)
-    latent = torch.cat([conv5_image, conv5_depth], dim=1)
+    if 4 in resolutions_backprojection:
+        hl, wl = conv_image.shape[-2:]
+        k_l = scale_intrinsics(intrinsics, h0, w0, h1, w1)  # Q1: always level-1 ratio
+        coords = camera_coordinates(k_l, hl, wl)
+        trace["intrinsics4"] = k_l
+        trace["coordinates4"] = coords
+        _, conv5_depth, conv5_fused = kb_block(conv_image, conv_depth, coords, conv_fused,
+                                               _sub(sd, "calibrated_backprojection4"), slope)   # Q3: block 4 again
+        latent = torch.cat([conv5_fused, conv5_depth], dim=1)
+    else:
+        src = conv_fused if conv_fused is not None else conv_image
+        conv5_image = vgg_block(src, sd, "conv5_image", 2, slope)
+        conv5_depth = vgg_block(conv_depth, sd, "conv5_depth", 2, slope)
+        latent = torch.cat([conv5_image, conv5_depth], dim=1)
     if return_trace:
         return latent, skips, trace
     return latent, skips

@@ -4,7 +4,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import kbnet_amd as kb
 from oracle import kbnet_oracle as orc
-cfg = kb.kitti_config(); sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+cfg = kb.kitti_config(); sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
 frames = kb.synthetic.make_frames(1, 352, 1216, "kitti", seed=1)
 print("cpu_count", os.cpu_count())
 for t in (8, 16, 32, 64, 128):

@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 torch.set_num_threads(16)
 cfg = kb.kitti_config()
 h, w = 352, 1216
-sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
 m = kb.modules.KBNetModel.from_config(cfg, dev)
 m.load_state_dicts(*sds)
 image, sparse, valid, k = kb.synthetic.make_frames(2, h, w, "kitti", seed=1, jitter_intrinsics=0.1)

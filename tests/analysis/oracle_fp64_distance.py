@@ -15,7 +15,7 @@ seeds = [int(a) for a in sys.argv[1:]] or [0, 3, 7, 11, 19]
 for preset, shape in (("kitti", (352, 1216)), ("void", (480, 640))):
     cfg = kb.PRESETS[preset]()
     for seed in seeds:
-        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3 if preset == "kitti" else 1.45)
+        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=kb.synthetic.PARITY_GAIN[preset])
         frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
         args = (cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
         t = time.time()

@@ -76,7 +76,7 @@ for preset in args.presets.split(","):
     cfg = kb.PRESETS[preset]()
     rows = []
     for seed in range(args.seeds):
-        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3 if preset == "kitti" else 1.45, trained_like=args.trained)
+        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=kb.synthetic.PARITY_GAIN[preset], trained_like=args.trained)
         frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
         a = (cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
         ref = orc.kbnet_forward(*frames, *sds, *a)

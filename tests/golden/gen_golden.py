@@ -17,11 +17,13 @@ Cases
              window, a depth of exactly 999.0 and one above 999.
   coords_*   encoder closures camera_coordinates/scale_intrinsics captured through
              forward pre-hooks on the four KB blocks (pins Q1/Q2/Q9).
-  kb_*       net_utils.CalibratedBackprojectionBlock with / without `fused`, odd size.
+  kb_*       net_utils.CalibratedBackprojectionBlock with / without `fused`, odd size; kb_stacked*: n_convolution_image /
+             n_convolution_depth > 1 (stride-1 convs stacked in front of the stride-2 conv of a branch).
   dec_*      networks.MultiScaleDecoder (n_resolution=1, 'up', linear output).
   fwd_*      KBNetModel.forward: KITTI preset, VOID preset (both narrow channels)
              and an odd 70x100 frame; fwd_kb012 / fwd_kb02: encoders with KB layers at levels
-             [0, 1, 2] / [0, 2] only (plain stride-2 blocks elsewhere).
+             [0, 1, 2] / [0, 2] only (plain stride-2 blocks elsewhere); fwd_kb01234*: a KB layer at resolution 4 as well --
+             the reference then calls calibrated_backprojection4 twice (quirk Q3; levels 2 and 3 of equal width).
   ckpt_kitti_narrow.pth  written by the reference's KBNetModel.save_model (same weights as fwd_kitti): the
              `.pth` layout restore_model must read (module.-prefixed keys, three state_dicts, optimizer state).
   io/*       input pipeline: small PNG / .npy files written by this script's own PNG writer
@@ -203,6 +205,45 @@ def gen_kb():
         save(f"kb_{name}", **arrays)
 
 
+def gen_kb_stacked():
+    """n_convolution_image / n_convolution_depth > 1 (reference src/net_utils.py:1311-1325, VGGNetBlock :900-958): stride-1 3x3
+    convs stacked in front of the stride-2 conv of the image / depth branch.  KBNet's presets use 1; the block takes any."""
+    g = torch.Generator().manual_seed(37)
+    act = net_utils.activation_func("leaky_relu")
+    for name, (ci, cd, cf_prev, fi, fd, ff, h, w, n_img, n_dep) in {
+        "stacked": (8, 4, 8, 16, 8, 16, 18, 24, 2, 3),
+        "stacked_odd": (6, 5, 0, 10, 6, 9, 13, 19, 3, 2),
+    }.items():
+        with_fused = cf_prev > 0
+        in_fused = ci + cf_prev if with_fused else ci
+        blk = net_utils.CalibratedBackprojectionBlock(
+            in_channels_image=ci, in_channels_depth=cd, in_channels_fused=in_fused,
+            n_filter_image=fi, n_filter_depth=fd, n_filter_fused=ff,
+            n_convolution_image=n_img, n_convolution_depth=n_dep, n_convolution_fused=2,
+            weight_initializer="xavier_normal", activation_func=act).eval()
+        sd = {k: torch.randn(v.shape, generator=g) * (2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+              for k, v in blk.state_dict().items()}
+        blk.load_state_dict(sd)
+        n = 2
+        image = torch.randn(n, ci, h, w, generator=g)
+        depth = torch.randn(n, cd, h, w, generator=g)
+        fused = torch.randn(n, cf_prev, h, w, generator=g) if with_fused else None
+        k = kb.synthetic.make_frames(n, h, w, "void", seed=33, jitter_intrinsics=0.2)[3]
+        k[:, 0, 0] = 30.0
+        k[:, 1, 1] = 28.0
+        k[:, 0, 2] = w / 2.0
+        k[:, 1, 2] = h / 2.0
+        xy = net_utils.meshgrid(n, h, w, device=torch.device("cpu"), homogeneous=True).view(n, 3, -1)
+        coords = torch.matmul(torch.inverse(k), xy).view(n, 3, h, w)
+        ci_o, cd_o, cf_o = blk(image=image, depth=depth, coordinates=coords, fused=fused)
+        arrays = dict(image=image, depth=depth, coordinates=coords, intrinsics=k,
+                      weights=np_sd(sd), conv_image=ci_o, conv_depth=cd_o, conv_fused=cf_o,
+                      n_convolution_image=np.array(n_img), n_convolution_depth=np.array(n_dep))
+        if with_fused:
+            arrays["fused"] = fused
+        save(f"kb_{name}", **arrays)
+
+
 # ---------------------------------------------------------------------- decoder
 def gen_decoder():
     cfg = kb.kitti_config().narrow()
@@ -235,12 +276,19 @@ def gen_forward(only=None):
                                                # encoder topologies other than KBNet's [0, 1, 2, 3]: plain stride-2
                                                # VGG blocks where a level has no KB layer (src/networks.py:150-299)
                                                ("kb012", "kitti", (64, 96), 2, (0, 1, 2)),
-                                               ("kb02", "void", (48, 80), 1, (0, 2))):
+                                               ("kb02", "void", (48, 80), 1, (0, 2)),
+                                               # KB layer at resolution 4 too: the reference's level-4 branch calls
+                                               # calibrated_backprojection4 a second time (src/networks.py:499-517, quirk Q3),
+                                               # which only runs when levels 2 and 3 have the same widths
+                                               ("kb01234", "kitti", (64, 96), 2, (0, 1, 2, 3, 4)),
+                                               ("kb01234_odd", "void", (70, 100), 1, (0, 1, 2, 3, 4))):
         if only and name not in only:
             continue
         cfg = kb.PRESETS[preset]().narrow()
         if kb_levels is not None:
             cfg = dataclasses.replace(cfg, resolutions_backprojection=kb_levels)
+        if kb_levels is not None and 4 in kb_levels:
+            cfg = dataclasses.replace(cfg, n_filters_encoder_image=(8, 16, 32, 32, 32), n_filters_encoder_depth=(4, 8, 16, 16, 16))
         # gain > 1 keeps the logits O(1) (random xavier weights shrink the signal), so the
         # sigmoid head is exercised off its saturated ends
         sds = kb.synthetic.make_state_dicts(cfg, seed=5, gain=1.3 if preset == "kitti" else 1.45)
@@ -263,6 +311,7 @@ def gen_forward(only=None):
         save(f"fwd_{name}", image=image, sparse_depth=sparse, validity_map=valid, intrinsics=k,
              output_depth=out, preset=np.array(preset),
              resolutions_backprojection=np.array(cfg.resolutions_backprojection),
+             n_filters_encoder_image=np.array(cfg.n_filters_encoder_image), n_filters_encoder_depth=np.array(cfg.n_filters_encoder_depth),
              s2d=np_sd(sds[0]), encoder=np_sd(sds[1]), decoder=np_sd(sds[2]))
 
 
@@ -435,12 +484,17 @@ if __name__ == "__main__":
     if "--only-topologies" in sys.argv:   # added later; leaves the other fixtures untouched
         gen_forward(only=("kb012", "kb02"))
         sys.exit(0)
+    if "--only-round5" in sys.argv:       # round 5: KB layer at resolution 4 (quirk Q3), stacked convs in the KB block
+        gen_forward(only=("kb01234", "kb01234_odd"))
+        gen_kb_stacked()
+        sys.exit(0)
     gen_pre_eval()
     if "--only-pre-eval" in sys.argv:
         sys.exit(0)
     gen_s2d()
     gen_coords()
     gen_kb()
+    gen_kb_stacked()
     gen_decoder()
     gen_forward()
     gen_checkpoint()

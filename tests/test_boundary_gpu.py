@@ -143,6 +143,34 @@ def test_patched_reference_shaped_model_on_side_stream(dev):
     assert float(((out2.cpu() - ref).abs() / ref.abs()).max()) < TOL
 
 
+def test_configs1_hybrid_full_size_batch8(dev):
+    """BASELINE configs[1] as it is written: KITTI 352x1216, batch 8, fp32, one MI355X, "S2D + KB-layer HIP kernels, convs still
+    PyTorch-ROCm" -- the two north-star modules patched into the reference-shaped model at FULL width and
+    FULL size, every other layer a torch.nn.functional op (MIOpen).  The first and the last frame go through the oracle; the all-HIP
+    model on the same frames is reported beside it."""
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
+    frames = kb.synthetic.make_frames(8, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
+    model = _ReferenceShapedModel(cfg, sds, dev)
+    dframes = [f.to(dev) for f in frames]
+    with torch.no_grad():
+        out = model.forward(*dframes)
+    torch.cuda.synchronize(dev)
+    assert tuple(out.shape) == (8, 1, 352, 1216)
+    full = kb.modules.KBNetModel.from_config(cfg, dev)
+    full.load_state_dicts(*sds)
+    out_hip = full.forward(*dframes)
+    worst = worst_hip = 0.0
+    for i in (0, 7):
+        ref = orc.kbnet_forward(*[f[i:i + 1] for f in frames], *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth,
+                                cfg.max_predict_depth)
+        worst = max(worst, float(((out[i:i + 1].cpu() - ref).abs() / ref.abs()).max()))
+        worst_hip = max(worst_hip, float(((out_hip[i:i + 1].cpu() - ref).abs() / ref.abs()).max()))
+    print(f"configs[1] hybrid (HIP S2D + KB blocks, torch convs) 8x352x1216: max rel err vs oracle {worst:.3e}; all-HIP {worst_hip:.3e}")
+    assert worst < TOL, worst
+    assert worst_hip < TOL, worst_hip
+
+
 def test_two_devices_in_one_process():
     """Kernel attributes (dynamic LDS limit) are per device and the launches follow the tensors' device, not the
     current one: a model on cuda:1 while cuda:0 is current (the reference accepts any `device`; DataParallel
@@ -215,6 +243,20 @@ def test_rccl_single_rank_group(dev):
         assert torch.equal(outs[0], ea) and torch.equal(outs[1], ec)
         assert kb.dist.max_over_ranks(3.0, dev) == 3.0
         kb.dist.barrier()
+        # the form bench.py runs: two rotating graph outputs, the all-gather reads the graph's own output tensor (no staging copy),
+        # and bench.timed_steps around it -- graph replay + async gather + drain() ordering with the real collective
+        replay2 = m.capture(*a, outputs=2)
+        r2 = kb.dist.ShardedRunner(replay2, 0, 1, gather_single=True)
+        assert r2.step_pipelined(a) is None
+        assert torch.equal(r2.step_pipelined(b), ea)
+        assert torch.equal(r2.step_pipelined(a), eb)
+        assert torch.equal(r2.step_pipelined(b), ea)
+        assert torch.equal(r2.drain(), eb)
+        assert all(slot[0] is None or slot[0].data_ptr() in [t.data_ptr() for t in replay2.static_outs] for slot in r2._ring)
+        import bench
+        r3 = kb.dist.ShardedRunner(m.capture(*a, outputs=2), 0, 1, gather_single=True)
+        elapsed, gathered = bench.timed_steps(r3, a, steps=6, warmup=3, dev=dev)
+        assert elapsed > 0 and torch.equal(gathered, ea)
     finally:
         dist.destroy_process_group()
 

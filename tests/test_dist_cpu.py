@@ -121,6 +121,109 @@ def test_pipelined_world1_returns_detached_previous_step():
     assert torch.equal(r.drain(), x2)
 
 
+class _RotatingForward:
+    """What modules.GraphedForward(outputs=2) looks like to the runner: two static output tensors, calls alternate."""
+    rotating_outputs = 2
+
+    def __init__(self):
+        self.outs = [torch.zeros(2, 1, 4, 4), torch.zeros(2, 1, 4, 4)]
+        self.turn = 0
+
+    def __call__(self, a, b, c, d):
+        out = self.outs[self.turn]
+        self.turn ^= 1
+        out.copy_(a)
+        return out
+
+
+def test_pipelined_world1_rotating_outputs_are_not_copied():
+    """A forward with two rotating outputs is gathered IN PLACE: the ring holds the forward's own tensors (no staging copy) and the
+    previous step's result survives the current step's forward."""
+    fwd = _RotatingForward()
+    r = kb.dist.ShardedRunner(fwd, 0, 1)
+    xs = [torch.full((2, 1, 4, 4), float(i)) for i in range(1, 5)]
+    assert r.step_pipelined((xs[0], None, None, None)) is None
+    for i in (1, 2, 3):
+        prev = r.step_pipelined((xs[i], None, None, None))
+        assert torch.equal(prev, xs[i - 1])
+        assert prev.data_ptr() in [o.data_ptr() for o in fwd.outs], "the ring slot IS the forward's output tensor"
+    assert torch.equal(r.drain(), xs[3])
+
+
+def _rotating_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    kb.dist.init("gloo")
+    fwd = _RotatingForward()
+    runner = kb.dist.ShardedRunner(fwd, rank, world)
+    mine = lambda step: torch.full((2, 1, 4, 4), float(10 * step + rank))
+    whole = lambda step: torch.cat([torch.full((2, 1, 4, 4), float(10 * step + r)) for r in range(world)])
+    ok = runner.step_pipelined((mine(0), None, None, None)) is None
+    for step in range(1, 5):
+        prev = runner.step_pipelined((mine(step), None, None, None))
+        ok = ok and torch.equal(prev, whole(step - 1))
+    ok = ok and torch.equal(runner.drain(), whole(4))
+    ok = ok and all(slot[0].data_ptr() in [o.data_ptr() for o in fwd.outs] for slot in runner._ring)
+    kb.dist.barrier()
+    q.put((rank, bool(ok), 1.0))
+    dist.destroy_process_group()
+
+
+def test_pipelined_rotating_outputs_world2_gloo():
+    results = _spawn(_rotating_worker, 2)
+    assert all(ok for _, ok, _ in results)
+
+
+# ---- BASELINE configs[3]'s rank arithmetic: 256 frames over EIGHT ranks (gloo, tiny frames, stand-in forward) --------
+MIXED8 = [("void", 24, 32, 19), ("void", 20, 28, 5), ("kitti", 16, 40, 256)]   # 19 and 5 frames over 8 ranks: ragged, empty ranks
+
+
+def _world8_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    kb.dist.init("gloo")
+    n_total = 256
+    frames = kb.synthetic.make_frames(n_total, 8, 12, "kitti", seed=7)
+    lo, hi = kb.dist.shard_bounds(n_total, rank, world)
+    ok = (hi - lo) == 32 and lo == 32 * rank                  # configs[3]: 32 frames per GPU, contiguous
+    local = kb.dist.shard_frames(frames, rank, world)
+    ref = _fake_forward(*frames)
+    runner = kb.dist.ShardedRunner(_fake_forward, rank, world)
+    ok = ok and torch.equal(runner.step(local, n_total=n_total), ref)
+    prunner = kb.dist.ShardedRunner(_fake_forward, rank, world)
+    ok = ok and prunner.step_pipelined(local) is None
+    ok = ok and torch.equal(prunner.step_pipelined(local), ref)
+    ok = ok and torch.equal(prunner.drain(), ref)
+    # a ragged global batch (250 frames: ranks 0-1 hold 32, the others 31) goes through the padded slots of step()
+    sub = [t[:250] for t in frames]
+    ok = ok and torch.equal(kb.dist.ShardedRunner(_fake_forward, rank, world).step(kb.dist.shard_frames(sub, rank, world), n_total=250), ref[:250])
+    # mixed-shape buckets: ranks without a frame of a shape still join that bucket's gather
+    buckets, refs = [], []
+    for i, (preset, h, w, n) in enumerate(MIXED8):
+        fr = list(kb.synthetic.make_frames(n, h, w, preset, seed=20 + i))
+        a, b = kb.dist.shard_bounds(n, rank, world)
+        buckets.append((_fake_forward, [t[a:b] for t in fr] if b > a else None, n, (1, h, w)))
+        refs.append(_fake_forward(*fr))
+    outs = runner.step_mixed(buckets)
+    ok = ok and all(torch.equal(o, r) for o, r in zip(outs, refs))
+    t = kb.dist.max_over_ranks(float(rank), torch.device("cpu"))
+    per_frame = torch.full((hi - lo, 4), float(rank))
+    mean = kb.dist.mean_metrics_over_ranks(per_frame)
+    ok = ok and bool(torch.allclose(mean, torch.full((4,), 3.5, dtype=torch.float64)))
+    kb.dist.barrier()
+    q.put((rank, bool(ok), t))
+    dist.destroy_process_group()
+
+
+def test_sharded_runner_world8_gloo_256_frames():
+    """BASELINE configs[3] (KITTI batch 256 over 8 GPUs) without the GPUs: shard_bounds, step, step_pipelined, a ragged batch, the
+    mixed-shape buckets of configs[4] with ranks that hold no frame of a shape, max / mean reductions -- at WORLD SIZE 8."""
+    results = _spawn(_world8_worker, 8)
+    assert len(results) == 8 and all(ok for _, ok, _ in results)
+    assert all(t == 7.0 for _, _, t in results)
+
+
 @pytest.mark.parametrize("n_total", [4, 5])
 def test_sharded_runner_world2_gloo(n_total):
     results = _spawn(_worker, 2, n_total)

@@ -357,6 +357,30 @@ def test_kb_block_golden(dev, name, mode):
     assert rel_err(cf, g["conv_fused"]) < TIGHT
 
 
+@pytest.mark.parametrize("name", ["kb_stacked", "kb_stacked_odd"])
+@pytest.mark.parametrize("mode", ["coordinates", "kinv"])
+def test_kb_block_stacked_convolutions_golden(dev, name, mode):
+    """n_convolution_image / n_convolution_depth > 1 (reference src/net_utils.py:1311-1325; goldens from the reference's block
+    with 2 / 3 and 3 / 2 convs per branch): stride-1 convs in front of a branch's stride-2 conv, conv_fused on the block's INPUTS."""
+    g = load_golden(name)
+    w = g["weights"]
+    n_img, n_dep = int(g["n_convolution_image"]), int(g["n_convolution_depth"])
+    fi, ci = w["conv_image.conv_block.0.conv.weight"].shape[:2]
+    fd, cd3 = w["conv_depth.conv_block.0.conv.weight"].shape[:2]
+    ff, cf3 = w["conv_fused.conv.weight"].shape[:2]
+    blk = kb.modules.CalibratedBackprojectionBlock(ci, cd3 - 3, cf3 - 3, fi, fd, ff, n_img, n_dep, 2, "xavier_normal",
+                                                   torch.nn.LeakyReLU(0.2)).to(dev)
+    assert set(blk.state_dict()) == set(w)
+    blk.load_state_dict(w)
+    image, depth = g["image"].to(dev), g["depth"].to(dev)
+    fused = g["fused"].to(dev) if "fused" in g else None
+    coords = g["coordinates"].to(dev) if mode == "coordinates" else kb.ops.intrinsics_inverse(g["intrinsics"].to(dev))
+    out_i, out_d, out_f = blk(image=image, depth=depth, coordinates=coords, fused=fused)
+    assert rel_err(out_i, g["conv_image"]) < TIGHT
+    assert rel_err(out_d, g["conv_depth"]) < TIGHT
+    assert rel_err(out_f, g["conv_fused"]) < TIGHT
+
+
 @pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [
     (48, 16, 0, 48, 16, 36, 56),     # KB1: no fused input, 3 n-blocks
     (48, 16, 48, 96, 32, 30, 44),    # KB2: two 48-filter tiles
@@ -1130,7 +1154,7 @@ def test_forward_with_and_without_depth_front_fusion(dev, kenv, preset, shape):
     """KBN_DEPTH_FRONT_FUSION=1 (or encoder.fuse_s2d = True) makes KBNetModel.forward run S2D inside the depth front's launch; the
     default is the two launches.  Same launches otherwise, results within single-op noise of each other, both within the gate of the oracle."""
     cfg = kb.PRESETS[preset]()
-    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.3)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=kb.synthetic.PARITY_GAIN[preset])
     frames = kb.synthetic.make_frames(2, *shape, preset, seed=5, jitter_intrinsics=0.1)
     m = kb.modules.KBNetModel.from_config(cfg, dev)
     m.load_state_dicts(*sds)
@@ -1227,7 +1251,7 @@ def test_bf16_leg_error_is_reported_not_gated(dev):
     on bf16 MFMAs.  The result is close to the fp32 forward in the bf16 sense (mean relative error < 2e-2) and NOT within
     the 1e-4 parity bar -- the reason bench.py reports this leg under its own keys."""
     cfg = kb.kitti_config()
-    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
     frames = to(dev, *kb.synthetic.make_frames(2, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1))
     m = kb.modules.KBNetModel.from_config(cfg, dev)
     m.load_state_dicts(*sds)
@@ -1251,15 +1275,17 @@ def _check_forward(out, ref):
     assert float(err) < TOL, f"max relative error {float(err):.3e}"
 
 
-@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02"])
+@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02", "fwd_kb01234", "fwd_kb01234_odd"])
 def test_forward_golden(dev, name):
-    """fwd_kb012 / fwd_kb02: encoder topologies with plain stride-2 blocks where a level has no KB layer."""
-    import dataclasses
+    """fwd_kb012 / fwd_kb02: encoder topologies with plain stride-2 blocks where a level has no KB layer; fwd_kb01234*: a KB layer at
+    resolution 4 too -- the reference then calls calibrated_backprojection4 twice and never its calibrated_backprojection5
+    (src/networks.py:499-517, quirk Q3), whose parameters still sit in the state_dict."""
+    from test_oracle_golden import golden_config
     g = load_golden(name)
-    cfg = kb.PRESETS[str(g["preset"])]().narrow()
-    if "resolutions_backprojection" in g:
-        cfg = dataclasses.replace(cfg, resolutions_backprojection=tuple(int(v) for v in g["resolutions_backprojection"]))
+    cfg = golden_config(g)
     m = kb.modules.KBNetModel.from_config(cfg, dev)
+    if 4 in cfg.resolutions_backprojection:
+        assert any(k.startswith("calibrated_backprojection5.") for k in g["encoder"])
     m.load_state_dicts(g["s2d"], g["encoder"], g["decoder"])
     out = m.forward(*to(dev, g["image"], g["sparse_depth"], g["validity_map"], g["intrinsics"]))
     _check_forward(out, g["output_depth"])
@@ -1269,7 +1295,7 @@ def test_forward_golden(dev, name):
 def test_forward_full_size_vs_oracle(dev, preset, shape):
     """BASELINE.json sizes, full-width network, one frame on the oracle (seconds on CPU)."""
     cfg = kb.PRESETS[preset]()
-    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3 if preset == "kitti" else 1.45)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN[preset])
     frames = kb.synthetic.make_frames(2, *shape, preset, seed=1, jitter_intrinsics=0.1)
     m = kb.modules.KBNetModel.from_config(cfg, dev)
     m.load_state_dicts(*sds)
@@ -1292,7 +1318,7 @@ def test_forward_batch32_full_size_vs_oracle(dev):
     """BASELINE configs[2] (fp32 leg) / configs[3]'s per-GPU share: KITTI 352x1216, 32 frames in one forward and in the
     graph the bench replays (two 16-frame branches).  Three frames incl. the last one go through the oracle."""
     cfg = kb.kitti_config()
-    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
     frames = kb.synthetic.make_frames(32, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
     m = kb.modules.KBNetModel.from_config(cfg, dev)
     m.load_state_dicts(*sds)
@@ -1307,6 +1333,29 @@ def test_forward_batch32_full_size_vs_oracle(dev):
                                 cfg.min_predict_depth, cfg.max_predict_depth)
         worst = max(worst, _worst_rel(out[i:i + 1], ref))
     print(f"batch 32 KITTI: worst element-wise relative error over frames 0/17/31 = {worst:.3e}")
+    assert worst < TOL, f"max relative error {worst:.3e}"
+
+
+def test_forward_batch8_full_size_vs_oracle(dev):
+    """BASELINE configs[1]'s workload -- KITTI 352x1216, batch 8, fp32, one GPU -- in the all-HIP form: eager, and as the graph
+    bench.py's `batch8_frames_per_s` replays (two branches of 4 frames: other tuned tile choices and another graph than batch 32's).
+    The first and the last frame go through the oracle; the graph must reproduce the eager batch bit for bit."""
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
+    frames = kb.synthetic.make_frames(8, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    dframes = to(dev, *frames)
+    out = m.forward(*dframes).clone()
+    replay = m.capture(*dframes)
+    assert replay.branches == 2
+    assert torch.equal(replay(*dframes), out), "graph replay (2 x 4 frames) must reproduce the eager batch"
+    worst = 0.0
+    for i in (0, 7):
+        ref = orc.kbnet_forward(*[f[i:i + 1] for f in frames], *sds, cfg.min_pools, cfg.max_pools,
+                                cfg.min_predict_depth, cfg.max_predict_depth)
+        worst = max(worst, _worst_rel(out[i:i + 1], ref))
+    print(f"batch 8 KITTI: worst element-wise relative error over frames 0/7 = {worst:.3e}")
     assert worst < TOL, f"max relative error {worst:.3e}"
 
 
@@ -1325,7 +1374,7 @@ def test_forward_follows_input_scale_without_calibration(dev):
     to 1e-4 there, split kernels or not -- tests/analysis/input_scale_margin.py prints both paths.)"""
     cfg = kb.kitti_config()
     h, w = 352, 1216
-    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
     m = kb.modules.KBNetModel.from_config(cfg, dev)
     m.load_state_dicts(*sds)
     image, sparse, valid, k = kb.synthetic.make_frames(2, h, w, "kitti", seed=1, jitter_intrinsics=0.1)
@@ -1388,7 +1437,7 @@ def test_forward_full_size_seed_sweep(dev, preset, shape):
     seeds = (0, 3, 4, 6, 7, 11, 19)
     per_seed, vs64 = [], []
     for seed in seeds:
-        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3 if preset == "kitti" else 1.45)
+        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=kb.synthetic.PARITY_GAIN[preset])
         frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
         m = kb.modules.KBNetModel.from_config(cfg, dev)
         m.load_state_dicts(*sds)
@@ -1421,8 +1470,9 @@ def _fp64_forward(cfg, sds, frames):
         torch.set_default_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("fuse_s2d", [False, True])
 @pytest.mark.parametrize("preset,shape,seeds", [("kitti", (352, 1216), (0, 1, 2)), ("void", (480, 640), (0, 5))])
-def test_forward_full_size_trained_like_weights(dev, preset, shape, seeds):
+def test_forward_full_size_trained_like_weights(dev, preset, shape, seeds, fuse_s2d):
     """the pretrained checkpoints are external files, and xavier noise has none of what trained weights do to
     an fp16 window -- so the full-size forward is stressed with TRAINED-LIKE statistics (synthetic.make_state_dicts(
     trained_like=True): Student-t entries, per-filter scales spread log-uniformly over 2^7, 10 % of the filters exactly zero =
@@ -1431,7 +1481,10 @@ def test_forward_full_size_trained_like_weights(dev, preset, shape, seeds):
     than on xavier weights, and most channels sit far below the window's top.  Asserted per seed: the 1e-4 gate against the
     fp32 oracle; against an fp64 evaluation the HIP path is at most 2x as far from the exact result as the fp32 oracle is
     (or within 2e-5: the resolution of a max over 4e5 pixels); every pair tensor's window slack stays below the 16 binades
-    the two-term format tolerates at no cost (tests/test_split_math_cpu.py::test_window_slack_costs_nothing)."""
+    the two-term format tolerates at no cost (tests/test_split_math_cpu.py::test_window_slack_costs_nothing).
+    `fuse_s2d`: the same stress with the opt-in S2D-in-the-depth-front launch, whose on-chip fp16 windows come from FIVE
+    chained worst-case L1 bounds (csrc/s2d_stage.h) instead of one bound per layer from a measured maximum -- filters whose scales
+    are spread over 2^7 are exactly what stacks slack there; the gates are the same."""
     cfg = kb.PRESETS[preset]()
     lines = []
     for seed in seeds:
@@ -1439,6 +1492,7 @@ def test_forward_full_size_trained_like_weights(dev, preset, shape, seeds):
         frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
         m = kb.modules.KBNetModel.from_config(cfg, dev)
         m.load_state_dicts(*sds)
+        m.encoder.fuse_s2d = fuse_s2d
         kb.ops.PairTensor.LOG = log = []
         try:
             out = m.forward(*to(dev, *frames))
@@ -1465,7 +1519,7 @@ def test_no_split_forward_launches_nothing_twice(dev, kenv):
     KBN_NO_SPLIT forward has exactly the launches of the three-launch path, none of them twice."""
     cfg = kb.kitti_config()   # full widths: the front kernels only take KBNet's 48 / 16 filters
     m = kb.modules.KBNetModel.from_config(cfg, dev)
-    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=3, gain=1.3))
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=3, gain=kb.synthetic.PARITY_GAIN["kitti"]))
     a = to(dev, *kb.synthetic.make_frames(2, 64, 96, "kitti", seed=9))
     ref = m.forward(*a).clone()
     kenv.setenv("KBN_NO_SPLIT", "1")
@@ -1494,7 +1548,7 @@ def test_fp16_one_term_leg_is_throughput_only(dev, kenv):
     the parity-gated path), the same launches run (no fallback to another kernel), and switching it off restores the bits."""
     cfg = kb.kitti_config()
     m = kb.modules.KBNetModel.from_config(cfg, dev)
-    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"]))
     a = to(dev, *kb.synthetic.make_frames(2, 128, 320, "kitti", seed=4))
 
     def run():
@@ -1522,7 +1576,7 @@ def test_intermediate_tensors_elementwise_full_size(dev):
     This is the element-wise check of every intermediate tensor of ONE full-size KITTI forward: |a-b| <= 1e-4 |b| +
     floor with floor = 1e-4 x the tensor's RMS (values near a zero crossing have no meaningful relative error)."""
     cfg = kb.kitti_config()
-    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
     image, sparse, valid, k = kb.synthetic.make_frames(1, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
     x = torch.cat([sparse, valid], 1)
     s2d_ref = orc.sparse_to_dense_pool(x, sds[0], cfg.min_pools, cfg.max_pools)
@@ -1613,6 +1667,32 @@ def test_channel_count_mismatch_raises(dev):
             coordinates=kinv, fused=torch.randn(1, 40, 8, 16, device=dev))
 
 
+@pytest.mark.parametrize("branches", [1, 2])
+def test_graph_replay_with_two_rotating_outputs(dev, branches):
+    """capture(outputs=2): the graph exists once per output tensor (one memory pool) and calls alternate between them, so the
+    tensor a call returns is not overwritten by the NEXT call -- what dist.ShardedRunner.step_pipelined needs to all-gather the
+    graph's output in place while the next step's forward runs (no staging copy).  Same bits as the eager forward."""
+    cfg = kb.kitti_config().narrow()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    a = to(dev, *kb.synthetic.make_frames(4, 64, 96, "kitti", seed=1, jitter_intrinsics=0.1))
+    b = to(dev, *kb.synthetic.make_frames(4, 64, 96, "kitti", seed=2, jitter_intrinsics=0.1))
+    ea, eb = m.forward(*a).clone(), m.forward(*b).clone()
+    replay = m.capture(*a, branches=branches, outputs=2)
+    assert replay.rotating_outputs == 2 and len(replay.graphs) == 2
+    oa = replay(*a)
+    ob = replay(*b)
+    assert oa.data_ptr() != ob.data_ptr()
+    assert torch.equal(oa, ea), "the first call's tensor survives the second call"
+    assert torch.equal(ob, eb)
+    oa2 = replay(*b)
+    assert oa2.data_ptr() == oa.data_ptr() and torch.equal(oa2, eb) and torch.equal(ob, eb)
+    single = m.capture(*a, branches=branches)
+    assert single.rotating_outputs == 0 and torch.equal(single(*a), ea)
+    with pytest.raises(kb._lib.KbnError):
+        m.capture(*a, outputs=3)
+
+
 def test_graph_replay_with_concurrent_branches(dev):
     """capture(..., branches=k): the batch runs as k concurrent sub-batches inside one graph; same bits
     as the eager forward of the whole batch, also after new inputs are copied in."""
@@ -1643,7 +1723,7 @@ def test_unused_image_conv_of_last_kb_level_changes_nothing(dev):
     the latent, every skip and the depth map bit-identical."""
     cfg = kb.kitti_config()
     m = kb.modules.KBNetModel.from_config(cfg, dev)
-    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=3, gain=1.3))
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=3, gain=kb.synthetic.PARITY_GAIN["kitti"]))
     a = to(dev, *kb.synthetic.make_frames(2, 96, 160, "kitti", seed=9))
     full = m.forward(*a).clone()
     kb.ops.PROFILE = names_hook = []   # ops records one entry per kernel launch while a list hangs here
@@ -1667,7 +1747,7 @@ def test_graph_replay_with_level_side_branches(dev):
     (modules._SideBranch): same bits as the eager forward, which keeps one stream, and the forks really happened."""
     cfg = kb.kitti_config()
     m = kb.modules.KBNetModel.from_config(cfg, dev)
-    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.3))
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=2, gain=kb.synthetic.PARITY_GAIN["kitti"]))
     a = to(dev, *kb.synthetic.make_frames(2, 96, 160, "kitti", seed=5))
     b = to(dev, *kb.synthetic.make_frames(2, 96, 160, "kitti", seed=6))
     eager_a, eager_b = m.forward(*a).clone(), m.forward(*b).clone()
@@ -1688,7 +1768,7 @@ def test_mixed_shape_stream_two_weight_sets(dev):
     for preset in ("kitti", "void"):
         cfg = kb.PRESETS[preset]()
         m = kb.modules.KBNetModel.from_config(cfg, dev)
-        m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=5, gain=1.3))
+        m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=5, gain=kb.synthetic.PARITY_GAIN[preset]))
         models[preset] = m
     stream = [("void", "void", (480, 640)), ("void", "nyu_v2", (416, 576)), ("kitti", "kitti", (352, 1216))]
     for preset, stats, shape in stream:

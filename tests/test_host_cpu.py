@@ -70,6 +70,26 @@ def test_reference_written_checkpoint_loads():
             assert torch.equal(v, g[name][k]), k
 
 
+def test_kb_layer_at_resolution_4_keeps_the_reference_state_dict():
+    """4 in resolutions_backprojection: the reference builds calibrated_backprojection5 (and no conv5_*), then calls
+    calibrated_backprojection4 twice (src/networks.py:266-283, :499-517, quirk Q3).  Same keys / shapes as the golden captured from
+    the reference's own model, and as config.encoder_param_shapes; the stacked-conv KB block keeps the reference's keys too."""
+    import dataclasses
+    g = load_golden("fwd_kb01234")
+    cfg = dataclasses.replace(kb.kitti_config().narrow(), resolutions_backprojection=(0, 1, 2, 3, 4),
+                              n_filters_encoder_image=(8, 16, 32, 32, 32), n_filters_encoder_depth=(4, 8, 16, 16, 16))
+    m = _model(cfg)
+    sd = m.encoder.state_dict()
+    assert set(sd) == set(g["encoder"]) == set(kb.config.encoder_param_shapes(cfg))
+    assert all(tuple(sd[k].shape) == tuple(g["encoder"][k].shape) for k in sd)
+    assert any(k.startswith("calibrated_backprojection5.") for k in sd) and not any(k.startswith("conv5_") for k in sd)
+    m.load_state_dicts(g["s2d"], g["encoder"], g["decoder"])
+    ks = load_golden("kb_stacked")["weights"]
+    blk = kb.modules.CalibratedBackprojectionBlock(8, 4, 16, 16, 8, 16, 2, 3, 2, "xavier_normal", torch.nn.LeakyReLU(0.2))
+    assert blk.stacked and set(blk.state_dict()) == set(ks)
+    assert all(tuple(v.shape) == tuple(ks[k].shape) for k, v in blk.state_dict().items())
+
+
 def test_error_behaviour_mirrors_reference():
     with pytest.raises(ValueError):  # reference src/net_utils.py:45
         kb.modules.activation_func("swish")
@@ -189,6 +209,13 @@ def test_host_switches_follow_the_library_reading_of_the_environment(monkeypatch
         enc.fuse_s2d = None
         assert not enc.fuse_s2d
         assert kb.ops.knob("KBN_NO_SUCH_SWITCH") == 0
+        # a switch set to something that is not a number ("true", "yes") is SET: it reads as 1 (the pre-kbn_knob host
+        # switches treated any non-empty value but "0" as set; atoi alone would read 0 and silently leave the path on)
+        for text, want in (("true", 1), ("yes", 1), ("0", 0), ("2", 2), (" 1", 1), ("", 0)):
+            monkeypatch.setenv("KBN_NO_PAIR_TAIL", text)
+            kb.ops.reload_env()
+            assert kb.ops.knob("KBN_NO_PAIR_TAIL") == want, (text, want)
+            assert dec.pair_tail == (want == 0)
     finally:
         monkeypatch.undo()
         kb.ops.reload_env()

@@ -40,8 +40,9 @@ def test_coordinates_match_reference(name):
         hl, wl = (hl + 1) // 2, (wl + 1) // 2
 
 
-@pytest.mark.parametrize("name", ["kb_nofused", "kb_fused", "kb_odd"])
+@pytest.mark.parametrize("name", ["kb_nofused", "kb_fused", "kb_odd", "kb_stacked", "kb_stacked_odd"])
 def test_kb_block_matches_reference(name):
+    """kb_stacked*: n_convolution_image / n_convolution_depth > 1 (reference src/net_utils.py:1311-1325)."""
     g = load_golden(name)
     ci, cd, cf = orc.kb_block(g["image"], g["depth"], g["coordinates"], g.get("fused"), g["weights"])
     assert torch.equal(ci, g["conv_image"])
@@ -57,11 +58,24 @@ def test_decoder_matches_reference(name):
     assert torch.equal(out, g["logits"])
 
 
-@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02"])
-def test_forward_matches_reference(name):
-    """fwd_kb012 / fwd_kb02: encoders with KB layers at levels [0, 1, 2] / [0, 2] only."""
-    g = load_golden(name)
+def golden_config(g):
+    """The KBNetConfig a fwd_* fixture was generated with (narrow widths; recorded widths / KB levels where they differ)."""
+    import dataclasses
     cfg = kb.PRESETS[str(g["preset"])]().narrow()
+    if "resolutions_backprojection" in g:
+        cfg = dataclasses.replace(cfg, resolutions_backprojection=tuple(int(v) for v in g["resolutions_backprojection"]))
+    if "n_filters_encoder_image" in g:
+        cfg = dataclasses.replace(cfg, n_filters_encoder_image=tuple(int(v) for v in g["n_filters_encoder_image"]),
+                                  n_filters_encoder_depth=tuple(int(v) for v in g["n_filters_encoder_depth"]))
+    return cfg
+
+
+@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02", "fwd_kb01234", "fwd_kb01234_odd"])
+def test_forward_matches_reference(name):
+    """fwd_kb012 / fwd_kb02: encoders with KB layers at levels [0, 1, 2] / [0, 2] only; fwd_kb01234*: a KB layer at resolution 4
+    too, where the reference calls calibrated_backprojection4 a second time (src/networks.py:499-517, quirk Q3)."""
+    g = load_golden(name)
+    cfg = golden_config(g)
     levels = tuple(int(v) for v in g["resolutions_backprojection"]) if "resolutions_backprojection" in g else (0, 1, 2, 3)
     out = orc.kbnet_forward(g["image"], g["sparse_depth"], g["validity_map"], g["intrinsics"],
                             g["s2d"], g["encoder"], g["decoder"],

@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 cfg = kb.kitti_config()
 m = kb.modules.KBNetModel.from_config(cfg, dev)
-m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"]))
 fr = [f.to(dev) for f in kb.synthetic.make_frames(B, 352, 1216, "kitti", seed=1)]
 x = torch.cat([fr[1], fr[2]], 1).contiguous()
 enc, s2d = m.encoder, m.sparse_to_dense_pool

@@ -10,7 +10,7 @@ from kbnet_amd import ops
 dev = torch.device("cuda:0")
 cfg = kb.kitti_config()
 m = kb.modules.KBNetModel.from_config(cfg, dev)
-m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"]))
 fr = [f.to(dev) for f in kb.synthetic.make_frames(8, 352, 1216, "kitti", seed=1)]
 
 

@@ -10,7 +10,7 @@ pat = sys.argv[2] if len(sys.argv) > 2 else ""
 dev = torch.device("cuda:0")
 cfg = kb.PRESETS["kitti"]()
 m = kb.modules.KBNetModel.from_config(cfg, dev)
-m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"]))
 fr = [f.to(dev) for f in kb.synthetic.make_frames(B, 352, 1216, "kitti", seed=1)]
 # A/B switches of the host mirror: LP_KB1_SPLIT=1, LP_NARROW_UP=1 (16-filter split tiles for deconv0's up-conv), LP_FUSED_MIN=<filters>
 # (conv_fused on split operands from this width on)

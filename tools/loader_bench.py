@@ -55,7 +55,7 @@ def run_loader(consume):
 print(f"loader (decode + H2D + unpack)     : {run_loader(lambda *b: None):8.1f} frames/s")
 cfg = kb.kitti_config()
 model = kb.modules.KBNetModel.from_config(cfg, dev)
-model.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+model.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"]))
 frames = [t.to(dev) for t in kb.synthetic.make_frames(8, H, W, "kitti", seed=1)]
 replay = model.capture(*frames)
 def step(image, sparse, k):

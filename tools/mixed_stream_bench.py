@@ -23,7 +23,7 @@ models = {}
 for preset in ("kitti", "void"):
     cfg = kb.PRESETS[preset]()
     m = kb.modules.KBNetModel.from_config(cfg, dev)
-    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN[preset]))
     models[preset] = m
 stream = [("void", "void", (480, 640)), ("void", "nyu_v2", (416, 576)), ("kitti", "kitti", (352, 1216))]
 local, replay = {}, {}

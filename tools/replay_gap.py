@@ -8,7 +8,7 @@ import torch, kbnet_amd as kb
 dev = torch.device("cuda:0")
 cfg = kb.kitti_config()
 m = kb.modules.KBNetModel.from_config(cfg, dev)
-m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.3))
+m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"]))
 fr = [f.to(dev) for f in kb.synthetic.make_frames(8, 352, 1216, "kitti", seed=1)]
 def timeit(fn, reps=40):
     for _ in range(3): fn()

@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 preset, shape = (sys.argv[1], (int(sys.argv[2]), int(sys.argv[3]))) if len(sys.argv) > 3 else ("void", (480, 640))
 cfg = kb.PRESETS[preset]()
 m = kb.modules.KBNetModel.from_config(cfg, dev)
-m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=1.4))
+m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["void"]))
 fr = [f.to(dev) for f in kb.synthetic.make_frames(8, *shape, preset, seed=1)]
 for _ in range(3):
     m.forward(*fr)
