@@ -1135,20 +1135,22 @@ class GraphedForward:
         self._weights = model.weight_state()
         self.branches = branches
         self._streams = [torch.cuda.Stream() for _ in range(branches - 1)]
-        self.graphs, self.static_outs = [], []
+        # The output tensors live OUTSIDE the graphs' memory pool (allocated here, before any capture): a second capture that
+        # shares the first one's pool may hand out memory the first capture's tensors occupy -- its activations on purpose, but an
+        # output tensor allocated under capture went the same way on ROCm 7.2 (both copies returned one address).
+        h, w = self.static_in[1].shape[-2:]
+        self.graphs = []
+        self.static_outs = [torch.empty((n, 1, h, w), device=self.static_in[0].device, dtype=torch.float32) for _ in range(outputs)]
         for k in range(outputs):
             graph = torch.cuda.CUDAGraph()
             # one memory pool for all copies: they replay one after the other on one stream, never concurrently
             with torch.cuda.graph(graph, pool=self.graphs[0].pool() if self.graphs else None):
-                static_out = self._record(model, parts, branches, per, n)
+                self._record(model, parts, branches, per, self.static_outs[k])
             self.graphs.append(graph)
-            self.static_outs.append(static_out)
         self.graph, self.static_out = self.graphs[0], self.static_outs[0]
 
-    def _record(self, model, parts, branches, per, n):
-        """The launches of one forward, issued under capture; returns the output tensor they write."""
-        h, w = self.static_in[1].shape[-2:]
-        static_out = torch.empty((n, 1, h, w), device=self.static_in[0].device, dtype=torch.float32)
+    def _record(self, model, parts, branches, per, static_out):
+        """The launches of one forward into `static_out`, issued under capture."""
         if branches == 1:
             model.forward(*self.static_in, out=static_out)
             return static_out
