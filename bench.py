@@ -423,6 +423,9 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                          "unused conv); by default an N-rank run is the timed region plus rank 0's roofline pass")
     ap.add_argument("--no-fp16", action="store_true", help="skip the throughput-only one-term fp16 leg (configs[2])")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-shape stream side measurement (configs[4] in miniature)")
+    ap.add_argument("--split-graphs", action="store_true",
+                    help="one HIP graph per sub-batch branch, replayed on concurrent streams (GraphedForward(split_graphs=True)): lets the "
+                         "encoder's level side branches run inside every sub-batch")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step / >= 3 s sustained-rate run")
     ap.add_argument("--no-batch1", action="store_true", help="skip the batch-1 latency side measurement")
     args = ap.parse_args(argv)
@@ -472,7 +475,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     # --branches: concurrent sub-batches inside the graph (default: 2 for even batches >= 4, see GraphedForward)
     # outputs=2: the graph writes two alternating output tensors, so the asynchronous all-gather of step i reads the graph's own
     # output while step i+1's forward runs -- no staging copy inside the step (dist.ShardedRunner.step_pipelined)
-    forward = model.forward if args.eager else model.capture(*frames, branches=args.branches or None, outputs=2)
+    forward = model.forward if args.eager else model.capture(*frames, branches=args.branches or None, outputs=2,
+                                                             split_graphs=args.split_graphs)
     runner = kb.dist.ShardedRunner(forward, rank, world)
     # Inputs live where the graph reads them (its static input tensors, filled once here): a producer such as
     # loader.InferenceFrameLoader writes there directly, so a step has no input copy.  Eager mode: the frames.
@@ -719,7 +723,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    "n_ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                    "rccl_version": rccl_version(),
                    "launch": "eager" if args.eager else
-                             f"HIP graph replay, {getattr(forward, 'branches', 1)} concurrent sub-batch branch(es)",
+                             f"HIP graph replay, {getattr(forward, 'branches', 1)} concurrent sub-batch branch(es)"
+                             + (", one graph per branch on its own stream" if getattr(forward, "split_graphs", False) else ""),
                    "value_source": value_source,
                    # the same runner / graph for >= 300 more steps and >= 3 s (power-capped part: steady state, not a burst)
                    "sustained": sustained,

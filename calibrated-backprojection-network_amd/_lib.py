@@ -21,7 +21,7 @@ KBN_ERR_UNSUPPORTED = -2
 KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ, KBN_SRC_PAIR = 0, 1, 2, 3
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
 KBN_MAX_SRC = 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class KbnError(RuntimeError):
@@ -78,6 +78,11 @@ SIGNATURES = {
     "kbn_kb1_front_query": (_I, [_I, _I, _I, _I, _I, _F]),
     "kbn_kb1_depth_front_query": (_I, [_I, _I, _I, _I, _I, _F]),
     "kbn_kb1_front_forward": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "kbn_kb1_front_next_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
+    "kbn_kb1_front_next_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "kbn_kb1_front_next_query": (_I, [_I, _I, _I, _I, _I, _I, _F]),
+    "kbn_kb1_front_next_forward": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P,
+                                        _P, _P, _L, _P, _L, _I, _F, _P, _P]),
     "kbn_kb1_depth_front_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_kb1_depth_front_pack_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "kbn_kb1_depth_front_forward": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F, _P, _P]),

@@ -50,12 +50,23 @@ struct FrontParams {
     int N, Cin, H, W, h, w, tilesX, tilesY, ntiles;
     float slope0, slope1;
     int vec4;
+    // NEXT (kbn_kb1_front_next_forward): the NEXT KB level's conv_fused in the same launch -- a 1x1 stride-2 conv over
+    // cat[conv_image, xyz of that level, conv_fused] reads exactly the even pixels of this tile's two outputs (no halo)
+    const float* tab2;            // [2^-e per filter FO][xyz weights FO x 3]
+    const _Float16* wn;           // [k-step][term][4 k-groups][FO filters][8]: K = (conv_image channels, conv_fused channels)
+    const float* xyz2;            // N x 3 x h2 x w2 (kbn_kb_xyz_s2_forward of the next level)
+    long long xyz2_bstride;
+    float* out2;                  // N x FO x h2 x w2
+    long long out2_bstride;
+    unsigned* amax_out2;
+    int h2, w2, vec4_2;
+    float slope2;
 };
 
 // LDS per workgroup: IN 10.5 KB + X 35.1 KB + one chunk of conv_image / conv_fused weights 33 KB = 78.6 KB: TWO workgroups
 // per CU, so that one's image loads, barriers and stores hide under the other's MFMAs.
-template <int NC0, int NBI>   // conv0 filters / 16, conv_image = conv_fused filters / 16
-__global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontParams p) {
+template <int NC0, int NBI, bool NEXT = false>   // conv0 filters / 16, conv_image = conv_fused filters / 16; NEXT: + the next level's conv_fused
+__global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(const FrontParams p) {
     constexpr int FI = NBI * 16;
     constexpr int IN_PART = FR_NIN * 8, IN_BYTES = 2 * IN_PART;            // [term][pixel][4 channels] fp16
     constexpr int X_KG = FR_NP1 * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
@@ -110,8 +121,7 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontPar
                 tm = fmaxf(tm, fabsf(raw[u][j]));
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+        tm = __uint_as_float(wave_max_bits(tm));
         float* red = reinterpret_cast<float*>(smem + OFF_X);   // X is idle until conv0 writes it (after the next barrier)
         if (lane == 0) red[wave] = tm;
         __syncthreads();
@@ -279,6 +289,11 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontPar
     // ---- D: a lane holds pixels x = 4 kq .. 4 kq + 3 of row yrow for filter 16 nb + l15
     const int Yo = oy0 + yrow, Xo = ox0 + 4 * kq;
     float amI = 0.f, amF = 0.f;
+    f32x2 eI[NEXT ? NBI : 1], eF[NEXT ? NBI : 1];   // NEXT: this lane's two EVEN pixels (x = 4 kq, 4 kq + 2) of both outputs, zero outside the map
+    if constexpr (NEXT) {
+#pragma unroll
+        for (int nb = 0; nb < NBI; ++nb) { eI[nb] = (f32x2){0.f, 0.f}; eF[nb] = eI[nb]; }
+    }
     if (row_live && Xo < p.w) {
         const long long oplane = (long long)p.h * p.w;
         const long long pix = (long long)Yo * p.w + Xo;
@@ -311,8 +326,22 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontPar
                 const float a = __builtin_fmaf(sI[nb][r], 0.00048828125f, mI[nb][r]) * scI;
                 vI[r] = a > 0.f ? a : a * p.slope1;
                 float b = __builtin_fmaf(sF[nb][r], 0.00048828125f, mF[nb][r]) * scF;
-                b += w0x * xz[0][r] + w1x * xz[1][r] + w2x * xz[2][r];
+                b = __builtin_fmaf(w2x, xz[2][r], __builtin_fmaf(w1x, xz[1][r], __builtin_fmaf(w0x, xz[0][r], b)));   // fixed order: the same bits in every instantiation
                 vF[r] = b > 0.f ? b : b * p.slope1;
+            }
+            if constexpr (NEXT) {
+                const bool two = Xo + 2 < p.w;
+                eI[nb] = (f32x2){vI[0], two ? vI[2] : 0.f};
+                eF[nb] = (f32x2){vF[0], two ? vF[2] : 0.f};
+            }
+            if constexpr (NEXT) {
+                // the values wait in the accumulator registers: every store of this kernel is issued BEHIND stage E, whose loads would
+                // otherwise queue behind these stores in the in-order vmcnt and wait for their write acknowledgements
+                mI[nb] = vI; mF[nb] = vF;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (p.vec4 || Xo + r < p.w) { amI = fmaxf(amI, fabsf(vI[r])); amF = fmaxf(amF, fabsf(vF[r])); }
+                continue;
             }
             float* oi = p.out_image + (long long)n * p.out_image_bstride + f * oplane + pix;
             float* of = p.out_fused + (long long)n * p.out_fused_bstride + f * oplane + pix;
@@ -331,8 +360,152 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_front_kernel(const FrontPar
             }
         }
     }
+    auto store_own = [&]() {   // NEXT: phase D's stores, issued after stage E
+        if (row_live && Xo < p.w) {
+            const long long oplane = (long long)p.h * p.w;
+            const long long pix = (long long)Yo * p.w + Xo;
+#pragma unroll
+            for (int nb = 0; nb < NBI; ++nb) {
+                const int f = nb * 16 + l15;
+                float* oi = p.out_image + (long long)n * p.out_image_bstride + f * oplane + pix;
+                float* of = p.out_fused + (long long)n * p.out_fused_bstride + f * oplane + pix;
+                if (p.vec4) {
+                    *reinterpret_cast<ff4*>(oi) = mI[nb];
+                    *reinterpret_cast<ff4*>(of) = mF[nb];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (Xo + r < p.w) { oi[r] = mI[nb][r]; of[r] = mF[nb][r]; }
+                }
+            }
+        }
+    };
     if (p.amax_out_image) absmax_commit(p.amax_out_image + n, amI);
     if (p.amax_out_fused) absmax_commit(p.amax_out_fused + n, amF);
+
+    // ---- E (NEXT): conv_fused of the next KB level, reference src/net_utils.py:1352-1369 one level down: a 1x1 stride-2 conv over
+    // cat[conv_image, xyz, conv_fused] of THIS level samples the pixels (2 y, 2 x) -- for this tile the 4 x 8 even pixels of the two
+    // outputs the lanes still hold.  They become split granules G [term][k-group = channel / 8][32 pixels][8] in the (idle) X buffer,
+    // window = the tile's own maximum; D[pixel][filter] over K = 2 FI channels, weights straight from L2 / L1 (36 KB, shared by every
+    // tile); the three backprojection channels of the next level enter in fp32 like this level's in phase D.
+    if constexpr (NEXT) {
+        constexpr int FO = 2 * FI, NBK = FO / 16, KG2 = 2 * FI / 8, KS2 = KG2 / 4;
+        static_assert(KG2 % 4 == 0, "whole k-steps");
+        constexpr int G_PART = KG2 * 32 * 16;
+        static_assert(2 * G_PART + 64 <= X_BYTES, "G overlays X");
+        unsigned char* const G = smem + OFF_X;
+        float* const red2 = reinterpret_cast<float*>(smem + OFF_X + 2 * G_PART);
+        const bool even_row = (yrow & 1) == 0;   // wave-uniform
+        float tm = 0.f;
+        if (even_row) {
+#pragma unroll
+            for (int nb = 0; nb < NBI; ++nb)
+                tm = fmaxf(fmaxf(tm, fmaxf(fabsf(eI[nb][0]), fabsf(eI[nb][1]))), fmaxf(fabsf(eF[nb][0]), fabsf(eF[nb][1])));
+        }
+        {
+            const unsigned tb = wave_max_bits(tm);
+            if (lane == 0) red2[wave] = __uint_as_float(tb);
+        }
+        // wave nbk < NBK owns the filter block 16 nbk .. 16 nbk + 15 for BOTH pixel blocks of the tile, so that a weight fragment is
+        // fetched once per tile (the 36 KB of weights against 32 pixels are what this stage costs: every tile pulls them from L2 / L1);
+        // the fragments are requested before the barriers
+        static_assert(NBK <= 8, "one filter block per wave");
+        const bool has_blk = wave < NBK;   // wave-uniform
+        fh8 wb1[KS2], wb2[KS2];
+        if (has_blk) {
+            const int f = 16 * wave + l15;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                wb1[ks] = *reinterpret_cast<const fh8*>(p.wn + ((long long)((ks * 2 + 0) * 4 + kq) * FO + f) * 8);
+                wb2[ks] = *reinterpret_cast<const fh8*>(p.wn + ((long long)((ks * 2 + 1) * 4 + kq) * FO + f) * 8);
+            }
+        }
+        __syncthreads();
+        tm = fmaxf(fmaxf(fmaxf(red2[0], red2[1]), fmaxf(red2[2], red2[3])), fmaxf(fmaxf(red2[4], red2[5]), fmaxf(red2[6], red2[7])));
+        float pre2, un2;
+        fr_scales(__builtin_amdgcn_readfirstlane(__float_as_uint(tm)), pre2, un2);
+        if (even_row) {
+            const int pbase = (yrow >> 1) * 8 + 2 * kq;
+#pragma unroll
+            for (int nb = 0; nb < NBI; ++nb) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {   // conv_image channels first, conv_fused channels behind them (the reference's cat order)
+                    const f32x2 v = (t == 0 ? eI[nb] : eF[nb]) * pre2;
+                    const fh2 c1 = __builtin_convertvector(v, fh2);
+                    const f32x2 f1 = {(float)c1[0], (float)c1[1]};
+                    const f32x2 r = (v - f1) * 2048.f;
+                    const fh2 c2 = __builtin_convertvector(r, fh2);
+                    const int kg = t * (FI / 8) + 2 * nb + (l15 >> 3);
+                    _Float16* g1 = reinterpret_cast<_Float16*>(G + (kg * 32 + pbase) * 16) + (l15 & 7);
+                    _Float16* g2 = reinterpret_cast<_Float16*>(G + G_PART + (kg * 32 + pbase) * 16) + (l15 & 7);
+                    g1[0] = c1[0]; g1[8] = c1[1];
+                    g2[0] = c2[0]; g2[8] = c2[1];
+                }
+            }
+        }
+        __syncthreads();
+        const float* inv2 = p.tab2;
+        const float* wx2 = p.tab2 + FO;
+        const long long plane2 = (long long)p.h2 * p.w2;
+        float am2 = 0.f;
+        if (has_blk) {
+            const int f = 16 * wave + l15;
+            ff4 m[2], sm[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) { m[mb] = (ff4){0.f, 0.f, 0.f, 0.f}; sm[mb] = m[mb]; }
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const fh8 a1 = *reinterpret_cast<const fh8*>(G + ((4 * ks + kq) * 32 + 16 * mb + l15) * 16);
+                    const fh8 a2 = *reinterpret_cast<const fh8*>(G + G_PART + ((4 * ks + kq) * 32 + 16 * mb + l15) * 16);
+                    m[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wb1[ks], m[mb], 0, 0, 0);
+                    sm[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wb2[ks], sm[mb], 0, 0, 0);
+                    sm[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wb1[ks], sm[mb], 0, 0, 0);
+                }
+            }
+            const float sc = inv2[f] * un2;
+            const float w0x = wx2[f * 3], w1x = wx2[f * 3 + 1], w2x = wx2[f * 3 + 2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                // rows 4 kq + r of the block = pixels 16 mb + 4 kq + r of the tile's 4 x 8 even pixels: row 2 mb + (kq >> 1), columns 4 (kq & 1) + r
+                const int Y2 = (oy0 >> 1) + 2 * mb + (kq >> 1), X2 = (ox0 >> 1) + 4 * (kq & 1);
+                if (Y2 < p.h2 && X2 < p.w2) {
+                    const long long pix2 = (long long)Y2 * p.w2 + X2;
+                    const float* xp = p.xyz2 + (long long)n * p.xyz2_bstride + pix2;
+                    float* op = p.out2 + (long long)n * p.out2_bstride + f * plane2 + pix2;
+                    ff4 xz[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        if (p.vec4_2) {
+                            xz[j] = *reinterpret_cast<const ff4*>(xp + j * plane2);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) xz[j][r] = X2 + r < p.w2 ? xp[j * plane2 + r] : 0.f;
+                        }
+                    }
+                    ff4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = __builtin_fmaf(sm[mb][r], 0.00048828125f, m[mb][r]) * sc;
+                        t = __builtin_fmaf(w2x, xz[2][r], __builtin_fmaf(w1x, xz[1][r], __builtin_fmaf(w0x, xz[0][r], t)));
+                        v[r] = t > 0.f ? t : t * p.slope2;
+                    }
+                    if (p.vec4_2) {
+                        *reinterpret_cast<ff4*>(op) = v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) am2 = fmaxf(am2, fabsf(v[r]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (X2 + r < p.w2) { op[r] = v[r]; am2 = fmaxf(am2, fabsf(v[r])); }
+                    }
+                }
+            }
+        }
+        store_own();
+        if (p.amax_out2) absmax_commit(p.amax_out2 + n, am2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -452,8 +625,7 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
                 tm = fmaxf(tm, fabsf(raw[u][j]));
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+        tm = __uint_as_float(wave_max_bits(tm));
         float* red = reinterpret_cast<float*>(smem + LD::OFF_RED);
         if (lane == 0) red[wave] = tm;
         __syncthreads();
@@ -875,6 +1047,39 @@ __global__ void front_packc_kernel(const float* __restrict__ wi, const float* __
     out[e] = h;
 }
 
+// next-level conv_fused panel (kb1_front_kernel<.., NEXT>): tab2 = [2^-e per filter FO][xyz weights FO x 3], then
+// [k-step][term][k-group 4][filter FO][8]: K index 32 ks + 8 kq + j = channel c of cat[conv_image (CI), conv_fused (CF)];
+// the reference's weight columns are [image CI | xyz 3 | fused CF] (src/net_utils.py:1362-1368)
+__global__ void front_next_pack_kernel(const float* __restrict__ wf, float* __restrict__ tab2, _Float16* __restrict__ out, int CI, int CF, int FO,
+                                       int total) {
+    __shared__ float inv[128];
+    const int per = CI + 3 + CF;
+    for (int f = threadIdx.x; f < FO; f += blockDim.x) {
+        float m = 0.f;
+        for (int c = 0; c < per; ++c)
+            if (c < CI || c >= CI + 3) m = fmaxf(m, fabsf(wf[(long long)f * per + c]));
+        int ex = FR_WEXP;
+        if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &ex);
+        int e = FR_WEXP - ex;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        inv[f] = ldexpf(1.f, -e);
+        tab2[f] = inv[f];
+        for (int j = 0; j < 3; ++j) tab2[FO + f * 3 + j] = wf[(long long)f * per + CI + j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        int r = e;
+        const int j = r & 7; r >>= 3;
+        const int f = r % FO; r /= FO;
+        const int kq = r & 3; r >>= 2;
+        const int term = r & 1; r >>= 1;
+        const int c = 32 * r + 8 * kq + j;
+        _Float16 h = (_Float16)0.f;
+        if (c < CI + CF) h = fr_term(wf[(long long)f * per + (c < CI ? c : c + 3)] / inv[f], term);
+        out[e] = h;
+    }
+}
+
 }  // namespace kbn
 
 extern "C" {
@@ -917,15 +1122,52 @@ int kbn_kb1_front_query(int image_channels, int conv0_filters, int kb_filters, i
     return KBN_OK;
 }
 
-int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const void* packed_weight,
-                          const float* xyz, long long xyz_batch_stride, float* out_image, long long out_image_batch_stride,
-                          float* out_fused, long long out_fused_batch_stride, int n, int image_channels, int conv0_filters,
-                          int kb_filters, int height, int width, float conv0_negative_slope, float kb_negative_slope,
-                          unsigned* out_image_absmax, unsigned* out_fused_absmax, kbn_stream_t stream) {
+// ---- the next level's conv_fused inside the same launch (kb1_front_kernel<3, 3, true>) ----
+static bool front_next_shape_ok(int ci, int cf, int fo) { return ci == 48 && cf == 48 && fo == 96; }
+static size_t front_next_tab_floats(int fo) { return (size_t)fo * 4; }
+static size_t front_next_halves(int ci, int cf, int fo) { return (size_t)((ci + cf) / 32) * 2 * 4 * fo * 8; }
+
+size_t kbn_kb1_front_next_packed_weight_bytes(int image_channels, int fused_channels, int filters) {
+    if (!front_next_shape_ok(image_channels, fused_channels, filters)) return 0;
+    return front_next_tab_floats(filters) * 4 + 2 * front_next_halves(image_channels, fused_channels, filters);
+}
+
+int kbn_kb1_front_next_pack_weight(const float* w_conv_fused, void* packed, int image_channels, int fused_channels, int filters,
+                                   kbn_stream_t stream) {
+    using namespace kbn;
+    if (!w_conv_fused || !packed) return KBN_ERR_INVALID_ARGUMENT;
+    if (!front_next_shape_ok(image_channels, fused_channels, filters)) return KBN_ERR_UNSUPPORTED;
+    float* tab2 = static_cast<float*>(packed);
+    hipLaunchKernelGGL(front_next_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w_conv_fused, tab2,
+                       reinterpret_cast<_Float16*>(tab2 + front_next_tab_floats(filters)), image_channels, fused_channels, filters,
+                       (int)front_next_halves(image_channels, fused_channels, filters));
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_kb1_front_next_query(int image_channels, int conv0_filters, int kb_filters, int next_filters, int height, int width,
+                             float conv0_negative_slope) {
+    using namespace kbn;
+    if (int rc = kbn_kb1_front_query(image_channels, conv0_filters, kb_filters, height, width, conv0_negative_slope)) return rc;
+    if (!front_next_shape_ok(kb_filters, kb_filters, next_filters) || knob(KNOB_NO_FRONT_NEXT)) return KBN_ERR_UNSUPPORTED;
+    return KBN_OK;
+}
+
+static int kb1_front_launch(const float* image, long long image_batch_stride, const void* packed_weight,
+                            const float* xyz, long long xyz_batch_stride, float* out_image, long long out_image_batch_stride,
+                            float* out_fused, long long out_fused_batch_stride, int n, int image_channels, int conv0_filters,
+                            int kb_filters, int height, int width, float conv0_negative_slope, float kb_negative_slope,
+                            unsigned* out_image_absmax, unsigned* out_fused_absmax, const void* packed_next, const float* xyz_next,
+                            long long xyz_next_batch_stride, float* out_next, long long out_next_batch_stride, int next_filters,
+                            float next_negative_slope, unsigned* out_next_absmax, kbn_stream_t stream) {
     using namespace kbn;
     if (!image || !packed_weight || !out_image || !out_fused || n < 1 || height < 1 || width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
     if (int rc = kbn_kb1_front_query(image_channels, conv0_filters, kb_filters, height, width, conv0_negative_slope)) return rc;
+    if (packed_next) {
+        if (!xyz_next || !out_next) return KBN_ERR_INVALID_ARGUMENT;
+        if (int rc = kbn_kb1_front_next_query(image_channels, conv0_filters, kb_filters, next_filters, height, width, conv0_negative_slope)) return rc;
+    }
     FrontParams p{};
     p.image = image; p.image_bstride = image_batch_stride;
     p.tab = static_cast<const float*>(packed_weight);
@@ -945,13 +1187,53 @@ int kbn_kb1_front_forward(const float* image, long long image_batch_stride, cons
     p.vec4 = !((p.w & 3) || (reinterpret_cast<uintptr_t>(out_image) & 15) || (reinterpret_cast<uintptr_t>(out_fused) & 15) ||
                (out_image_batch_stride & 3) || (out_fused_batch_stride & 3) || (reinterpret_cast<uintptr_t>(xyz) & 15) ||
                (xyz_batch_stride & 3)) ? 1 : 0;
-    auto kern = kb1_front_kernel<3, 3>;
     constexpr size_t lds = 2 * FR_NIN * 8 + 2 * 2 * FR_NP1 * 16 + (5 * 2 * 4 + 2 * 2) * 48 * 16;
-    static DeviceOnce once;
-    if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
+    if (packed_next) {
+        p.tab2 = static_cast<const float*>(packed_next);
+        p.wn = reinterpret_cast<const _Float16*>(p.tab2 + front_next_tab_floats(next_filters));
+        p.xyz2 = xyz_next; p.xyz2_bstride = xyz_next_batch_stride;
+        p.out2 = out_next; p.out2_bstride = out_next_batch_stride;
+        p.amax_out2 = out_next_absmax;
+        p.h2 = ceil_div(p.h, 2); p.w2 = ceil_div(p.w, 2);
+        p.slope2 = next_negative_slope;
+        p.vec4_2 = !((p.w2 & 3) || (reinterpret_cast<uintptr_t>(out_next) & 15) || (out_next_batch_stride & 3) ||
+                     (reinterpret_cast<uintptr_t>(xyz_next) & 15) || (xyz_next_batch_stride & 3)) ? 1 : 0;
+        auto kern = kb1_front_kernel<3, 3, true>;
+        static DeviceOnce once_next;
+        if (int rc = set_max_dynamic_lds(once_next, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
+        hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
+    } else {
+        auto kern = kb1_front_kernel<3, 3, false>;
+        static DeviceOnce once;
+        if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
+        hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
+    }
     KBN_CHECK_LAUNCH();
     return KBN_OK;
+}
+
+int kbn_kb1_front_forward(const float* image, long long image_batch_stride, const void* packed_weight,
+                          const float* xyz, long long xyz_batch_stride, float* out_image, long long out_image_batch_stride,
+                          float* out_fused, long long out_fused_batch_stride, int n, int image_channels, int conv0_filters,
+                          int kb_filters, int height, int width, float conv0_negative_slope, float kb_negative_slope,
+                          unsigned* out_image_absmax, unsigned* out_fused_absmax, kbn_stream_t stream) {
+    return kb1_front_launch(image, image_batch_stride, packed_weight, xyz, xyz_batch_stride, out_image, out_image_batch_stride, out_fused,
+                            out_fused_batch_stride, n, image_channels, conv0_filters, kb_filters, height, width, conv0_negative_slope,
+                            kb_negative_slope, out_image_absmax, out_fused_absmax, nullptr, nullptr, 0, nullptr, 0, 0, 0.f, nullptr, stream);
+}
+
+int kbn_kb1_front_next_forward(const float* image, long long image_batch_stride, const void* packed_weight,
+                               const float* xyz, long long xyz_batch_stride, float* out_image, long long out_image_batch_stride,
+                               float* out_fused, long long out_fused_batch_stride, int n, int image_channels, int conv0_filters,
+                               int kb_filters, int height, int width, float conv0_negative_slope, float kb_negative_slope,
+                               unsigned* out_image_absmax, unsigned* out_fused_absmax, const void* packed_next, const float* xyz_next,
+                               long long xyz_next_batch_stride, float* out_next_fused, long long out_next_fused_batch_stride, int next_filters,
+                               float next_negative_slope, unsigned* out_next_fused_absmax, kbn_stream_t stream) {
+    if (!packed_next) return KBN_ERR_INVALID_ARGUMENT;
+    return kb1_front_launch(image, image_batch_stride, packed_weight, xyz, xyz_batch_stride, out_image, out_image_batch_stride, out_fused,
+                            out_fused_batch_stride, n, image_channels, conv0_filters, kb_filters, height, width, conv0_negative_slope,
+                            kb_negative_slope, out_image_absmax, out_fused_absmax, packed_next, xyz_next, xyz_next_batch_stride,
+                            out_next_fused, out_next_fused_batch_stride, next_filters, next_negative_slope, out_next_fused_absmax, stream);
 }
 
 static bool depth_front_shape_ok(int c_in, int f0, int fd) { return c_in >= 1 && c_in <= 8 && f0 == 16 && fd == 16; }

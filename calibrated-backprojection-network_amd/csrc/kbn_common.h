@@ -32,11 +32,34 @@ __device__ __forceinline__ float leaky_relu(float v, float slope) { return v > 0
 // data of THIS forward, frame by frame, with no host round trip and no state between calls.
 // `m` >= 0: this thread's maximum (NaNs never enter: fmaxf drops them).  One atomic per wave, and only when the wave
 // would raise the slot (the plain load may be stale -- then the atomic is merely redundant).
+// Bit pattern of the maximum of a NON-NEGATIVE float over the wave, wave-uniform (an SGPR).  DPP butterflies inside each row of 16
+// lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: max is idempotent, any covering pattern does), then the four rows
+// meet through v_readlane + s_max_u32.  No LDS crossbar: __shfl_xor is ds_bpermute_b32 with a per-lane address register for every
+// distance -- six registers that hipcc computes in a kernel's prologue, and in a kernel at its register limit SPILLS, so that every
+// step of the reduction became scratch_load + s_waitcnt vmcnt(0), i.e. a wait for all the stores the epilogue had just issued
+// (kb1_front_kernel<.., NEXT>: + 330 us per 32 KITTI frames, round 5).
+__device__ __forceinline__ unsigned wave_max_bits(float m) {
+#define KBN_DPP_MAX(ctrl) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), ctrl, 0xf, 0xf, true)))
+    KBN_DPP_MAX(0xB1);    // quad_perm [1, 0, 3, 2]
+    KBN_DPP_MAX(0x4E);    // quad_perm [2, 3, 0, 1]
+    KBN_DPP_MAX(0x141);   // row_half_mirror
+    KBN_DPP_MAX(0x140);   // row_mirror
+#undef KBN_DPP_MAX
+    const int v = __float_as_int(m);
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane(v, 0), b = (unsigned)__builtin_amdgcn_readlane(v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane(v, 32), d = (unsigned)__builtin_amdgcn_readlane(v, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;   // non-negative floats order like their bit patterns
+}
+// x + its three quad neighbours (lanes 4 q .. 4 q + 3), in every lane of the quad: two DPP quad_perm moves instead of two ds_bpermute
+__device__ __forceinline__ float quad_sum(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));   // quad_perm [1, 0, 3, 2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));   // quad_perm [2, 3, 0, 1]
+    return x;
+}
 __device__ __forceinline__ void absmax_commit(unsigned* slot, float m) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const unsigned b = wave_max_bits(m);
     if ((threadIdx.x & 63) == 0) {
-        const unsigned b = __float_as_uint(m);
         if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
     }
 }
@@ -74,7 +97,7 @@ enum Knob {
     KNOB_NO_HEAD_FUSION, KNOB_NO_SPLIT,
     // switches of the host mirror (modules.py asks kbn_knob(): one reading of the environment for both sides)
     KNOB_NO_OVERLAP, KNOB_NO_PAIR, KNOB_NO_PAIR_MID, KNOB_NO_PAIR_ENC, KNOB_NO_PAIR_TAIL, KNOB_NO_DEPTH_FRONT_FUSION,
-    KNOB_FP16_ONE_TERM, KNOB_DEPTH_FRONT_FUSION, KNOB_COUNT
+    KNOB_FP16_ONE_TERM, KNOB_DEPTH_FRONT_FUSION, KNOB_NO_FRONT_NEXT, KNOB_COUNT
 };
 struct KnobValue { int set, value; };
 extern KnobValue g_knobs[KNOB_COUNT];

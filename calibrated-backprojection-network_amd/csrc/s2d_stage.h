@@ -126,8 +126,7 @@ __device__ __forceinline__ void s2d_stage_run(const S2DStageParams& sp, unsigned
                 if (vz[u] != -INFINITY) tm = fmaxf(tm, fabsf(vz[u]));
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+        tm = __uint_as_float(wave_max_bits(tm));
         if (lane == 0) red[wave] = tm;
     }
     __syncthreads();

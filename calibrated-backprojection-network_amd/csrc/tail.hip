@@ -83,6 +83,15 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
     const int H = p.H, W = p.W, C = p.C;
     const long long plane = (long long)H * W;
     float* const F = reinterpret_cast<float*>(smem + OFF_F);
+    // the conv's A fragments (weights, 10 KB shared by every tile): requested FIRST, so that their L2 / L1 latency runs under the
+    // tile's input DMA instead of behind the barrier that ends it (hipcc otherwise sinks the loads to their first use)
+    th8 a1[5], a2[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        a1[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 0) * 512 + lane * 8);
+        a2[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 1) * 512 + lane * 8);
+    }
+    asm volatile("" ::: "memory");   // keeps the requests above the DMA issue below
 
     // ---- A: input tile -> split granules; the fp16 window is the tile's own (max |x| over the pixels loaded here)
     float un_in;
@@ -123,8 +132,7 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
                 tm = fmaxf(tm, fabsf(raw[u][j]));
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+        tm = __uint_as_float(wave_max_bits(tm));
         if (lane == 0) F[wave] = tm;   // the feature planes are idle until the conv writes them (two barriers on)
         __syncthreads();
         tm = fmaxf(fmaxf(fmaxf(F[0], F[1]), fmaxf(F[2], F[3])), fmaxf(fmaxf(F[4], F[5]), fmaxf(F[6], F[7])));
@@ -182,12 +190,6 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
 
     // ---- B: the C -> C conv on the 612 pixels the head reads
     {
-        th8 a1[5], a2[5];
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-            a1[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 0) * 512 + lane * 8);
-            a2[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 1) * 512 + lane * 8);
-        }
         tf4 sc = *reinterpret_cast<const tf4*>(p.tab + 4 * kq);   // 2^-e of this lane's four filters
         sc *= un_in;
         const f32x2 sc01 = {sc[0], sc[1]}, sc23 = {sc[2], sc[3]};
@@ -196,13 +198,23 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
             if (i < nblk) {
                 const unsigned char* inb = smem + inoff[i];
                 tf4 m = (tf4){0.f, 0.f, 0.f, 0.f}, s = m;
+                // the block's ten fragment reads go out together: one LDS latency per block instead of one per K step
+                // the block's ten fragment reads go out together (one LDS latency per block instead of one per K step): with the weights
+                // requested first, 486 -> 474 us per 32 KITTI frames inside the forward (round 5; output0's weights must NOT move ahead of a
+                // barrier -- __syncthreads waits for every outstanding load: + 120 us -- nor to the top of the kernel: 27 more live
+                // registers cross the 128 that keep two workgroups per CU, 884 us)
+                th8 b1[5], b2[5];
 #pragma unroll
                 for (int ks = 0; ks < 5; ++ks) {
-                    const th8 b1 = *reinterpret_cast<const th8*>(inb + tapoff[ks]);
-                    const th8 b2 = *reinterpret_cast<const th8*>(inb + IN_PART + tapoff[ks]);
-                    m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b1, m, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2, s, 0, 0, 0);
+                    b1[ks] = *reinterpret_cast<const th8*>(inb + tapoff[ks]);
+                    b2[ks] = *reinterpret_cast<const th8*>(inb + IN_PART + tapoff[ks]);
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks) {
+                    m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b1[ks], m, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1[ks], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2[ks], s, 0, 0, 0);
                 }
                 f32x2 t01 = (f32x2){s[0], s[1]} * 0.00048828125f + (f32x2){m[0], m[1]};
                 f32x2 t23 = (f32x2){s[2], s[3]} * 0.00048828125f + (f32x2){m[2], m[3]};
@@ -218,35 +230,36 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
             }
         }
     }
+    // output0's weights of this lane's channels (t, t + 4, t + 8 of at most 12): requested before the barrier
     __syncthreads();
 
     // ---- C: output0 + sigmoid mapping.  Four lanes share a quad of 4 consecutive output pixels, each summing a third /
-    // quarter of the channels (a 3 x 6 window per channel: one 16-byte + one 8-byte LDS read per row), then two shuffles.
+    // quarter of the channels (a 3 x 6 window per channel: one 16-byte + one 8-byte LDS read per row), then two DPP moves.
     {
         const int t = lane & 3, quad = tid >> 2;           // 128 quads: row quad >> 3, columns 4 (quad & 7) ..
         const int y = quad >> 3, x0 = 4 * (quad & 7);
         tf4 acc = (tf4){0.f, 0.f, 0.f, 0.f};
-        for (int c = t; c < C; c += 4) {
-            const float* fc = F + c * TL_FP + y * TL_FW + x0;
-            const float* wc = p.wout + c * 9;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const tf4 a = *reinterpret_cast<const tf4*>(fc + ky * TL_FW);
-                const f32x2 b = *reinterpret_cast<const f32x2*>(fc + ky * TL_FW + 4);
-                const float win[6] = {a[0], a[1], a[2], a[3], b[0], b[1]};
+        for (int ci = 0; ci < 3; ++ci) {
+            const int c = t + 4 * ci;
+            if (c < C) {
+                const float* fc = F + c * TL_FP + y * TL_FW + x0;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float w = wc[ky * 3 + kx];
+                for (int ky = 0; ky < 3; ++ky) {
+                    const tf4 a = *reinterpret_cast<const tf4*>(fc + ky * TL_FW);
+                    const f32x2 b = *reinterpret_cast<const f32x2*>(fc + ky * TL_FW + 4);
+                    const float win[6] = {a[0], a[1], a[2], a[3], b[0], b[1]};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(w, win[i + kx], acc[i]);
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float w = p.wout[c * 9 + ky * 3 + kx];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(w, win[i + kx], acc[i]);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i] += __shfl_xor(acc[i], 1);
-            acc[i] += __shfl_xor(acc[i], 2);
-        }
+        for (int i = 0; i < 4; ++i) acc[i] = quad_sum(acc[i]);
         const int Y = oy0 + y, X = ox0 + x0 + t;           // lane t of the quad stores pixel t
         const float a = t == 0 ? acc[0] : (t == 1 ? acc[1] : (t == 2 ? acc[2] : acc[3]));
         if (Y < H && X < W) {

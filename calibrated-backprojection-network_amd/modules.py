@@ -477,10 +477,12 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
 
     def run(self, image, depth, coordinates, fused, out_image=None, out_depth=None, out_fused=None,
             amax_image=None, amax_fused=None, out_amax_image=None, out_amax_skip=None, stats=None, need_image=True,
-            pair_image_out=False):
+            pair_image_out=False, fused_done=False):
         """amax_image / amax_fused: per-frame max |a| slots of `image` / `fused` (ops.ActStats; measured here when a
         split-operand conv needs one that is missing); out_amax_image: slot to fill for conv_image's output;
         out_amax_skip: ONE slot for conv_fused's and conv_depth's outputs (the encoder keeps them in one skip tensor)."""
+        # `fused_done`: `out_fused` already holds this block's conv_fused (the previous level's launch computed it: ops.kb1_front's
+        # `next_fused`); the paths that can honour it leave the layer out, the others recompute it (same values within single-op noise)
         # `image` may be an ops.PairTensor (with its fp32 even-pixel side output) and `pair_image_out` asks for conv_image's result
         # as one: the encoder's chain of stride-2 split convs (KBNetEncoder.encode); None when the pair kernels decline
         pair_in = isinstance(image, ops.PairTensor)
@@ -544,7 +546,7 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             if res is not None:
                 with branch:
                     self._depth_and_fused(image, depth, fused, kinv, n, h, w, oh, ow, out_depth, out_fused, ci, cf,
-                                          amax_image, amax_fused, out_amax_skip, stats)
+                                          amax_image, amax_fused, out_amax_skip, stats, skip_fused=fused_done)
                 return out_image, out_depth, out_fused
         return ops.kb_block(image, depth, coords, kinv, fused,
                             self.conv_image.conv_block[0].packed(), self.conv_depth.conv_block[0].packed(),
@@ -581,10 +583,12 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         return out_image, out_depth, out_fused
 
     def _depth_and_fused(self, image, depth, fused, kinv, n, h, w, oh, ow, out_depth, out_fused, ci, cf, amax_image, amax_fused,
-                         out_amax_skip, stats):
+                         out_amax_skip, stats, skip_fused=False):
         """conv_depth and conv_fused of the split path (their inputs are synthesized in-kernel: K^-1 [x y 1]^T, backprojection)."""
         self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth,
                                           out_absmax=out_amax_skip)
+        if skip_fused:
+            return
         if (self.split_fused and (fused is None or _dense(fused)) and self.proj_depth._slope is not None
                 and self.conv_fused.split_fused_qualifies(ci, cf)):
             # conv_fused's tensor channels on the matrix core too; its backprojection channels, computed once at the
@@ -702,6 +706,9 @@ class KBNetEncoder(torch.nn.Module):
     # (KBN_DEPTH_FRONT_FUSION=1 or `encoder.fuse_s2d = True`): measured inside the forward it is level with the two launches it
     # replaces -- it removes their 0.9 GB HBM round trip of the S2D tensor, not time
     fuse_s2d = _KnobSwitch("KBN_NO_DEPTH_FRONT_FUSION", enable="KBN_DEPTH_FRONT_FUSION")
+    # level 1's conv_fused (1x1 stride 2 over cat[conv_image, xyz, conv_fused] of level 0) inside level 0's image launch: the layer
+    # reads only the even pixels of the two tensors that launch's lanes hold (ops.kb1_front next_fused; KBN_NO_FRONT_NEXT=1: own launch)
+    front_next = _KnobSwitch("KBN_NO_FRONT_NEXT")
 
     def __init__(self, input_channels_image=3, input_channels_depth=1,
                  n_filters_image=[48, 96, 192, 384, 384], n_filters_depth=[16, 32, 64, 128, 128],
@@ -752,17 +759,20 @@ class KBNetEncoder(torch.nn.Module):
         # OFF by default (the reference computes it): do not launch conv_image of KB level 3, whose output nothing reads
         self.skip_unused_image = False
         self._packed_front = _PackedFront()
+        self._packed_front_next = _PackedFront(lambda w, out=None: ops.pack_kb1_front_next_weight(w, fi[0], out=out))
         self._packed_depth_front = _PackedFront(ops.pack_kb1_depth_front_weight)
         # the blob of the on-chip S2D stage (`fuse_s2d`): KBNetModel.forward hands encode() the S2D module and its input instead of the
         # S2D tensor, and _front decides where the layer runs
         self._packed_s2d_front = _PackedFront(lambda a, b, c, d, out=None: ops.pack_s2d_depth_front_weight([a, b, c], d, out=out))
 
-    def _front(self, image, depth, kinv, stats, s2d=None):
+    def _front(self, image, depth, kinv, stats, s2d=None, kinv_next=None):
         """Level 0 with conv0_image / conv0_depth fused in (their outputs stay on the CU): (skip, conv_image, conv_depth,
         conv_fused, amax_image, amax_skip), or None when the shapes are outside ops.kb1_front's (the caller runs the conv0s
         and the block on their own; nothing has been launched then).  `depth`: the S2D output, or None with `s2d` =
         (SparseToDensePool module, its N x 2 x H x W input): the S2D layer then runs inside the depth branch's launch
-        (ops.s2d_depth_front) or, where that declines, on its own in front of it."""
+        (ops.s2d_depth_front) or, where that declines, on its own in front of it.  `kinv_next`: callable giving the level-1 inverse
+        intrinsics; when the next level is a KB level of KBNet's widths its conv_fused rides along in the image launch and the tuple
+        ends with (its skip tensor, that tensor's absmax slot) instead of None."""
         blk = self.calibrated_backprojection1
         ci, cf, cd = blk.conv_image.conv_block[0], blk.conv_fused, blk.conv_depth.conv_block[0]
         c0 = self.conv0_image
@@ -813,10 +823,25 @@ class KBNetEncoder(torch.nn.Module):
             conv_depth0 = c0d(depth)
             xyz = ops.kb_xyz_s2(conv_depth0, blk.proj_depth.conv.weight, kinv, blk.proj_depth._slope)
             cd.run([ops.tensor_src(conv_depth0, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth, out_absmax=a_skip)
+        nxt, nxt_info = None, None
+        blk2 = getattr(self, "calibrated_backprojection2", None) if 1 in self.resolutions_backprojection else None
+        if (self.front_next and blk2 is not None and kinv_next is not None and not blk2.stacked and blk2.split_image
+                and blk2.conv_image.conv_block[0].split and not blk2.conv_image.conv_block[0].bf16
+                and blk2.conv_fused.in_channels == ci.out_channels + 3 + cf.out_channels and blk2.proj_depth._slope is not None
+                and ops.kb1_front_next_supported(image.shape[1], c0.out_channels, ci.out_channels, blk2.n_filter_fused, h, w, c0._slope)):
+            packed_n = self._packed_front_next.get(blk2.conv_fused.conv.weight)
+            if packed_n is not None:
+                h2, w2 = (oh + 1) // 2, (ow + 1) // 2
+                skip2 = torch.empty((n, ff[1] + fd[1], h2, w2), device=dev, dtype=torch.float32)
+                a_skip2 = stats.new()
+                xyz2 = ops.kb_xyz_s2(out_depth, blk2.proj_depth.conv.weight, kinv_next(), blk2.proj_depth._slope)
+                slope2 = blk2.conv_fused._slope
+                nxt = (packed_n, xyz2, skip2[:, :ff[1]], 1.0 if slope2 is None else slope2, a_skip2)
+                nxt_info = (skip2, a_skip2)
         if ops.kb1_front(image, packed, xyz, c0.out_channels, ci.out_channels, out_image, out_fused,
-                         c0._slope, blk._slope, a_img, a_skip) is None:
+                         c0._slope, blk._slope, a_img, a_skip, next_fused=nxt) is None:
             raise KbnError("kb1_front declined a problem kbn_kb1_front_query accepted")
-        return skip, out_image, out_depth, out_fused, a_img, a_skip
+        return skip, out_image, out_depth, out_fused, a_img, a_skip, nxt_info
 
     def set_bf16(self, enabled: bool = True):
         """THROUGHPUT-ONLY switch (see MultiScaleDecoder.set_bf16): the stride-2 image convs of the KB blocks and both
@@ -847,32 +872,41 @@ class KBNetEncoder(torch.nn.Module):
         intrinsics = intrinsics.contiguous()
 
         kinv = ops.intrinsics_inverse(intrinsics, 1.0, 1.0)
-        front = self._front(image, depth, kinv, stats, s2d) if 0 in self.resolutions_backprojection else None
+        h, w = h0, w0
+        h1, w1 = (h0 + 1) // 2, (w0 + 1) // 2
+        # Q1: every deeper KB level scales K by the level-1 ratio (reference src/networks.py:342-343)
+        sx, sy = w1 / w0, h1 / h0
+        kinv1_box = []   # the level-1 inverse serves every deeper level (Q1): computed once, by whoever needs it first
+
+        def kinv1_get():
+            if not kinv1_box:
+                kinv1_box.append(ops.intrinsics_inverse(intrinsics, sx, sy))
+            return kinv1_box[0]
+
+        front = self._front(image, depth, kinv, stats, s2d, kinv_next=kinv1_get) if 0 in self.resolutions_backprojection else None
         if front is None:
             if depth is None:
                 depth = s2d[0](s2d[1])
             conv_image = self.conv0_image(image)
             conv_depth = self.conv0_depth(depth)
-        h, w = h0, w0
-        h1, w1 = (h0 + 1) // 2, (w0 + 1) // 2
-        # Q1: every deeper KB level scales K by the level-1 ratio (reference src/networks.py:342-343)
-        sx, sy = w1 / w0, h1 / h0
         conv_fused = None
         skips, amax_skips = [], []
         amax_image = amax_skip = None   # slots of the current conv_image tensor / of the previous level's skip tensor
-        kinv1 = None   # the level-1 inverse serves every deeper level (Q1): computed once
+        next_done = None                # (skip tensor, slot) of level 1 when level 0's launch already wrote its conv_fused
         for level in range(4):
             oh, ow = (h + 1) // 2, (w + 1) // 2
             a_img, a_skip = stats.new(), stats.new()
             if level == 0 and front is not None:
-                skip, conv_image, conv_depth, conv_fused, amax_image, a_skip = front
+                skip, conv_image, conv_depth, conv_fused, amax_image, a_skip, next_done = front
             elif level in self.resolutions_backprojection:
                 blk = getattr(self, f"calibrated_backprojection{level + 1}")
                 if level > 0:
-                    if kinv1 is None:
-                        kinv1 = ops.intrinsics_inverse(intrinsics, sx, sy)
-                    kinv = kinv1
-                skip = torch.empty((n, ff[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
+                    kinv = kinv1_get()
+                fused_done = level == 1 and next_done is not None
+                if fused_done:
+                    skip, a_skip = next_done
+                else:
+                    skip = torch.empty((n, ff[level] + fd[level], oh, ow), device=dev, dtype=torch.float32)
                 out_fused, out_depth = skip[:, :ff[level]], skip[:, ff[level]:]
                 # the image branch of the last KB level in front of a plain level 4 feeds nothing (reference
                 # src/networks.py:475-523: conv5_image reads conv4_fused, conv4_image only lends its shape)
@@ -885,14 +919,14 @@ class KBNetEncoder(torch.nn.Module):
                     res = blk.run(conv_image, conv_depth, kinv, conv_fused, None, out_depth, out_fused,
                                   amax_image=amax_image, amax_fused=amax_skip if conv_fused is not None else None,
                                   out_amax_image=a_img, out_amax_skip=a_skip, stats=stats, need_image=not unused,
-                                  pair_image_out=want_pair)
+                                  pair_image_out=want_pair, fused_done=fused_done)
                 if res is None:
                     if isinstance(conv_image, ops.PairTensor):   # a pair tensor the next level declined: decode it (rare, not fast)
                         conv_image, amax_image = conv_image.float(), None
                     res = blk.run(
                         conv_image, conv_depth, kinv, conv_fused, None, out_depth, out_fused,
                         amax_image=amax_image if level > 0 else None, amax_fused=amax_skip if conv_fused is not None else None,
-                        out_amax_image=a_img, out_amax_skip=a_skip, stats=stats, need_image=not unused)
+                        out_amax_image=a_img, out_amax_skip=a_skip, stats=stats, need_image=not unused, fused_done=fused_done)
                 conv_image, conv_depth, conv_fused = res
                 amax_image = a_img
             else:
@@ -926,10 +960,8 @@ class KBNetEncoder(torch.nn.Module):
             blk = self.calibrated_backprojection4
             if isinstance(conv_image, ops.PairTensor):
                 conv_image, amax_image = conv_image.float(), None
-            if kinv1 is None:
-                kinv1 = ops.intrinsics_inverse(intrinsics, sx, sy)
             latent = torch.empty((n, blk.n_filter_fused + blk.n_filter_depth, oh, ow), device=dev, dtype=torch.float32)
-            blk.run(conv_image, conv_depth, kinv1, conv_fused, None, latent[:, blk.n_filter_fused:], latent[:, :blk.n_filter_fused],
+            blk.run(conv_image, conv_depth, kinv1_get(), conv_fused, None, latent[:, blk.n_filter_fused:], latent[:, :blk.n_filter_fused],
                     amax_image=amax_image, amax_fused=amax_skip if conv_fused is not None else None, out_amax_image=stats.new(),
                     out_amax_skip=amax_latent, stats=stats, need_image=not self.skip_unused_image)
             return latent, skips, amax_latent, amax_skips
@@ -1098,9 +1130,15 @@ class GraphedForward:
     `outputs` = 2 captures the graph TWICE, each copy writing its own output tensor (one memory pool: the activations are
     shared, only the N x 1 x H x W result exists twice), and calls alternate between them (`rotating_outputs`): the tensor a
     call returns stays untouched until the next-but-one call, so an asynchronous consumer -- the all-gather of
-    dist.ShardedRunner.step_pipelined, in flight under the next step's forward -- reads it in place instead of from a copy."""
+    dist.ShardedRunner.step_pipelined, in flight under the next step's forward -- reads it in place instead of from a copy.
 
-    def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1):
+    `split_graphs` (with branches > 1): ONE GRAPH PER SUB-BATCH instead of one graph that forks -- a replay launches them on
+    concurrent streams and joins.  A fork inside a forked capture crashes hipStreamEndCapture on ROCm 7.2, which keeps the
+    per-level side branches (conv_depth / conv_fused of a KB level beside its conv_image: _SideBranch) off inside a forking graph;
+    a graph of its own per sub-batch forks only once, so both kinds of concurrency run together.  Same bits either way."""
+
+    def __init__(self, model, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1,
+                 split_graphs=False):
         # the static sparse depth / validity inputs are the two planes of one buffer (paired_planes: no torch.cat in the graph)
         sd, vm = new_depth_input_pair(sparse_depth.shape[0], sparse_depth.shape[2], sparse_depth.shape[3], sparse_depth.device)
         sd.copy_(sparse_depth)
@@ -1117,6 +1155,7 @@ class GraphedForward:
         parts = [[t[i * per:(i + 1) * per] for t in self.static_in] for i in range(branches)]
         self.model = model
         self.rotating_outputs = outputs if outputs > 1 else 0
+        self.split_graphs = bool(split_graphs) and branches > 1
         self._turn = 0
         dev = self.static_in[0].device
         with torch.cuda.device(dev):
@@ -1142,6 +1181,16 @@ class GraphedForward:
         self.graphs = []
         self.static_outs = [torch.empty((n, 1, h, w), device=self.static_in[0].device, dtype=torch.float32) for _ in range(outputs)]
         for k in range(outputs):
+            if self.split_graphs:
+                # one graph per sub-batch (each with its own pool: they replay concurrently; copy k shares copy 0's pool of the same branch)
+                row = []
+                for i in range(branches):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.graphs[0][i].pool() if self.graphs else None):
+                        model.forward(*parts[i], out=self.static_outs[k][i * per:(i + 1) * per])
+                    row.append(g)
+                self.graphs.append(row)
+                continue
             graph = torch.cuda.CUDAGraph()
             # one memory pool for all copies: they replay one after the other on one stream, never concurrently
             with torch.cuda.graph(graph, pool=self.graphs[0].pool() if self.graphs else None):
@@ -1192,7 +1241,18 @@ class GraphedForward:
                 dst.copy_(src)
         k = self._turn
         self._turn = (k + 1) % len(self.graphs)
-        self.graphs[k].replay()
+        if self.split_graphs:
+            cur = torch.cuda.current_stream()
+            for st in self._streams:
+                st.wait_stream(cur)
+            for i, st in enumerate(self._streams):
+                with torch.cuda.stream(st):
+                    self.graphs[k][i + 1].replay()
+            self.graphs[k][0].replay()
+            for st in self._streams:
+                cur.wait_stream(st)
+        else:
+            self.graphs[k].replay()
         return self.static_outs[k]
 
 
@@ -1269,14 +1329,14 @@ class KBNetModel(object):
         self.decoder.set_bf16(enabled)
         return self
 
-    def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1):
+    def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1, split_graphs=False):
         """Captures one forward of this batch shape into a HIP graph and returns a callable
         `replay(image, sparse_depth, validity_map_depth, intrinsics) -> depth` (inputs are copied
         into the graph's static buffers unless they ARE those buffers; the output tensor is
         re-used between replays).  Removes the ~35 per-launch host round trips of a forward.
         `tune`: time candidate launch geometries during the warm-up (results are bit-identical either way).
         `outputs` = 2: two alternating output tensors (GraphedForward: what dist.ShardedRunner.step_pipelined gathers in place)."""
-        return GraphedForward(self, image, sparse_depth, validity_map_depth, intrinsics, branches, tune, outputs)
+        return GraphedForward(self, image, sparse_depth, validity_map_depth, intrinsics, branches, tune, outputs, split_graphs)
 
     def weight_state(self):
         """(storage pointer, version) of every parameter: what a captured graph depends on."""
@@ -1298,6 +1358,7 @@ class KBNetModel(object):
                     sub._packed_tail.refresh()
                 elif isinstance(sub, KBNetEncoder):
                     sub._packed_front.refresh()
+                    sub._packed_front_next.refresh()
                     sub._packed_depth_front.refresh()
                     sub._packed_s2d_front.refresh()
 

@@ -907,11 +907,41 @@ def kb1_front_supported(image_channels: int, conv0_filters: int, kb_filters: int
 
 
 @_on_tensor_device
+def pack_kb1_front_next_weight(w_conv_fused: torch.Tensor, image_channels: int, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Blob of kb1_front's `next` stage (kbn_kb1_front_next_pack_weight) from the NEXT KB block's conv_fused weight,
+    F x (image_channels + 3 + fused_channels) x 1 x 1.  None when the widths are outside the kernel's (48 + 3 + 48 -> 96)."""
+    lib = _lib.load()
+    wf = w_conv_fused.detach().contiguous()
+    _require(wf, "w_conv_fused", 4)
+    fo, cin = wf.shape[0], wf.shape[1]
+    cf = cin - 3 - image_channels
+    if tuple(wf.shape[2:]) != (1, 1) or cf < 0:
+        return None
+    nbytes = lib.kbn_kb1_front_next_packed_weight_bytes(int(image_channels), int(cf), int(fo))
+    if nbytes == 0:
+        return None
+    packed = out if _reusable(out, nbytes // 4, wf) else torch.empty(nbytes // 4, device=wf.device, dtype=torch.float32)
+    check(lib.kbn_kb1_front_next_pack_weight(wf.data_ptr(), packed.data_ptr(), int(image_channels), int(cf), int(fo), _stream()),
+          "kbn_kb1_front_next_pack_weight")
+    return packed
+
+
+def kb1_front_next_supported(image_channels: int, conv0_filters: int, kb_filters: int, next_filters: int, height: int, width: int,
+                             conv0_negative_slope: float) -> bool:
+    """Would kb1_front take the next level's conv_fused along?  (kbn_kb1_front_next_query; KBN_NO_FRONT_NEXT=1 says no)"""
+    return _lib.load().kbn_kb1_front_next_query(int(image_channels), int(conv0_filters), int(kb_filters), int(next_filters), int(height),
+                                                int(width), float(conv0_negative_slope)) == _lib.KBN_OK
+
+
+@_on_tensor_device
 def kb1_front(image: torch.Tensor, packed_weight: torch.Tensor, xyz: Optional[torch.Tensor],
               conv0_filters: int, kb_filters: int, out_image: torch.Tensor, out_fused: torch.Tensor,
-              conv0_negative_slope: float = 0.2, kb_negative_slope: float = 0.2, out_image_absmax=None, out_fused_absmax=None):
+              conv0_negative_slope: float = 0.2, kb_negative_slope: float = 0.2, out_image_absmax=None, out_fused_absmax=None,
+              next_fused=None):
     """conv0_image -> (conv_image, conv_fused) of the level-0 KB block in one launch, conv0's output kept on the CU
-    (kbn_kb1_front_forward).  `xyz`: the backprojection channels from kb_xyz_s2.  None when the shape does not qualify."""
+    (kbn_kb1_front_forward).  `xyz`: the backprojection channels from kb_xyz_s2.  None when the shape does not qualify.
+    `next_fused` = (packed_next, xyz_next, out_next_fused, negative_slope, out_next_absmax): the NEXT KB level's conv_fused in the
+    same launch (kbn_kb1_front_next_forward) -- its inputs are the even pixels of this launch's two outputs."""
     lib = _lib.load()
     iptr, ibs = _planes(image, "image")
     n, c, h, w = image.shape
@@ -930,12 +960,30 @@ def kb1_front(image: torch.Tensor, packed_weight: torch.Tensor, xyz: Optional[to
     # issued fp16 MFMA FLOPs: per 8 x 16 tile and 16-filter chunk 36 x 9 (conv0) + 8 x 6 x 3 x 3 (conv_image, conv_fused) MFMAs of 16 x 16 x 32
     tiles = n * (-(-oh // 8)) * (-(-ow // 16))
     executed = tiles * (conv0_filters // 16) * (36 * 9 + 8 * 6 * (kb_filters // 16) * 3) * 2.0 * 16 * 16 * 32
-    status = _launch("kb1_front", flops,
-                     lambda: lib.kbn_kb1_front_forward(iptr, ibs, packed_weight.data_ptr(), xptr, xbs,
-                                                       oi, oibs, of, ofbs, n, c, conv0_filters, kb_filters, h, w,
-                                                       float(conv0_negative_slope), float(kb_negative_slope),
-                                                       _slot_ptr(out_image_absmax, n), _slot_ptr(out_fused_absmax, n), _stream()),
-                     executed=executed, pipe="fp16", nbytes=4.0 * n * (h * w * c + oh * ow * (2 * kb_filters + (3 if xyz is not None else 0))))
+    nbytes = 4.0 * n * (h * w * c + oh * ow * (2 * kb_filters + (3 if xyz is not None else 0)))
+    if next_fused is None:
+        call = lambda: lib.kbn_kb1_front_forward(iptr, ibs, packed_weight.data_ptr(), xptr, xbs,
+                                                 oi, oibs, of, ofbs, n, c, conv0_filters, kb_filters, h, w,
+                                                 float(conv0_negative_slope), float(kb_negative_slope),
+                                                 _slot_ptr(out_image_absmax, n), _slot_ptr(out_fused_absmax, n), _stream())
+    else:
+        packed_next, xyz_next, out_next, slope_next, amax_next = next_fused
+        h2, w2 = (oh + 1) // 2, (ow + 1) // 2
+        fo = out_next.shape[1]
+        if tuple(out_next.shape) != (n, fo, h2, w2) or tuple(xyz_next.shape) != (n, 3, h2, w2):
+            raise KbnError(f"next_fused: out {tuple(out_next.shape)} / xyz {tuple(xyz_next.shape)}, expected {(n, fo, h2, w2)} / {(n, 3, h2, w2)}")
+        on, onbs = _planes(out_next, "out_next_fused")
+        xn, xnbs = _planes(xyz_next, "xyz_next")
+        flops += 2.0 * n * h2 * w2 * (2 * kb_filters + 3) * fo
+        executed += tiles * 2 * (fo // 16) * (2 * kb_filters // 32) * 3 * 2.0 * 16 * 16 * 32   # 2 pixel blocks x filter blocks x k-steps x 3 products
+        nbytes += 4.0 * n * h2 * w2 * (fo + 3)
+        call = lambda: lib.kbn_kb1_front_next_forward(iptr, ibs, packed_weight.data_ptr(), xptr, xbs,
+                                                      oi, oibs, of, ofbs, n, c, conv0_filters, kb_filters, h, w,
+                                                      float(conv0_negative_slope), float(kb_negative_slope),
+                                                      _slot_ptr(out_image_absmax, n), _slot_ptr(out_fused_absmax, n),
+                                                      packed_next.data_ptr(), xn, xnbs, on, onbs, fo, float(slope_next),
+                                                      _slot_ptr(amax_next, n), _stream())
+    status = _launch("kb1_front", flops, call, executed=executed, pipe="fp16", nbytes=nbytes)
     if status == _lib.KBN_ERR_UNSUPPORTED:
         if PROFILE is not None:
             PROFILE.pop()

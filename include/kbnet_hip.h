@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KBN_ABI_VERSION 4
+#define KBN_ABI_VERSION 5
 
 typedef void* kbn_stream_t; /* hipStream_t */
 
@@ -49,7 +49,7 @@ void kbn_reload_env(void);
 /* Value of a KBN_* switch AS THE LIBRARY READ IT (at load time / the last kbn_reload_env()): 0 when unset or unknown.  The
  * host mirror asks here instead of reading the environment itself, so its A/B switches (KBN_NO_SPLIT, KBN_NO_PAIR,
  * KBN_NO_PAIR_MID, KBN_NO_PAIR_ENC, KBN_NO_PAIR_TAIL, KBN_NO_OVERLAP, KBN_DEPTH_FRONT_FUSION, KBN_NO_DEPTH_FRONT_FUSION,
- * KBN_FP16_ONE_TERM) change together with the library's.  Values are integers (atoi); a variable that is set to
+ * KBN_FP16_ONE_TERM, KBN_NO_FRONT_NEXT) change together with the library's.  Values are integers (atoi); a variable that is set to
  * something that is not a number ("true", "yes", "on") reads as 1, so that KBN_NO_PAIR=true still switches the path off. */
 int kbn_knob(const char* name);
 
@@ -377,6 +377,34 @@ int kbn_kb1_front_forward(const float* image, long long image_batch_stride, cons
                           int image_channels, int conv0_filters, int kb_filters, int height, int width,
                           float conv0_negative_slope, float kb_negative_slope, unsigned* out_image_absmax,
                           unsigned* out_fused_absmax, kbn_stream_t stream);
+
+/* The same launch PLUS conv_fused of the NEXT KB level (round 5):
+ *     conv_fused_next = act(conv1x1 s2 (cat[conv_image, xyz_next, conv_fused]))     reference src/net_utils.py:1352-1369, the block of
+ *                                                                                   level 1 (src/networks.py:401-405)
+ * A 1x1 stride-2 conv reads only the pixels (2y, 2x) of its inputs -- for a tile of this kernel the 4 x 8 even pixels of the two
+ * outputs its lanes still hold: no halo, no second pass over conv_image / conv_fused (as its own launch the layer is the one
+ * HBM-bound conv of the network: it fetches every other ROW of 96 channels at half resolution to use every other pixel of it).
+ * The even pixels are split tile by tile (window = the tile's own maximum) and multiplied on the fp16 matrix core like every other
+ * split-operand conv; the three backprojection channels of the next level enter in fp32.
+ *   packed_next     from kbn_kb1_front_next_pack_weight: the next block's conv_fused weight, filters x (kb_filters + 3 + kb_filters)
+ *                   x 1 x 1, input order [conv_image channels, xyz, conv_fused channels]
+ *   xyz_next        N x 3 x h2 x w2 (h2 = ceil(ceil(H/2)/2)): kbn_kb_xyz_s2_forward on the level-0 conv_depth output with the next
+ *                   block's proj_depth weight and the level-1 inverse intrinsics
+ *   out_next_fused  N x next_filters x h2 x w2, frames out_next_fused_batch_stride apart; out_next_fused_absmax its slot (or NULL)
+ * KBN_ERR_UNSUPPORTED (kbn_kb1_front_next_query tells beforehand) unless kb_filters == 48 and next_filters == 96 -- KBNet's levels 0 / 1
+ * in all presets -- or with KBN_NO_FRONT_NEXT=1: the caller then runs kbn_kb1_front_forward and the next block's conv_fused on its own. */
+size_t kbn_kb1_front_next_packed_weight_bytes(int image_channels, int fused_channels, int filters);
+int kbn_kb1_front_next_pack_weight(const float* w_conv_fused, void* packed, int image_channels, int fused_channels, int filters,
+                                   kbn_stream_t stream);
+int kbn_kb1_front_next_query(int image_channels, int conv0_filters, int kb_filters, int next_filters, int height, int width,
+                             float conv0_negative_slope);
+int kbn_kb1_front_next_forward(const float* image, long long image_batch_stride, const void* packed_weight, const float* xyz,
+                               long long xyz_batch_stride, float* out_image, long long out_image_batch_stride, float* out_fused,
+                               long long out_fused_batch_stride, int n, int image_channels, int conv0_filters, int kb_filters, int height,
+                               int width, float conv0_negative_slope, float kb_negative_slope, unsigned* out_image_absmax,
+                               unsigned* out_fused_absmax, const void* packed_next, const float* xyz_next, long long xyz_next_batch_stride,
+                               float* out_next_fused, long long out_next_fused_batch_stride, int next_filters, float next_negative_slope,
+                               unsigned* out_next_fused_absmax, kbn_stream_t stream);
 
 /* The depth branch of the same front:
  *     conv0_depth = act(conv3x3(depth))                                 reference src/networks.py:366-367

@@ -1017,6 +1017,105 @@ def test_kb1_front_kernel(dev, hw, amag):
             assert rel_err(got[i], r32[i]) < TIGHT, (name, i)
 
 
+@pytest.mark.parametrize("hw", [(32, 64), (35, 70), (16, 32), (52, 100), (33, 47), (64, 26)])
+@pytest.mark.parametrize("amag", [1.0, 255.0, 1e-3])
+def test_kb1_front_kernel_with_next_conv_fused(dev, hw, amag):
+    """kbn_kb1_front_next_forward: the front's launch PLUS conv_fused of the NEXT KB level -- the 1x1 stride-2 conv over
+    cat[conv_image, xyz_next, conv_fused] of level 0 (reference src/net_utils.py:1352-1369 for the block of level 1), evaluated on the
+    even pixels the launch's lanes hold.  Its own two outputs must be the bits of the launch without the extra stage; the extra output is
+    held to the bars of the other split kernels (vs an fp64 evaluation of the whole chain and vs the oracle's fp32 convs), with odd
+    sizes at both levels, tiles cut by the border, per-frame magnitudes and filters of very different scale."""
+    h, w = hw
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    h2, w2 = (oh + 1) // 2, (ow + 1) // 2
+    g = torch.Generator().manual_seed(h * w + 7)
+    n, c, f0, fi, fo = 2, 3, 48, 48, 96
+    lrelu = torch.nn.functional.leaky_relu
+    image = amag * torch.rand(n, c, h, w, generator=g)
+    image[1] *= 0.037
+    w0 = torch.randn(f0, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    wi = torch.randn(fi, f0, 3, 3, generator=g) / (f0 * 9) ** 0.5
+    wf = torch.randn(fi, f0 + 3, 1, 1, generator=g) / (f0 + 3) ** 0.5
+    wn = torch.randn(fo, fi + 3 + fi, 1, 1, generator=g) / (2 * fi + 3) ** 0.5
+    w0[1] *= 1e-3; wi[2] *= 40.0; wf[3] *= 1e-2; wn[5] *= 30.0; wn[7] *= 1e-3; wn[:, 11] *= 25.0
+    xyz = amag * torch.randn(n, 3, oh, ow, generator=g)
+    xyz2 = amag * torch.randn(n, 3, h2, w2, generator=g)
+
+    def chain(dt, conv):
+        x0 = conv(image.to(dt), w0.to(dt), 1)
+        img = conv(x0, wi.to(dt), 2)
+        up = torch.zeros(n, 3, h, w, dtype=dt)
+        up[:, :, ::2, ::2] = xyz.to(dt)                     # a 1x1 stride-2 conv reads the even pixels only
+        fus = conv(torch.cat([x0, up], 1), wf.to(dt), 2)
+        up2 = torch.zeros(n, 3, oh, ow, dtype=dt)
+        up2[:, :, ::2, ::2] = xyz2.to(dt)
+        nxt = conv(torch.cat([img, up2, fus], 1), wn.to(dt), 2)   # the reference's cat order: [image, xyz, fused]
+        return img, fus, nxt
+
+    c64 = lambda x, wt, stride: lrelu(torch.nn.functional.conv2d(x, wt, stride=stride, padding=wt.shape[-1] // 2), 0.2)
+    img_64, fus_64, nxt_64 = chain(torch.float64, c64)
+    img_32, fus_32, nxt_32 = chain(torch.float32, lambda x, wt, stride: orc.conv2d(x, wt, stride, 0.2))
+    assert tuple(nxt_32.shape) == (n, fo, h2, w2)
+    stats = kb.ops.ActStats(n, dev)
+    imd = image.to(dev)
+    packed = kb.ops.pack_kb1_front_weight(w0.to(dev), wi.to(dev), wf.to(dev))
+    packed_n = kb.ops.pack_kb1_front_next_weight(wn.to(dev), fi)
+    assert packed is not None and packed_n is not None
+    assert kb.ops.pack_kb1_front_next_weight(wn[:64].contiguous().to(dev), fi) is None, "widths outside the kernel's are declined at pack time"
+    assert kb.ops.kb1_front_next_supported(c, f0, fi, fo, h, w, 0.2)
+    base_i, base_f = torch.empty(n, fi, oh, ow, device=dev), torch.empty(n, fi, oh, ow, device=dev)
+    assert kb.ops.kb1_front(imd, packed, xyz.to(dev), f0, fi, base_i, base_f, 0.2, 0.2) is not None
+    out_i = torch.full((n, fi, oh, ow), float("nan"), device=dev)
+    out_f = torch.full((n, fi, oh, ow), float("nan"), device=dev)
+    skip2 = torch.full((n, fo + 5, h2, w2), float("nan"), device=dev)   # the extra output is a channel slice of the next skip tensor
+    s_i, s_f, s_n = stats.new(), stats.new(), stats.new()
+    res = kb.ops.kb1_front(imd, packed, xyz.to(dev), f0, fi, out_i, out_f, 0.2, 0.2, s_i, s_f,
+                           next_fused=(packed_n, xyz2.to(dev), skip2[:, :fo], 0.2, s_n))
+    assert res is not None
+    assert torch.equal(out_i, base_i) and torch.equal(out_f, base_f), "the launch's own outputs do not change with the extra stage"
+    out_n = skip2[:, :fo]
+    assert bool(torch.isnan(skip2[:, fo:]).all()), "nothing is written outside the slice"
+    assert torch.equal(kb.ops.slot_values(s_n), out_n.abs().amax(dim=(1, 2, 3)))
+    rms = nxt_64.pow(2).mean(dim=(2, 3), keepdim=True).sqrt()       # per filter and frame
+    e_hip = ((out_n.cpu().double() - nxt_64) / rms).abs()
+    e_orc = ((nxt_32.double() - nxt_64) / rms).abs()
+    print(f"front next conv_fused vs fp64: max {float(e_hip.max()):.2e} rms {float(e_hip.pow(2).mean().sqrt()):.2e}; "
+          f"oracle fp32 convs vs fp64: max {float(e_orc.max()):.2e} rms {float(e_orc.pow(2).mean().sqrt()):.2e}")
+    assert float(e_hip.pow(2).mean().sqrt()) < max(3.5 * float(e_orc.pow(2).mean().sqrt()), 6e-7)
+    assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5
+    for i in range(n):
+        assert rel_err(out_n[i], nxt_32[i]) < TIGHT, i
+
+
+def test_forward_with_and_without_front_next(dev, kenv):
+    """KBN_NO_FRONT_NEXT=1 runs level 1's conv_fused as its own launch (the fp32 1x1 stride-2 kernel); by default it rides in level 0's
+    image launch (ops.kb1_front next_fused).  Results within single-op noise of each other, both within the gate."""
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=kb.synthetic.PARITY_GAIN["kitti"])
+    frames = kb.synthetic.make_frames(2, 96, 160, "kitti", seed=5, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+
+    def launches():
+        kb.ops.PROFILE = []
+        try:
+            out = m.forward(*to(dev, *frames))
+            torch.cuda.synchronize()
+            return out.clone(), [r[0] for r in kb.ops.PROFILE]
+        finally:
+            kb.ops.PROFILE = None
+
+    on, names_on = launches()
+    kenv.setenv("KBN_NO_FRONT_NEXT", "1")
+    off, names_off = launches()
+    one_by_one = lambda names: sum(nm.startswith(("conv_dma<1,2", "conv_igemm<1,2")) for nm in names)   # fp32 1x1 stride-2 launches
+    assert one_by_one(names_on) == one_by_one(names_off) - 1, (names_on, names_off)
+    assert names_on.count("kb_xyz") == names_off.count("kb_xyz") + 1   # its backprojection channels: computed ahead, once (12 us)
+    assert _worst_rel(on, ref) < TOL and _worst_rel(off, ref) < TOL
+    assert float(((on - off).abs() / off.abs()).max()) < 2e-5
+
+
 @pytest.mark.parametrize("hw", [(32, 64), (35, 70), (16, 32), (52, 100), (33, 47)])
 @pytest.mark.parametrize("amag", [1.0, 80.0, 1e-3])
 def test_kb1_depth_front_kernel(dev, hw, amag):
@@ -1691,6 +1790,32 @@ def test_graph_replay_with_two_rotating_outputs(dev, branches):
     assert single.rotating_outputs == 0 and torch.equal(single(*a), ea)
     with pytest.raises(kb._lib.KbnError):
         m.capture(*a, outputs=3)
+
+
+def test_graph_replay_one_graph_per_branch(dev):
+    """capture(split_graphs=True): one HIP graph per sub-batch, replayed on concurrent streams and joined -- each graph forks only
+    once, so the encoder's per-level side branches run inside every sub-batch (they must stay off inside ONE forking graph: nested
+    forks crash hipStreamEndCapture on ROCm 7.2).  Bit-identical to the eager batch, also with two rotating outputs and after an
+    in-place weight update."""
+    cfg = kb.kitti_config()   # full widths: the level side branches and the front kernels are in play
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"]))
+    a = to(dev, *kb.synthetic.make_frames(4, 96, 160, "kitti", seed=1, jitter_intrinsics=0.1))
+    b = to(dev, *kb.synthetic.make_frames(4, 96, 160, "kitti", seed=2, jitter_intrinsics=0.1))
+    ea, eb = m.forward(*a).clone(), m.forward(*b).clone()
+    replay = m.capture(*a, branches=2, outputs=2, split_graphs=True)
+    assert replay.split_graphs and len(replay.graphs) == 2 and len(replay.graphs[0]) == 2
+    oa = replay(*a)
+    ob = replay(*b)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ea) and torch.equal(ob, eb) and oa.data_ptr() != ob.data_ptr()
+    for _ in range(3):
+        assert torch.equal(replay(*a), ea)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=7, gain=kb.synthetic.PARITY_GAIN["kitti"]))
+    fresh = m.forward(*a).clone()
+    assert not torch.equal(fresh, ea)
+    assert torch.equal(replay(*a), fresh), "the per-branch graphs follow an in-place weight update like the single graph"
+    assert not m.capture(*a, branches=1, split_graphs=True).split_graphs
 
 
 def test_graph_replay_with_concurrent_branches(dev):
