@@ -200,9 +200,9 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
                 tf4 m = (tf4){0.f, 0.f, 0.f, 0.f}, s = m;
                 // the block's ten fragment reads go out together: one LDS latency per block instead of one per K step
                 // the block's ten fragment reads go out together (one LDS latency per block instead of one per K step): with the weights
-                // requested first, 486 -> 474 us per 32 KITTI frames inside the forward (round 5; output0's weights must NOT move ahead of a
-                // barrier -- __syncthreads waits for every outstanding load: + 120 us -- nor to the top of the kernel: 27 more live
-                // registers cross the 128 that keep two workgroups per CU, 884 us)
+                // requested first, 486 -> 474 us per 32 KITTI frames inside the forward (round 5; output0's 27 weights per lane, fetched in
+                // front of the second barrier instead of inside the channel loop: 604 us; at the top of the kernel: 27 more live registers
+                // cross the 128 that keep two workgroups per CU, 884 us -- both measured, both dropped)
                 th8 b1[5], b2[5];
 #pragma unroll
                 for (int ks = 0; ks < 5; ++ks) {
