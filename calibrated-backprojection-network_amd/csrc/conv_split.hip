@@ -990,7 +990,7 @@ __global__ void uf16_pack_kernel(const float* __restrict__ w, const float* __res
 // (Measured and not kept, DESIGN.md round 3: persistent workgroups, with the weights from L2 as here or resident in LDS.)
 // PIN: the input is a pair tensor, staged by LDS-DMA (see upconv2x_split64_kernel); POUT: the output is written as one with
 // 16 channels (two k-groups; channels past OC are zero) -- the decoder tail (csrc/tail.hip) stages it by DMA
-template <int NW, bool PIN, bool POUT = false>
+template <int NW, bool PIN, bool POUT = false, bool ONE = false>   // ONE: h1 w1 alone (KBN_FP16_ONE_TERM, throughput only; see conv3x3_split_kernel)
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_kernel(const SplitConvParams p) {
     static_assert(NW == 8 || NW == 4, "8 waves (16-row tiles) or 4 waves (8-row tiles)");
     constexpr bool DB = NW == 8;
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
     constexpr int A_PART = KG * NPIX * 16, A_BYTES = 2 * A_PART;      // [part][k-group][pixel][8 fp16]
     constexpr int PR = (NPIX + TPG - 1) / TPG;                         // staging rounds of a quarter of the threads (one k-group each)
     // pair input: a staged chunk is 8 planes (term, k-group) x NPIX granules; wave-wide DMA id = plane * NR + round
-    constexpr int NR = (NPIX + 63) / 64, NDMA = 2 * KG * NR, DPW = NDMA / NW;
+    constexpr int NR = (NPIX + 63) / 64, NDMA = (ONE ? 1 : 2) * KG * NR, DPW = NDMA / NW;   // ONE: the h1 planes only
     static_assert(NDMA % NW == 0, "the same number of DMAs in every wave (the vmcnt arithmetic counts them)");
     constexpr int NA_ALL = PIN ? DPW : PR * 8;                         // vector-memory operations of a wave per staged chunk
     constexpr int B_ITEM = 2 * KG * U16_NT * 16, NBL = 2, D = 3;      // bytes per weight set; loads per set; sets fetched ahead
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
     auto slot = [](int r, int ox) constexpr { return (r == 2 || r == 3) && (ox & 1) ? r + 4 : r; };
     auto load_arow = [&](int abuf, int r, int ox) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < (ONE ? 1 : 2); ++t)
             af[slot(r, ox)][t] = *reinterpret_cast<const sph8*>(aptr + abuf + t * A_PART + (r * COLS + ox) * 16);
     };
 
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
             __builtin_amdgcn_sched_barrier(0);
             constexpr int TA[3] = {0, 0, 1};
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < (ONE ? 1 : 3); ++k)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     if (CHK && oy0 + 4 * rg + mb >= sH) continue;      // low-resolution row below the map: no MFMAs (wave-uniform)
@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
                 if (x < sW) {                               // even kq: the whole granule of pixel 2 x, odd kq: of pixel 2 x + 1
                     const long long o = ((long long)(2 * Y + py) * W + 2 * x + (kq & 1)) * 8;
                     *reinterpret_cast<spu4*>(k0 + o) = g1;
-                    *reinterpret_cast<spu4*>(k0 + oph + o) = g2;
+                    if constexpr (!ONE) *reinterpret_cast<spu4*>(k0 + oph + o) = g2;   // (the one-term consumer never fetches the h2 planes)
                 }
             }
         }
@@ -1354,7 +1354,7 @@ __device__ __forceinline__ void c1_wait_a(float (&v)[8]) {
     asm volatile("s_waitcnt vmcnt(%8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "n"(N));
 }
 
-template <int RG, int NB>   // RG row groups x 8 / RG filter groups of waves; a wave: 8 / RG rows x NB 32-filter blocks (RG * NB = 4: 128 filters per tile)
+template <int RG, int NB, bool ONE = false>   // RG row groups x 8 / RG filter groups of waves; a wave: 8 / RG rows x NB 32-filter blocks (RG * NB = 4: 128 filters per tile); ONE: h1 w1 alone (throughput only)
 __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const SplitConvParams p) {
     constexpr int TH = 8, MB = TH / RG, NT = 128, NPIX = TH * SP_TW;
     static_assert(32 * NB * (8 / RG) == NT, "128 filters per workgroup");
@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv1x1s2_split_kernel(const Sp
                 for (int t = 0; t < 2; ++t) a[mb][t] = *reinterpret_cast<const sph8*>(aptr + abuf + t * A_PART + mb * SP_TW * 16);
             constexpr int TA[3] = {0, 0, 1}, TBP[3] = {0, 1, 0};   // h1 w1 | h1 (w2 2^11), h2 w1
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int t = 0; t < (ONE ? 1 : 3); ++t)
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1733,7 +1733,10 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
                 hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), 2 * 4 * 10 * 34 * 16, (hipStream_t)stream, p);
                 return KBN_OK;
             };
-            if (p.pair_out) rc = p.pair_src ? launch4(upconv2x_split16_kernel<4, true, true>, o16po) : launch4(upconv2x_split16_kernel<4, false, true>, o16o);
+            if (one_term && p.pair_src && p.pair_out) {   // THROUGHPUT-ONLY: the decoder's pair chain in one-term mode (the shipped form of deconv0's up-conv)
+                static DeviceOnce o16po1;
+                rc = launch4(upconv2x_split16_kernel<4, true, true, true>, o16po1);
+            } else if (p.pair_out) rc = p.pair_src ? launch4(upconv2x_split16_kernel<4, true, true>, o16po) : launch4(upconv2x_split16_kernel<4, false, true>, o16o);
             else rc = p.pair_src ? launch4(upconv2x_split16_kernel<4, true>, o16p) : launch4(upconv2x_split16_kernel<4, false>, o16);
         }
         if (rc != KBN_OK) return rc;
@@ -1939,6 +1942,8 @@ int kbn_conv1x1s2_split_forward(const kbn_conv_src* srcs, int n_src, const void*
     // 2 row groups x 4 filter groups (a wave: 4 rows x one 32-filter block): every weight fragment is fetched by two waves
     // instead of four (KBN_DEBUG & 128: the 4 x 2 form, for A/B runs)
     if (knob(KNOB_DEBUG) & 128) hipLaunchKernelGGL((conv1x1s2_split_kernel<4, 2>), dim3(p.nblocks), dim3(SP_THREADS), 2 * 2 * 2 * 256 * 16, (hipStream_t)stream, p);
+    else if (knob(KNOB_FP16_ONE_TERM))   // THROUGHPUT-ONLY: h1 w1 alone
+        hipLaunchKernelGGL((conv1x1s2_split_kernel<2, 1, true>), dim3(p.nblocks), dim3(SP_THREADS), 2 * 2 * 2 * 256 * 16, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv1x1s2_split_kernel<2, 1>), dim3(p.nblocks), dim3(SP_THREADS), 2 * 2 * 2 * 256 * 16, (hipStream_t)stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;

@@ -65,7 +65,9 @@ struct FrontParams {
 
 // LDS per workgroup: IN 10.5 KB + X 35.1 KB + one chunk of conv_image / conv_fused weights 33 KB = 78.6 KB: TWO workgroups
 // per CU, so that one's image loads, barriers and stores hide under the other's MFMAs.
-template <int NC0, int NBI, bool NEXT = false>   // conv0 filters / 16, conv_image = conv_fused filters / 16; NEXT: + the next level's conv_fused
+// ONE: the THROUGHPUT-ONLY one-term mode (KBN_FP16_ONE_TERM=1, BASELINE configs[2]'s 16-bit leg): every product is h1 w1 alone -- plain fp16
+// operands, fp32 accumulation, a third of the MFMAs, no h2 granules written or read
+template <int NC0, int NBI, bool NEXT = false, bool ONE = false>   // conv0 filters / 16, conv_image = conv_fused filters / 16; NEXT: + the next level's conv_fused
 __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(const FrontParams p) {
     constexpr int FI = NBI * 16;
     constexpr int IN_PART = FR_NIN * 8, IN_BYTES = 2 * IN_PART;            // [term][pixel][4 channels] fp16
@@ -217,13 +219,15 @@ __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(con
                 for (int ks = 0; ks < 2; ++ks) {
                     const fh4 b1l = *reinterpret_cast<const fh4*>(inb + goff[ks]);
                     const fh4 b1h = *reinterpret_cast<const fh4*>(inb + goff[ks] + 8);
-                    const fh4 b2l = *reinterpret_cast<const fh4*>(inb + IN_PART + goff[ks]);
-                    const fh4 b2h = *reinterpret_cast<const fh4*>(inb + IN_PART + goff[ks] + 8);
                     const fh8 b1 = __builtin_shufflevector(b1l, b1h, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const fh8 b2 = __builtin_shufflevector(b2l, b2h, 0, 1, 2, 3, 4, 5, 6, 7);
                     m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b1, m, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2, s, 0, 0, 0);
+                    if constexpr (!ONE) {
+                        const fh4 b2l = *reinterpret_cast<const fh4*>(inb + IN_PART + goff[ks]);
+                        const fh4 b2h = *reinterpret_cast<const fh4*>(inb + IN_PART + goff[ks] + 8);
+                        const fh8 b2 = __builtin_shufflevector(b2l, b2h, 0, 1, 2, 3, 4, 5, 6, 7);
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1, s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2, s, 0, 0, 0);
+                    }
                 }
                 // (main + 2^-11 small) 2^-e 2^(k0 - k), LeakyReLU as max(t, slope t) (0 <= slope <= 1), in packed fp32
                 f32x2 t01 = (f32x2){s[0], s[1]} * 0.00048828125f + (f32x2){m[0], m[1]};
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(con
                 fr_split4(v, h1, h2);
                 if (!BORDER || ((valid >> i) & 1)) {
                     *reinterpret_cast<fh4*>(smem + xoff[i]) = h1;
-                    *reinterpret_cast<fh4*>(smem + xoff[i] + X_PART) = h2;
+                    if constexpr (!ONE) *reinterpret_cast<fh4*>(smem + xoff[i] + X_PART) = h2;
                 }
             };
             if (interior) {
@@ -257,28 +261,34 @@ __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(con
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
                 const fh8 a1 = *reinterpret_cast<const fh8*>(smem + aoff[s]);
-                const fh8 a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff[s]);
+                fh8 a2 = a1;
+                if constexpr (!ONE) a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff[s]);
 #pragma unroll
                 for (int nb = 0; nb < NBI; ++nb) {
                     const fh8 b1 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + nb * 256);
-                    const fh8 b2 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + WC_PART + nb * 256);
                     mI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mI[nb], 0, 0, 0);
-                    sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sI[nb], 0, 0, 0);
-                    sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sI[nb], 0, 0, 0);
+                    if constexpr (!ONE) {
+                        const fh8 b2 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + WC_PART + nb * 256);
+                        sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sI[nb], 0, 0, 0);
+                        sI[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sI[nb], 0, 0, 0);
+                    }
                 }
             }
             {   // conv_fused: K = this chunk's 16 channels at the centre tap; k-groups 2, 3 of the MFMA are zeroed on the A side
                 fh8 a1 = *reinterpret_cast<const fh8*>(smem + aoff_f);
-                fh8 a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff_f);
+                fh8 a2 = a1;
+                if constexpr (!ONE) a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff_f);
                 if (kq >= 2) { a1 = (fh8)(_Float16)0.f; a2 = a1; }
                 const unsigned char* wf = smem + OFF_WC + 5 * WC_KS + (kq & 1) * WC_KQ + l15 * 16;
 #pragma unroll
                 for (int nb = 0; nb < NBI; ++nb) {
                     const fh8 b1 = *reinterpret_cast<const fh8*>(wf + nb * 256);
-                    const fh8 b2 = *reinterpret_cast<const fh8*>(wf + 2 * WC_KQ + nb * 256);
                     mF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mF[nb], 0, 0, 0);
-                    sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sF[nb], 0, 0, 0);
-                    sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sF[nb], 0, 0, 0);
+                    if constexpr (!ONE) {
+                        const fh8 b2 = *reinterpret_cast<const fh8*>(wf + 2 * WC_KQ + nb * 256);
+                        sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sF[nb], 0, 0, 0);
+                        sF[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sF[nb], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(con
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
                 wb1[ks] = *reinterpret_cast<const fh8*>(p.wn + ((long long)((ks * 2 + 0) * 4 + kq) * FO + f) * 8);
-                wb2[ks] = *reinterpret_cast<const fh8*>(p.wn + ((long long)((ks * 2 + 1) * 4 + kq) * FO + f) * 8);
+                if constexpr (!ONE) wb2[ks] = *reinterpret_cast<const fh8*>(p.wn + ((long long)((ks * 2 + 1) * 4 + kq) * FO + f) * 8);
             }
         }
         __syncthreads();
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(con
                     _Float16* g1 = reinterpret_cast<_Float16*>(G + (kg * 32 + pbase) * 16) + (l15 & 7);
                     _Float16* g2 = reinterpret_cast<_Float16*>(G + G_PART + (kg * 32 + pbase) * 16) + (l15 & 7);
                     g1[0] = c1[0]; g1[8] = c1[1];
-                    g2[0] = c2[0]; g2[8] = c2[1];
+                    if constexpr (!ONE) { g2[0] = c2[0]; g2[8] = c2[1]; }
                 }
             }
         }
@@ -458,10 +468,12 @@ __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(con
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     const fh8 a1 = *reinterpret_cast<const fh8*>(G + ((4 * ks + kq) * 32 + 16 * mb + l15) * 16);
-                    const fh8 a2 = *reinterpret_cast<const fh8*>(G + G_PART + ((4 * ks + kq) * 32 + 16 * mb + l15) * 16);
                     m[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wb1[ks], m[mb], 0, 0, 0);
-                    sm[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wb2[ks], sm[mb], 0, 0, 0);
-                    sm[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wb1[ks], sm[mb], 0, 0, 0);
+                    if constexpr (!ONE) {
+                        const fh8 a2 = *reinterpret_cast<const fh8*>(G + G_PART + ((4 * ks + kq) * 32 + 16 * mb + l15) * 16);
+                        sm[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wb2[ks], sm[mb], 0, 0, 0);
+                        sm[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wb1[ks], sm[mb], 0, 0, 0);
+                    }
                 }
             }
             const float sc = inv2[f] * un2;
@@ -568,7 +580,7 @@ struct DepthFrontLds {
     static_assert(BYTES <= 80 * 1024, "two workgroups per CU");
 };
 
-template <typename S2DCFG>
+template <typename S2DCFG, bool ONE = false>   // ONE: h1 w1 alone (KBN_FP16_ONE_TERM, throughput only; the two-launch form only)
 __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const DepthFrontParams p) {
     using LD = DepthFrontLds<S2DCFG>;
     constexpr bool FUSED = LD::L::FUSED;
@@ -706,10 +718,12 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
                 const fh8 b1 = *reinterpret_cast<const fh8*>(inb + tapoff[ks]);
-                const fh8 b2 = *reinterpret_cast<const fh8*>(inb + IN_PART + tapoff[ks]);
                 m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b1, m, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2, s, 0, 0, 0);
+                if constexpr (!ONE) {
+                    const fh8 b2 = *reinterpret_cast<const fh8*>(inb + IN_PART + tapoff[ks]);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2, s, 0, 0, 0);
+                }
             }
             f32x2 t01 = (f32x2){s[0], s[1]} * 0.00048828125f + (f32x2){m[0], m[1]};
             f32x2 t23 = (f32x2){s[2], s[3]} * 0.00048828125f + (f32x2){m[2], m[3]};
@@ -721,7 +735,7 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
             fr_split4(v, h1, h2);
             if (!BORDER || ((valid >> i) & 1)) {
                 *reinterpret_cast<fh4*>(smem + xoff[i]) = h1;
-                *reinterpret_cast<fh4*>(smem + xoff[i] + X_PART) = h2;
+                if constexpr (!ONE) *reinterpret_cast<fh4*>(smem + xoff[i] + X_PART) = h2;
             }
         };
         if (FUSED && (p.s2d.dbg & 32)) {
@@ -746,12 +760,14 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             const fh8 a1 = *reinterpret_cast<const fh8*>(smem + aoff[s]);
-            const fh8 a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff[s]);
             const fh8 b1 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS);
-            const fh8 b2 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + WC_PART);
             mD = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, mD, 0, 0, 0);
-            sD = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sD, 0, 0, 0);
-            sD = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sD, 0, 0, 0);
+            if constexpr (!ONE) {
+                const fh8 a2 = *reinterpret_cast<const fh8*>(smem + X_PART + aoff[s]);
+                const fh8 b2 = *reinterpret_cast<const fh8*>(wcb + s * WC_KS + WC_PART);
+                sD = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, sD, 0, 0, 0);
+                sD = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, sD, 0, 0, 0);
+            }
         }
     }
     const float* ki = p.kinv + (long long)n * 9;
@@ -762,7 +778,8 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
     // lane kq = j < 3 then stores xyz channel j of pixel x
     {
         const fh4 h1 = *reinterpret_cast<const fh4*>(smem + zoff);
-        const fh4 h2 = *reinterpret_cast<const fh4*>(smem + zoff + X_PART);
+        fh4 h2 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};   // ONE: no h2 granules exist
+        if constexpr (!ONE) h2 = *reinterpret_cast<const fh4*>(smem + zoff + X_PART);
         const ff4 pw = *reinterpret_cast<const ff4*>(p.tab + 36 + 4 * kq);
         float z = 0.f;
 #pragma unroll
@@ -1198,15 +1215,18 @@ static int kb1_front_launch(const float* image, long long image_batch_stride, co
         p.slope2 = next_negative_slope;
         p.vec4_2 = !((p.w2 & 3) || (reinterpret_cast<uintptr_t>(out_next) & 15) || (out_next_batch_stride & 3) ||
                      (reinterpret_cast<uintptr_t>(xyz_next) & 15) || (xyz_next_batch_stride & 3)) ? 1 : 0;
-        auto kern = kb1_front_kernel<3, 3, true>;
-        static DeviceOnce once_next;
-        if (int rc = set_max_dynamic_lds(once_next, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
+    }
+    const bool one_term = knob(KNOB_FP16_ONE_TERM) != 0;   // THROUGHPUT-ONLY: h1 w1 alone
+    static DeviceOnce once[4];
+    auto go = [&](auto kern, DeviceOnce& o) -> int {
+        if (int rc = set_max_dynamic_lds(o, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
         hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
-    } else {
-        auto kern = kb1_front_kernel<3, 3, false>;
-        static DeviceOnce once;
-        if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
-        hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), lds, (hipStream_t)stream, p);
+        return KBN_OK;
+    };
+    {
+        if (int rc = packed_next ? (one_term ? go(kb1_front_kernel<3, 3, true, true>, once[3]) : go(kb1_front_kernel<3, 3, true, false>, once[2]))
+                                 : (one_term ? go(kb1_front_kernel<3, 3, false, true>, once[1]) : go(kb1_front_kernel<3, 3, false, false>, once[0])))
+            return rc;
     }
     KBN_CHECK_LAUNCH();
     return KBN_OK;
@@ -1321,6 +1341,14 @@ int kbn_kb1_depth_front_forward(const float* depth, long long depth_batch_stride
     if (int rc = depth_front_params(p, kinv, packed_weight, out_depth, out_depth_batch_stride, xyz, xyz_batch_stride, n, depth_channels, height,
                                     width, conv0_negative_slope, kb_negative_slope, proj_activation, proj_negative_slope, out_depth_absmax))
         return rc;
+    if (knob(KNOB_FP16_ONE_TERM)) {   // THROUGHPUT-ONLY: h1 w1 alone
+        static DeviceOnce once1;
+        auto kern = kb1_depth_front_kernel<NoS2D, true>;
+        if (int rc = set_max_dynamic_lds(once1, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
+        hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(FR_THREADS), DepthFrontLds<NoS2D>::BYTES, (hipStream_t)stream, p);
+        KBN_CHECK_LAUNCH();
+        return KBN_OK;
+    }
     return depth_front_launch<NoS2D>(p, (hipStream_t)stream);
 }
 

@@ -64,7 +64,9 @@ __device__ __forceinline__ void tl_split8(const float (&v)[8], float pre, th8& h
 
 // PIN: the input is the up-conv's PAIR tensor (16 channels: two k-groups): stage A is 6 LDS-DMAs per wave -- no loads into
 // registers, no tile maximum, no splitting; the window is the producer's
-template <bool PIN>
+// ONE: the THROUGHPUT-ONLY one-term mode (KBN_FP16_ONE_TERM=1, BASELINE configs[2]'s 16-bit leg): h1 w1 alone -- plain fp16 operands,
+// fp32 accumulation, a third of the MFMAs; the h2 planes of a pair input are neither fetched nor read
+template <bool PIN, bool ONE = false>
 __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailParams p) {
     constexpr int IN_KG = TL_NP0 * 16, IN_PART = 2 * IN_KG, IN_BYTES = 2 * IN_PART;   // [term][k-group][pixel][8 ch] fp16
     constexpr int OFF_F = IN_BYTES;                                                    // [C][TL_FP] fp32
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
     // ---- A: input tile -> split granules; the fp16 window is the tile's own (max |x| over the pixels loaded here)
     float un_in;
     if constexpr (PIN) {
-        constexpr int NR = (TL_NP0 + 63) / 64, NDMA = 4 * NR, DPW = NDMA / 8;   // 4 planes (term, k-group) x 12 rounds of 64 pixels
+        constexpr int NR = (TL_NP0 + 63) / 64, NDMA = (ONE ? 2 : 4) * NR, DPW = NDMA / 8;   // 4 planes (term, k-group; ONE: the two h1 planes) x 12 rounds of 64 pixels
         static_assert(NDMA % 8 == 0, "whole rounds of the eight waves");
         un_in = 1.f / p.xscale[n];
         const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
@@ -207,14 +209,16 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
 #pragma unroll
                 for (int ks = 0; ks < 5; ++ks) {
                     b1[ks] = *reinterpret_cast<const th8*>(inb + tapoff[ks]);
-                    b2[ks] = *reinterpret_cast<const th8*>(inb + IN_PART + tapoff[ks]);
+                    if constexpr (!ONE) b2[ks] = *reinterpret_cast<const th8*>(inb + IN_PART + tapoff[ks]);
                 }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int ks = 0; ks < 5; ++ks) {
                     m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b1[ks], m, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1[ks], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2[ks], s, 0, 0, 0);
+                    if constexpr (!ONE) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[ks], b1[ks], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], b2[ks], s, 0, 0, 0);
+                    }
                 }
                 f32x2 t01 = (f32x2){s[0], s[1]} * 0.00048828125f + (f32x2){m[0], m[1]};
                 f32x2 t23 = (f32x2){s[2], s[3]} * 0.00048828125f + (f32x2){m[2], m[3]};
@@ -351,14 +355,16 @@ static int conv_tail_launch(const float* x, long long x_batch_stride, const void
     p.dmin = min_predict_depth;
     p.ratio = (float)((double)min_predict_depth / (double)max_predict_depth);   // evaluated in double like the reference's scalar
     const size_t lds = (size_t)2 * 2 * TL_NP0 * 16 + (size_t)channels * TL_FP * 4;
-    static DeviceOnce once, oncep;
-    if (x_pair) {
-        if (int rc = set_max_dynamic_lds(oncep, reinterpret_cast<const void*>(conv_tail_kernel<true>), 80 * 1024)) return rc;
-        hipLaunchKernelGGL(conv_tail_kernel<true>, dim3(p.ntiles), dim3(TL_THREADS), lds, (hipStream_t)stream, p);
-    } else {
-        if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv_tail_kernel<false>), 80 * 1024)) return rc;
-        hipLaunchKernelGGL(conv_tail_kernel<false>, dim3(p.ntiles), dim3(TL_THREADS), lds, (hipStream_t)stream, p);
-    }
+    static DeviceOnce once, oncep, once1, oncep1;
+    const bool one_term = knob(KNOB_FP16_ONE_TERM) != 0;   // THROUGHPUT-ONLY: h1 w1 alone
+    auto go = [&](auto kern, DeviceOnce& o) -> int {
+        if (int rc = set_max_dynamic_lds(o, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
+        hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(TL_THREADS), lds, (hipStream_t)stream, p);
+        return KBN_OK;
+    };
+    if (int rc = x_pair ? (one_term ? go(conv_tail_kernel<true, true>, oncep1) : go(conv_tail_kernel<true, false>, oncep))
+                        : (one_term ? go(conv_tail_kernel<false, true>, once1) : go(conv_tail_kernel<false, false>, once)))
+        return rc;
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }

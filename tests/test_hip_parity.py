@@ -1642,8 +1642,8 @@ def test_no_split_forward_launches_nothing_twice(dev, kenv):
 
 
 def test_fp16_one_term_leg_is_throughput_only(dev, kenv):
-    """KBN_FP16_ONE_TERM=1 (bench.py's `fp16_one_term_leg`, BASELINE configs[2]'s 16-bit figure): the tuned split / pair kernels
-    issue h1 w1 alone.  The result is a 16-bit-grade depth map (mean relative error around 1e-3, far off the 1e-4 gate: never
+    """KBN_FP16_ONE_TERM=1 (bench.py's `fp16_one_term_leg`, BASELINE configs[2]'s 16-bit figure): EVERY split-operand kernel -- concat
+    convs, folded up-convs, stride-2 and 1x1 stride-2 convs, both front kernels (with level 1's conv_fused), the tail -- issues h1 w1 alone.  The result is a 16-bit-grade depth map (mean relative error around 1e-3, far off the 1e-4 gate: never
     the parity-gated path), the same launches run (no fallback to another kernel), and switching it off restores the bits."""
     cfg = kb.kitti_config()
     m = kb.modules.KBNetModel.from_config(cfg, dev)
@@ -1664,6 +1664,7 @@ def test_fp16_one_term_leg_is_throughput_only(dev, kenv):
     kenv.delenv("KBN_FP16_ONE_TERM")
     again, _ = run()
     assert launches_one == launches and "conv_split" in launches and "conv_split_upfold" in launches and "conv_split_s2" in launches
+    assert "kb1_front" in launches and "kb1_depth_front" in launches and "conv_tail" in launches and "conv_split_1x1s2" in launches
     assert torch.equal(again, full)
     rel = ((one - full).abs() / full.abs())
     print(f"one-term fp16 leg vs the fp32-grade path: max rel {float(rel.max()):.3e}, mean {float(rel.mean()):.3e}")
