@@ -280,9 +280,9 @@ def self_spawn(argv, gpus: int, backend: str):
     process per GPU) under torch.distributed.run on 127.0.0.1, pass their stdout / stderr through (rank 0 prints the ONE
     JSON line) and return their exit code.  Replaces the three DataParallel wrappers of reference
     src/kbnet_model.py:408-415 as the way more than one GPU is driven."""
+    if backend in ("nccl", "gloo-cuda") and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if backend == "nccl":
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
         have = torch.cuda.device_count()
         if have < gpus:
             raise SystemExit(f"--gpus {gpus} but only {have} GPU(s) are visible")
@@ -311,9 +311,18 @@ def setup_ranks(gpus: int, backend: str):
             raise SystemExit(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    elif backend == "gloo-cuda":
+        # TEST MODE (KBN_BENCH_TEST_BACKEND=gloo-cuda): every rank drives cuda:0 and the collectives go through gloo, which moves CUDA
+        # tensors between processes that share a device -- RCCL refuses two ranks on one GPU ("Duplicate GPU detected").  Lets a ONE-GPU
+        # box run this script's whole N > 1 path (real graphed forward on every rank, pipelined gather, max-over-ranks timing, rank-0
+        # roofline pass, ranks leaving together); the figure it prints is N ranks time-sharing one GPU, not a scaling point.
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
     else:
         dev = torch.device("cpu")
-    kb.dist.init(backend)
+    kb.dist.init("gloo" if backend == "gloo-cuda" else backend)
     return rank, local_rank, world, dev
 
 
@@ -401,7 +410,9 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     the self-spawn path can be tested on CPU): KBN_BENCH_TEST_BACKEND=gloo runs `standin_forward` on tiny frames."""
     global HEIGHT, WIDTH
     argv = list(sys.argv[1:] if argv is None else argv)
-    if os.environ.get("KBN_BENCH_TEST_BACKEND") and forward_factory is None:
+    if os.environ.get("KBN_BENCH_TEST_BACKEND") == "gloo-cuda" and forward_factory is None:
+        backend = "gloo-cuda"      # the REAL forward on every rank, all ranks on cuda:0, gloo collectives (setup_ranks)
+    elif os.environ.get("KBN_BENCH_TEST_BACKEND") and forward_factory is None:
         backend = os.environ["KBN_BENCH_TEST_BACKEND"]
         forward_factory = lambda rank, dev, frames: standin_forward
         HEIGHT, WIDTH = 16, 24
@@ -484,6 +495,10 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
 
     elapsed, out = timed_steps(runner, step_inputs, args.steps, args.warmup, dev)
     out = out.clone()
+    # this rank's slice of the gathered tensor must be the bits its own forward produces (the gather reads the graph's output in place)
+    gather_ok = bool(torch.equal(out[rank * per:(rank + 1) * per], forward(*step_inputs)))
+    if tuple(out.shape) != (per * world, 1, HEIGHT, WIDTH):
+        raise SystemExit(f"gathered output has shape {tuple(out.shape)}, expected {(per * world, 1, HEIGHT, WIDTH)}")
 
     # Sustained rate: the SAME runner and graph for at least 300 more steps and at least 3 s (the part is power-capped: clocks settle
     # over seconds, and K = 50 steps is half a second).  Reported beside `value`; if it falls more than 3 % below, it REPLACES `value`.
@@ -707,6 +722,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    "gflop_per_frame": round(gflop_frame, 3),
                    "parallelism": f"frames sharded over {world} rank(s), RCCL all-gather of outputs",
                    "n_ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   "collective_backend": backend + (" (TEST MODE: all ranks share cuda:0, gloo collectives -- not a scaling point)" if backend == "gloo-cuda" else ""),
+                   "gathered_frames": int(out.shape[0]), "gather_matches_local_forward_rank0": gather_ok,
                    "rccl_version": rccl_version(),
                    "launch": "eager" if args.eager else
                              f"HIP graph replay, {getattr(forward, 'branches', 1)} concurrent sub-batch branch(es)"
