@@ -996,7 +996,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
     constexpr bool DB = NW == 8;
     constexpr int ROWS = 2 * NW, TPG = 16 * NW;                        // low-resolution rows per tile; threads per k-group in staging
     constexpr int COLS = 34, NPIX = (ROWS + 2) * COLS, KG = 4;
-    constexpr int A_PART = KG * NPIX * 16, A_BYTES = 2 * A_PART;      // [part][k-group][pixel][8 fp16]
+    // plane pitch of a k-group, padded to a multiple of 16 granules: ds_read_b128 serves lanes {0-3, 12-15, 20-27} together, i.e. the kq = 0 and
+    // kq = 1 halves of an A fragment, conflict-free only when they sit 0 (mod 256 B) apart (340 granules: SQ_LDS_BANK_CONFLICT / IDX_ACTIVE 0.50)
+    constexpr int NPP = (NPIX + 15) / 16 * 16;
+    constexpr int A_PART = KG * NPP * 16, A_BYTES = 2 * A_PART;       // [part][k-group][pixel (pitch NPP)][8 fp16]
     constexpr int PR = (NPIX + TPG - 1) / TPG;                         // staging rounds of a quarter of the threads (one k-group each)
     // pair input: a staged chunk is 8 planes (term, k-group) x NPIX granules; wave-wide DMA id = plane * NR + round
     constexpr int NR = (NPIX + 63) / 64, NDMA = (ONE ? 1 : 2) * KG * NR, DPW = NDMA / NW;   // ONE: the h1 planes only
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
         }
     };
     auto store_round = [&](int buf, int u) {
-        unsigned char* A = smem + buf * A_BYTES + kg_st * NPIX * 16;
+        unsigned char* A = smem + buf * A_BYTES + kg_st * NPP * 16;
 #pragma unroll
         for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));
         const int pix = u * TPG + t128;
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
             const int t = plane / KG, kgl = plane - t * KG;
             const unsigned long long mask = (j == NR - 1 && (NPIX & 63)) ? ((1ull << (NPIX & 63)) - 1) : ~0ull;
             lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)(kgl * 2 + t) * pplane), dvoff[i],
-                         lds0 + (unsigned)(buf * A_BYTES + t * A_PART + (kgl * NPIX + j * 64) * 16), mask);
+                         lds0 + (unsigned)(buf * A_BYTES + t * A_PART + (kgl * NPP + j * 64) * 16), mask);
         }
     };
     const unsigned boff = (unsigned)(lane * 16);                       // [k-group kq][filter lp][8 channels]
@@ -1104,7 +1107,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void upconv2x_split16_ker
         for (int i = 0; i < 4; ++i) acc[a >> 2][(a >> 1) & 1][a & 1][i] = 0.f;
 
     // staged row r (0..5 of the wave's six) at column offset ox lives in register slot r, rows 2 and 3 at odd ox in 6 and 7
-    const unsigned char* const aptr = smem + (kq * NPIX + 4 * rg * COLS + 16 * mblk + lp) * 16;
+    const unsigned char* const aptr = smem + (kq * NPP + 4 * rg * COLS + 16 * mblk + lp) * 16;
     sph8 af[8][2];
     auto slot = [](int r, int ox) constexpr { return (r == 2 || r == 3) && (ox & 1) ? r + 4 : r; };
     auto load_arow = [&](int abuf, int r, int ox) {
@@ -1720,8 +1723,8 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     if (mode == 3 && uf_narrow(out_channels, cin)) {
         if (knob(KNOB_DEBUG) & 128) {   // A/B: 16-row tiles, one workgroup per CU
             static DeviceOnce o8p;
-            rc = p.pair_src ? launch(upconv2x_split16_kernel<8, true>, 2 * 2 * 4 * 18 * 34 * 16, o8p)
-                            : launch(upconv2x_split16_kernel<8, false>, 2 * 2 * 4 * 18 * 34 * 16, o[4]);
+            rc = p.pair_src ? launch(upconv2x_split16_kernel<8, true>, 2 * 2 * 4 * ((18 * 34 + 15) / 16 * 16) * 16, o8p)
+                            : launch(upconv2x_split16_kernel<8, false>, 2 * 2 * 4 * ((18 * 34 + 15) / 16 * 16) * 16, o[4]);
         } else {             // 8 x 32 low-resolution pixels per workgroup of 4 waves, two workgroups per CU
             p.tilesY = ceil_div(p.sH, 8);
             const long long blocks8 = (long long)p.tilesX * p.tilesY * n * p.nTilesN;
@@ -1730,7 +1733,7 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
             static DeviceOnce o16, o16p, o16o, o16po;
             auto launch4 = [&](auto kern, DeviceOnce& once) -> int {
                 if (int r = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
-                hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), 2 * 4 * 10 * 34 * 16, (hipStream_t)stream, p);
+                hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), 2 * 4 * ((10 * 34 + 15) / 16 * 16) * 16, (hipStream_t)stream, p);
                 return KBN_OK;
             };
             if (one_term && p.pair_src && p.pair_out) {   // THROUGHPUT-ONLY: the decoder's pair chain in one-term mode (the shipped form of deconv0's up-conv)

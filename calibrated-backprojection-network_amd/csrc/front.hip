@@ -71,7 +71,7 @@ template <int NC0, int NBI, bool NEXT = false, bool ONE = false>   // conv0 filt
 __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(const FrontParams p) {
     constexpr int FI = NBI * 16;
     constexpr int IN_PART = FR_NIN * 8, IN_BYTES = 2 * IN_PART;            // [term][pixel][4 channels] fp16
-    constexpr int X_KG = FR_NP1 * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
+    constexpr int X_KG = FR_XP * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
     constexpr int WC_KQ = FI * 16, WC_PART = 4 * WC_KQ, WC_KS = 2 * WC_PART, WC_FUSED = 2 * 2 * WC_KQ, WC_CHUNK = 5 * WC_KS + WC_FUSED;
     constexpr int OFF_X = IN_BYTES, OFF_WC = OFF_X + X_BYTES;
     static_assert(OFF_WC + WC_CHUNK <= 80 * 1024, "two workgroups per CU");
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(FR_THREADS, NEXT ? 4 : 2) void kb1_front_kernel(con
             const int tap = min(2 * s + tsel, 8);
             const int ky = tap / 3, kx = tap % 3;
             const int col = kx == 0 ? l15 : (kx == 1 ? (FR_R1W + 1) / 2 + l15 : l15 + 1);
-            aoff[s] = OFF_X + (kg * FR_NP1 + (2 * yrow + ky) * FR_R1W + col) * 16;
+            aoff[s] = OFF_X + (kg * FR_XP + (2 * yrow + ky) * FR_R1W + col) * 16;
         }
-        aoff_f = OFF_X + (kg * FR_NP1 + (2 * yrow + 1) * FR_R1W + (FR_R1W + 1) / 2 + l15) * 16;
+        aoff_f = OFF_X + (kg * FR_XP + (2 * yrow + 1) * FR_R1W + (FR_R1W + 1) / 2 + l15) * 16;
     }
     const bool row_live = oy0 + yrow < p.h;   // wave-uniform
     const int nblk = wave + 8 * (NBLK - 1) < FR_NB0 ? NBLK : NBLK - 1;   // wave-uniform
@@ -570,7 +570,7 @@ template <typename S2DCFG>
 struct DepthFrontLds {
     using L = DepthFrontLayout<S2DCFG>;
     static constexpr int IN_PART = FR_NIN * 16, IN_BYTES = 2 * IN_PART;            // [term][pixel][8 channels] fp16
-    static constexpr int X_KG = FR_NP1 * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
+    static constexpr int X_KG = FR_XP * 16, X_PART = 2 * X_KG, X_BYTES = 2 * X_PART;
     static constexpr int WC_KQ = 16 * 16, WC_PART = 4 * WC_KQ, WC_KS = 2 * WC_PART, WC_BYTES = 5 * WC_KS;   // 10 KB
     // NoS2D: [IN][X][WC].  On-chip S2D: X and WC overlay the stage's bytes (dead once IN is complete), IN and the reduction scratch behind them
     static constexpr int OFF_X = L::FUSED ? 0 : IN_BYTES, OFF_WC = OFF_X + X_BYTES;
@@ -691,10 +691,10 @@ __global__ __launch_bounds__(FR_THREADS, 2) void kb1_depth_front_kernel(const De
             const int tap = min(2 * s + tsel, 8);
             const int ky = tap / 3, kx = tap % 3;
             const int col = kx == 0 ? l15 : (kx == 1 ? (FR_R1W + 1) / 2 + l15 : l15 + 1);
-            aoff[s] = OFF_X + (kg * FR_NP1 + (2 * yrow + ky) * FR_R1W + col) * 16;
+            aoff[s] = OFF_X + (kg * FR_XP + (2 * yrow + ky) * FR_R1W + col) * 16;
         }
     }
-    const int zoff = OFF_X + ((kq >> 1) * FR_NP1 + (2 * yrow + 1) * FR_R1W + (FR_R1W + 1) / 2 + l15) * 16 + (kq & 1) * 8;   // centre tap, this lane's 4 channels
+    const int zoff = OFF_X + ((kq >> 1) * FR_XP + (2 * yrow + 1) * FR_R1W + (FR_R1W + 1) / 2 + l15) * 16 + (kq & 1) * 8;   // centre tap, this lane's 4 channels
     const bool row_live = oy0 + yrow < p.h;
     const int nblk = wave + 8 * (NBLK - 1) < FR_NB0 ? NBLK : NBLK - 1;
     __syncthreads();   // IN complete
@@ -1204,7 +1204,7 @@ static int kb1_front_launch(const float* image, long long image_batch_stride, co
     p.vec4 = !((p.w & 3) || (reinterpret_cast<uintptr_t>(out_image) & 15) || (reinterpret_cast<uintptr_t>(out_fused) & 15) ||
                (out_image_batch_stride & 3) || (out_fused_batch_stride & 3) || (reinterpret_cast<uintptr_t>(xyz) & 15) ||
                (xyz_batch_stride & 3)) ? 1 : 0;
-    constexpr size_t lds = 2 * FR_NIN * 8 + 2 * 2 * FR_NP1 * 16 + (5 * 2 * 4 + 2 * 2) * 48 * 16;
+    constexpr size_t lds = 2 * FR_NIN * 8 + 2 * 2 * FR_XP * 16 + (5 * 2 * 4 + 2 * 2) * 48 * 16;
     if (packed_next) {
         p.tab2 = static_cast<const float*>(packed_next);
         p.wn = reinterpret_cast<const _Float16*>(p.tab2 + front_next_tab_floats(next_filters));
