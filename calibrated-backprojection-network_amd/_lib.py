@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkbnet_hip.so")
+LIB_PATH = os.environ.get("KBN_LIB_PATH") or os.path.join(HERE, "libkbnet_hip.so")   # KBN_LIB_PATH: an alternative build (same-box A/B of compile-time variants, tools/ab_lib.sh)
 
 KBN_OK = 0
 KBN_ERR_UNSUPPORTED = -2

@@ -22,7 +22,11 @@ constexpr int FR_TAB = 400;                                                     
 // and kq = 1 -- the two k-groups of one tap in the stride-2 convs' A fragments -- and is conflict-free only when the two halves sit
 // 0 (mod 256 B) apart.  With the unpadded 561 they were 1 granule off: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.18 (kb1_front),
 // 0.26 (kb1_depth_front), round 5.
+#ifdef KBN_LDS_PITCH_OLD   // A/B builds (tools/ab_lib.sh): the unpadded pitches of rounds 3-4
+constexpr int FR_XP = FR_NP1;
+#else
 constexpr int FR_XP = (FR_NP1 + 15) / 16 * 16;
+#endif
 constexpr int FR_NB0 = (FR_NP1 + 15) / 16;                                                   // 16-pixel blocks of conv0 outputs: 36
 
 __device__ __forceinline__ void fr_scales(unsigned bits, float& pre, float& un) {   // max in [2^14, 2^15) of the fp16 window

@@ -31,7 +31,11 @@ constexpr int TL_R0H = TL_R1H + 2, TL_R0W = TL_R1W + 2, TL_NP0 = TL_R0H * TL_R0W
 // feature rows padded to 36 floats (16-byte aligned quads); the plane pitch 18 x 36 = 648 is padded to 656 floats = 164 granules, 4 (mod 16):
 // the head's ds_read_b128 lane groups mix the four channel lanes of four quads -- planes 4 granules apart make the 16 of a group distinct --
 // and the conv's ds_write_b32 (channels 4 kq + r, 32 lanes per group) lands 16 banks apart (648: SQ_LDS_BANK_CONFLICT / IDX_ACTIVE 0.32)
+#ifdef KBN_LDS_PITCH_OLD
+constexpr int TL_FW = 36, TL_FP = TL_R1H * TL_FW;
+#else
 constexpr int TL_FW = 36, TL_FP = TL_R1H * TL_FW + 8;
+#endif
 constexpr int TL_NB = 39, TL_NBLK = 5;                                                 // 16-pixel blocks of the 18 x 34 region; per wave
 constexpr int TL_WEXP = 13;
 constexpr int TL_TAB = 16;                                                             // floats: 2^-e per filter
