@@ -244,6 +244,30 @@ def gen_kb_stacked():
         save(f"kb_{name}", **arrays)
 
 
+def gen_encoder_stacked():
+    """networks.KBNetEncoder with n_convolutions_* > 1 (reference src/networks.py:52-299; KBNetModel always passes ones, so this is the
+    encoder's own constructor surface): stacked stride-1 convs in a KB level (level 2) and in plain VGG levels (1, 3, 4)."""
+    g = torch.Generator().manual_seed(43)
+    fi, fd = [8, 16, 32, 32, 32], [4, 8, 16, 16, 16]
+    n_img, n_dep = [1, 2, 2, 1, 2], [1, 1, 3, 2, 1]
+    enc = networks.KBNetEncoder(input_channels_image=3, input_channels_depth=8, n_filters_image=fi, n_filters_depth=fd,
+                                n_filters_fused=fi, n_convolutions_image=n_img, n_convolutions_depth=n_dep,
+                                n_convolutions_fused=[1, 1, 1, 1, 1], resolutions_backprojection=[0, 2],
+                                weight_initializer="xavier_normal", activation_func="leaky_relu").eval()
+    sd = {k: torch.randn(v.shape, generator=g) * 1.2 * (2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+          for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    n, h, w = 2, 38, 52
+    image = torch.rand(n, 3, h, w, generator=g)
+    depth = torch.nn.functional.leaky_relu(torch.randn(n, 8, h, w, generator=g), 0.2)
+    k = kb.synthetic.make_frames(n, h, w, "void", seed=44, jitter_intrinsics=0.1)[3]
+    k[:, 0, 0] = 60.0; k[:, 1, 1] = 58.0; k[:, 0, 2] = w / 2.0; k[:, 1, 2] = h / 2.0
+    latent, skips = enc(image, depth, k)
+    save("enc_stacked", image=image, depth=depth, intrinsics=k, weights=np_sd(sd), latent=latent,
+         n_convolutions_image=np.array(n_img), n_convolutions_depth=np.array(n_dep), n_filters_image=np.array(fi), n_filters_depth=np.array(fd),
+         resolutions_backprojection=np.array([0, 2]), **{f"skip{i + 1}": s_ for i, s_ in enumerate(skips)})
+
+
 # ---------------------------------------------------------------------- decoder
 def gen_decoder():
     cfg = kb.kitti_config().narrow()
@@ -487,6 +511,7 @@ if __name__ == "__main__":
     if "--only-round5" in sys.argv:       # round 5: KB layer at resolution 4 (quirk Q3), stacked convs in the KB block
         gen_forward(only=("kb01234", "kb01234_odd"))
         gen_kb_stacked()
+        gen_encoder_stacked()
         sys.exit(0)
     gen_pre_eval()
     if "--only-pre-eval" in sys.argv:
@@ -495,6 +520,7 @@ if __name__ == "__main__":
     gen_coords()
     gen_kb()
     gen_kb_stacked()
+    gen_encoder_stacked()
     gen_decoder()
     gen_forward()
     gen_checkpoint()

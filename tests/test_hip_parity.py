@@ -381,6 +381,22 @@ def test_kb_block_stacked_convolutions_golden(dev, name, mode):
     assert rel_err(out_f, g["conv_fused"]) < TIGHT
 
 
+def test_encoder_with_stacked_convolutions_golden(dev):
+    """KBNetEncoder(n_convolutions_image=[1, 2, 2, 1, 2], n_convolutions_depth=[1, 1, 3, 2, 1], resolutions_backprojection=[0, 2]) against
+    the reference's own encoder (golden enc_stacked): stacked stride-1 convs inside a KB level and in plain VGG levels, odd sizes."""
+    g = load_golden("enc_stacked")
+    enc = kb.modules.KBNetEncoder(3, 8, [int(v) for v in g["n_filters_image"]], [int(v) for v in g["n_filters_depth"]],
+                                  [int(v) for v in g["n_filters_image"]], [int(v) for v in g["n_convolutions_image"]],
+                                  [int(v) for v in g["n_convolutions_depth"]], [1, 1, 1, 1, 1],
+                                  [int(v) for v in g["resolutions_backprojection"]], "xavier_normal", "leaky_relu").to(dev)
+    assert set(enc.state_dict()) == set(g["weights"])
+    enc.load_state_dict(g["weights"])
+    latent, skips = enc(g["image"].to(dev), g["depth"].to(dev), g["intrinsics"].to(dev))
+    assert rel_err(latent, g["latent"]) < TIGHT
+    for i, s_ in enumerate(skips):
+        assert tuple(s_.shape) == tuple(g[f"skip{i + 1}"].shape) and rel_err(s_, g[f"skip{i + 1}"]) < TIGHT, i
+
+
 @pytest.mark.parametrize("ci,cd,cf,fi,fd,h,w", [
     (48, 16, 0, 48, 16, 36, 56),     # KB1: no fused input, 3 n-blocks
     (48, 16, 48, 96, 32, 30, 44),    # KB2: two 48-filter tiles

@@ -50,6 +50,17 @@ def test_kb_block_matches_reference(name):
     assert torch.equal(cf, g["conv_fused"])
 
 
+def test_encoder_with_stacked_convolutions_matches_reference():
+    """enc_stacked: networks.KBNetEncoder with n_convolutions_image / _depth > 1 (src/networks.py:52-299), KB layers at levels 0 and 2,
+    plain VGG levels with stacked convs elsewhere, an odd frame size -- the oracle follows the state_dict's conv_block.<i> keys."""
+    g = load_golden("enc_stacked")
+    levels = tuple(int(v) for v in g["resolutions_backprojection"])
+    latent, skips = orc.encoder(g["image"], g["depth"], g["intrinsics"], g["weights"], resolutions_backprojection=levels)
+    assert torch.equal(latent, g["latent"])
+    for i, s_ in enumerate(skips):
+        assert torch.equal(s_, g[f"skip{i + 1}"]), i
+
+
 @pytest.mark.parametrize("name", ["dec_even", "dec_odd"])
 def test_decoder_matches_reference(name):
     g = load_golden(name)
