@@ -83,10 +83,13 @@ class ShardedRunner:
         # that read the tensor this call is about to overwrite was issued two steps ago; it is awaited here, BEFORE the forward.
         rotating = int(getattr(self.forward_fn, "rotating_outputs", 0) or 0) >= 2
         if rotating and self._ring is not None:
-            stale = self._ring[self._step & 1]
-            if stale[2] is not None:
-                stale[2].wait()
-                stale[2] = None
+            # by tensor identity, not by step parity: somebody else may have called the forward in between (bench.py's gather check
+            # does), which shifts the rotation against this runner's step count
+            nxt = self.forward_fn.next_output() if hasattr(self.forward_fn, "next_output") else None
+            for stale in self._ring:
+                if stale[2] is not None and (nxt is None or stale[0] is None or stale[0].data_ptr() == nxt.data_ptr()):
+                    stale[2].wait()
+                    stale[2] = None
         out = self.forward_fn(*local_inputs)
         if self._ring is None:
             if self.collective:   # a ragged shard would hang or fail inside the collective: check once

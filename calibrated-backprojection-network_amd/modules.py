@@ -1221,6 +1221,11 @@ class GraphedForward:
             _SideBranch.only_from = None
         return static_out
 
+    def next_output(self):
+        """The tensor the NEXT call will write (and return): with two rotating outputs, what an asynchronous reader of an earlier
+        result has to be done with before that call (dist.ShardedRunner.step_pipelined asks)."""
+        return self.static_outs[self._turn]
+
     def __call__(self, image, sparse_depth, validity_map_depth, intrinsics):
         with torch.cuda.device(self.static_out.device):
             return self._replay(image, sparse_depth, validity_map_depth, intrinsics)

@@ -129,6 +129,9 @@ class _RotatingForward:
         self.outs = [torch.zeros(2, 1, 4, 4), torch.zeros(2, 1, 4, 4)]
         self.turn = 0
 
+    def next_output(self):
+        return self.outs[self.turn]
+
     def __call__(self, a, b, c, d):
         out = self.outs[self.turn]
         self.turn ^= 1
@@ -148,6 +151,11 @@ def test_pipelined_world1_rotating_outputs_are_not_copied():
         assert torch.equal(prev, xs[i - 1])
         assert prev.data_ptr() in [o.data_ptr() for o in fwd.outs], "the ring slot IS the forward's output tensor"
     assert torch.equal(r.drain(), xs[3])
+    # a call from outside shifts the rotation against the runner's step count: results stay right (the runner goes by tensor identity)
+    fwd(xs[0], None, None, None)
+    assert r.step_pipelined((xs[1], None, None, None)) is not None
+    assert torch.equal(r.step_pipelined((xs[2], None, None, None)), xs[1])
+    assert torch.equal(r.drain(), xs[2])
 
 
 def _rotating_worker(rank, world, port, q):
@@ -164,6 +172,11 @@ def _rotating_worker(rank, world, port, q):
         ok = ok and torch.equal(prev, whole(step - 1))
     ok = ok and torch.equal(runner.drain(), whole(4))
     ok = ok and all(slot[0].data_ptr() in [o.data_ptr() for o in fwd.outs] for slot in runner._ring)
+    fwd(mine(9), None, None, None)     # an outside call shifts the rotation: the next steps must still gather the right tensors
+    for step in range(5, 8):
+        prev = runner.step_pipelined((mine(step), None, None, None))
+        ok = ok and (step == 5 or torch.equal(prev, whole(step - 1)))
+    ok = ok and torch.equal(runner.drain(), whole(7))
     kb.dist.barrier()
     q.put((rank, bool(ok), 1.0))
     dist.destroy_process_group()
