@@ -21,7 +21,7 @@ KBN_ERR_UNSUPPORTED = -2
 KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ, KBN_SRC_PAIR = 0, 1, 2, 3
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
 KBN_MAX_SRC = 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class KbnError(RuntimeError):
@@ -69,6 +69,8 @@ SIGNATURES = {
     "kbn_upconv2x_packed_weight_bytes": (C.c_size_t, [_I, _I]),
     "kbn_upconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
     "kbn_upconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "kbn_deconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
+    "kbn_deconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "kbn_upconv2x_query": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_conv2d_query": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "kbn_kb_block_forward": (_I, [_P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P,

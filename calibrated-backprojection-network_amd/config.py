@@ -133,7 +133,10 @@ def decoder_param_shapes(cfg: KBNetConfig) -> Dict[str, Tuple[int, ...]]:
     cin = cfg.n_filters_encoder_image[-1] + cfg.n_filters_encoder_depth[-1]
     s = {}
     for i, name in enumerate(("deconv4", "deconv3", "deconv2", "deconv1", "deconv0")):
-        s[f"{name}.deconv.conv.conv.weight"] = (f[i], cin, 3, 3)
+        if cfg.deconv_type == "transpose":   # TransposeConv2d.deconv = ConvTranspose2d: in x out x 3 x 3 (reference src/net_utils.py:383-390)
+            s[f"{name}.deconv.deconv.weight"] = (cin, f[i], 3, 3)
+        else:
+            s[f"{name}.deconv.conv.conv.weight"] = (f[i], cin, 3, 3)
         s[f"{name}.conv.conv.weight"] = (f[i], f[i] + skips[i], 3, 3)
         cin = f[i]
     s["output0.conv.weight"] = (1, f[4], 3, 3)

@@ -619,10 +619,21 @@ __host__ __device__ constexpr UfItem uf_item(int it) {
     const int px = ox == 0 ? 0 : (ox == 2 ? 1 : colidx);
     return UfItem{ox, s, py, s - py, px, ox - px};
 }
-// folded weight of (py, dy) x (px, dx) from the nine taps of one (filter, channel)
-__device__ __forceinline__ float uf_fold(const float* w9, int py, int dy, int px, int dx) {
-    const int r0 = (py == 0) ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2), r1 = (py == 0) ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
-    const int c0 = (px == 0) ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), c1 = (px == 0) ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+// folded weight of (py, dy) x (px, dx) from the nine taps of one (filter, channel).  tr = 0: conv3x3(upsample2x(x)) -- the taps that
+// land on the same low-resolution pixel are summed.  tr = 1: ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1)
+// (reference src/net_utils.py:383-390) in the same four-parity form: out[2i - 1 + ky] += in[i] w[ky] gives an even output row (py 0) the one
+// tap ky = 1 of row Y (dy 1), an odd one (py 1) ky = 2 of row Y (dy 0) and ky = 0 of row Y + 1 (dy 1); columns alike.  Nine of the sixteen
+// folded weights are taps, seven are zero (`w9`: the weight with out_channels leading, i.e. the module's in x out x 3 x 3 weight with its first
+// two axes swapped -- the host does that).
+__device__ __forceinline__ void uf_taps(int p, int d, int tr, int& k0, int& k1) {
+    if (tr) { k0 = p == 0 ? 1 : (d == 0 ? 2 : 0); k1 = (p == 0 && d == 0) ? 0 : k0; return; }   // (0,0): empty range
+    k0 = (p == 0) ? (d == 0 ? 0 : 1) : (d == 0 ? 0 : 2);
+    k1 = (p == 0) ? (d == 0 ? 0 : 2) : (d == 0 ? 1 : 2);
+}
+__device__ __forceinline__ float uf_fold(const float* w9, int py, int dy, int px, int dx, int tr = 0) {
+    int r0, r1, c0, c1;
+    uf_taps(py, dy, tr, r0, r1);
+    uf_taps(px, dx, tr, c0, c1);
     float acc = 0.f;
     for (int r = r0; r <= r1; ++r) {
         float row = 0.f;
@@ -632,7 +643,7 @@ __device__ __forceinline__ float uf_fold(const float* w9, int py, int dy, int px
     return acc;
 }
 
-__global__ void uf_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int OC, int Cin) {
+__global__ void uf_scale_kernel(const float* __restrict__ w, float* __restrict__ inv_scale, int OC, int Cin, int tr) {
     const int oc = blockIdx.x;
     __shared__ float red[256];
     float m = 0.f;
@@ -640,7 +651,7 @@ __global__ void uf_scale_kernel(const float* __restrict__ w, float* __restrict__
         for (int i = threadIdx.x; i < Cin * UF_ITEMS; i += 256) {
             const int c = i / UF_ITEMS;
             const UfItem t = uf_item(i % UF_ITEMS);
-            m = fmaxf(m, fabsf(uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx)));
+            m = fmaxf(m, fabsf(uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx, tr)));
         }
     red[threadIdx.x] = m;
     __syncthreads();
@@ -659,7 +670,7 @@ __global__ void uf_scale_kernel(const float* __restrict__ w, float* __restrict__
 
 // OIHW fp32 -> [n-tile][chunk][item][part][k-group][32 filters][8 channels] fp16 of the folded weights
 __global__ void uf_pack_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, _Float16* __restrict__ packed,
-                               int OC, int Cin, int nchunks, long long total) {
+                               int OC, int Cin, int nchunks, long long total, int tr) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     constexpr int per_item = 2 * 2 * UF_NT * 8, per_chunk = UF_ITEMS * per_item;
@@ -674,7 +685,7 @@ __global__ void uf_pack_kernel(const float* __restrict__ w, const float* __restr
     _Float16 h = (_Float16)0.f;
     if (c < Cin && oc < OC) {
         const UfItem t = uf_item(item);
-        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx) * (1.f / inv_scale[oc]);
+        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx, tr) * (1.f / inv_scale[oc]);
         const _Float16 w1 = (_Float16)ws;
         h = part == 0 ? w1 : (_Float16)(ws - (float)w1);
     }
@@ -961,7 +972,7 @@ __host__ __device__ constexpr bool uf_narrow(int out_channels, int in_channels) 
 
 // OIHW fp32 -> [n-tile][chunk][set][part][k-group (4)][16 filters][8 channels] fp16 of the folded weights
 __global__ void uf16_pack_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, _Float16* __restrict__ packed,
-                                 int OC, int Cin, int nchunks, long long total) {
+                                 int OC, int Cin, int nchunks, long long total, int tr) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     constexpr int per_item = 2 * 4 * U16_NT * 8, per_chunk = UF_ITEMS * per_item;
@@ -976,7 +987,7 @@ __global__ void uf16_pack_kernel(const float* __restrict__ w, const float* __res
     _Float16 h = (_Float16)0.f;
     if (c < Cin && oc < OC) {
         const UfItem t = uf_item(item);
-        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx) * (1.f / inv_scale[oc]);
+        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx, tr) * (1.f / inv_scale[oc]);
         const _Float16 w1 = (_Float16)ws;
         h = part == 0 ? w1 : (_Float16)(ws - (float)w1);
     }
@@ -1292,7 +1303,7 @@ __host__ __device__ constexpr bool uf_wide(int out_channels) {   // whole 64-wid
 }
 
 __global__ void uf64_pack_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, _Float16* __restrict__ packed,
-                                 int OC, int Cin, int nchunks, long long total) {
+                                 int OC, int Cin, int nchunks, long long total, int tr) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     constexpr int per_item = 2 * 2 * U64_NT * 8, per_chunk = UF_ITEMS * per_item;
@@ -1307,7 +1318,7 @@ __global__ void uf64_pack_kernel(const float* __restrict__ w, const float* __res
     _Float16 h = (_Float16)0.f;
     if (c < Cin && oc < OC) {
         const UfItem t = uf_item(item);
-        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx) * (1.f / inv_scale[oc]);
+        const float ws = uf_fold(w + ((long long)oc * Cin + c) * 9, t.py, t.dy, t.px, t.dx, tr) * (1.f / inv_scale[oc]);
         const _Float16 w1 = (_Float16)ws;
         h = part == 0 ? w1 : (_Float16)(ws - (float)w1);
     }
@@ -1583,6 +1594,7 @@ static int split_nt(int mode, int out_channels, int in_channels) {
 
 size_t kbn_conv3x3_split_packed_weight_bytes(int out_channels, int in_channels, int mode) {
     using namespace kbn;
+    if (mode == 4) mode = 3;   // the transposed conv runs the folded up-conv's kernels on its own folded weights: same blob layout
     if (out_channels < 1 || in_channels < 1 || (in_channels % SP_CK) != 0 || mode < 0 || mode > 3) return 0;
     const int nt = split_nt(mode, out_channels, in_channels), tiles = ceil_div(out_channels, nt);
     return (size_t)tiles * nt * 4 + (size_t)tiles * (in_channels / SP_CK) * ((mode == 3 ? UF_ITEMS : 9) * 2 * 2 * nt * 16)   // per 16 channels: [set][part][2 k-groups][nt][8] fp16
@@ -1594,6 +1606,8 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
     using namespace kbn;
     const size_t bytes = kbn_conv3x3_split_packed_weight_bytes(out_channels, in_channels, mode);
     if (!weight || !packed || bytes == 0) return KBN_ERR_INVALID_ARGUMENT;
+    const int tr = mode == 4 ? 1 : 0;   // ConvTranspose2d taps instead of the nearest-2x fold (uf_fold)
+    if (tr) mode = 3;
     const int nt = split_nt(mode, out_channels, in_channels), ocpad = ceil_div(out_channels, nt) * nt;
     float* inv = static_cast<float*>(packed);
     _Float16* wp = reinterpret_cast<_Float16*>(inv + ocpad);
@@ -1602,21 +1616,21 @@ int kbn_conv3x3_split_pack_weight(const float* weight, void* packed, int out_cha
     hipLaunchKernelGGL(split_l1_kernel, dim3(in_channels / SP_CK), dim3(256), 0, (hipStream_t)stream, weight,
                        reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + bytes - l1_bytes), out_channels, in_channels, 9);
     if (mode == 3) {
-        hipLaunchKernelGGL(uf_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels);
+        hipLaunchKernelGGL(uf_scale_kernel, dim3(ocpad), dim3(256), 0, (hipStream_t)stream, weight, inv, out_channels, in_channels, tr);
         if (uf_narrow(out_channels, in_channels)) {
             hipLaunchKernelGGL(uf16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv,
-                               wp, out_channels, in_channels, in_channels / U16_CK, total);
+                               wp, out_channels, in_channels, in_channels / U16_CK, total, tr);
             KBN_CHECK_LAUNCH();
             return KBN_OK;
         }
         if (nt == U64_NT) {
             hipLaunchKernelGGL(uf64_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv,
-                               wp, out_channels, in_channels, in_channels / SP_CK, total);
+                               wp, out_channels, in_channels, in_channels / SP_CK, total, tr);
             KBN_CHECK_LAUNCH();
             return KBN_OK;
         }
         hipLaunchKernelGGL(uf_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, inv, wp,
-                           out_channels, in_channels, in_channels / SP_CK, total);
+                           out_channels, in_channels, in_channels / SP_CK, total, tr);
         KBN_CHECK_LAUNCH();
         return KBN_OK;
     }
@@ -1639,6 +1653,7 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     if (act_exponent < -60 || act_exponent > 60) return KBN_ERR_INVALID_ARGUMENT;
     if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || (!out && !pair_out) || n < 1 || out_channels < 1 || height < 1 || width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
+    if (mode == 4) mode = 3;   // ConvTranspose2d(3, stride 2, padding 1, output_padding 1): the folded kernels on a blob packed with mode 4
     if (mode < 0 || mode > 3) return KBN_ERR_INVALID_ARGUMENT;
     if (knob(KNOB_NO_SPLIT)) return KBN_ERR_UNSUPPORTED;
     const bool vec4 = pair_out || !((width & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (out_batch_stride & 3));

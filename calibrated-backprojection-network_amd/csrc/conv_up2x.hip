@@ -44,8 +44,11 @@ __host__ __device__ inline Up2xPlan make_up2x_plan(int oc, int cin) {
     return pl;
 }
 
+// tr = 1: the four-phase weights of ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1) (reference src/net_utils.py:383-390)
+// instead of the nearest-2x fold: out[2i - 1 + ky] += in[i] w[ky] puts tap ky = 1 of row Y (dy 1) on an even output row (a = 0) and taps
+// ky = 2 of row Y (dy 0), ky = 0 of row Y + 1 (dy 1) on an odd one; columns alike.  `w`: out_channels x in_channels x 3 x 3 either way.
 __global__ void pack_up2x_kernel(const float* __restrict__ w, float* __restrict__ packed, int OC, int Cin,
-                                 Up2xPlan pl, long long total) {
+                                 Up2xPlan pl, long long total, int tr) {
     long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const int NT = pl.NT, CK = pl.CK, NC4 = CK / 4;
@@ -70,10 +73,14 @@ __global__ void pack_up2x_kernel(const float* __restrict__ w, float* __restrict_
     float v = 0.f;
     if (c < Cin && oc < OC) {
         const float* wk = w + ((long long)oc * Cin + c) * 9;
-        const int ky0 = (a == 0) ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2);
-        const int ky1 = (a == 0) ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
-        const int kx0 = (b == 0) ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2);
-        const int kx1 = (b == 0) ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+        int ky0 = (a == 0) ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2);
+        int ky1 = (a == 0) ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+        int kx0 = (b == 0) ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2);
+        int kx1 = (b == 0) ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+        if (tr) {   // one tap or none: (phase 0, offset 0) reads nothing
+            ky0 = a == 0 ? 1 : (dy == 0 ? 2 : 0); ky1 = (a == 0 && dy == 0) ? 0 : ky0;
+            kx0 = b == 0 ? 1 : (dx == 0 ? 2 : 0); kx1 = (b == 0 && dx == 0) ? 0 : kx0;
+        }
         for (int ky = ky0; ky <= ky1; ++ky)
             for (int kx = kx0; kx <= kx1; ++kx) v += wk[ky * 3 + kx];
     }
@@ -850,7 +857,7 @@ int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channel
     kbn::Up2xPlan pl = kbn::make_up2x_plan(out_channels, in_channels);
     long long total = 2LL * pl.nTilesN * pl.Cpad * 8 * pl.NT;
     hipLaunchKernelGGL(kbn::pack_up2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, weight, packed, out_channels, in_channels, pl, total);
+                       (hipStream_t)stream, weight, packed, out_channels, in_channels, pl, total, 0);
     KBN_CHECK_LAUNCH();
     const long long total3 = 2LL * pl.nTilesN * pl.Cpad * 6 * pl.NT;
     hipLaunchKernelGGL(kbn::pack_up2x3_kernel, dim3((unsigned)((total3 + 255) / 256)), dim3(256), 0,
@@ -868,7 +875,8 @@ int kbn_upconv2x_pack_weight(const float* weight, float* packed, int out_channel
 
 static int upconv2x_forward_impl(const float* src, long long src_batch_stride, const float* packed_weight, float* out,
                                  long long out_batch_stride, int n, int in_channels, int out_channels, int src_height,
-                                 int src_width, int apply_activation, float negative_slope, kbn_stream_t stream) {
+                                 int src_width, int apply_activation, float negative_slope, kbn_stream_t stream, bool plain = false) {
+    // `plain`: the blob holds four-phase weights only (kbn_deconv2x_pack_weight) -- the 3- and 9-product forms rest on the nearest-2x fold
     using namespace kbn;
     if (!src || !packed_weight || !out || n < 1 || in_channels < 1 || out_channels < 1 || src_height < 1 ||
         src_width < 1)
@@ -903,7 +911,7 @@ static int upconv2x_forward_impl(const float* src, long long src_batch_stride, c
         }
         // 9-product form (both row phases in one workgroup) where the filter count allows; like the 3-product form a
         // property of the layer (it rounds differently), never a tuner choice -- the tuner only picks the tile width.
-        if (up2x9_eligible(out_channels) && !knob(KNOB_NO_UP2X9) && !knob(KNOB_NO_UP2X3)) {
+        if (up2x9_eligible(out_channels) && !knob(KNOB_NO_UP2X9) && !knob(KNOB_NO_UP2X3) && !plain) {
             const Up2x9Plan q9 = make_up2x9_plan(out_channels);
             auto launch9 = [&](int cand) -> int {   // candidate = TWB - 1
                 Up2xParams q = p;
@@ -918,7 +926,7 @@ static int upconv2x_forward_impl(const float* src, long long src_batch_stride, c
         // The 3-product form (3/4 of the MFMAs, see pack_up2x3_kernel) is a property of the layer, not a tuning
         // choice: it rounds differently from the 4-phase form, and results must not depend on the batch size or on
         // what the tuner measured.  The tuner only picks the tile shape (bit-identical among themselves).
-        const int t3 = knob(KNOB_NO_UP2X3) ? 0 : 1;
+        const int t3 = (knob(KNOB_NO_UP2X3) || plain) ? 0 : 1;
         auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
             Up2xParams q = p;
             const int t = (cand & 1) + 1, half = (cand >> 1) & 1;
@@ -932,7 +940,7 @@ static int upconv2x_forward_impl(const float* src, long long src_batch_stride, c
     // maps whose rows are not 16-byte aligned: the same kernel with dword DMA granules (wide outputs only)
     if (!aligned && pl.NB >= 3 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad && !knob(KNOB_NO_UP2X_DMA) &&
         !knob(KNOB_UP_MW)) {
-        const int t3 = knob(KNOB_NO_UP2X3) ? 0 : 1;
+        const int t3 = (knob(KNOB_NO_UP2X3) || plain) ? 0 : 1;
         auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
             Up2xParams q = p;
             const int t = (cand & 1) + 1, half = (cand >> 1) & 1;
@@ -989,6 +997,27 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
                                    src_height, src_width, apply_activation, negative_slope, stream);
     // these fp32 kernels are fallbacks since the folded split-operand up-conv: the slot is filled by a pass of its own
     if (rc == KBN_OK && out_absmax && !kbn::knob(kbn::KNOB_NO_SPLIT))   // KBN_NO_SPLIT: nothing reads slots
+        rc = kbn::absmax_frames_launch(out, out_batch_stride, n, 4LL * out_channels * src_height * src_width, out_absmax,
+                                       (hipStream_t)stream);
+    return rc;
+}
+
+int kbn_deconv2x_pack_weight(const float* weight, float* packed, int out_channels, int in_channels, kbn_stream_t stream) {
+    if (!weight || !packed || out_channels < 1 || in_channels < 1) return KBN_ERR_INVALID_ARGUMENT;
+    kbn::Up2xPlan pl = kbn::make_up2x_plan(out_channels, in_channels);
+    const long long total = 2LL * pl.nTilesN * pl.Cpad * 8 * pl.NT;
+    hipLaunchKernelGGL(kbn::pack_up2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, weight, packed, out_channels, in_channels, pl, total, 1);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}
+
+int kbn_deconv2x_forward(const float* src, long long src_batch_stride, const float* packed_weight, float* out,
+                         long long out_batch_stride, int n, int in_channels, int out_channels, int src_height,
+                         int src_width, int apply_activation, float negative_slope, unsigned* out_absmax, kbn_stream_t stream) {
+    int rc = upconv2x_forward_impl(src, src_batch_stride, packed_weight, out, out_batch_stride, n, in_channels, out_channels,
+                                   src_height, src_width, apply_activation, negative_slope, stream, true);
+    if (rc == KBN_OK && out_absmax && !kbn::knob(kbn::KNOB_NO_SPLIT))
         rc = kbn::absmax_frames_launch(out, out_batch_stride, n, 4LL * out_channels * src_height * src_width, out_absmax,
                                        (hipStream_t)stream);
     return rc;

@@ -87,6 +87,10 @@ class _PackedWeight:
                 self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, stride=stride)
             elif up2x == "split_up":   # the same for the folded nearest-2x up-conv
                 self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, folded_up2x=True)
+            elif up2x == "split_up_t":   # ... and for the transposed conv on those kernels (TransposeConv2d)
+                self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, folded_up2x=True, transposed=True)
+            elif up2x == "up2x_t":       # the transposed conv on the fp32 four-phase kernels
+                self._packed = ops.pack_upconv2x_weight(weight, out=self._packed, transposed=True)
             elif isinstance(up2x, tuple) and up2x[0] == "split_1x1s2":   # conv_fused of the KB block; up2x[1] = first xyz channel
                 self._packed = ops.pack_conv1x1s2_split_weight(weight, up2x[1], out=self._packed)
             else:
@@ -147,6 +151,38 @@ class _PackedFront:
 
 
 # ------------------------------------------------------------------------ layers
+def _run_split(self, weight, srcs, n, h, w, out=None, up2x=False, out_absmax=None, stats=None, pair_out=False, transposed=False):
+    """Conv2d.run_split for `self` = a Conv2d (weight = its OIHW parameter) or, with `transposed` and `up2x`, a TransposeConv2d
+    (weight = its in x out x 3 x 3 parameter: the folded up-conv kernels on the layer's own taps)."""
+    kinds_ok = all((s.kind == _lib.KBN_SRC_TENSOR or (i == 0 and s.kind == _lib.KBN_SRC_PAIR)) and s.channels % 16 == 0
+                   for i, s in enumerate(srcs))
+    if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2 or (up2x and self.stride != 1)
+            or not kinds_ok):
+        return None
+    # narrow layers stay on the fp32 kernels (a 64-filter tile would be mostly padding) -- except the folded up-conv,
+    # which has 16-filter tiles for them (deconv0's 64 -> 12 at full resolution)
+    narrow_up = up2x and self.split_narrow_up and self.out_channels <= 16 and self.in_channels % 32 == 0
+    if self.out_channels < 48 and not narrow_up:
+        return None
+    dev = weight.device
+    srcs = Conv2d._with_slots(srcs, n, dev, stats)
+    if pair_out:
+        if stats is None or (self.out_channels % 8 and not narrow_up) or (self.stride != 1 and up2x):
+            return None
+        # (the narrow folded up-conv writes 16 channels, zeros past its filters: the decoder tail's input)
+        out = ops.PairTensor(n, 16 if narrow_up else self.out_channels, h, w, dev, stats)
+        if self.stride == 2:
+            out.with_sub()   # the even pixels in fp32 too: the next level's 1x1 stride-2 conv_fused reads those
+        if out_absmax is not None:
+            out.absmax = out_absmax
+    elif out is None:
+        out = torch.empty((n, self.out_channels, h, w), device=dev, dtype=torch.float32)
+    packed = (self._packed_split_up.get(weight, 1, up2x="split_up_t" if transposed else "split_up") if up2x
+              else self._packed_split.get(weight, self.stride, up2x="split"))
+    return ops.conv3x3_split(srcs, packed, n, self.out_channels, h, w, out, up2x=up2x, negative_slope=self._slope,
+                             stride=self.stride, folded_up2x=up2x, out_absmax=out_absmax, transposed=transposed)
+
+
 class Conv2d(torch.nn.Module):
     """Bias-free conv (padding k//2) + activation; kernel sizes 1 and 3, strides 1 and 2."""
 
@@ -200,33 +236,7 @@ class Conv2d(torch.nn.Module):
         is the OUTPUT size.  None when the layer or the shape does not qualify.  `pair_out`: the result as an
         ops.PairTensor (for a split-operand consumer; its absmax slot is `out_absmax` when given); source 0 may be one
         (ops.pair_src).  A shape the pair kernels decline returns None like any other: the caller retries in fp32."""
-        kinds_ok = all((s.kind == _lib.KBN_SRC_TENSOR or (i == 0 and s.kind == _lib.KBN_SRC_PAIR)) and s.channels % 16 == 0
-                       for i, s in enumerate(srcs))
-        if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2 or (up2x and self.stride != 1)
-                or not kinds_ok):
-            return None
-        # narrow layers stay on the fp32 kernels (a 64-filter tile would be mostly padding) -- except the folded up-conv,
-        # which has 16-filter tiles for them (deconv0's 64 -> 12 at full resolution)
-        narrow_up = up2x and self.split_narrow_up and self.out_channels <= 16 and self.in_channels % 32 == 0
-        if self.out_channels < 48 and not narrow_up:
-            return None
-        dev = self.conv.weight.device
-        srcs = self._with_slots(srcs, n, dev, stats)
-        if pair_out:
-            if stats is None or (self.out_channels % 8 and not narrow_up) or (self.stride != 1 and up2x):
-                return None
-            # (the narrow folded up-conv writes 16 channels, zeros past its filters: the decoder tail's input)
-            out = ops.PairTensor(n, 16 if narrow_up else self.out_channels, h, w, dev, stats)
-            if self.stride == 2:
-                out.with_sub()   # the even pixels in fp32 too: the next level's 1x1 stride-2 conv_fused reads those
-            if out_absmax is not None:
-                out.absmax = out_absmax
-        elif out is None:
-            out = torch.empty((n, self.out_channels, h, w), device=dev, dtype=torch.float32)
-        packed = (self._packed_split_up.get(self.conv.weight, 1, up2x="split_up") if up2x
-                  else self._packed_split.get(self.conv.weight, self.stride, up2x="split"))
-        return ops.conv3x3_split(srcs, packed, n, self.out_channels, h, w, out, up2x=up2x, negative_slope=self._slope,
-                                 stride=self.stride, folded_up2x=up2x, out_absmax=out_absmax)
+        return _run_split(self, self.conv.weight, srcs, n, h, w, out, up2x, out_absmax, stats, pair_out)
 
     def split_fused_qualifies(self, ci, cf):
         return (self.split and self.kernel_size == 1 and self.stride == 2 and ci % 16 == 0 and cf % 16 == 0
@@ -375,6 +385,9 @@ class UpConv2d(torch.nn.Module):
         self._packed_up2x = _PackedWeight()
         self.split_up = True    # folded 16-product form on split operands (ops.conv3x3_split(folded_up2x=True))
 
+    bf16 = property(lambda self: self.conv.bf16)
+    out_channels = property(lambda self: self.conv.out_channels)
+
     def forward(self, x, shape, amax=None, out_absmax=None, stats=None, pair_out=False):
         """`amax` / `out_absmax` / `stats` (extensions): the per-frame max |a| slot of `x`, the slot to fill for the result,
         the slot pool of the forward (ops.ActStats).  `x` may be an ops.PairTensor (the previous concat conv's output in
@@ -411,6 +424,55 @@ class UpConv2d(torch.nn.Module):
             return ops.upconv2x(x, self._packed_up2x.get(self.conv.conv.weight, 1, up2x=True),
                                 self.conv.out_channels, out, self.conv._slope, out_absmax=out_absmax)
         return self.conv.run([ops.tensor_src(x, "x", amax)], n, oh, ow, resize=True, out_absmax=out_absmax, stats=stats)
+
+
+class TransposeConv2d(torch.nn.Module):
+    """ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1, no bias) + activation: the decoder blocks' up-sampling layer
+    with deconv_type='transpose' (reference src/net_utils.py:350-440; parameter `deconv.weight`, in x out x 3 x 3).  The output is
+    exactly twice the input; by output parity the layer is four small convs on its input, i.e. the folded up-conv's kernels with the
+    layer's nine taps in nine of their sixteen phase weights (csrc/conv_split.hip uf_fold, csrc/conv_up2x.hip pack_up2x_kernel)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, weight_initializer="kaiming_uniform",
+                 activation_func=torch.nn.LeakyReLU(negative_slope=0.10, inplace=True),
+                 use_batch_norm=False, use_instance_norm=False):
+        super().__init__()
+        if use_batch_norm or use_instance_norm:
+            raise ValueError("normalisation layers are not part of the KBNet inference path")
+        if kernel_size != 3:
+            raise ValueError("the HIP transposed conv is the decoder's: kernel_size 3")
+        self.deconv = torch.nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=2,
+                                               padding=kernel_size // 2, output_padding=1, bias=False)
+        _init_weight(self.deconv.weight, weight_initializer)
+        self.activation_func = activation_func
+        self.kernel_size, self.stride = kernel_size, 1    # as _run_split sees the layer: an up-conv
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._slope = _slope(activation_func)
+        self._packed_split = None                         # (never used: the layer has no plain-conv form)
+        self._packed_split_up = _PackedWeight()
+        self._packed_up2x = _PackedWeight()
+        self.split = True
+        self.split_narrow_up = True
+        self.bf16 = False                                 # no bf16 leg for this layer
+
+    def forward(self, x, shape=None, amax=None, out_absmax=None, stats=None, pair_out=False):
+        """`shape` is accepted and ignored, as in the reference's DecoderBlock (:1468-1469: the transposed conv fixes the size).
+        Extensions as UpConv2d.forward; None when `x` is an ops.PairTensor or `pair_out` is asked for and the split kernels
+        decline the layer or the shape."""
+        if x.shape[1] != self.in_channels:
+            raise KbnError(f"expected {self.in_channels} input channels, got {x.shape[1]}")
+        pair_in = isinstance(x, ops.PairTensor)
+        if not pair_in:
+            x = x if _dense(x) else x.contiguous()
+        n, _, h, w = x.shape
+        oh, ow = 2 * h, 2 * w
+        w_t = self.deconv.weight
+        src = ops.pair_src(x, "x") if pair_in else ops.tensor_src(x, "x", amax)
+        res = _run_split(self, w_t, [src], n, oh, ow, up2x=True, out_absmax=out_absmax, stats=stats, pair_out=pair_out, transposed=True)
+        if res is not None or pair_in or pair_out:
+            return res
+        out = torch.empty((n, self.out_channels, oh, ow), device=x.device, dtype=torch.float32)
+        return ops.upconv2x(x, self._packed_up2x.get(w_t, 1, up2x="up2x_t"), self.out_channels, out, self._slope,
+                            out_absmax=out_absmax, transposed=True)
 
 
 class VGGNetBlock(torch.nn.Module):
@@ -620,12 +682,15 @@ class DecoderBlock(torch.nn.Module):
                  use_batch_norm=False, use_instance_norm=False, deconv_type="up",
                  use_depthwise_separable=False):
         super().__init__()
-        if deconv_type != "up" or use_depthwise_separable:
-            raise ValueError("only deconv_type='up' (KBNet's setting) is implemented")
+        if use_depthwise_separable:
+            raise ValueError("depthwise separable convolutions are not part of the KBNet path")
+        if deconv_type not in ("up", "transpose"):   # (the reference builds such a block and fails in forward: `deconv` unbound)
+            raise ValueError("Unsupported deconv_type: {}".format(deconv_type))
         self.skip_channels = skip_channels
         self.deconv_type = deconv_type
-        self.deconv = UpConv2d(in_channels, out_channels, 3, weight_initializer, activation_func,
-                               use_batch_norm, use_instance_norm)
+        # reference src/net_utils.py:1413-1434: TransposeConv2d / UpConv2d, kernel 3, the block's activation
+        deconv = TransposeConv2d if deconv_type == "transpose" else UpConv2d
+        self.deconv = deconv(in_channels, out_channels, 3, weight_initializer, activation_func, use_batch_norm, use_instance_norm)
         self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer,
                            activation_func, use_batch_norm, use_instance_norm)
 
@@ -634,10 +699,17 @@ class DecoderBlock(torch.nn.Module):
         for the result and the slot pool of the forward (ops.ActStats); missing input slots are measured.  `x` may be an
         ops.PairTensor and `pair_out` asks for one (the decoder's chain of split-operand kernels, MultiScaleDecoder);
         None when the pair kernels decline a shape (the caller repeats the block in fp32)."""
-        if pair_out and (self.conv.bf16 or self.deconv.conv.bf16 or not self.conv.split or self.conv.out_channels < 48
+        if pair_out and (self.conv.bf16 or self.deconv.bf16 or not self.conv.split or self.conv.out_channels < 48
                          or self.conv.out_channels % 8 or self.conv.kernel_size != 3):
             return None   # declined before anything is launched
-        if skip is not None:
+        if self.deconv_type == "transpose":
+            # the transposed conv fixes the size (reference :1468-1469: `shape` and the skip's size are not consulted); a skip of
+            # another size fails in the reference's torch.cat -- here before anything is launched
+            shape = (2 * x.shape[2], 2 * x.shape[3])
+            if skip is not None and self.skip_channels > 0 and tuple(skip.shape[2:4]) != shape:
+                raise RuntimeError(f"Sizes of tensors must match except in dimension 1. Expected size {shape} but got size "
+                                   f"{tuple(skip.shape[2:4])} for the skip connection (deconv_type='transpose' doubles the size)")
+        elif skip is not None:
             shape = skip.shape[2:4]
         elif shape is None:
             shape = (2 * x.shape[2], 2 * x.shape[3])
@@ -647,7 +719,7 @@ class DecoderBlock(torch.nn.Module):
         # inside the pair chain the up-conv's output goes to the concat conv as a PairTensor too (that kernel wants at least
         # two 16-channel chunks from each of its two sources)
         deconv = None
-        if (pair_out and self.pair_mid and skip is not None and self.skip_channels >= 32 and self.deconv.conv.out_channels >= 32
+        if (pair_out and self.pair_mid and skip is not None and self.skip_channels >= 32 and self.deconv.out_channels >= 32
                 and not self.conv.bf16):
             deconv = self.deconv(x, shape=shape, amax=amax_x, out_absmax=amax_deconv, stats=stats, pair_out=True)
         if deconv is None:
@@ -1359,6 +1431,9 @@ class KBNetModel(object):
                     sub._packed_split_1x1.refresh(sub.conv.weight)
                 elif isinstance(sub, UpConv2d):
                     sub._packed_up2x.refresh(sub.conv.conv.weight)
+                elif isinstance(sub, TransposeConv2d):
+                    sub._packed_up2x.refresh(sub.deconv.weight)
+                    sub._packed_split_up.refresh(sub.deconv.weight)
                 elif isinstance(sub, MultiScaleDecoder):
                     sub._packed_tail.refresh()
                 elif isinstance(sub, KBNetEncoder):

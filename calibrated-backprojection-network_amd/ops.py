@@ -115,10 +115,19 @@ def conv_executed_flops(n, out_channels, in_channels, kernel_size, stride, in_he
     return 2.0 * pl["workgroups"] * (4 * pl["MW"] * 16) * (pl["NB"] * 16) * cpad * kernel_size * kernel_size
 
 
-def upconv2x_executed_flops(n, in_channels, out_channels, src_height, src_width):
+def upconv2x_executed_flops(n, in_channels, out_channels, src_height, src_width, plain=False):
+    """`plain`: the four-phase form whatever the shape (the transposed conv: kbn_deconv2x_forward)."""
     info = (C.c_int * 4)()
     check(_lib.load().kbn_upconv2x_query(n, in_channels, out_channels, src_height, src_width, info), "kbn_upconv2x_query")
-    return 2.0 * n * src_height * src_width * info[0] * info[1] * info[2]
+    if plain and info[0] == 9:   # the 9-product form has its own filter tiling: the four-phase one pads to make_up2x_plan's tiles
+        nblk = -(-out_channels // 16)
+        best, bestpad = 1, 1 << 30
+        for nb in range(1, 5):
+            pad = -(-nblk // nb) * nb
+            if pad < bestpad or (pad == bestpad and nb > best):
+                best, bestpad = nb, pad
+        info[1] = bestpad * 16
+    return 2.0 * n * src_height * src_width * (16 if plain else info[0]) * info[1] * info[2]
 
 
 _PLAN_CACHE = {}
@@ -467,40 +476,59 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
 
 
 # ---------------------------------------------------------------------- up-conv 2x
+def _deconv_weight(weight: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d's in x out x 3 x 3 parameter with out_channels leading: the layout the packers read."""
+    return weight.detach().permute(1, 0, 2, 3).contiguous()
+
+
 @_on_tensor_device
-def pack_upconv2x_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """OIHW 3x3 weight -> phase-summed MFMA blob for `upconv2x` (once per weight)."""
+def pack_upconv2x_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None, transposed: bool = False) -> torch.Tensor:
+    """OIHW 3x3 weight -> phase-summed MFMA blob for `upconv2x` (once per weight).  `transposed`: `weight` is a
+    ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1) parameter, in x out x 3 x 3, and the blob is
+    for `upconv2x(transposed=True)` (kbn_deconv2x_pack_weight)."""
     lib = _lib.load()
-    w = weight.detach().contiguous()
+    w = _deconv_weight(weight) if transposed else weight.detach().contiguous()
     _require(w, "weight", 4)
     oc, cin, kh, kw = w.shape
     if (kh, kw) != (3, 3):
         raise KbnError("upconv2x needs a 3x3 weight")
     nfloats = lib.kbn_upconv2x_packed_weight_bytes(oc, cin) // 4
     packed = out if _reusable(out, nfloats, w) else torch.empty(nfloats, device=w.device, dtype=torch.float32)
-    check(lib.kbn_upconv2x_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, _stream()),
-          "kbn_upconv2x_pack_weight")
+    if transposed:
+        check(lib.kbn_deconv2x_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, _stream()), "kbn_deconv2x_pack_weight")
+    else:
+        check(lib.kbn_upconv2x_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, _stream()),
+              "kbn_upconv2x_pack_weight")
     return packed
 
 
 @_on_tensor_device
 def upconv2x(x: torch.Tensor, packed_weight: torch.Tensor, out_channels: int, out: torch.Tensor,
-             negative_slope: Optional[float] = 0.2, out_absmax: Optional[torch.Tensor] = None):
-    """nearest 2x upsample + conv3x3 (+ LeakyReLU): x N x C x h x w -> out N x out_channels x 2h x 2w."""
+             negative_slope: Optional[float] = 0.2, out_absmax: Optional[torch.Tensor] = None, transposed: bool = False):
+    """nearest 2x upsample + conv3x3 (+ LeakyReLU): x N x C x h x w -> out N x out_channels x 2h x 2w.
+    `transposed`: ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1) (+ LeakyReLU) instead, same sizes
+    (kbn_deconv2x_forward; blob from pack_upconv2x_weight(transposed=True))."""
     lib = _lib.load()
     xptr, xbs = _planes(x, "x")
     n, cin, h, w = x.shape
     optr, obs = _planes(out, "out")
     if tuple(out.shape) != (n, out_channels, 2 * h, 2 * w):
         raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, 2 * h, 2 * w)}")
-    # algorithmic work of the reference formulation (9 taps at the upsampled resolution)
-    check(_launch("conv_up2x", 2.0 * n * 4 * h * w * cin * 9 * out_channels,
-                  lambda: lib.kbn_upconv2x_forward(xptr, xbs, packed_weight.data_ptr(), optr, obs, n, cin,
-                                                   out_channels, h, w, 0 if negative_slope is None else 1,
-                                                   0.0 if negative_slope is None else float(negative_slope),
-                                                   _slot_ptr(out_absmax, n), _stream()),
-                  executed=lambda: upconv2x_executed_flops(n, cin, out_channels, h, w), pipe="fp32",
-                  nbytes=4.0 * n * h * w * (cin + 4 * out_channels)), "kbn_upconv2x_forward")
+    fwd = lib.kbn_deconv2x_forward if transposed else lib.kbn_upconv2x_forward
+    name = "kbn_deconv2x_forward" if transposed else "kbn_upconv2x_forward"
+    # algorithmic work of the reference formulation (9 taps at the upsampled resolution; transposed: 9 taps per SOURCE pixel)
+    work = 2.0 * n * h * w * cin * 9 * out_channels * (1 if transposed else 4)
+    if transposed:   # always the four-phase form: 16 channel products per source pixel over the padded channel counts
+        executed = lambda: upconv2x_executed_flops(n, cin, out_channels, h, w, plain=True)
+    else:
+        executed = lambda: upconv2x_executed_flops(n, cin, out_channels, h, w)
+    check(_launch("conv_up2x", work,
+                  lambda: fwd(xptr, xbs, packed_weight.data_ptr(), optr, obs, n, cin,
+                              out_channels, h, w, 0 if negative_slope is None else 1,
+                              0.0 if negative_slope is None else float(negative_slope),
+                              _slot_ptr(out_absmax, n), _stream()),
+                  executed=executed, pipe="fp32",
+                  nbytes=4.0 * n * h * w * (cin + 4 * out_channels)), name)
     return out
 
 
@@ -692,13 +720,15 @@ def conv_tail(x, packed_w_conv, w_out, min_predict_depth: float, max_predict_dep
 # ----------------------------------------------------- fp32-grade convs on the 16-bit matrix core (split operands)
 @_on_tensor_device
 def pack_conv3x3_split_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None, stride: int = 1,
-                              folded_up2x: bool = False) -> torch.Tensor:
+                              folded_up2x: bool = False, transposed: bool = False) -> torch.Tensor:
     """OIHW fp32 3x3 weight -> per-filter scaled two-term fp16 split in MFMA order for `conv3x3_split` with the same
     `stride` / `folded_up2x` (in_channels % 16 == 0).  `folded_up2x`: the sixteen 2x2 parity weights of the nearest-2x
-    up-conv (sums of the 3x3 taps that read the same source pixel) instead of the nine taps."""
-    mode = 3 if folded_up2x else (2 if stride == 2 else 0)
+    up-conv (sums of the 3x3 taps that read the same source pixel) instead of the nine taps.  `transposed`: `weight` is a
+    ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1) parameter (in x out x 3 x 3) and the blob is the one
+    `conv3x3_split(up2x=True, folded_up2x=True, transposed=True)` reads (mode 4: the folded kernels, the layer's own taps)."""
+    mode = 4 if transposed else (3 if folded_up2x else (2 if stride == 2 else 0))
     lib = _lib.load()
-    w = weight.detach().contiguous()
+    w = _deconv_weight(weight) if transposed else weight.detach().contiguous()
     _require(w, "weight", 4)
     oc, cin, kh, kw = w.shape
     nbytes = lib.kbn_conv3x3_split_packed_weight_bytes(oc, cin, mode) if (kh, kw) == (3, 3) else 0
@@ -747,7 +777,8 @@ def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1, 
 @_on_tensor_device
 def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
                   out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1,
-                  act_exponent: int = -6, folded_up2x: bool = False, out_absmax: Optional[torch.Tensor] = None):
+                  act_exponent: int = -6, folded_up2x: bool = False, out_absmax: Optional[torch.Tensor] = None,
+                  transposed: bool = False):
     """3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
     `stride` 2: sources are the 2x larger input planes), fp32 in / fp32 out, every product taken as three fp16 MFMAs
     over two-term splits of both operands (kbn_conv3x3_split_forward): fp32-grade accuracy at 3/16 of the fp32 MFMA's
@@ -755,8 +786,11 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     slot (tensor_src(absmax=)): per frame, on the device; only sources without slots fall back to the static
     `act_exponent` k (|a| 2^k < 65504).  `out_absmax`: slot that receives max |out| per frame.
     `folded_up2x` (with `up2x`): the folded 16-product form, weights from
-    pack_conv3x3_split_weight(folded_up2x=True).  Returns None when the shape does not qualify (the caller stays on the
-    fp32-MFMA kernels)."""
+    pack_conv3x3_split_weight(folded_up2x=True).  `transposed` (with both): the layer is a ConvTranspose2d(kernel 3, stride 2,
+    padding 1, output_padding 1) instead -- same kernels, blob from pack_conv3x3_split_weight(transposed=True).  Returns None
+    when the shape does not qualify (the caller stays on the fp32-MFMA kernels)."""
+    if transposed and not (up2x and folded_up2x):
+        raise KbnError("conv3x3_split: transposed goes with up2x and folded_up2x")
     if up2x and stride != 1:
         raise KbnError("conv3x3_split: up2x and stride 2 are mutually exclusive")
     lib = _lib.load()
@@ -772,9 +806,9 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     if tuple(out.shape) != want:
         raise KbnError(f"out has shape {tuple(out.shape)}, expected {want}")
     cin = sum(s.channels for s in srcs)
-    flops = 2.0 * n * height * width * cin * 9 * out_channels
-    mode = (3 if folded_up2x else 1) if up2x else (2 if stride == 2 else 0)
-    status = _launch(("conv_split", "conv_split_up", "conv_split_s2", "conv_split_upfold")[mode], flops,
+    flops = 2.0 * n * height * width * cin * 9 * out_channels / (4 if transposed else 1)   # transposed: nine taps per SOURCE pixel
+    mode = (4 if transposed else (3 if folded_up2x else 1)) if up2x else (2 if stride == 2 else 0)
+    status = _launch(("conv_split", "conv_split_up", "conv_split_s2", "conv_split_upfold", "conv_split_upfold")[mode], flops,
                      lambda: lib.kbn_conv3x3_split_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
                                                            out_channels, height, width,
                                                            mode, max(-60, min(60, int(act_exponent))),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KBN_ABI_VERSION 5
+#define KBN_ABI_VERSION 6
 
 typedef void* kbn_stream_t; /* hipStream_t */
 
@@ -224,6 +224,23 @@ int kbn_upconv2x_forward(const float* src, long long src_batch_stride, const flo
  * executes 2 * n * src_height * src_width * info[0] * info[1] * info[2] FLOP on the matrix cores. */
 int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height, int src_width, int* info);
 
+/* ------------------------------------------------------- transposed conv 2x -------
+ * net_utils.TransposeConv2d.forward -- the decoder blocks' up-sampling layer with deconv_type='transpose'
+ * (run_kbnet.py --deconv_type transpose; reference src/net_utils.py:350-440, DecoderBlock :1468-1469):
+ * torch.nn.ConvTranspose2d(in, out, kernel_size=3, stride=2, padding=1, output_padding=1, bias=False) (+ activation),
+ *     out[n, o, 2i - 1 + ky, 2j - 1 + kx] += src[n, c, i, j] w[c, o, ky, kx],    output exactly 2 src_height x 2 src_width.
+ * By output parity this is four small convs on the source (1, 2, 2 and 4 taps), i.e. the four-phase form of the up-conv
+ * above with nine of its sixteen phase weights taken from w and seven zero: same kernels, same blob size
+ * (kbn_upconv2x_packed_weight_bytes), always the four-phase form.
+ *   weight  out_channels x in_channels x 3 x 3: the module's in x out x 3 x 3 parameter with its first two axes swapped
+ *           (the Python mirror does that: ops.pack_upconv2x_weight(transposed=True)). */
+int kbn_deconv2x_pack_weight(const float* weight, float* packed, int out_channels, int in_channels,
+                             kbn_stream_t stream);
+int kbn_deconv2x_forward(const float* src, long long src_batch_stride, const float* packed_weight,
+                         float* out, long long out_batch_stride, int n, int in_channels,
+                         int out_channels, int src_height, int src_width, int apply_activation,
+                         float negative_slope, unsigned* out_absmax, kbn_stream_t stream);
+
 /* ------------------------------- fp32-grade 3x3 convs on the 16-bit matrix core --
  * gfx950 executes fp32 MFMAs on the fp32 vector datapath (157 TFLOP/s); the matrix core proper takes
  * 16-bit operands (2.5 PFLOP/s dense).  These entry points feed it fp32 operands as pairs of fp16 values:
@@ -242,7 +259,12 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
  *             covers 0.0039 .. 4.2e6).  Range -60 .. 60.
  *   mode      0: 3x3 stride 1 over height x width sources; 1: nearest-2x up-conv (ONE source with
  *             (height/2) x (width/2) planes); 2: 3x3 stride 2 (source planes h x w with ceil(h/2) = height,
- *             ceil(w/2) = width: the image convs of the KB blocks, reference src/net_utils.py:1348)
+ *             ceil(w/2) = width: the image convs of the KB blocks, reference src/net_utils.py:1348); 3: mode 1 in its folded
+ *             form (four 2x2 convs on the low-resolution source, 16 instead of 36 channel products per source pixel: what the
+ *             decoder runs); 4: ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1) -- deconv_type='transpose',
+ *             reference src/net_utils.py:383-390 -- on mode 3's kernels (nine of the sixteen folded weights are the layer's taps,
+ *             seven are zero; `weight` for kbn_conv3x3_split_pack_weight: out x in x 3 x 3, the module's parameter with its
+ *             first two axes swapped); whatever this text says of mode 3 holds for mode 4
  *   srcs      1 or 2 KBN_SRC_TENSOR sources, each a multiple of 16 channels; source 0 may be a KBN_SRC_PAIR (above)
  *   pair_out  NULL, or the output as a PAIR tensor (then `out` is ignored and may be NULL), with
  *             pair_out_batch_stride (fp16 elements) and pair_out_scale (n floats).  Mode 2 with pair_out (one source): a

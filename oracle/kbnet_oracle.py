@@ -229,15 +229,22 @@ def encoder(image, depth, intrinsics, sd, resolutions_backprojection=(0, 1, 2, 3
 
 # ---------------------------------------------------------------------- decoder
 def decoder_block(x, skip, shape, sd, slope=NEGATIVE_SLOPE):
-    """Nearest-resize -> conv3x3 -> cat skip -> conv3x3.
+    """Nearest-resize -> conv3x3 -> cat skip -> conv3x3 (deconv_type='up'), or ConvTranspose2d(3, stride 2, padding 1,
+    output_padding 1) -> activation -> cat skip -> conv3x3 (deconv_type='transpose': the state dict then holds
+    `deconv.deconv.weight`, in x out x 3 x 3).
 
-    Reference: DecoderBlock.forward src/net_utils.py:1453-1487 and
-    UpConv2d.forward :484-499.
+    Reference: DecoderBlock.forward src/net_utils.py:1453-1487, UpConv2d.forward :484-499,
+    TransposeConv2d :383-390 (ctor) and :417-437 (forward).
     """
-    if skip is not None:
-        shape = skip.shape[2:4]
-    up = F.interpolate(x, size=tuple(shape), mode="nearest")
-    y = conv2d(up, sd["deconv.conv.conv.weight"], 1, slope)
+    if "deconv.deconv.weight" in sd:
+        y = F.conv_transpose2d(x, sd["deconv.deconv.weight"], bias=None, stride=2, padding=1, output_padding=1)
+        if slope is not None:
+            y = F.leaky_relu(y, negative_slope=slope)
+    else:
+        if skip is not None:
+            shape = skip.shape[2:4]
+        up = F.interpolate(x, size=tuple(shape), mode="nearest")
+        y = conv2d(up, sd["deconv.conv.conv.weight"], 1, slope)
     if skip is not None:
         y = torch.cat([y, skip], dim=1)
     return conv2d(y, sd["conv.conv.weight"], 1, slope)
@@ -245,8 +252,9 @@ def decoder_block(x, skip, shape, sd, slope=NEGATIVE_SLOPE):
 
 def decoder(latent, skips, shape, sd, slope=NEGATIVE_SLOPE):
     """MultiScaleDecoder.forward with n_resolution=1, output_func='linear',
-    deconv_type='up' (reference src/networks.py:1855-1989 as configured at
-    src/kbnet_model.py:127-137).  Returns the full-resolution logits."""
+    deconv_type 'up' or 'transpose' -- whichever the state dict holds (reference
+    src/networks.py:1855-1989 as configured at src/kbnet_model.py:127-137).
+    Returns the full-resolution logits."""
     x = latent
     for name, skip in (("deconv4", skips[3]), ("deconv3", skips[2]),
                        ("deconv2", skips[1]), ("deconv1", skips[0])):

@@ -269,26 +269,32 @@ def gen_encoder_stacked():
 
 
 # ---------------------------------------------------------------------- decoder
-def gen_decoder():
-    cfg = kb.kitti_config().narrow()
-    sd = kb.synthetic.make_state_dicts(cfg, seed=4, gain=1.5)[2]
-    enc_ch = [i + z for i, z in zip(cfg.n_filters_encoder_image, cfg.n_filters_encoder_depth)]
-    dec = networks.MultiScaleDecoder(
-        input_channels=enc_ch[-1], output_channels=1, n_resolution=1,
-        n_filters=list(cfg.n_filters_decoder), n_skips=cfg.n_skips,
-        weight_initializer="xavier_normal", activation_func="leaky_relu",
-        output_func="linear", use_batch_norm=False, deconv_type="up").eval()
-    load(dec, sd)
-    g = torch.Generator().manual_seed(41)
-    for name, (h, w) in {"even": (64, 96), "odd": (70, 100)}.items():
-        sizes = [(h, w)]
-        for _ in range(5):
-            sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
-        latent = torch.randn(1, enc_ch[4], *sizes[5], generator=g)
-        skips = [torch.randn(1, enc_ch[i], *sizes[i + 1], generator=g) for i in range(4)]
-        out = dec(latent, skips, (h, w))[-1]
-        save(f"dec_{name}", latent=latent, weights=np_sd(sd), logits=out, shape=np.array([h, w]),
-             **{f"skip{i + 1}": s for i, s in enumerate(skips)})
+def gen_decoder(only=None):
+    import dataclasses
+    # dec_transpose: deconv_type='transpose' (run_kbnet.py --deconv_type transpose): TransposeConv2d in every block
+    # (src/net_utils.py:350-440); even sizes only -- the transposed conv doubles the size whatever the skip's is
+    for deconv_type, cases in (("up", {"even": (64, 96), "odd": (70, 100)}), ("transpose", {"transpose": (64, 96)})):
+        cfg = dataclasses.replace(kb.kitti_config().narrow(), deconv_type=deconv_type)
+        sd = kb.synthetic.make_state_dicts(cfg, seed=4, gain=1.5)[2]
+        enc_ch = [i + z for i, z in zip(cfg.n_filters_encoder_image, cfg.n_filters_encoder_depth)]
+        dec = networks.MultiScaleDecoder(
+            input_channels=enc_ch[-1], output_channels=1, n_resolution=1,
+            n_filters=list(cfg.n_filters_decoder), n_skips=cfg.n_skips,
+            weight_initializer="xavier_normal", activation_func="leaky_relu",
+            output_func="linear", use_batch_norm=False, deconv_type=deconv_type).eval()
+        load(dec, sd)
+        g = torch.Generator().manual_seed(41)
+        for name, (h, w) in cases.items():
+            sizes = [(h, w)]
+            for _ in range(5):
+                sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+            latent = torch.randn(1, enc_ch[4], *sizes[5], generator=g)
+            skips = [torch.randn(1, enc_ch[i], *sizes[i + 1], generator=g) for i in range(4)]
+            if only and name not in only:
+                continue
+            out = dec(latent, skips, (h, w))[-1]
+            save(f"dec_{name}", latent=latent, weights=np_sd(sd), logits=out, shape=np.array([h, w]),
+                 **{f"skip{i + 1}": s for i, s in enumerate(skips)})
 
 
 # ----------------------------------------------------------------- full forward
@@ -305,10 +311,16 @@ def gen_forward(only=None):
                                                # calibrated_backprojection4 a second time (src/networks.py:499-517, quirk Q3),
                                                # which only runs when levels 2 and 3 have the same widths
                                                ("kb01234", "kitti", (64, 96), 2, (0, 1, 2, 3, 4)),
-                                               ("kb01234_odd", "void", (70, 100), 1, (0, 1, 2, 3, 4))):
+                                               ("kb01234_odd", "void", (70, 100), 1, (0, 1, 2, 3, 4)),
+                                               # deconv_type='transpose' (run_kbnet.py --deconv_type): the decoder's up-sampling
+                                               # layers are ConvTranspose2d(3, stride 2, padding 1, output_padding 1)
+                                               ("transpose", "kitti", (64, 96), 2, None),
+                                               ("transpose_void", "void", (96, 128), 1, None)):
         if only and name not in only:
             continue
         cfg = kb.PRESETS[preset]().narrow()
+        if name.startswith("transpose"):
+            cfg = dataclasses.replace(cfg, deconv_type="transpose")
         if kb_levels is not None:
             cfg = dataclasses.replace(cfg, resolutions_backprojection=kb_levels)
         if kb_levels is not None and 4 in kb_levels:
@@ -333,7 +345,7 @@ def gen_forward(only=None):
             valid = (sparse > 0).float()
         out = model.forward(image, sparse, valid, k)
         save(f"fwd_{name}", image=image, sparse_depth=sparse, validity_map=valid, intrinsics=k,
-             output_depth=out, preset=np.array(preset),
+             output_depth=out, preset=np.array(preset), deconv_type=np.array(cfg.deconv_type),
              resolutions_backprojection=np.array(cfg.resolutions_backprojection),
              n_filters_encoder_image=np.array(cfg.n_filters_encoder_image), n_filters_encoder_depth=np.array(cfg.n_filters_encoder_depth),
              s2d=np_sd(sds[0]), encoder=np_sd(sds[1]), decoder=np_sd(sds[2]))
@@ -512,6 +524,10 @@ if __name__ == "__main__":
         gen_forward(only=("kb01234", "kb01234_odd"))
         gen_kb_stacked()
         gen_encoder_stacked()
+        sys.exit(0)
+    if "--only-transpose" in sys.argv:    # round 5: deconv_type='transpose'
+        gen_decoder(only=("transpose",))
+        gen_forward(only=("transpose", "transpose_void"))
         sys.exit(0)
     gen_pre_eval()
     if "--only-pre-eval" in sys.argv:

@@ -179,6 +179,73 @@ def test_upconv2x_wide_outputs_any_alignment(dev, cin, cout, hw):
     assert torch.equal(up(x.to(dev), (2 * h, 2 * w)), first)   # tuned geometry, same bits
 
 
+# cin, cout, source (h, w): fp32 four-phase kernels (narrow / unaligned layers: DMA tiles, dword granules, the general kernel) and the
+# split-operand kernels (Cin % 16 == 0 and >= 48 filters: 32- and 64-filter tiles; <= 16 filters and Cin % 32 == 0: 16-filter tiles)
+TRANSPOSE_CASES = [(24, 16, (5, 7)), (8, 4, (11, 38)), (32, 24, (9, 16)), (64, 40, (11, 38)), (20, 52, (6, 10)),
+                   (64, 64, (11, 38)), (128, 64, (10, 18)), (64, 96, (18, 38)), (32, 192, (9, 66)), (48, 64, (25, 34)),
+                   (64, 12, (18, 38)), (32, 16, (35, 4)), (96, 5, (4, 66))]
+
+
+@pytest.mark.parametrize("cin,cout,hw", TRANSPOSE_CASES)
+def test_transpose_conv2d_vs_torch(dev, cin, cout, hw):
+    """TransposeConv2d (deconv_type='transpose', reference src/net_utils.py:350-440) = ConvTranspose2d(3, stride 2, padding 1,
+    output_padding 1) + LeakyReLU against torch's own transposed conv on the CPU, fp32 and fp64.  Whichever kernel family
+    takes the layer runs the up-conv's four-parity form on the layer's nine taps."""
+    h, w = hw
+    g = torch.Generator().manual_seed(cin * 7 + cout + w)
+    n = 2
+    x = torch.nn.functional.leaky_relu(torch.randn(n, cin, h, w, generator=g), 0.2)
+    x[1] *= 0.05
+    wt = torch.randn(cin, cout, 3, 3, generator=g) / (cin * 2.25) ** 0.5       # 2.25 taps per output on average
+    ref32 = torch.nn.functional.leaky_relu(torch.nn.functional.conv_transpose2d(x, wt, stride=2, padding=1, output_padding=1), 0.2)
+    ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv_transpose2d(x.double(), wt.double(), stride=2, padding=1,
+                                                                                output_padding=1), 0.2)
+    assert tuple(ref32.shape) == (n, cout, 2 * h, 2 * w)
+    m = kb.modules.TransposeConv2d(cin, cout, 3, "xavier_normal", torch.nn.LeakyReLU(0.2)).to(dev)
+    assert list(m.state_dict()) == ["deconv.weight"] and tuple(m.deconv.weight.shape) == (cin, cout, 3, 3)
+    m.deconv.weight.data.copy_(wt)
+    stats = kb.ops.ActStats(n, dev)
+    slot = stats.new()
+    kb.ops.PROFILE = []
+    try:
+        out = m(x.to(dev), out_absmax=slot, stats=stats)
+        names = [r[0] for r in kb.ops.PROFILE if r[0].startswith("conv_")]
+    finally:
+        kb.ops.PROFILE = None
+    split = cin % 16 == 0 and (2 * w) % 4 == 0 and (cout >= 48 or (cout <= 16 and cin % 32 == 0))
+    assert names == (["conv_split_upfold"] if split else ["conv_up2x"]), names
+    assert torch.equal(kb.ops.slot_values(slot), out.abs().amax(dim=(1, 2, 3)))
+    assert rel_err(out, ref32) < TIGHT
+    rms = ref64.pow(2).mean(dim=(2, 3), keepdim=True).sqrt()
+    e_hip = ((out.cpu().double() - ref64) / rms).abs()
+    e_t32 = ((ref32.double() - ref64) / rms).abs()
+    print(f"transposed conv vs fp64: rms {float(e_hip.pow(2).mean().sqrt()):.2e} max {float(e_hip.max()):.2e}; "
+          f"torch fp32: rms {float(e_t32.pow(2).mean().sqrt()):.2e} max {float(e_t32.max()):.2e}")
+    assert float(e_hip.pow(2).mean().sqrt()) < 1.5e-6 and float(e_hip.max()) < 2e-5
+    # a weight update is followed (the blob is re-packed), shape is accepted and ignored as in the reference's DecoderBlock
+    with torch.no_grad():
+        m.deconv.weight.mul_(2.0)
+    assert rel_err(m(x.to(dev), shape=(3, 3)), 2 * ref32) < TIGHT
+
+
+def test_transpose_decoder_block_vs_oracle(dev):
+    """DecoderBlock(deconv_type='transpose'): a skip of twice the input's size is concatenated; any other size fails before a launch
+    (the reference fails in torch.cat)."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 32, 9, 14, generator=g)
+    skip = torch.randn(2, 24, 18, 28, generator=g)
+    sd = {"deconv.deconv.weight": torch.randn(32, 16, 3, 3, generator=g) / 9,
+          "conv.conv.weight": torch.randn(16, 16 + 24, 3, 3, generator=g) / 19}
+    ref = orc.decoder_block(x, skip, None, sd)
+    blk = kb.modules.DecoderBlock(32, 24, 16, "xavier_normal", torch.nn.LeakyReLU(0.2), deconv_type="transpose").to(dev)
+    blk.load_state_dict(sd)
+    assert rel_err(blk(x.to(dev), skip.to(dev)), ref) < TIGHT
+    with pytest.raises(RuntimeError):
+        blk(x.to(dev), skip.to(dev)[:, :, :17])
+    with pytest.raises(ValueError):
+        kb.modules.DecoderBlock(32, 24, 16, deconv_type="bilinear")
+
+
 def test_decoder_block_concat_and_slice_output(dev):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 32, 9, 13, generator=g)
@@ -483,14 +550,16 @@ def test_kb_block_paired_kernel_on_channel_slices(dev):
 
 
 # -------------------------------------------------------------------------- decoder
-@pytest.mark.parametrize("name", ["dec_even", "dec_odd"])
+@pytest.mark.parametrize("name", ["dec_even", "dec_odd", "dec_transpose"])
 def test_decoder_golden(dev, name):
+    """dec_transpose: deconv_type='transpose' (TransposeConv2d in every block, reference src/net_utils.py:350-440)."""
     g = load_golden(name)
     cfg = kb.kitti_config().narrow()
     enc_ch = [i + z for i, z in zip(cfg.n_filters_encoder_image, cfg.n_filters_encoder_depth)]
     dec = kb.modules.MultiScaleDecoder(enc_ch[-1], 1, 1, list(cfg.n_filters_decoder), cfg.n_skips,
-                                       "xavier_normal", "leaky_relu", "linear", False, False, "up").to(dev)
-    dec.load_state_dict(g["weights"])
+                                       "xavier_normal", "leaky_relu", "linear", False, False,
+                                       "transpose" if name == "dec_transpose" else "up").to(dev)
+    dec.load_state_dict(g["weights"])   # strict: the reference's own keys (deconvN.deconv.deconv.weight for 'transpose')
     skips = [g[f"skip{i}"].to(dev) for i in range(1, 5)]
     out = dec(g["latent"].to(dev), skips, tuple(int(v) for v in g["shape"]))[-1]
     assert rel_err(out, g["logits"]) < TOL
@@ -1390,7 +1459,8 @@ def _check_forward(out, ref):
     assert float(err) < TOL, f"max relative error {float(err):.3e}"
 
 
-@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02", "fwd_kb01234", "fwd_kb01234_odd"])
+@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02", "fwd_kb01234", "fwd_kb01234_odd",
+                                  "fwd_transpose", "fwd_transpose_void"])
 def test_forward_golden(dev, name):
     """fwd_kb012 / fwd_kb02: encoder topologies with plain stride-2 blocks where a level has no KB layer; fwd_kb01234*: a KB layer at
     resolution 4 too -- the reference then calls calibrated_backprojection4 twice and never its calibrated_backprojection5
@@ -1423,6 +1493,31 @@ def test_forward_full_size_vs_oracle(dev, preset, shape):
     # gives the bits it gave inside the batch
     alone = m.forward(*to(dev, *[f[1:2] for f in frames]))
     assert torch.equal(alone, out[1:2])
+
+
+def test_forward_full_size_transpose_decoder_vs_oracle(dev):
+    """KITTI 352x1216, full-width network, deconv_type='transpose' (run_kbnet.py --deconv_type transpose): every decoder level's
+    up-sampling layer a TransposeConv2d on the folded up-conv's split-operand kernels (pair tensors in and out), eager and as the
+    captured two-branch graph; one frame through the oracle."""
+    import dataclasses
+    cfg = dataclasses.replace(kb.kitti_config(), deconv_type="transpose")
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
+    frames = kb.synthetic.make_frames(4, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    dframes = to(dev, *frames)
+    kb.ops.PROFILE = []
+    try:
+        out, logits = m.forward(*dframes, return_logits=True)
+        names = [r[0] for r in kb.ops.PROFILE]
+    finally:
+        kb.ops.PROFILE = None
+    assert names.count("conv_split_upfold") == 5 and "conv_up2x" not in names, names   # all five on the split kernels
+    ref = orc.kbnet_forward(*[f[3:4] for f in frames], *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+    _check_forward(out[3:4], ref)
+    assert float(logits.std()) > 0.1
+    graphed = m.capture(*dframes)
+    assert torch.equal(graphed(*dframes), out)
 
 
 def _worst_rel(out, ref):

@@ -90,6 +90,24 @@ def test_kb_layer_at_resolution_4_keeps_the_reference_state_dict():
     assert all(tuple(v.shape) == tuple(ks[k].shape) for k, v in blk.state_dict().items())
 
 
+def test_transpose_decoder_keeps_the_reference_state_dict():
+    """deconv_type='transpose' (run_kbnet.py --deconv_type): every decoder block's up-sampling layer is a TransposeConv2d whose
+    parameter is `deconvN.deconv.deconv.weight`, in x out x 3 x 3 (reference src/net_utils.py:383-390, :1416-1424).  Same keys /
+    shapes as the golden captured from the reference's own model and as config.decoder_param_shapes; the golden loads strictly."""
+    import dataclasses
+    g = load_golden("fwd_transpose")
+    cfg = dataclasses.replace(kb.kitti_config().narrow(), deconv_type="transpose")
+    m = _model(cfg)
+    sd = m.decoder.state_dict()
+    assert set(sd) == set(g["decoder"]) == set(kb.config.decoder_param_shapes(cfg))
+    assert all(tuple(sd[k].shape) == tuple(g["decoder"][k].shape) for k in sd)
+    assert tuple(sd["deconv4.deconv.deconv.weight"].shape) == (cfg.n_filters_encoder_image[-1] + cfg.n_filters_encoder_depth[-1],
+                                                              cfg.n_filters_decoder[0], 3, 3)
+    m.load_state_dicts(g["s2d"], g["encoder"], g["decoder"])
+    with pytest.raises(ValueError):
+        _model(dataclasses.replace(cfg, deconv_type="bilinear"))
+
+
 def test_error_behaviour_mirrors_reference():
     with pytest.raises(ValueError):  # reference src/net_utils.py:45
         kb.modules.activation_func("swish")

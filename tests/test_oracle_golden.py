@@ -61,9 +61,12 @@ def test_encoder_with_stacked_convolutions_matches_reference():
         assert torch.equal(s_, g[f"skip{i + 1}"]), i
 
 
-@pytest.mark.parametrize("name", ["dec_even", "dec_odd"])
+@pytest.mark.parametrize("name", ["dec_even", "dec_odd", "dec_transpose"])
 def test_decoder_matches_reference(name):
+    """dec_transpose: deconv_type='transpose' -- ConvTranspose2d(3, stride 2, padding 1, output_padding 1) up-sampling layers
+    (reference src/net_utils.py:350-440); the oracle follows the state dict's `deconv.deconv.weight` keys."""
     g = load_golden(name)
+    assert ("deconv4.deconv.deconv.weight" in g["weights"]) == (name == "dec_transpose")
     skips = [g[f"skip{i}"] for i in range(1, 5)]
     out = orc.decoder(g["latent"], skips, tuple(int(v) for v in g["shape"]), g["weights"])
     assert torch.equal(out, g["logits"])
@@ -78,13 +81,17 @@ def golden_config(g):
     if "n_filters_encoder_image" in g:
         cfg = dataclasses.replace(cfg, n_filters_encoder_image=tuple(int(v) for v in g["n_filters_encoder_image"]),
                                   n_filters_encoder_depth=tuple(int(v) for v in g["n_filters_encoder_depth"]))
+    if "deconv_type" in g:
+        cfg = dataclasses.replace(cfg, deconv_type=str(g["deconv_type"]))
     return cfg
 
 
-@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02", "fwd_kb01234", "fwd_kb01234_odd"])
+@pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02", "fwd_kb01234", "fwd_kb01234_odd",
+                                  "fwd_transpose", "fwd_transpose_void"])
 def test_forward_matches_reference(name):
     """fwd_kb012 / fwd_kb02: encoders with KB layers at levels [0, 1, 2] / [0, 2] only; fwd_kb01234*: a KB layer at resolution 4
-    too, where the reference calls calibrated_backprojection4 a second time (src/networks.py:499-517, quirk Q3)."""
+    too, where the reference calls calibrated_backprojection4 a second time (src/networks.py:499-517, quirk Q3); fwd_transpose*:
+    deconv_type='transpose'."""
     g = load_golden(name)
     cfg = golden_config(g)
     levels = tuple(int(v) for v in g["resolutions_backprojection"]) if "resolutions_backprojection" in g else (0, 1, 2, 3)
