@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("KBN_LIB_PATH") or os.path.join(HERE, "libkbnet_hip.so
 KBN_OK = 0
 KBN_ERR_UNSUPPORTED = -2
 KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ, KBN_SRC_PAIR = 0, 1, 2, 3
+KBN_ACT_ELU, KBN_ACT_SIGMOID = 1, 2
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
 KBN_MAX_SRC = 3
 ABI_VERSION = 6
@@ -69,6 +70,8 @@ SIGNATURES = {
     "kbn_upconv2x_packed_weight_bytes": (C.c_size_t, [_I, _I]),
     "kbn_upconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
     "kbn_upconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "kbn_activation_forward": (_I, [_P, _L, _I, _L, _I, _P]),
+    "kbn_scale_planes_forward": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "kbn_deconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
     "kbn_deconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "kbn_upconv2x_query": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),

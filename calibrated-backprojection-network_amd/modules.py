@@ -31,27 +31,52 @@ from .config import KBNetConfig
 
 # ------------------------------------------------------------------- activations
 def activation_func(activation_fn: str):
-    """Same factory contract as reference src/net_utils.py:23-45; the kernels fuse
-    LeakyReLU (slope 0.20 from this factory), ReLU (slope 0) and linear."""
+    """Same factory contract as reference src/net_utils.py:23-45 (same substring tests, same order, same modules).  The kernels
+    fuse LeakyReLU (slope 0.20 from this factory), ReLU (slope 0) and linear; ELU and sigmoid run as a pass of their own behind a
+    conv launched without activation (_post), which takes the whole model to its layer-by-layer form."""
     if "linear" in activation_fn:
         return None
     if "leaky_relu" in activation_fn:
         return torch.nn.LeakyReLU(negative_slope=0.20, inplace=True)
     if "relu" in activation_fn:
         return torch.nn.ReLU()
-    if activation_fn in ("elu", "sigmoid"):
-        raise ValueError("Activation not supported by the fused HIP kernels: {}".format(activation_fn))
+    if "elu" in activation_fn:
+        return torch.nn.ELU()
+    if "sigmoid" in activation_fn:
+        return torch.nn.Sigmoid()
     raise ValueError("Unsupported activation function: {}".format(activation_fn))
 
 
 def _slope(act) -> Optional[float]:
-    if act is None:
+    """What the conv kernels fuse: the slope of max(v, slope v), or None for a launch without activation (a linear layer, or one
+    whose activation follows as its own pass: _post)."""
+    if act is None or _post(act) is not None:
         return None
     if isinstance(act, torch.nn.LeakyReLU):
         return float(act.negative_slope)
     if isinstance(act, torch.nn.ReLU):
         return 0.0
-    raise ValueError("Activation not supported by the fused HIP kernels: {}".format(type(act).__name__))
+    raise ValueError("Activation not supported by the HIP kernels: {}".format(type(act).__name__))
+
+
+def _post(act) -> Optional[str]:
+    """'elu' / 'sigmoid' for the activations that run behind the conv (ops.activation_), else None."""
+    if isinstance(act, torch.nn.ELU):
+        if act.alpha != 1.0:
+            raise ValueError("ELU: alpha = 1 (torch.nn.ELU(), what the reference's factory builds) is what the HIP kernel computes")
+        return "elu"
+    if isinstance(act, torch.nn.Sigmoid):
+        return "sigmoid"
+    return None
+
+
+def _finish(layer, out, out_absmax, stats):
+    """The activation pass of a layer whose activation the kernels do not fuse; the slot its conv was NOT given stays unfilled."""
+    if layer._post is not None:
+        ops.activation_(out, layer._post)
+        if stats is not None:
+            stats.skip(out_absmax)
+    return out
 
 
 def _init_weight(weight, weight_initializer):
@@ -202,6 +227,7 @@ class Conv2d(torch.nn.Module):
         self.kernel_size, self.stride = kernel_size, stride
         self.in_channels, self.out_channels = in_channels, out_channels
         self._slope = _slope(activation_func)
+        self._post = _post(activation_func)
         self._packed = _PackedWeight()
         self._packed_bf16 = _PackedWeight()
         self._packed_split = _PackedWeight()
@@ -211,7 +237,9 @@ class Conv2d(torch.nn.Module):
         # KITTI frames); at KB2's 96 filters the layer is bound by its stride-2 HBM reads either way (365 vs 342 us)
         self.split_fused_min_filters = 192
         self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
-        self.split = True   # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies
+        # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies; not behind an ELU / sigmoid layer, whose kernels
+        # would fold max |out| BEFORE the activation into the slot their consumers place their fp16 windows on
+        self.split = self._post is None
         # the folded up-conv of a layer with at most 16 filters has 16-filter tiles (upconv2x_split16_kernel): deconv0's
         # 64 -> 12 up-conv.  Level with the fp32 9-product kernel on random operands (650 vs 640 us per 32 KITTI frames),
         # 8-11 % faster inside the forward (660-690 vs 745 us, tools/layer_profile.py)
@@ -280,6 +308,12 @@ class Conv2d(torch.nn.Module):
         if cin != self.in_channels:   # the packed blob carries no size: a wrong count would read past the weight panel
             raise KbnError(f"expected {self.in_channels} input channels in total, got {cin}")
         oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)
+        if self._post is not None:   # ELU / sigmoid: the fp32 conv without activation, then the activation in place
+            if out is None:
+                out = torch.empty((n, self.out_channels, oh, ow), device=self.conv.weight.device, dtype=torch.float32)
+            res = ops.conv2d(srcs, self.packed(), n, self.out_channels, self.kernel_size, self.stride, in_h, in_w, out,
+                             resize=resize, negative_slope=None)
+            return _finish(self, res, out_absmax, stats)
         if self.bf16 and not resize:
             res = self.run_bf16(srcs, n, oh, ow, out=out)
             if res is not None:
@@ -421,8 +455,9 @@ class UpConv2d(torch.nn.Module):
                     return res
             # exact 2x: four 2x2 phase convs on the low-res input (4/9 of the MACs)
             out = torch.empty((n, self.conv.out_channels, oh, ow), device=x.device, dtype=torch.float32)
-            return ops.upconv2x(x, self._packed_up2x.get(self.conv.conv.weight, 1, up2x=True),
-                                self.conv.out_channels, out, self.conv._slope, out_absmax=out_absmax)
+            res = ops.upconv2x(x, self._packed_up2x.get(self.conv.conv.weight, 1, up2x=True), self.conv.out_channels, out,
+                               self.conv._slope, out_absmax=None if self.conv._post else out_absmax)
+            return _finish(self.conv, res, out_absmax, stats)
         return self.conv.run([ops.tensor_src(x, "x", amax)], n, oh, ow, resize=True, out_absmax=out_absmax, stats=stats)
 
 
@@ -447,10 +482,11 @@ class TransposeConv2d(torch.nn.Module):
         self.kernel_size, self.stride = kernel_size, 1    # as _run_split sees the layer: an up-conv
         self.in_channels, self.out_channels = in_channels, out_channels
         self._slope = _slope(activation_func)
+        self._post = _post(activation_func)
         self._packed_split = None                         # (never used: the layer has no plain-conv form)
         self._packed_split_up = _PackedWeight()
         self._packed_up2x = _PackedWeight()
-        self.split = True
+        self.split = self._post is None                   # (as Conv2d.split)
         self.split_narrow_up = True
         self.bf16 = False                                 # no bf16 leg for this layer
 
@@ -471,8 +507,9 @@ class TransposeConv2d(torch.nn.Module):
         if res is not None or pair_in or pair_out:
             return res
         out = torch.empty((n, self.out_channels, oh, ow), device=x.device, dtype=torch.float32)
-        return ops.upconv2x(x, self._packed_up2x.get(w_t, 1, up2x="up2x_t"), self.out_channels, out, self._slope,
-                            out_absmax=out_absmax, transposed=True)
+        res = ops.upconv2x(x, self._packed_up2x.get(w_t, 1, up2x="up2x_t"), self.out_channels, out, self._slope,
+                           out_absmax=None if self._post else out_absmax, transposed=True)
+        return _finish(self, res, out_absmax, stats)
 
 
 class VGGNetBlock(torch.nn.Module):
@@ -534,8 +571,9 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         self.split_image = n_filter_image >= 96   # conv_image on the split-operand kernel (KB1's 48 filters: the fused kernel wins)
         self.split_fused = True   # ... and with it conv_fused (1x1 stride 2) on split operands, xyz in fp32
         self._slope = _slope(activation_func)
-        if self._slope is None:
-            raise ValueError("the fused KB block needs a (leaky) ReLU activation")
+        # the fused launches are written around max(v, slope v): a block without activation, or with ELU / sigmoid (reference
+        # src/net_utils.py:23-45), runs conv by conv like a stacked one, z = act(proj_depth . depth) as a tensor of its own
+        self.layerwise = self._slope is None
 
     def run(self, image, depth, coordinates, fused, out_image=None, out_depth=None, out_fused=None,
             amax_image=None, amax_fused=None, out_amax_image=None, out_amax_skip=None, stats=None, need_image=True,
@@ -550,7 +588,7 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         pair_in = isinstance(image, ops.PairTensor)
         if (pair_in or pair_image_out) and not (self.conv_image.conv_block[0].split and self.split_image and self.split_fused
                                                 and coordinates.dim() == 3 and not self.conv_image.conv_block[0].bf16 and stats is not None
-                                                and not self.stacked):
+                                                and not self.stacked and not self.layerwise):
             return None
         n, ci, h, w = image.shape
         cd, cf = depth.shape[1], (0 if fused is None else fused.shape[1])
@@ -558,7 +596,7 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
                 self.conv_fused.in_channels - 3 - self.conv_image.conv_block[0].in_channels)
         if (ci, cd, cf) != want:   # the kernels trust these counts when they walk the packed weight panels
             raise KbnError(f"KB block built for (image, depth, fused) channels {want}, got {(ci, cd, cf)}")
-        if self.stacked:
+        if self.stacked or self.layerwise:
             return self._run_stacked(image, depth, coordinates, fused, out_image, out_depth, out_fused, out_amax_image,
                                      out_amax_skip, stats, need_image)
         oh, ow = (h + 1) // 2, (w + 1) // 2
@@ -638,10 +676,16 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
             self.conv_image.run([ops.tensor_src(image, "image")], n, h, w, out=out_image, out_absmax=out_amax_image, stats=stats)
         csrc = ops.tensor_src(coordinates, "coordinates") if dense else ops.coords_src(coordinates)
         self.conv_depth.run([ops.tensor_src(depth, "depth"), csrc], n, h, w, out=out_depth, out_absmax=out_amax_skip, stats=stats)
-        xyz = (ops.xyz_src(depth, self.proj_depth.conv.weight, None, coordinates=coordinates) if dense
-               else ops.xyz_src(depth, self.proj_depth.conv.weight, coordinates))
+        if self.proj_depth._post is not None:
+            # ELU / sigmoid: z = act(proj_depth . depth) and xyz = coordinates * z as tensors (reference src/net_utils.py:1352-1359);
+            # the conv kernels synthesize the backprojection only around max(v, slope v)
+            z = self.proj_depth.run([ops.tensor_src(depth, "depth")], n, h, w)
+            xyz = ops.tensor_src(ops.scale_planes(coordinates if dense else ops.camera_coordinates(coordinates, h, w), z), "xyz")
+        else:
+            xyz = (ops.xyz_src(depth, self.proj_depth.conv.weight, None, coordinates=coordinates) if dense
+                   else ops.xyz_src(depth, self.proj_depth.conv.weight, coordinates))
         srcs = [ops.tensor_src(image, "image"), xyz] + ([] if fused is None else [ops.tensor_src(fused, "fused")])
-        self.conv_fused.run(srcs, n, h, w, out=out_fused, out_absmax=out_amax_skip)
+        self.conv_fused.run(srcs, n, h, w, out=out_fused, out_absmax=out_amax_skip, stats=stats)
         return out_image, out_depth, out_fused
 
     def _depth_and_fused(self, image, depth, fused, kinv, n, h, w, oh, ow, out_depth, out_fused, ci, cf, amax_image, amax_fused,
@@ -757,10 +801,19 @@ class SparseToDensePool(torch.nn.Module):
         self.conv = Conv2d(n_filter + input_channels, n_filter, kernel_size=3, stride=1,
                            weight_initializer=weight_initializer, activation_func=act)
         self._slope = _slope(act)
-        if self._slope is None:
-            raise ValueError("the fused S2D kernel needs a (leaky) ReLU activation")
+        # the layers one by one where the fused kernel does not go: no activation / ELU / sigmoid (it is written around max(v, slope v)),
+        # more than 8 filters, more than 4 1x1 convs, more than 2 input channels (kbn_s2d_forward's limits, include/kbnet_hip.h)
+        self.layerwise = self._slope is None or n_filter > 8 or n_convolution > 4 or input_channels > 2
 
     def forward(self, x):
+        if self.layerwise:
+            # reference src/networks.py:2168-2196: pyramid -> 1x1 convs -> cat[., x] (two sources of one launch) -> 3x3 conv
+            x = x if _dense(x) else x.contiguous()
+            n, _, h, w = x.shape
+            y = ops.s2d_pyramid(x, self.min_pool_sizes, self.max_pool_sizes)
+            for conv in self.pool_convs:
+                y = conv.run([ops.tensor_src(y, "pool")], n, h, w)
+            return self.conv.run([ops.tensor_src(y, "pool"), ops.tensor_src(x, "x")], n, h, w)
         return ops.s2d_forward(x, [c.conv.weight for c in self.pool_convs], self.conv.conv.weight,
                                self.min_pool_sizes, self.max_pool_sizes, self._slope)
 
@@ -1150,10 +1203,11 @@ class MultiScaleDecoder(torch.nn.Module):
                                     max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
                 if res is not None:
                     return res
-            res = ops.conv_head(up, d0.conv.conv.weight, self.output0.conv.weight, min_predict_depth,
-                                max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
-            if res is not None:
-                return res
+            if d0.conv._post is None:   # (an ELU / sigmoid conv runs on its own, then the output0 + mapping head)
+                res = ops.conv_head(up, d0.conv.conv.weight, self.output0.conv.weight, min_predict_depth,
+                                    max_predict_depth, d0.conv._slope, return_logits=return_logits, out=out)
+                if res is not None:
+                    return res
             feats = d0.conv.run([ops.tensor_src(up, "deconv")], up.shape[0], up.shape[2], up.shape[3])
         else:
             feats = d0(x, None, shape=tuple(shape)[-2:], amax_x=amax, stats=stats)

@@ -475,6 +475,45 @@ def conv2d(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channel
     return out
 
 
+# ------------------------------------------------- layer-by-layer form: activation in place, backprojection
+ACT_KINDS = {"elu": _lib.KBN_ACT_ELU, "sigmoid": _lib.KBN_ACT_SIGMOID}
+
+
+@_on_tensor_device
+def activation_(t: torch.Tensor, kind: str) -> torch.Tensor:
+    """t <- ELU(t) / sigmoid(t) in place (kbn_activation_forward): the activation of a conv that was launched without one, for
+    the activations the fused kernels do not carry (reference src/net_utils.py:38-43).  `t`: a dense N x C x H x W tensor or a
+    channel slice of one."""
+    lib = _lib.load()
+    tptr, tbs = _planes(t, "t")
+    n = t.shape[0]
+    per = t.shape[1] * t.shape[2] * t.shape[3]
+    check(_launch("activation", 0.0, lambda: lib.kbn_activation_forward(tptr, tbs, n, per, ACT_KINDS[kind], _stream()),
+                  nbytes=8.0 * n * per), "kbn_activation_forward")
+    return t
+
+
+@_on_tensor_device
+def scale_planes(x: torch.Tensor, z: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[n, c] = x[n, c] * z[n, 0] (kbn_scale_planes_forward): the KB block's xyz = coordinates * z (reference
+    src/net_utils.py:1357-1359) when z is a tensor of its own."""
+    lib = _lib.load()
+    xptr, xbs = _planes(x, "x")
+    zptr, zbs = _planes(z, "z")
+    n, c, h, w = x.shape
+    if tuple(z.shape) != (n, 1, h, w):
+        raise KbnError(f"scale_planes: z has shape {tuple(z.shape)}, expected {(n, 1, h, w)}")
+    if out is None:
+        out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    optr, obs = _planes(out, "out")
+    if tuple(out.shape) != (n, c, h, w):
+        raise KbnError(f"scale_planes: out has shape {tuple(out.shape)}, expected {(n, c, h, w)}")
+    check(_launch("scale_planes", 1.0 * n * c * h * w,
+                  lambda: lib.kbn_scale_planes_forward(xptr, xbs, zptr, zbs, optr, obs, n, c, h, w, _stream()),
+                  nbytes=4.0 * n * h * w * (2 * c + 1)), "kbn_scale_planes_forward")
+    return out
+
+
 # ---------------------------------------------------------------------- up-conv 2x
 def _deconv_weight(weight: torch.Tensor) -> torch.Tensor:
     """ConvTranspose2d's in x out x 3 x 3 parameter with out_channels leading: the layout the packers read."""

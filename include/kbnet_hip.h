@@ -197,6 +197,20 @@ int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_
                        int stride, int in_height, int in_width, int resize, int apply_activation,
                        float negative_slope, unsigned* out_absmax, kbn_stream_t stream);
 
+/* --------------------------------------------- layer-by-layer form: activation, backprojection -------
+ * The fused kernels are written around max(v, slope v): LeakyReLU(0.20), ReLU (slope 0) and -- with slope 1 -- no activation.
+ * net_utils.activation_func also builds torch.nn.ELU() and torch.nn.Sigmoid() (reference src/net_utils.py:38-43; run_kbnet.py
+ * --activation_func elu | sigmoid).  A model with one of those runs layer by layer: every conv is launched WITHOUT activation
+ * (apply_activation = 0) and followed by kbn_activation_forward in place; the KB block's z = act(proj_depth . depth)
+ * (:1352-1355) is then a tensor of its own and xyz = coordinates * z (:1357-1359) one kbn_scale_planes_forward.
+ *   kbn_activation_forward    x: n frames of per_frame contiguous floats, batch_stride apart; kind KBN_ACT_ELU (v > 0 ? v :
+ *                             expm1(v), alpha = 1) or KBN_ACT_SIGMOID (1 / (1 + exp(-v)))
+ *   kbn_scale_planes_forward  out[n, c, y, x] = x[n, c, y, x] * z[n, 0, y, x], c < channels; dense planes, frames *_batch_stride apart */
+enum { KBN_ACT_ELU = 1, KBN_ACT_SIGMOID = 2 };
+int kbn_activation_forward(float* x, long long batch_stride, int n, long long per_frame, int kind, kbn_stream_t stream);
+int kbn_scale_planes_forward(const float* x, long long x_batch_stride, const float* z, long long z_batch_stride, float* out,
+                             long long out_batch_stride, int n, int channels, int height, int width, kbn_stream_t stream);
+
 /* ------------------------------------------------------------ up-conv 2x -------
  * net_utils.UpConv2d.forward when the target size is exactly twice the input:
  * interpolate(nearest) + conv3x3 (+ activation)       reference src/net_utils.py:484-499

@@ -37,17 +37,44 @@ def strip_prefix(state_dict, prefix="module."):
     return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in state_dict.items()}
 
 
+def activation_slope(activation_fn):
+    """The `slope` argument of every function below for the reference's activation_func STRING (src/net_utils.py:23-45, same
+    substring tests in the same order): 'linear' -> None, 'leaky_relu' -> 0.20, 'relu' -> 0.0 (a LeakyReLU of slope 0 differs from
+    ReLU in the sign of zeros only), 'elu' / 'sigmoid' -> that name."""
+    if "linear" in activation_fn:
+        return None
+    if "leaky_relu" in activation_fn:
+        return NEGATIVE_SLOPE
+    if "relu" in activation_fn:
+        return 0.0
+    if "elu" in activation_fn:
+        return "elu"
+    if "sigmoid" in activation_fn:
+        return "sigmoid"
+    raise ValueError("Unsupported activation function: {}".format(activation_fn))
+
+
+def activate(y, slope):
+    """`slope`: None (no activation), a LeakyReLU slope, or 'elu' / 'sigmoid' (torch.nn.ELU() / torch.nn.Sigmoid(), reference
+    src/net_utils.py:38-43)."""
+    if slope is None:
+        return y
+    if slope == "elu":
+        return F.elu(y)
+    if slope == "sigmoid":
+        return torch.sigmoid(y)
+    return F.leaky_relu(y, negative_slope=slope)
+
+
 def conv2d(x, weight, stride=1, slope=NEGATIVE_SLOPE):
-    """Bias-free conv, padding k//2, optional LeakyReLU.
+    """Bias-free conv, padding k//2, optional activation (`slope`: see `activate`).
 
     Reference: net_utils.Conv2d, src/net_utils.py:85-93 (ctor) and :120-141
     (forward).  `slope=None` is the reference's activation_func=None.
     """
     k = weight.shape[-1]
     y = F.conv2d(x, weight, bias=None, stride=stride, padding=k // 2)
-    if slope is not None:
-        y = F.leaky_relu(y, negative_slope=slope)
-    return y
+    return activate(y, slope)
 
 
 # --------------------------------------------------------------------------- S2D
@@ -238,8 +265,7 @@ def decoder_block(x, skip, shape, sd, slope=NEGATIVE_SLOPE):
     """
     if "deconv.deconv.weight" in sd:
         y = F.conv_transpose2d(x, sd["deconv.deconv.weight"], bias=None, stride=2, padding=1, output_padding=1)
-        if slope is not None:
-            y = F.leaky_relu(y, negative_slope=slope)
+        y = activate(y, slope)
     else:
         if skip is not None:
             shape = skip.shape[2:4]

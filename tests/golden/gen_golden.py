@@ -315,19 +315,31 @@ def gen_forward(only=None):
                                                # deconv_type='transpose' (run_kbnet.py --deconv_type): the decoder's up-sampling
                                                # layers are ConvTranspose2d(3, stride 2, padding 1, output_padding 1)
                                                ("transpose", "kitti", (64, 96), 2, None),
-                                               ("transpose_void", "void", (96, 128), 1, None)):
+                                               ("transpose_void", "void", (96, 128), 1, None),
+                                               # run_kbnet.py --activation_func: every factory branch of net_utils.activation_func
+                                               # (src/net_utils.py:23-45) other than the default leaky_relu
+                                               ("act_relu", "kitti", (64, 96), 1, None),
+                                               ("act_elu", "kitti", (64, 96), 1, None),
+                                               ("act_sigmoid", "void", (70, 100), 1, None),
+                                               ("act_linear", "kitti", (64, 96), 1, None),
+                                               ("act_elu_kb012_transpose", "void", (64, 96), 1, (0, 1, 2))):
         if only and name not in only:
             continue
         cfg = kb.PRESETS[preset]().narrow()
-        if name.startswith("transpose"):
+        if "transpose" in name:
             cfg = dataclasses.replace(cfg, deconv_type="transpose")
+        if name.startswith("act_"):
+            cfg = dataclasses.replace(cfg, activation_func=name.split("_")[1])
         if kb_levels is not None:
             cfg = dataclasses.replace(cfg, resolutions_backprojection=kb_levels)
         if kb_levels is not None and 4 in kb_levels:
             cfg = dataclasses.replace(cfg, n_filters_encoder_image=(8, 16, 32, 32, 32), n_filters_encoder_depth=(4, 8, 16, 16, 16))
         # gain > 1 keeps the logits O(1) (random xavier weights shrink the signal), so the
         # sigmoid head is exercised off its saturated ends
-        sds = kb.synthetic.make_state_dicts(cfg, seed=5, gain=1.3 if preset == "kitti" else 1.45)
+        gain = 1.3 if preset == "kitti" else 1.45
+        if name.startswith("act_"):   # the same off-saturation, O(1) logits for the other activations (a linear net grows like gain^21)
+            gain = {"linear": 0.75, "relu": 1.2, "elu": 1.2, "sigmoid": 1.45}[cfg.activation_func]
+        sds = kb.synthetic.make_state_dicts(cfg, seed=5, gain=gain)
         model = build_reference_model(cfg)
         model.eval()
         load(model.sparse_to_dense_pool, sds[0])
@@ -345,7 +357,7 @@ def gen_forward(only=None):
             valid = (sparse > 0).float()
         out = model.forward(image, sparse, valid, k)
         save(f"fwd_{name}", image=image, sparse_depth=sparse, validity_map=valid, intrinsics=k,
-             output_depth=out, preset=np.array(preset), deconv_type=np.array(cfg.deconv_type),
+             output_depth=out, preset=np.array(preset), deconv_type=np.array(cfg.deconv_type), activation_func=np.array(cfg.activation_func),
              resolutions_backprojection=np.array(cfg.resolutions_backprojection),
              n_filters_encoder_image=np.array(cfg.n_filters_encoder_image), n_filters_encoder_depth=np.array(cfg.n_filters_encoder_depth),
              s2d=np_sd(sds[0]), encoder=np_sd(sds[1]), decoder=np_sd(sds[2]))
@@ -528,6 +540,9 @@ if __name__ == "__main__":
     if "--only-transpose" in sys.argv:    # round 5: deconv_type='transpose'
         gen_decoder(only=("transpose",))
         gen_forward(only=("transpose", "transpose_void"))
+        sys.exit(0)
+    if "--only-activations" in sys.argv:  # round 5: activation_func other than leaky_relu
+        gen_forward(only=("act_relu", "act_elu", "act_sigmoid", "act_linear", "act_elu_kb012_transpose"))
         sys.exit(0)
     gen_pre_eval()
     if "--only-pre-eval" in sys.argv:

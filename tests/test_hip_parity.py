@@ -448,6 +448,68 @@ def test_kb_block_stacked_convolutions_golden(dev, name, mode):
     assert rel_err(out_f, g["conv_fused"]) < TIGHT
 
 
+@pytest.mark.parametrize("kind", ["elu", "sigmoid"])
+@pytest.mark.parametrize("shape", [(2, 8, 37, 70), (3, 5, 16, 64), (1, 1, 7, 3)])
+def test_activation_pass_vs_torch(dev, kind, shape):
+    """kbn_activation_forward: torch.nn.ELU() / torch.nn.Sigmoid() in place, on a dense tensor and on a channel slice of a bigger one
+    (the skip tensors' halves); what lies outside the slice is untouched."""
+    g = torch.Generator().manual_seed(shape[1] * 10 + shape[3])
+    x = 4.0 * torch.randn(*shape, generator=g)
+    x[0, 0, 0, :3] = torch.tensor([0.0, -1e-8, 30.0])[:min(3, shape[3])]
+    ref = torch.nn.functional.elu(x) if kind == "elu" else torch.sigmoid(x)
+    got = kb.ops.activation_(x.to(dev).clone(), kind)
+    assert float((got.cpu() - ref).abs().max()) < 2e-7 and rel_err(got, ref) < 2e-6
+    big = torch.cat([x, x, x], dim=1).to(dev)
+    c = shape[1]
+    kb.ops.activation_(big[:, c:2 * c], kind)
+    assert torch.equal(big[:, :c].cpu(), x) and torch.equal(big[:, 2 * c:].cpu(), x) and torch.equal(big[:, c:2 * c], got)
+
+
+def test_scale_planes_is_the_backprojection_product(dev):
+    """kbn_scale_planes_forward: xyz = coordinates * z (reference src/net_utils.py:1357-1359), one fp32 product per element: exact."""
+    g = torch.Generator().manual_seed(3)
+    coords, z = torch.randn(2, 3, 19, 33, generator=g), torch.randn(2, 1, 19, 33, generator=g)
+    assert torch.equal(kb.ops.scale_planes(coords.to(dev), z.to(dev)).cpu(), coords * z)
+
+
+@pytest.mark.parametrize("act", ["elu", "sigmoid", "linear", "relu"])
+@pytest.mark.parametrize("mode", ["coordinates", "kinv"])
+def test_kb_block_other_activations_vs_oracle(dev, act, mode):
+    """CalibratedBackprojectionBlock with every activation net_utils.activation_func builds (reference src/net_utils.py:23-45) besides
+    leaky_relu, called like the reference calls it (keywords; dense coordinates) and with K^-1: relu on the fused kernel, the others conv
+    by conv (ELU / sigmoid: z = act(proj_depth . depth) and xyz as tensors)."""
+    g = torch.Generator().manual_seed(17)
+    n, ci, cd, cf, h, w = 2, 16, 8, 16, 23, 38
+    image, depth, fused = (torch.randn(n, c, h, w, generator=g) for c in (ci, cd, cf))
+    k = kb.synthetic.make_frames(n, h, w, "kitti", seed=2, jitter_intrinsics=0.1)[3]
+    coords = orc.camera_coordinates(k, h, w)
+    blk = kb.modules.CalibratedBackprojectionBlock(ci, cd, ci + cf, 32, 16, 32, 1, 1, 1, "xavier_normal", kb.modules.activation_func(act)).to(dev)
+    sd = {k_: v.detach().cpu() for k_, v in blk.state_dict().items()}
+    ref = orc.kb_block(image, depth, coords, fused, sd, orc.activation_slope(act))
+    assert blk.layerwise == (act != "relu")
+    c_in = coords.to(dev) if mode == "coordinates" else kb.ops.intrinsics_inverse(k.to(dev))
+    out = blk(image=image.to(dev), depth=depth.to(dev), coordinates=c_in, fused=fused.to(dev))
+    for o, r, what in zip(out, ref, ("conv_image", "conv_depth", "conv_fused")):
+        assert rel_err(o, r) < TIGHT, what
+
+
+@pytest.mark.parametrize("act,n_filter,n_convolution", [("elu", 8, 3), ("sigmoid", 8, 2), ("linear", 8, 3), ("leaky_relu", 16, 3),
+                                                        ("leaky_relu", 8, 5), ("relu", 8, 3)])
+def test_s2d_layer_by_layer_vs_oracle(dev, act, n_filter, n_convolution):
+    """SparseToDensePool where the fused kernel does not go -- ELU / sigmoid / no activation, run_kbnet.py
+    --n_filter_sparse_to_dense_pool above 8, --n_convolution_sparse_to_dense_pool above 4 -- as pyramid + convs, against the oracle;
+    relu stays on the fused kernel."""
+    cfg = kb.kitti_config()
+    m = kb.modules.SparseToDensePool(2, list(cfg.min_pools), list(cfg.max_pools), n_filter=n_filter, n_convolution=n_convolution,
+                                     weight_initializer="xavier_normal", activation_func=act).to(dev)
+    assert m.layerwise == (act != "relu") and len(m.pool_convs) == n_convolution and m.conv.out_channels == n_filter
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    f = kb.synthetic.make_frames(2, 45, 70, "kitti", seed=4)
+    x = torch.cat([f[1], f[2]], dim=1)
+    ref = orc.sparse_to_dense_pool(x, sd, cfg.min_pools, cfg.max_pools, orc.activation_slope(act))
+    assert rel_err(m(x.to(dev)), ref) < TIGHT
+
+
 def test_encoder_with_stacked_convolutions_golden(dev):
     """KBNetEncoder(n_convolutions_image=[1, 2, 2, 1, 2], n_convolutions_depth=[1, 1, 3, 2, 1], resolutions_backprojection=[0, 2]) against
     the reference's own encoder (golden enc_stacked): stacked stride-1 convs inside a KB level and in plain VGG levels, odd sizes."""
@@ -1460,11 +1522,14 @@ def _check_forward(out, ref):
 
 
 @pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02", "fwd_kb01234", "fwd_kb01234_odd",
-                                  "fwd_transpose", "fwd_transpose_void"])
+                                  "fwd_transpose", "fwd_transpose_void", "fwd_act_relu", "fwd_act_elu", "fwd_act_sigmoid", "fwd_act_linear",
+                                  "fwd_act_elu_kb012_transpose"])
 def test_forward_golden(dev, name):
     """fwd_kb012 / fwd_kb02: encoder topologies with plain stride-2 blocks where a level has no KB layer; fwd_kb01234*: a KB layer at
     resolution 4 too -- the reference then calls calibrated_backprojection4 twice and never its calibrated_backprojection5
-    (src/networks.py:499-517, quirk Q3), whose parameters still sit in the state_dict."""
+    (src/networks.py:499-517, quirk Q3), whose parameters still sit in the state_dict; fwd_transpose*: deconv_type='transpose';
+    fwd_act_*: run_kbnet.py --activation_func relu (the fused kernels with slope 0) / elu / sigmoid / linear (the layer-by-layer form:
+    convs without activation + kbn_activation_forward, z and xyz of the KB blocks as tensors)."""
     from test_oracle_golden import golden_config
     g = load_golden(name)
     cfg = golden_config(g)
@@ -1518,6 +1583,25 @@ def test_forward_full_size_transpose_decoder_vs_oracle(dev):
     assert float(logits.std()) > 0.1
     graphed = m.capture(*dframes)
     assert torch.equal(graphed(*dframes), out)
+
+
+@pytest.mark.parametrize("act", ["elu", "relu"])
+def test_forward_full_size_other_activation_vs_oracle(dev, act):
+    """KITTI 352x1216, full-width network, run_kbnet.py --activation_func elu (layer by layer: fp32 convs + activation passes) and relu
+    (the shipped kernels with slope 0); one frame through the oracle, and the captured graph gives the eager bits."""
+    import dataclasses
+    cfg = dataclasses.replace(kb.kitti_config(), activation_func=act)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
+    frames = kb.synthetic.make_frames(2, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    dframes = to(dev, *frames)
+    out = m.forward(*dframes)
+    ref = orc.kbnet_forward(*[f[1:2] for f in frames], *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth,
+                            slope=orc.activation_slope(act))
+    print(f"{act}: max relative error {_worst_rel(out[1:2], ref):.3e}, depth std {float(ref.std()):.3f}")
+    _check_forward(out[1:2], ref)
+    assert torch.equal(m.capture(*dframes)(*dframes), out)
 
 
 def _worst_rel(out, ref):

@@ -83,22 +83,26 @@ def golden_config(g):
                                   n_filters_encoder_depth=tuple(int(v) for v in g["n_filters_encoder_depth"]))
     if "deconv_type" in g:
         cfg = dataclasses.replace(cfg, deconv_type=str(g["deconv_type"]))
+    if "activation_func" in g:
+        cfg = dataclasses.replace(cfg, activation_func=str(g["activation_func"]))
     return cfg
 
 
 @pytest.mark.parametrize("name", ["fwd_kitti", "fwd_void", "fwd_odd", "fwd_kb012", "fwd_kb02", "fwd_kb01234", "fwd_kb01234_odd",
-                                  "fwd_transpose", "fwd_transpose_void"])
+                                  "fwd_transpose", "fwd_transpose_void", "fwd_act_relu", "fwd_act_elu", "fwd_act_sigmoid", "fwd_act_linear",
+                                  "fwd_act_elu_kb012_transpose"])
 def test_forward_matches_reference(name):
     """fwd_kb012 / fwd_kb02: encoders with KB layers at levels [0, 1, 2] / [0, 2] only; fwd_kb01234*: a KB layer at resolution 4
     too, where the reference calls calibrated_backprojection4 a second time (src/networks.py:499-517, quirk Q3); fwd_transpose*:
-    deconv_type='transpose'."""
+    deconv_type='transpose'; fwd_act_*: activation_func relu / elu / sigmoid / linear on every layer (reference
+    src/net_utils.py:23-45; orc.activation_slope maps the string)."""
     g = load_golden(name)
     cfg = golden_config(g)
     levels = tuple(int(v) for v in g["resolutions_backprojection"]) if "resolutions_backprojection" in g else (0, 1, 2, 3)
     out = orc.kbnet_forward(g["image"], g["sparse_depth"], g["validity_map"], g["intrinsics"],
                             g["s2d"], g["encoder"], g["decoder"],
                             cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth,
-                            resolutions_backprojection=levels)
+                            resolutions_backprojection=levels, slope=orc.activation_slope(cfg.activation_func))
     assert torch.equal(out, g["output_depth"])
     assert out.min() >= cfg.min_predict_depth * 0.98 and out.max() <= cfg.max_predict_depth * 1.001
 
