@@ -803,14 +803,21 @@ class SparseToDensePool(torch.nn.Module):
         self._slope = _slope(act)
         # the layers one by one where the fused kernel does not go: no activation / ELU / sigmoid (it is written around max(v, slope v)),
         # more than 8 filters, more than 4 1x1 convs, more than 2 input channels (kbn_s2d_forward's limits, include/kbnet_hip.h)
-        self.layerwise = self._slope is None or n_filter > 8 or n_convolution > 4 or input_channels > 2
+        # or more than 8 pools
+        self.layerwise = self._slope is None or n_filter > 8 or n_convolution > 4 or input_channels > 2 or self.len_pool_sizes > 8
 
     def forward(self, x):
         if self.layerwise:
             # reference src/networks.py:2168-2196: pyramid -> 1x1 convs -> cat[., x] (two sources of one launch) -> 3x3 conv
             x = x if _dense(x) else x.contiguous()
             n, _, h, w = x.shape
-            y = ops.s2d_pyramid(x, self.min_pool_sizes, self.max_pool_sizes)
+            if self.len_pool_sizes <= 8:
+                y = ops.s2d_pyramid(x, self.min_pool_sizes, self.max_pool_sizes)
+            else:   # the pyramid kernel holds eight pools: the min pools, then the max pools, eight at a time (channel order as :2170-2189)
+                mins, maxs = self.min_pool_sizes, self.max_pool_sizes
+                parts = [ops.s2d_pyramid(x, mins[i:i + 8], []) for i in range(0, len(mins), 8)]
+                parts += [ops.s2d_pyramid(x, [], maxs[i:i + 8]) for i in range(0, len(maxs), 8)]
+                y = torch.cat(parts, dim=1)
             for conv in self.pool_convs:
                 y = conv.run([ops.tensor_src(y, "pool")], n, h, w)
             return self.conv.run([ops.tensor_src(y, "pool"), ops.tensor_src(x, "x")], n, h, w)

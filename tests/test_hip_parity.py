@@ -500,6 +500,9 @@ def test_s2d_layer_by_layer_vs_oracle(dev, act, n_filter, n_convolution):
     --n_filter_sparse_to_dense_pool above 8, --n_convolution_sparse_to_dense_pool above 4 -- as pyramid + convs, against the oracle;
     relu stays on the fused kernel."""
     cfg = kb.kitti_config()
+    if n_convolution == 5:   # ... and more than eight pools (the pyramid kernel's count): eight at a time
+        import dataclasses
+        cfg = dataclasses.replace(cfg, min_pool_sizes_sparse_to_dense_pool=(3, 5, 7, 9, 11, 13), max_pool_sizes_sparse_to_dense_pool=(15, 17, 19, 21, 23))
     m = kb.modules.SparseToDensePool(2, list(cfg.min_pools), list(cfg.max_pools), n_filter=n_filter, n_convolution=n_convolution,
                                      weight_initializer="xavier_normal", activation_func=act).to(dev)
     assert m.layerwise == (act != "relu") and len(m.pool_convs) == n_convolution and m.conv.out_channels == n_filter
