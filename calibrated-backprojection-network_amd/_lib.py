@@ -96,7 +96,7 @@ SIGNATURES = {
     "kbn_s2d_depth_front_query": (_I, [_I, C.POINTER(_I), _I, C.POINTER(_I), _I, _I, _I, _I, _I, _I, _I, _F, _F]),
     "kbn_s2d_depth_front_forward": (_I, [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, C.POINTER(_I), _I, C.POINTER(_I), _I, _I, _I, _I, _I,
                                         _I, _I, _F, _F, _F, _I, _F, _P, _P]),
-    "kbn_preprocess_forward": (_I, [_P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _P]),
+    "kbn_preprocess_forward": (_I, [_P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _I, _P]),
     "kbn_eval_accumulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "kbn_depth_head_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "kbn_conv_head_forward": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P]),

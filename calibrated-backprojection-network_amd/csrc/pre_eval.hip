@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
                                                          float* __restrict__ out_image, float* __restrict__ out_validity,
                                                          float* __restrict__ out_sparse, const unsigned* __restrict__ maxbits,
                                                          int C, int H, int W, int tilesX, int tilesY, int radius,
-                                                         float threshold) {
+                                                         float threshold, int signed_range) {
     __shared__ float tile[(PRE_TH + 2 * PRE_MAXR) * (PRE_TW + 2 * PRE_MAXR)];
     __shared__ float hmin[(PRE_TH + 2 * PRE_MAXR) * PRE_TW];
     const int tid = threadIdx.x;
@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
         if (image) {
             for (int ch = 0; ch < C; ++ch) {
                 const long long io = ((long long)n * C + ch) * HW + o;
-                out_image[io] = image[io] / 255.0f;
+                const float t = image[io] / 255.0f;
+                // [-1, 1]: 2.0 * (images / 255.0) - 1.0 (reference src/transforms.py:205-208); 2 t is exact, one rounding either way
+                out_image[io] = signed_range ? __fsub_rn(2.0f * t, 1.0f) : t;
             }
         }
     }
@@ -147,8 +149,9 @@ extern "C" {
 int kbn_preprocess_forward(const float* image, const float* sparse_depth, float* out_image, float* out_validity,
                            float* out_sparse_depth, void* workspace, size_t workspace_bytes, int n,
                            int image_channels, int height, int width, int kernel_size, float threshold,
-                           kbn_stream_t stream) {
+                           int image_range, kbn_stream_t stream) {
     using namespace kbn;
+    if (image_range != KBN_IMAGE_RANGE_0_1 && image_range != KBN_IMAGE_RANGE_M1_1) return KBN_ERR_INVALID_ARGUMENT;
     if (!sparse_depth || !out_validity || n < 1 || height < 1 || width < 1) return KBN_ERR_INVALID_ARGUMENT;
     if ((image == nullptr) != (out_image == nullptr) || (image && image_channels < 1)) return KBN_ERR_INVALID_ARGUMENT;
     if (kernel_size < 1 || (kernel_size & 1) == 0) return KBN_ERR_INVALID_ARGUMENT;
@@ -164,7 +167,7 @@ int kbn_preprocess_forward(const float* image, const float* sparse_depth, float*
     const int tilesX = ceil_div(width, PRE_TW), tilesY = ceil_div(height, PRE_TH);
     hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((long long)tilesX * tilesY * n)), dim3(256), 0, st, image,
                        sparse_depth, out_image, out_validity, out_sparse_depth, maxbits, image_channels, height, width,
-                       tilesX, tilesY, kernel_size / 2, threshold);
+                       tilesX, tilesY, kernel_size / 2, threshold, image_range == KBN_IMAGE_RANGE_M1_1 ? 1 : 0);
     KBN_CHECK_LAUNCH();
     return KBN_OK;
 }

@@ -1258,9 +1258,17 @@ def conv3x3_bf16(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_c
 
 # ------------------------------------------------------- pre-model stage / evaluation
 @_on_tensor_device
-def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5, normalize_image: bool = True):
-    """Validity map + outlier removal (+ image / 255): what reference src/kbnet.py:899-912 does
-    before calling the model.  Returns (image_normalized or None, filtered_validity, filtered_sparse)."""
+def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5, normalize_image: bool = True,
+               normalized_image_range=(0, 1)):
+    """Validity map + outlier removal (+ image normalisation): what reference src/kbnet.py:899-912 does
+    before calling the model.  `normalized_image_range` as run_kbnet.py --normalized_image_range (reference
+    src/transforms.py:185-214): [0, 1] image / 255, [-1, 1] 2 (image / 255) - 1, [0, 255] untouched (like normalize_image=False),
+    anything else ValueError.  Returns (image_normalized or None, filtered_validity, filtered_sparse)."""
+    rng = [float(v) for v in normalized_image_range]
+    if rng == [0.0, 255.0]:
+        normalize_image = False
+    elif rng not in ([0.0, 1.0], [-1.0, 1.0]):
+        raise ValueError("Unsupported normalization range: {}".format(list(normalized_image_range)))
     lib = _lib.load()
     _require(sparse_depth, "sparse_depth", 4)
     sd = sparse_depth.contiguous()
@@ -1278,7 +1286,7 @@ def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5
     check(lib.kbn_preprocess_forward(img.data_ptr() if img is not None else None, sd.data_ptr(),
                                      out_img.data_ptr() if out_img is not None else None, validity.data_ptr(),
                                      filtered.data_ptr(), ws.data_ptr(), 4, n, c, h, w, int(kernel_size),
-                                     float(threshold), _stream()), "kbn_preprocess_forward")
+                                     float(threshold), 1 if rng == [-1.0, 1.0] else 0, _stream()), "kbn_preprocess_forward")
     return out_img, validity, filtered
 
 

@@ -538,14 +538,15 @@ int kbn_conv_tail_forward_pair(const void* x_pair, long long x_pair_batch_stride
  *     (k x k min filter over the depth with invalid pixels and the padding set to
  *      10 * max(sparse_depth) -- a BATCH-global maximum; a point is dropped if
  *      min < depth - threshold)
- *   image / 255                                                     reference src/transforms.py:201-204
+ *   image / 255, or 2 (image / 255) - 1 (image_range KBN_IMAGE_RANGE_M1_1)   reference src/transforms.py:201-208
  * image/out_image: N x image_channels x H x W (both may be NULL to skip the normalisation);
  * out_validity: the filtered validity map the model is fed; out_sparse_depth (may be NULL): the
  * filtered sparse depth.  workspace: >= 4 bytes of device memory.  kernel_size odd, <= 15. */
+enum { KBN_IMAGE_RANGE_0_1 = 0, KBN_IMAGE_RANGE_M1_1 = 1 };   /* run_kbnet.py --normalized_image_range 0 1 | -1 1 (0 255: pass NULL images) */
 int kbn_preprocess_forward(const float* image, const float* sparse_depth, float* out_image,
                            float* out_validity, float* out_sparse_depth, void* workspace,
                            size_t workspace_bytes, int n, int image_channels, int height, int width,
-                           int kernel_size, float threshold, kbn_stream_t stream);
+                           int kernel_size, float threshold, int image_range, kbn_stream_t stream);
 
 /* ------------------------------------------------- on-device evaluation
  * The reference's per-sample metrics                  reference src/kbnet.py:932-950,

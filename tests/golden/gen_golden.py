@@ -401,9 +401,14 @@ def gen_pre_eval():
     validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)           # src/kbnet.py:899-902
     removal = net_utils.OutlierRemoval(7, 1.5)
     f_sparse, f_valid = removal.remove_outliers(sparse_depth=sparse, validity_map=validity)
-    image_n = image / 255.0                                                      # src/transforms.py:201-204
+    import transforms as ref_transforms  # reference: Transforms.normalize_images, src/transforms.py:185-214
+    tr = ref_transforms.Transforms(normalized_image_range=[0, 1])
+    image_n = tr.normalize_images([image], [0, 1])[0]
+    assert torch.equal(image_n, image / 255.0)
+    image_m = tr.normalize_images([image], [-1, 1])[0]                           # run_kbnet.py --normalized_image_range -1 1
     save("pre_outlier", image=image, sparse_depth=sparse, validity_map=validity, filtered_sparse_depth=f_sparse,
-         filtered_validity_map=f_valid, image_normalized=image_n, kernel_size=np.array(7), threshold=np.array(1.5))
+         filtered_validity_map=f_valid, image_normalized=image_n, image_normalized_m1_1=image_m,
+         kernel_size=np.array(7), threshold=np.array(1.5))
 
     # evaluation: reference src/kbnet.py:932-950 on one frame
     h, w = 48, 80

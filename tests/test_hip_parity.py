@@ -1607,6 +1607,24 @@ def test_forward_full_size_other_activation_vs_oracle(dev, act):
     assert torch.equal(m.capture(*dframes)(*dframes), out)
 
 
+@pytest.mark.parametrize("width", ["narrow", "full"])
+def test_forward_single_channel_image_vs_oracle(dev, width):
+    """run_kbnet.py --input_channels_image 1: a gray image.  The full-width network's front kernel is built for three channels and
+    declines; conv0_image then runs as a conv of its own."""
+    import dataclasses
+    cfg = kb.kitti_config() if width == "full" else kb.kitti_config().narrow()
+    cfg = dataclasses.replace(cfg, input_channels_image=1)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=3, gain=kb.synthetic.PARITY_GAIN["kitti"] if width == "full" else 1.3)
+    assert tuple(sds[1]["conv0_image.conv.weight"].shape[1:]) == (1, 3, 3)
+    frames = list(kb.synthetic.make_frames(2, 96, 160, "kitti", seed=9, jitter_intrinsics=0.1))
+    frames[0] = frames[0][:, :1].contiguous()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    out = m.forward(*to(dev, *frames))
+    ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+    _check_forward(out, ref)
+
+
 def _worst_rel(out, ref):
     return float(((out.cpu() - ref).abs() / ref.abs()).max())
 
@@ -2127,6 +2145,12 @@ def test_preprocess_golden_bit_exact(dev):
     assert torch.equal(valid.cpu(), g["filtered_validity_map"])
     assert torch.equal(fsparse.cpu(), g["filtered_sparse_depth"])
     assert torch.equal(img.cpu(), g["image_normalized"])
+    # run_kbnet.py --normalized_image_range -1 1 / 0 255 (reference src/transforms.py:205-210)
+    img_m, valid_m, _ = kb.ops.preprocess(g["image"].to(dev), g["sparse_depth"].to(dev), normalized_image_range=[-1, 1])
+    assert torch.equal(img_m.cpu(), g["image_normalized_m1_1"]) and torch.equal(valid_m, valid)
+    assert kb.ops.preprocess(g["image"].to(dev), g["sparse_depth"].to(dev), normalized_image_range=[0, 255])[0] is None
+    with pytest.raises(ValueError):
+        kb.ops.preprocess(g["image"].to(dev), g["sparse_depth"].to(dev), normalized_image_range=[0, 2])
 
 
 @pytest.mark.parametrize("shape", [(2, 352, 1216), (1, 37, 45), (3, 16, 64)])
