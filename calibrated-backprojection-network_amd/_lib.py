@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KBN_LIB_PATH") or os.path.join(HERE, "libkbnet_hip.so")   # KBN_LIB_PATH: an alternative build (same-box A/B of compile-time variants, tools/ab_lib.sh)
 
 KBN_OK = 0
-KBN_ERR_UNSUPPORTED = -2
+KBN_ERR_INVALID_ARGUMENT, KBN_ERR_UNSUPPORTED, KBN_ERR_WORKSPACE, KBN_ERR_LAUNCH = -1, -2, -3, -4
 KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ, KBN_SRC_PAIR = 0, 1, 2, 3
 KBN_ACT_ELU, KBN_ACT_SIGMOID = 1, 2
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
@@ -118,6 +118,9 @@ SIGNATURES = {
     "kbn_png_info": (_I, [_P, C.c_size_t, _P, _P, _P, _P]),
     "kbn_png_decode": (_I, [_P, C.c_size_t, _P, C.c_size_t]),
     "kbn_png_decode_batch": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "kbn_depth_to_u16_forward": (_I, [_P, _P, _L, _P]),
+    "kbn_png_encode_gray16_bound": (C.c_size_t, [_I, _I]),
+    "kbn_png_encode_gray16": (_I, [_P, _I, _I, _P, C.c_size_t, _P, _I]),
     "kbn_unpack_frames_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 

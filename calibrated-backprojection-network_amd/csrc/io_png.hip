@@ -221,3 +221,79 @@ int kbn_png_decode_batch(const unsigned char* const* files, const size_t* file_b
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// PNG writer of the output side: data_utils.save_depth (reference src/data_utils.py:154-167: np.uint32(z * 256) ->
+// Image.fromarray(mode='I').save(path), which PIL writes as a 16-bit grayscale PNG, samples clipped at 65535) for the depth
+// maps run_kbnet.py --save_outputs stores (src/kbnet.py:1018-1026).  The samples come from kbn_depth_to_u16_forward; this is
+// the file: signature, IHDR (16-bit gray, non-interlaced), ONE IDAT (zlib deflate of the scanlines, filter 0, big-endian
+// samples), IEND.  Readers recover the samples bit for bit (kbn_png_decode, PIL); the bytes of the file differ from PIL's
+// (its encoder picks other filters) -- a PNG's content is its pixels.
+namespace {
+
+inline void put_be32(unsigned char* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
+
+size_t put_chunk(unsigned char* out, const char type[4], const unsigned char* data, uint32_t n) {
+    put_be32(out, n);
+    memcpy(out + 4, type, 4);
+    if (n) memcpy(out + 8, data, n);
+    uLong crc = crc32(0L, Z_NULL, 0);
+    crc = crc32(crc, out + 4, n + 4);
+    put_be32(out + 8 + n, (uint32_t)crc);
+    return (size_t)n + 12;
+}
+
+int png_encode_gray16_impl(const unsigned short* pixels, int width, int height, unsigned char* out, size_t out_capacity,
+                           size_t* out_bytes, int level) {
+    if (!pixels || !out || !out_bytes || width < 1 || height < 1 || level < -1 || level > 9) return KBN_ERR_INVALID_ARGUMENT;
+    const size_t row = 1 + 2 * (size_t)width, raw = row * height;
+    if (raw > 0xffffffffull) return KBN_ERR_UNSUPPORTED;
+    std::vector<unsigned char> lines(raw);
+    for (int y = 0; y < height; ++y) {
+        unsigned char* l = lines.data() + row * y;
+        l[0] = 0;   // filter type None
+        const unsigned short* src = pixels + (size_t)width * y;
+        for (int x = 0; x < width; ++x) { l[1 + 2 * x] = (unsigned char)(src[x] >> 8); l[2 + 2 * x] = (unsigned char)(src[x] & 0xff); }
+    }
+    uLongf zn = compressBound((uLong)raw);
+    if (8 + 25 + 12 + (size_t)zn + 12 > out_capacity) return KBN_ERR_WORKSPACE;   // kbn_png_encode_gray16_bound says how much
+    unsigned char* p = out;
+    memcpy(p, kSignature, 8); p += 8;
+    unsigned char ihdr[13];
+    put_be32(ihdr, (uint32_t)width); put_be32(ihdr + 4, (uint32_t)height);
+    ihdr[8] = 16; ihdr[9] = 0; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    p += put_chunk(p, "IHDR", ihdr, 13);
+    if (compress2(p + 8, &zn, lines.data(), (uLong)raw, level) != Z_OK) return KBN_ERR_LAUNCH;
+    if (zn > 0x7fffffffUL) return KBN_ERR_UNSUPPORTED;
+    put_be32(p, (uint32_t)zn);
+    memcpy(p + 4, "IDAT", 4);
+    uLong crc = crc32(0L, Z_NULL, 0);
+    crc = crc32(crc, p + 4, (uInt)zn + 4);
+    put_be32(p + 8 + zn, (uint32_t)crc);
+    p += (size_t)zn + 12;
+    p += put_chunk(p, "IEND", nullptr, 0);
+    *out_bytes = (size_t)(p - out);
+    return KBN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t kbn_png_encode_gray16_bound(int width, int height) {
+    if (width < 1 || height < 1) return 0;
+    const unsigned long long raw = (1ull + 2ull * (unsigned long long)width) * (unsigned long long)height;
+    if (raw > 0xffffffffull) return 0;
+    return 8 + 25 + 12 + (size_t)compressBound((uLong)raw) + 12;
+}
+
+int kbn_png_encode_gray16(const unsigned short* pixels, int width, int height, unsigned char* out, size_t out_capacity,
+                          size_t* out_bytes, int level) {
+    try {
+        return png_encode_gray16_impl(pixels, width, height, out, out_capacity, out_bytes, level);
+    } catch (...) {
+        return KBN_ERR_WORKSPACE;
+    }
+}
+
+}  // extern "C"

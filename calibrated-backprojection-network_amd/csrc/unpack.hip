@@ -79,3 +79,24 @@ extern "C" int kbn_unpack_frames_forward(const unsigned char* image_u8, const vo
                                             x_offset, image_channels, (hipStream_t)stream);
     return KBN_ERR_UNSUPPORTED;
 }
+
+// The other direction, for data_utils.save_depth (reference src/data_utils.py:154-167): np.uint32(z * 256.0) and PIL's clip of a
+// mode 'I' image to the 16 bits of the PNG it writes -- samples = min(trunc(z * 256), 65535); z * 256 is exact in fp32.  Negative or NaN
+// depths (numpy leaves their conversion undefined) give 0.  One read, one 2-byte write per pixel.
+namespace kbn {
+__global__ __launch_bounds__(256) void depth_to_u16_kernel(const float* __restrict__ depth, unsigned short* __restrict__ out, long long total) {
+    const long long step = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += step) {
+        const float v = depth[i] * 256.0f;
+        out[i] = (unsigned short)(v >= 65535.0f ? 65535u : (v >= 0.f ? (unsigned)v : 0u));
+    }
+}
+}  // namespace kbn
+
+extern "C" int kbn_depth_to_u16_forward(const float* depth, unsigned short* samples, long long count, kbn_stream_t stream) {
+    if (!depth || !samples || count < 1) return KBN_ERR_INVALID_ARGUMENT;
+    const int blocks = (int)std::min<long long>(4096, (count + 255) / 256);
+    hipLaunchKernelGGL(kbn::depth_to_u16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, samples, count);
+    KBN_CHECK_LAUNCH();
+    return KBN_OK;
+}

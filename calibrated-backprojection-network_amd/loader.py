@@ -118,6 +118,60 @@ def load_depth(path: str, data_format: str = "HW") -> np.ndarray:
     return z
 
 
+# ---------------------------------------------------------------------- output side
+def encode_depth_png(samples: np.ndarray, level: int = 6) -> bytes:
+    """H x W uint16 samples (depth * 256) -> the bytes of a 16-bit grayscale PNG (kbn_png_encode_gray16)."""
+    lib = _lib.load()
+    a = np.ascontiguousarray(samples, dtype=np.uint16)
+    if a.ndim != 2:
+        raise KbnError("encode_depth_png: expected an H x W array")
+    h, w = a.shape
+    cap = lib.kbn_png_encode_gray16_bound(w, h)
+    buf = (C.c_ubyte * cap)()
+    n = C.c_size_t()
+    check(lib.kbn_png_encode_gray16(a.ctypes.data_as(C.c_void_p), w, h, buf, cap, C.byref(n), int(level)), "kbn_png_encode_gray16")
+    return bytes(memoryview(buf)[:n.value])
+
+
+def depth_samples(z) -> np.ndarray:
+    """What reference src/data_utils.py:165-167 stores for a depth map: np.uint32(z * 256.0), clipped to the PNG's 16 bits as PIL
+    clips a mode 'I' image -- as uint16.  `z`: a numpy array (converted here) or a device tensor of any shape
+    (kbn_depth_to_u16_forward, then one device-to-host copy of 2 bytes per pixel)."""
+    if torch.is_tensor(z) and z.is_cuda:
+        zc = z.detach().contiguous().float()
+        out = torch.empty(zc.shape, device=zc.device, dtype=torch.int16)
+        with torch.cuda.device(zc.device):
+            check(_lib.load().kbn_depth_to_u16_forward(zc.data_ptr(), out.data_ptr(), zc.numel(),
+                                                       torch.cuda.current_stream().cuda_stream), "kbn_depth_to_u16_forward")
+        return out.cpu().numpy().view(np.uint16)
+    a = np.asarray(z.detach().cpu().numpy() if torch.is_tensor(z) else z, dtype=np.float32) * np.float32(256.0)
+    return np.clip(np.nan_to_num(a, nan=0.0), 0.0, 65535.0).astype(np.uint32).astype(np.uint16)
+
+
+def save_depth(z, path: str) -> None:
+    """reference src/data_utils.py:154-167: a depth map (H x W, numpy or tensor) as a 16-bit PNG holding depth * 256."""
+    s = depth_samples(z)
+    s = s.reshape(s.shape[-2:]) if s.ndim > 2 and int(np.prod(s.shape[:-2])) == 1 else s
+    with open(path, "wb") as f:
+        f.write(encode_depth_png(s))
+
+
+def save_depth_batch(z: torch.Tensor, paths: Sequence[str], threads: int = 8) -> None:
+    """N x 1 x H x W (or N x H x W) depth maps -> one PNG each (run_kbnet.py --save_outputs, reference src/kbnet.py:1018-1026): ONE
+    device pass and copy for the batch, the files encoded and written by `threads` host threads (the encoder runs without the GIL)."""
+    s = depth_samples(z)
+    s = s.reshape((-1,) + s.shape[-2:])
+    if s.shape[0] != len(paths):
+        raise KbnError(f"save_depth_batch: {s.shape[0]} maps, {len(paths)} paths")
+
+    def one(i):
+        with open(paths[i], "wb") as f:
+            f.write(encode_depth_png(s[i]))
+
+    with ThreadPoolExecutor(max_workers=max(1, int(threads))) as ex:
+        list(ex.map(one, range(len(paths))))
+
+
 # ------------------------------------------------------------------- batched device loader
 class InferenceFrameLoader:
     """Iterates `(image N x 3 x H x W in 0..255, sparse_depth N x 1 x H x W, intrinsics N x 3 x 3)` device

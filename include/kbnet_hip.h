@@ -581,6 +581,19 @@ int kbn_png_decode(const unsigned char* file, size_t file_bytes, void* pixels, s
 int kbn_png_decode_batch(const unsigned char* const* files, const size_t* file_bytes, void* const* pixels,
                          const size_t* pixels_bytes, int n, int threads, int* status);
 
+/* The output side -- data_utils.save_depth, reference src/data_utils.py:154-167 (np.uint32(z * 256.0) ->
+ * Image.fromarray(mode='I').save(path): a 16-bit grayscale PNG, samples clipped at 65535), which run_kbnet.py --save_outputs
+ * calls for the output, the filtered sparse depth and the ground truth (src/kbnet.py:1018-1026).
+ *   kbn_depth_to_u16_forward   DEVICE: count depths (any shape, contiguous) -> samples = min(trunc(z * 256), 65535)
+ *   kbn_png_encode_gray16      HOST: height x width samples (host byte order) -> a PNG file image in `out` (one IDAT, filter 0,
+ *                              zlib `level` -1 .. 9); *out_bytes = its size.  out_capacity >= kbn_png_encode_gray16_bound(width,
+ *                              height), else KBN_ERR_WORKSPACE.  Thread-safe, no GPU work: a pool of host threads writes a batch.
+ * Readers (kbn_png_decode, PIL) recover the samples bit for bit; the file's bytes are not PIL's (other filters). */
+int kbn_depth_to_u16_forward(const float* depth, unsigned short* samples, long long count, kbn_stream_t stream);
+size_t kbn_png_encode_gray16_bound(int width, int height);
+int kbn_png_encode_gray16(const unsigned short* pixels, int width, int height, unsigned char* out, size_t out_capacity,
+                          size_t* out_bytes, int level);
+
 /* Decoded pixels (device buffers) -> the tensors the reference's dataset returns:
  *   image_u8     N x height x raw_width x image_channels uint8 (1 gray, 3 RGB, 4 RGBA); columns
  *                [x_offset, x_offset + width) are taken (x_offset = width, raw_width = 3 * width for

@@ -527,7 +527,29 @@ def gen_io():
     print("io: %d files, %d expected arrays" % (len(os.listdir(d)), len(exp)))
 
 
+def gen_saved_depth():
+    """The output side: a depth map written by the REFERENCE's data_utils.save_depth (src/data_utils.py:154-167), the file and what
+    the reference's load_depth reads back from it."""
+    import data_utils  # noqa: E402  (reference)
+    g = np.random.Generator(np.random.Philox(91))
+    h, w = 37, 50
+    z = (g.random((h, w), dtype=np.float32) * 120.0 * (g.random((h, w)) < 0.7)).astype(np.float32)
+    z[0, :6] = [0.0, 1.5, 100.0, 255.99, 256.0, 300.0]          # the last two lie past the 16 bits of the PNG: PIL clips them
+    z[1, :3] = [1.0 / 256.0, 0.999 / 256.0, 65535.0 / 256.0]
+    path = os.path.join(HERE, "io", "saved_depth.png")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        data_utils.save_depth(z, path)
+    back = data_utils.load_depth(path, data_format="HW")
+    np.savez_compressed(os.path.join(HERE, "saved_depth.npz"), z=z, loaded=back)
+    print("saved_depth: %d bytes, max sample %d" % (os.path.getsize(path), int(back.max() * 256)))
+
+
 if __name__ == "__main__":
+    if "--only-save-depth" in sys.argv:   # round 5: the writer of run_kbnet.py --save_outputs
+        gen_saved_depth()
+        sys.exit(0)
     if "--only-io" in sys.argv:
         gen_io()
         sys.exit(0)
@@ -560,3 +582,4 @@ if __name__ == "__main__":
     gen_decoder()
     gen_forward()
     gen_checkpoint()
+    gen_saved_depth()

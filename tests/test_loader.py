@@ -92,6 +92,66 @@ def test_png_reader_error_behaviour():
 
 
 # ------------------------------------------------------------------------- device side
+# ------------------------------------------------------------------ output side: data_utils.save_depth
+SAVED = dict(np.load(os.path.join(GOLDEN_DIR, "saved_depth.npz")))
+
+
+def test_save_depth_matches_the_reference_writer(tmp_path):
+    """loader.save_depth against a file written by the REFERENCE's data_utils.save_depth (src/data_utils.py:154-167; gen_golden.py
+    --only-save-depth) from the same depth map: same samples, and the reference's load_depth reads the same array from both -- incl.
+    depths past the PNG's 16 bits (clipped at 65535, as PIL clips) and just below one sample (truncated, not rounded)."""
+    z = SAVED["z"]
+    path = str(tmp_path / "out.png")
+    kb.loader.save_depth(z, path)
+    mine, ref = kb.loader.decode_png(read(path)), kb.loader.decode_png(read(os.path.join(IO, "saved_depth.png")))
+    assert mine.dtype == np.uint16 and np.array_equal(mine, ref)
+    assert np.array_equal(mine, np.minimum(np.floor(z.astype(np.float64) * 256.0), 65535).astype(np.uint16))
+    assert np.array_equal(kb.loader.load_depth(path), SAVED["loaded"])
+    assert kb.loader.png_info(read(path)) == (z.shape[1], z.shape[0], 1, 16)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(np.array(Image.open(path)), ref)   # a reader that is not ours agrees
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 1), (2, 1300), (97, 33)])
+@pytest.mark.parametrize("level", [0, 1, 9])
+def test_png_encoder_round_trip_and_errors(shape, level):
+    g = np.random.Generator(np.random.Philox(shape[1] + level))
+    a = g.integers(0, 65536, size=shape, dtype=np.uint16)
+    a.flat[0] = 65535
+    data = kb.loader.encode_depth_png(a, level=level)
+    assert np.array_equal(kb.loader.decode_png(data), a)
+    lib = kb._lib.load()
+    import ctypes as C
+    cap = lib.kbn_png_encode_gray16_bound(shape[1], shape[0])
+    buf, n = (C.c_ubyte * cap)(), C.c_size_t()
+    args = (a.ctypes.data_as(C.c_void_p), shape[1], shape[0], buf)
+    assert lib.kbn_png_encode_gray16(*args, cap - 1, C.byref(n), level) == kb._lib.KBN_ERR_WORKSPACE
+    assert lib.kbn_png_encode_gray16(*args, cap, C.byref(n), 10) == kb._lib.KBN_ERR_INVALID_ARGUMENT
+    assert lib.kbn_png_encode_gray16(None, shape[1], shape[0], buf, cap, C.byref(n), level) == kb._lib.KBN_ERR_INVALID_ARGUMENT
+    assert lib.kbn_png_encode_gray16_bound(0, 5) == 0
+
+
+@pytest.mark.gpu
+def test_save_depth_batch_from_device(dev, tmp_path):
+    """run_kbnet.py --save_outputs (reference src/kbnet.py:1018-1026) for a batch of device depth maps: one device pass
+    (kbn_depth_to_u16_forward = np.uint32(z * 256) with PIL's clip), host threads write the files."""
+    z = np.stack([SAVED["z"], SAVED["z"][::-1].copy(), SAVED["z"] * 0.5])
+    zt = torch.from_numpy(z).unsqueeze(1).to(dev)
+    assert np.array_equal(kb.loader.depth_samples(zt), kb.loader.depth_samples(z).reshape(zt.shape))
+    bad = torch.tensor([float("nan"), -1.0, float("inf"), 255.998], device=dev)
+    assert kb.loader.depth_samples(bad).tolist() == [0, 0, 65535, 65535]
+    paths = [str(tmp_path / f"{i}.png") for i in range(3)]
+    kb.loader.save_depth_batch(zt, paths, threads=3)
+    assert np.array_equal(kb.loader.load_depth(paths[0]), SAVED["loaded"])
+    for i in range(3):
+        assert np.array_equal(kb.loader.decode_png(read(paths[i])), np.minimum(np.floor(z[i].astype(np.float64) * 256), 65535).astype(np.uint16))
+    kb.loader.save_depth(zt[1], paths[0])   # a single device map
+    assert np.array_equal(kb.loader.decode_png(read(paths[0])), kb.loader.decode_png(read(paths[1])))
+
+
 @pytest.mark.gpu
 def test_unpack_frames_bit_exact(dev):
     raw = np.stack([kb.loader.decode_png(read(p)) for p in IMAGES])            # 3 x H x 3W x 3 uint8
