@@ -12,7 +12,7 @@ and the largest window slack of the forward's pair tensors (binades between the 
 from its BOUND and the maximum it then measured).  Two fp32 evaluation orders of a 35-conv network cannot agree better
 with each other than each agrees with the exact result: the fp64 columns are what discriminates.
 
-usage: parity_margin.py [--seeds N] [--trained] [--out FILE] [--presets kitti,void,nyu_v2]
+usage: parity_margin.py [--seeds N] [--trained] [--out FILE] [--presets kitti,void,nyu_v2] [--deconv-type transpose] [--activation elu]
 """
 import argparse
 import os
@@ -30,6 +30,8 @@ ap.add_argument("--seeds", type=int, default=32)
 ap.add_argument("--trained", action="store_true", help="trained-like weight statistics (synthetic.make_state_dicts(trained_like=True))")
 ap.add_argument("--out", default=None)
 ap.add_argument("--presets", default="kitti,void,nyu_v2")
+ap.add_argument("--deconv-type", default="up", help="run_kbnet.py --deconv_type (up | transpose)")
+ap.add_argument("--activation", default="leaky_relu", help="run_kbnet.py --activation_func (leaky_relu | relu | elu | sigmoid | linear)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -67,22 +69,24 @@ def hip_forward(cfg, sds, frames, no_split):
         kb.ops.reload_env()
 
 
-say(f"# parity margin: {args.seeds} seeds x presets {args.presets}; weights {'trained-like (t3 entries, 2^7 filter spread, 10 % dead)' if args.trained else 'xavier'}; "
+say(f"# parity margin: {args.seeds} seeds x presets {args.presets}; deconv_type {args.deconv_type}, activation {args.activation}; weights {'trained-like (t3 entries, 2^7 filter spread, 10 % dead)' if args.trained else 'xavier'}; "
     f"device {torch.cuda.get_device_name(0)}; columns: max element-wise relative error of the depth map")
 say("# preset seed | hip_vs_oracle hip_vs_fp64 | nosplit_vs_oracle nosplit_vs_fp64 | oracle_vs_fp64 | max pair-window slack (binades), pair tensors")
 t_all = time.time()
 for preset in args.presets.split(","):
     shape = SHAPES[preset]
-    cfg = kb.PRESETS[preset]()
+    import dataclasses
+    cfg = dataclasses.replace(kb.PRESETS[preset](), deconv_type=args.deconv_type, activation_func=args.activation)
+    slope = orc.activation_slope(args.activation)
     rows = []
     for seed in range(args.seeds):
         sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=kb.synthetic.PARITY_GAIN[preset], trained_like=args.trained)
         frames = kb.synthetic.make_frames(1, *shape, preset, seed=1 + seed, jitter_intrinsics=0.1)
         a = (cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
-        ref = orc.kbnet_forward(*frames, *sds, *a)
+        ref = orc.kbnet_forward(*frames, *sds, *a, slope=slope)
         torch.set_default_dtype(torch.float64)      # the oracle's pixel grid follows the default dtype (reference quirk Q8)
         try:
-            ref64 = orc.kbnet_forward(*[f.double() for f in frames], *[{k: v.double() for k, v in sd.items()} for sd in sds], *a)
+            ref64 = orc.kbnet_forward(*[f.double() for f in frames], *[{k: v.double() for k, v in sd.items()} for sd in sds], *a, slope=slope)
         finally:
             torch.set_default_dtype(torch.float32)
         out, slack, npair = hip_forward(cfg, sds, frames, no_split=False)
