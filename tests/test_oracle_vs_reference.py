@@ -25,11 +25,15 @@ def _reference_model(cfg):
     return gen_golden.build_reference_model(cfg), gen_golden.load
 
 
-@pytest.mark.parametrize("preset,shape", [("kitti", (352, 1216)), ("void", (480, 640))])
-def test_full_size_bitwise(preset, shape):
-    cfg = kb.PRESETS[preset]()
+@pytest.mark.parametrize("preset,shape,options", [("kitti", (352, 1216), {}), ("void", (480, 640), {}),
+                                                  # run_kbnet.py --deconv_type transpose / --activation_func elu | sigmoid
+                                                  ("kitti", (352, 1216), {"deconv_type": "transpose", "activation_func": "elu"}),
+                                                  ("void", (480, 640), {"activation_func": "sigmoid"})])
+def test_full_size_bitwise(preset, shape, options):
+    import dataclasses
+    cfg = dataclasses.replace(kb.PRESETS[preset](), **options)
     model, load = _reference_model(cfg)
-    sds = kb.synthetic.make_state_dicts(cfg, seed=0)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN[preset] if options else 1.0)
     load(model.sparse_to_dense_pool, sds[0])
     load(model.encoder, sds[1])
     load(model.decoder, sds[2])
@@ -38,6 +42,6 @@ def test_full_size_bitwise(preset, shape):
     with torch.no_grad():
         ref = model.forward(image, sparse, valid, k)
     out = orc.kbnet_forward(image, sparse, valid, k, *sds, cfg.min_pools, cfg.max_pools,
-                            cfg.min_predict_depth, cfg.max_predict_depth)
+                            cfg.min_predict_depth, cfg.max_predict_depth, slope=orc.activation_slope(cfg.activation_func))
     assert torch.equal(ref, out)
     assert float(out.std()) > 0
