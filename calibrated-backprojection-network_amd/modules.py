@@ -1522,6 +1522,16 @@ class KBNetModel(object):
             m.to(device)
         self.device = device
 
+    def data_parallel(self):
+        """Reference src/kbnet_model.py:408-415 wraps its three sub-networks in torch.nn.DataParallel (one process, replicas fed by
+        threads, weights re-broadcast every forward).  Here the batch splits across GPUs as ONE PROCESS PER GPU (dist.ShardedRunner:
+        frames sharded, weights resident, one RCCL all-gather of the outputs), so this call -- the reference's constructor makes it --
+        has nothing to wrap and changes nothing; checkpoints still carry the `module.` prefix its wrappers produce (save_model)."""
+        return self
+
+    def compute_loss(self, *args, **kwargs):
+        raise KbnError("the HIP path is inference only (reference src/kbnet_model.py:188-304 is the training loss)")
+
     def load_state_dicts(self, sd_s2d, sd_encoder, sd_decoder):
         """Accepts keys with or without the DataParallel `module.` prefix."""
         for m, sd in zip(self.modules(), (sd_s2d, sd_encoder, sd_decoder)):

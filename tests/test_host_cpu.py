@@ -117,6 +117,21 @@ def test_error_behaviour_mirrors_reference():
         kb.modules.KBNetEncoder(n_filters_image=[8, 16, 32])
 
 
+def test_model_object_has_the_methods_the_reference_run_loop_calls():
+    """reference src/kbnet.py:804-807, 915 (restore_model, eval, parameters, forward) and src/kbnet_model.py:140-141 (data_parallel, to)."""
+    m = _model(kb.kitti_config().narrow())
+    assert m.data_parallel() is m
+    m.eval()
+    m.to(torch.device("cpu"))
+    assert sum(p.numel() for p in m.parameters()) == sum(p.numel() for mod in m.modules() for p in mod.parameters())
+    for name in ("forward", "restore_model", "save_model", "parameters", "eval", "to", "data_parallel"):
+        assert callable(getattr(m, name))
+    with pytest.raises(RuntimeError):
+        m.train()
+    with pytest.raises(RuntimeError):
+        m.compute_loss()
+
+
 def test_hip_path_rejects_cpu_tensors():
     """No silent CPU fallback: CPU tensors fail loudly."""
     m = _model(kb.kitti_config().narrow())
