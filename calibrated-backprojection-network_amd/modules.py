@@ -176,36 +176,36 @@ class _PackedFront:
 
 
 # ------------------------------------------------------------------------ layers
-def _run_split(self, weight, srcs, n, h, w, out=None, up2x=False, out_absmax=None, stats=None, pair_out=False, transposed=False):
-    """Conv2d.run_split for `self` = a Conv2d (weight = its OIHW parameter) or, with `transposed` and `up2x`, a TransposeConv2d
+def _run_split(layer, weight, srcs, n, h, w, out=None, up2x=False, out_absmax=None, stats=None, pair_out=False, transposed=False):
+    """Conv2d.run_split for `layer` = a Conv2d (weight = its OIHW parameter) or, with `transposed` and `up2x`, a TransposeConv2d
     (weight = its in x out x 3 x 3 parameter: the folded up-conv kernels on the layer's own taps)."""
     kinds_ok = all((s.kind == _lib.KBN_SRC_TENSOR or (i == 0 and s.kind == _lib.KBN_SRC_PAIR)) and s.channels % 16 == 0
                    for i, s in enumerate(srcs))
-    if (not self.split or self.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2 or (up2x and self.stride != 1)
+    if (not layer.split or layer.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2 or (up2x and layer.stride != 1)
             or not kinds_ok):
         return None
     # narrow layers stay on the fp32 kernels (a 64-filter tile would be mostly padding) -- except the folded up-conv,
     # which has 16-filter tiles for them (deconv0's 64 -> 12 at full resolution)
-    narrow_up = up2x and self.split_narrow_up and self.out_channels <= 16 and self.in_channels % 32 == 0
-    if self.out_channels < 48 and not narrow_up:
+    narrow_up = up2x and layer.split_narrow_up and layer.out_channels <= 16 and layer.in_channels % 32 == 0
+    if layer.out_channels < 48 and not narrow_up:
         return None
     dev = weight.device
     srcs = Conv2d._with_slots(srcs, n, dev, stats)
     if pair_out:
-        if stats is None or (self.out_channels % 8 and not narrow_up) or (self.stride != 1 and up2x):
+        if stats is None or (layer.out_channels % 8 and not narrow_up) or (layer.stride != 1 and up2x):
             return None
         # (the narrow folded up-conv writes 16 channels, zeros past its filters: the decoder tail's input)
-        out = ops.PairTensor(n, 16 if narrow_up else self.out_channels, h, w, dev, stats)
-        if self.stride == 2:
+        out = ops.PairTensor(n, 16 if narrow_up else layer.out_channels, h, w, dev, stats)
+        if layer.stride == 2:
             out.with_sub()   # the even pixels in fp32 too: the next level's 1x1 stride-2 conv_fused reads those
         if out_absmax is not None:
             out.absmax = out_absmax
     elif out is None:
-        out = torch.empty((n, self.out_channels, h, w), device=dev, dtype=torch.float32)
-    packed = (self._packed_split_up.get(weight, 1, up2x="split_up_t" if transposed else "split_up") if up2x
-              else self._packed_split.get(weight, self.stride, up2x="split"))
-    return ops.conv3x3_split(srcs, packed, n, self.out_channels, h, w, out, up2x=up2x, negative_slope=self._slope,
-                             stride=self.stride, folded_up2x=up2x, out_absmax=out_absmax, transposed=transposed)
+        out = torch.empty((n, layer.out_channels, h, w), device=dev, dtype=torch.float32)
+    packed = (layer._packed_split_up.get(weight, 1, up2x="split_up_t" if transposed else "split_up") if up2x
+              else layer._packed_split.get(weight, layer.stride, up2x="split"))
+    return ops.conv3x3_split(srcs, packed, n, layer.out_channels, h, w, out, up2x=up2x, negative_slope=layer._slope,
+                             stride=layer.stride, folded_up2x=up2x, out_absmax=out_absmax, transposed=transposed)
 
 
 class Conv2d(torch.nn.Module):
