@@ -625,6 +625,9 @@ def kb_block(image, depth, coordinates, kinv, fused, packed_w_image, packed_w_de
 
 
 # ---------------------------------------------------------------------- depth head
+HEAD_MAX_CHANNELS = 16   # csrc/head.hip HD_MAXC
+
+
 @_on_tensor_device
 def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, return_logits=False, out=None):
     """`out`: optional contiguous N x 1 x H x W destination (e.g. a batch slice of a larger output buffer)."""
@@ -636,6 +639,14 @@ def depth_head(x, weight, min_predict_depth: float, max_predict_depth: float, re
     n, c, h, wd = x.shape
     if tuple(w.shape) != (1, c, 3, 3):
         raise KbnError(f"depth head weight must be 1 x {c} x 3 x 3")
+    if c > HEAD_MAX_CHANNELS:
+        # run_kbnet.py --n_filters_decoder with a last width past the head kernel's 16 channels: output0 as a conv of its own, then the
+        # mapping as the head kernel over that one plane with an identity tap (1.0 * logit + eight exact zeros: the logits as they are)
+        plane = conv2d([tensor_src(x, "x")], pack_conv_weight(w, 1), n, 1, 3, 1, h, wd,
+                       torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32), negative_slope=None)
+        # (device ops only -- a fill and a pad: this runs under HIP-graph capture too)
+        ident = torch.nn.functional.pad(torch.ones((1, 1, 1, 1), device=x.device, dtype=torch.float32), (1, 1, 1, 1))
+        return depth_head(plane, ident, min_predict_depth, max_predict_depth, return_logits=return_logits, out=out)
     if out is None:
         depth = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32)
     else:

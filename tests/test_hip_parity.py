@@ -5,6 +5,7 @@ the min/max pyramid is compare/select only and must be bit-exact.
     python -m pytest tests -m gpu -q
 """
 import math
+import os
 
 import pytest
 import torch
@@ -1623,6 +1624,70 @@ def test_forward_single_channel_image_vs_oracle(dev, width):
     out = m.forward(*to(dev, *frames))
     ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
     _check_forward(out, ref)
+
+
+def _random_configuration(seed):
+    """A KBNet the reference's command line can build (run_kbnet.py's architecture switches, drawn at random): pool sizes, S2D widths,
+    encoder / decoder widths, KB levels (a subset holding 0; level 4 with its quirk when levels 2 and 3 are equally wide), deconv_type,
+    activation, image channels, batch and frame size (odd sizes with deconv_type='up' only: a transposed conv doubles the size)."""
+    import dataclasses
+    import random
+    r = random.Random(1000 + seed)
+    odd = lambda lo, hi: r.choice(range(lo, hi + 1, 2))
+    n_min, n_max = r.choice([(2, 3), (5, 2), (1, 1), (0, 3), (4, 0), (6, 5)])
+    wi = [r.choice([6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96]) for _ in range(5)]
+    wd = [r.choice([3, 4, 8, 16, 32]) for _ in range(5)]
+    levels = [0] + [l for l in (1, 2, 3) if r.random() < 0.6]
+    if 3 in levels and r.random() < 0.4:
+        # the reference's level-4 KB branch re-uses block 4 (quirk Q3): levels 2 and 3 equally wide, and the decoder is built for
+        # the latent's level-4 widths while block 4 delivers level 3's
+        wi[3], wd[3] = wi[2], wd[2]
+        wi[4], wd[4] = wi[3], wd[3]
+        if 2 in levels:
+            levels.append(4)
+    deconv = r.choice(["up", "up", "transpose"])
+    shape = (r.choice([(64, 96), (96, 128), (32, 160), (128, 32)]) if deconv == "transpose"
+             else r.choice([(64, 96), (70, 100), (45, 132), (33, 47), (16, 24), (17, 33), (128, 160)]))
+    return dataclasses.replace(
+        kb.kitti_config(), name=f"random{seed}",
+        input_channels_image=r.choice([3, 3, 1]),
+        min_pool_sizes_sparse_to_dense_pool=tuple(sorted(odd(3, 17) for _ in range(n_min))),
+        max_pool_sizes_sparse_to_dense_pool=tuple(sorted(odd(3, 31) for _ in range(n_max))),
+        n_convolution_sparse_to_dense_pool=r.choice([1, 2, 3, 5]), n_filter_sparse_to_dense_pool=r.choice([4, 8, 8, 16]),
+        n_filters_encoder_image=tuple(wi), n_filters_encoder_depth=tuple(wd), resolutions_backprojection=tuple(levels),
+        n_filters_decoder=tuple(r.choice([5, 8, 12, 16, 24, 32, 48, 64, 96]) for _ in range(5)), deconv_type=deconv,
+        activation_func=r.choice(["leaky_relu", "leaky_relu", "relu", "elu", "sigmoid", "linear"])), shape, r.choice([1, 2, 3])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KBN_FUZZ_SEEDS", "48"))))
+def test_random_configurations_vs_oracle(dev, seed):
+    """48 (KBN_FUZZ_SEEDS) random architectures off the shipped presets -- each a combination of run_kbnet.py switches nobody wrote a kernel for -- through
+    KBNetModel.from_config against the oracle, on the LOGITS (in units of their largest magnitude: random widths and activations leave
+    the sigmoid head anywhere between flat and saturated, where the depth map would hide an error) and on the depth map."""
+    cfg, (h, w), n = _random_configuration(seed)
+    sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.2)
+    frames = list(kb.synthetic.make_frames(n, h, w, "kitti", seed=seed + 77, jitter_intrinsics=0.1))
+    frames[0] = frames[0][:, :cfg.input_channels_image].contiguous()
+    slope = orc.activation_slope(cfg.activation_func)
+    with torch.no_grad():
+        x = torch.cat([frames[1], frames[2]], dim=1)
+        d = orc.sparse_to_dense_pool(x, sds[0], cfg.min_pools, cfg.max_pools, slope)
+        latent, skips = orc.encoder(frames[0], d, frames[3], sds[1], cfg.resolutions_backprojection, slope)
+        ref_logits = orc.decoder(latent, skips, (h, w), sds[2], slope)
+        ref = orc.depth_head(ref_logits, cfg.min_predict_depth, cfg.max_predict_depth)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    assert {k: tuple(v.shape) for k, v in m.encoder.state_dict().items()} == kb.config.encoder_param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.decoder.state_dict().items()} == kb.config.decoder_param_shapes(cfg)
+    m.load_state_dicts(*sds)
+    out, logits = m.forward(*to(dev, *frames), return_logits=True)
+    scale = float(ref_logits.abs().max())
+    err = float((logits.cpu() - ref_logits).abs().max()) / scale
+    print(f"{cfg}\n{n} x {h} x {w}: logits within {err:.2e} of their maximum {scale:.3g}; depth {_worst_rel(out, ref):.2e}")
+    assert scale > 0 and err < 2e-5
+    # d depth / depth = sigmoid' / (sigmoid + d_min / d_max) * d logit <= d logit: the depth map to 1e-4, or to what the logits' absolute
+    # error allows where a linear / ReLU net of random widths drives them to the hundreds
+    assert _worst_rel(out, ref) < max(TOL, 1.5 * err * scale)
+    assert torch.equal(m.capture(*to(dev, *frames))(*to(dev, *frames)), out)
 
 
 def _worst_rel(out, ref):
