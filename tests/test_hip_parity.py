@@ -1659,13 +1659,11 @@ def _random_configuration(seed):
         activation_func=r.choice(["leaky_relu", "leaky_relu", "relu", "elu", "sigmoid", "linear"])), shape, r.choice([1, 2, 3])
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("KBN_FUZZ_SEEDS", "48"))))
-def test_random_configurations_vs_oracle(dev, seed):
-    """48 (KBN_FUZZ_SEEDS) random architectures off the shipped presets -- each a combination of run_kbnet.py switches nobody wrote a kernel for -- through
-    KBNetModel.from_config against the oracle, on the LOGITS (in units of their largest magnitude: random widths and activations leave
-    the sigmoid head anywhere between flat and saturated, where the depth map would hide an error) and on the depth map."""
-    cfg, (h, w), n = _random_configuration(seed)
-    sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.2)
+def _compare_with_oracle(dev, cfg, n, h, w, seed, gain, check_graph=True):
+    """One forward of a KBNetModel built from `cfg` against the oracle: the LOGITS in units of their largest magnitude (random widths and
+    activations leave the sigmoid head anywhere between flat and saturated, where the depth map would hide an error), the depth map,
+    the state_dict layout, and the captured graph against the eager bits."""
+    sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=gain)
     frames = list(kb.synthetic.make_frames(n, h, w, "kitti", seed=seed + 77, jitter_intrinsics=0.1))
     frames[0] = frames[0][:, :cfg.input_channels_image].contiguous()
     slope = orc.activation_slope(cfg.activation_func)
@@ -1687,7 +1685,56 @@ def test_random_configurations_vs_oracle(dev, seed):
     # d depth / depth = sigmoid' / (sigmoid + d_min / d_max) * d logit <= d logit: the depth map to 1e-4, or to what the logits' absolute
     # error allows where a linear / ReLU net of random widths drives them to the hundreds
     assert _worst_rel(out, ref) < max(TOL, 1.5 * err * scale)
-    assert torch.equal(m.capture(*to(dev, *frames))(*to(dev, *frames)), out)
+    if check_graph:
+        assert torch.equal(m.capture(*to(dev, *frames))(*to(dev, *frames)), out)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KBN_FUZZ_SEEDS", "48"))))
+def test_random_configurations_vs_oracle(dev, seed):
+    """48 (KBN_FUZZ_SEEDS) random architectures off the shipped presets -- each a combination of run_kbnet.py switches nobody wrote a
+    kernel for -- through KBNetModel.from_config against the oracle."""
+    cfg, (h, w), n = _random_configuration(seed)
+    _compare_with_oracle(dev, cfg, n, h, w, seed, gain=1.2)
+
+
+# the full-width KITTI network with ONE thing changed: what decides, layer by layer, between the fused fast kernels and the general ones
+# (front eligibility, pair-tensor chains, 16-filter up-conv tiles, the fused tail, graph branches) sees a neighbour of the shipped preset
+PRESET_PERTURBATIONS = {
+    "odd_frame_350x1214": (dict(), (350, 1214), 2),
+    "odd_frame_353x1217": (dict(), (353, 1217), 1),
+    "batch_3": (dict(), (176, 608), 3),
+    "batch_5": (dict(), (96, 320), 5),
+    "kb_levels_012": (dict(resolutions_backprojection=(0, 1, 2)), (176, 608), 2),
+    "kb_levels_023": (dict(resolutions_backprojection=(0, 2, 3)), (176, 608), 2),
+    "kb_level_0_only": (dict(resolutions_backprojection=(0,)), (176, 608), 2),
+    "kb_levels_01234": (dict(resolutions_backprojection=(0, 1, 2, 3, 4), n_filters_encoder_image=(48, 96, 192, 192, 192),
+                             n_filters_encoder_depth=(16, 32, 64, 64, 64)), (176, 608), 2),
+    "decoder_last_16": (dict(n_filters_decoder=(256, 128, 128, 64, 16)), (176, 608), 2),
+    "decoder_last_8": (dict(n_filters_decoder=(256, 128, 128, 64, 8)), (176, 608), 2),
+    "decoder_last_24": (dict(n_filters_decoder=(256, 128, 128, 64, 24)), (176, 608), 2),
+    "decoder_half": (dict(n_filters_decoder=(128, 64, 64, 32, 12)), (176, 608), 2),
+    "decoder_odd_widths": (dict(n_filters_decoder=(250, 130, 100, 60, 12)), (176, 608), 2),
+    "encoder_image_32": (dict(n_filters_encoder_image=(32, 64, 128, 256, 256)), (176, 608), 2),
+    "encoder_image_64": (dict(n_filters_encoder_image=(64, 96, 192, 384, 384)), (176, 608), 2),
+    "encoder_depth_8": (dict(n_filters_encoder_depth=(8, 16, 32, 64, 64)), (176, 608), 2),
+    "encoder_depth_24": (dict(n_filters_encoder_depth=(24, 32, 64, 128, 128)), (176, 608), 2),
+    "s2d_16_filters": (dict(n_filter_sparse_to_dense_pool=16), (176, 608), 2),
+    "s2d_one_conv": (dict(n_convolution_sparse_to_dense_pool=1), (176, 608), 2),
+    "void_pools": (dict(min_pool_sizes_sparse_to_dense_pool=(15, 17), max_pool_sizes_sparse_to_dense_pool=(23, 27, 29)), (176, 608), 2),
+    "gray_image": (dict(input_channels_image=1), (176, 608), 2),
+    "transpose": (dict(deconv_type="transpose"), (160, 608), 3),
+    "relu": (dict(activation_func="relu"), (176, 608), 2),
+    "elu_transpose": (dict(activation_func="elu", deconv_type="transpose"), (160, 320), 2),
+    "depth_range_void": (dict(min_predict_depth=0.1, max_predict_depth=8.0), (176, 608), 2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PRESET_PERTURBATIONS))
+def test_preset_perturbations_vs_oracle(dev, name):
+    import dataclasses
+    changes, (h, w), n = PRESET_PERTURBATIONS[name]
+    cfg = dataclasses.replace(kb.kitti_config(), name=name, **changes)
+    _compare_with_oracle(dev, cfg, n, h, w, seed=11, gain=kb.synthetic.PARITY_GAIN["kitti"])
 
 
 def _worst_rel(out, ref):
