@@ -92,6 +92,16 @@ def test_png_reader_error_behaviour():
 
 
 # ------------------------------------------------------------------------- device side
+def test_png_reader_survives_mutated_files():
+    """The reader parses files it did not write: 3000 mutations of the fixture PNGs (tests/png_fuzz.py) in a child process -- each call
+    returns a status, none takes the process down."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "png_fuzz.py"), "3000"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "survived" in res.stdout, (res.returncode, res.stdout[-300:], res.stderr[-600:])
+
+
 # ------------------------------------------------------------------ output side: data_utils.save_depth
 SAVED = dict(np.load(os.path.join(GOLDEN_DIR, "saved_depth.npz")))
 
