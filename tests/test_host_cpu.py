@@ -176,6 +176,16 @@ def test_library_exports_every_declared_symbol():
     assert (deep["kernel"], deep["MW"], deep["TWB"], deep["workgroups"]) == ("wino", 6, 10, 256)
 
 
+def test_every_entry_point_rejects_null_arguments():
+    """tests/abi_null_args.py in a child process: all-null / all-zero arguments to every declared entry point -> an error status
+    (KBN_ERR_*), never a crash, never KBN_OK."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "abi_null_args.py")],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().endswith("accepted all-zero arguments: []"), (res.returncode, res.stdout[-400:], res.stderr[-600:])
+
+
 def test_synthetic_frames_are_deterministic_and_well_formed():
     a = kb.synthetic.make_frames(2, 32, 48, "kitti", seed=3)
     b = kb.synthetic.make_frames(2, 32, 48, "kitti", seed=3)
