@@ -1699,6 +1699,28 @@ def test_random_configurations_vs_oracle(dev, seed):
 
 # the full-width KITTI network with ONE thing changed: what decides, layer by layer, between the fused fast kernels and the general ones
 # (front eligibility, pair-tensor chains, 16-filter up-conv tiles, the fused tail, graph branches) sees a neighbour of the shipped preset
+def test_forward_accepts_strided_views(dev):
+    """Inputs as the views user code produces -- every other frame of a bigger batch, a channels-last image, a crop of a wider frame,
+    K as a slice of a 3 x 4 projection matrix: same bits as the contiguous tensors, eager and as a captured graph."""
+    cfg = kb.kitti_config().narrow()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.3)
+    image, sparse, valid, k = to(dev, *kb.synthetic.make_frames(2, 64, 96, "kitti", seed=8, jitter_intrinsics=0.1))
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    ref = m.forward(image, sparse, valid, k)
+    big = torch.zeros(4, 3, 64, 96, device=dev)
+    big[::2] = image
+    wide = torch.zeros(2, 1, 64, 200, device=dev)
+    wide[..., 50:146] = sparse
+    p34 = torch.zeros(2, 3, 4, device=dev)
+    p34[:, :, :3] = k
+    views = (big[::2], image.contiguous(memory_format=torch.channels_last), image.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2))
+    for img in views:
+        assert torch.equal(m.forward(img, wide[..., 50:146], valid, p34[:, :, :3]), ref)
+    g = m.capture(image, sparse, valid, k)
+    assert torch.equal(g(big[::2], wide[..., 50:146], valid, p34[:, :, :3]), ref)
+
+
 PRESET_PERTURBATIONS = {
     "odd_frame_350x1214": (dict(), (350, 1214), 2),
     "odd_frame_353x1217": (dict(), (353, 1217), 1),
