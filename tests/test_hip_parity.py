@@ -1721,6 +1721,27 @@ def test_forward_accepts_strided_views(dev):
     assert torch.equal(g(big[::2], wide[..., 50:146], valid, p34[:, :, :3]), ref)
 
 
+@pytest.mark.parametrize("width", ["narrow", "full"])
+def test_non_finite_inputs_stay_in_their_frame(dev, width):
+    """A NaN / Inf pixel in frame 0's image: the frames of a batch are independent (per-frame fp16 windows included) -- frame 1 keeps its
+    bits; frame 0 turns NaN exactly where the reference's does (its receptive field) and stays finite elsewhere.  1e30 overflows nothing
+    the reference does not overflow."""
+    cfg = kb.kitti_config() if width == "full" else kb.kitti_config().narrow()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=1.1)
+    fr = list(kb.synthetic.make_frames(2, 96, 160, "kitti", seed=8))
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    clean = m.forward(*to(dev, *fr))
+    for val in (float("nan"), float("inf"), 1e30):
+        f2 = [f.clone() for f in fr]
+        f2[0][0, 1, 40, 70] = val
+        out = m.forward(*to(dev, *f2))
+        ref = orc.kbnet_forward(*[f[0:1] for f in f2], *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+        assert torch.equal(out[1], clean[1])
+        assert torch.equal(out[0:1].cpu().isnan(), ref.isnan())
+        assert bool(out[0:1].cpu()[~ref.isnan()].isfinite().all())
+
+
 PRESET_PERTURBATIONS = {
     "odd_frame_350x1214": (dict(), (350, 1214), 2),
     "odd_frame_353x1217": (dict(), (353, 1217), 1),
