@@ -20,6 +20,40 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north_star: "within 1e-4 relative fp32"
 
 
+@pytest.mark.gpu
+def test_concurrent_host_threads_share_one_model(dev):
+    """SURVEY 8(b) threading: the library keeps no mutable state between calls and launches on the caller's stream, ctypes drops the GIL
+    around every call -- DataParallel-style host threads may drive ONE model at once.  Four threads, each on a stream of its own with
+    inputs of its own, 12 forwards each, against the same forwards issued one after the other."""
+    import threading
+    cfg = kb.kitti_config().narrow()
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*kb.synthetic.make_state_dicts(cfg, seed=1, gain=1.3))
+    inputs = [[f.to(dev) for f in kb.synthetic.make_frames(2, 64, 96 + 32 * (t % 2), "kitti", seed=20 + t)] for t in range(4)]
+    expect = [m.forward(*fr).clone() for fr in inputs]      # also packs every weight blob once, before the threads start
+    torch.cuda.synchronize()
+    results, errors = [None] * 4, []
+
+    def work(t):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                outs = [m.forward(*inputs[t]) for _ in range(12)]
+            st.synchronize()
+            results[t] = outs
+        except Exception as e:   # noqa: BLE001 (reported by the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        assert all(torch.equal(o, expect[t]) for o in results[t]), t
+
+
 @pytest.fixture(scope="module")
 def dev():
     if not torch.cuda.is_available():
