@@ -439,6 +439,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                          "encoder's level side branches run inside every sub-batch")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step / >= 3 s sustained-rate run")
     ap.add_argument("--no-batch1", action="store_true", help="skip the batch-1 latency side measurement")
+    ap.add_argument("--no-options", action="store_true", help="skip the side measurement of --deconv_type transpose / --activation_func relu | elu")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -456,7 +457,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
             raise SystemExit(f"bench.py: {', '.join(bad)} set in the environment -- the timed region would not be the parity-gated "
                              "path; unset it (the bench runs those modes itself as side legs)")
     if world > 1 and not args.side:
-        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = args.no_mixed = args.no_batch1 = True
+        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = args.no_mixed = args.no_batch1 = args.no_options = True
     per = args.frames_per_gpu
     # rank r holds frames [r*per, (r+1)*per) of the global batch (seed 1+rank; frame 0 of
     # rank 0 is the frame the CPU oracle sees)
@@ -546,6 +547,23 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         # all ranks run their frames at the same time: whole-job rate = frames of all ranks / slowest rank's time
         void_fps, _ = replay_rate(vreplay, vreplay.static_in, 10, 3, per, world, dev)
         del vreplay, vmodel, vframes
+
+    # The reference's other architecture switches (run_kbnet.py --deconv_type transpose, --activation_func relu | elu) at the headline's
+    # batch and size: what a user of those options gets -- the transposed decoder on the folded up-conv's split kernels, relu in the
+    # shipped kernels (slope 0), elu layer by layer on the fp32-MFMA kernels.  Side measurements, forward only.
+    options_fps = None
+    if not args.no_options and not args.eager:
+        import dataclasses
+        options_fps = {}
+        for label, changes in (("deconv_type=transpose", {"deconv_type": "transpose"}), ("activation_func=relu", {"activation_func": "relu"}),
+                               ("activation_func=elu", {"activation_func": "elu"})):
+            ocfg = dataclasses.replace(cfg, **changes)
+            omodel = kb.modules.KBNetModel.from_config(ocfg, dev)
+            omodel.load_state_dicts(*kb.synthetic.make_state_dicts(ocfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"]))
+            oreplay = omodel.capture(*frames)
+            fps, _ = replay_rate(oreplay, oreplay.static_in, 10, 3, per, world, dev)
+            options_fps[label] = round(fps, 1)
+            del oreplay, omodel
 
     # configs[1] (batch 8 per GPU, the round-1 headline) as a side measurement on the same weights
     side_fps = None
@@ -737,6 +755,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    "reference_style_region_ms_per_step": round(refstyle_ms, 4),
                    # side measurement: VOID preset, 480x640, same batch per GPU, forward only (no all-gather)
                    "void_480x640_frames_per_s": None if void_fps is None else round(void_fps, 1),
+                   # side measurement: the reference's other architecture switches at the same batch and size, forward only
+                   "reference_options_frames_per_s": options_fps,
                    # side measurement: BASELINE configs[1] (batch 8 per GPU), forward only
                    "batch8_frames_per_s": None if side_fps is None else round(side_fps, 1),
                    # side measurement: the forward without the one conv of the reference's graph whose result nothing reads
