@@ -70,7 +70,7 @@ SIGNATURES = {
     "kbn_upconv2x_packed_weight_bytes": (C.c_size_t, [_I, _I]),
     "kbn_upconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
     "kbn_upconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
-    "kbn_activation_forward": (_I, [_P, _L, _I, _L, _I, _P]),
+    "kbn_activation_forward": (_I, [_P, _L, _I, _L, _I, _P, _P]),
     "kbn_scale_planes_forward": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "kbn_deconv2x_pack_weight": (_I, [_P, _P, _I, _I, _P]),
     "kbn_deconv2x_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

@@ -1,7 +1,8 @@
 // elementwise.hip -- the two byte-bound passes of the LAYER-BY-LAYER form of the network, which runs when the model's activation is
 // not a (leaky) ReLU (run_kbnet.py --activation_func elu | sigmoid | linear; reference src/net_utils.py:23-45) and the fused kernels
 // -- all written around max(v, slope v) -- step aside:
-//   kbn_activation_forward   x <- act(x) in place after a conv launched without activation: ELU (alpha 1, torch.nn.ELU()) or sigmoid
+//   kbn_activation_forward   x <- act(x) in place after a conv launched without activation: ELU (alpha 1, torch.nn.ELU()) or sigmoid; folds
+//                            max |act(x)| per frame into the tensor's slot, so that split-operand convs downstream place their windows on it
 //   kbn_scale_planes_forward xyz = coordinates * z, the KB block's backprojection (src/net_utils.py:1352-1359) once z = act(proj_depth . depth)
 //                            is a tensor of its own instead of a value inside the conv's staging
 // Both are one read and one write per element: 16-byte accesses where the planes allow, a grid-stride loop over (frame, element).
@@ -18,20 +19,32 @@ __device__ __forceinline__ float act_apply(float v) {
 }
 
 template <int KIND, bool VEC>
-__global__ __launch_bounds__(256) void activation_kernel(float* __restrict__ x, long long batch_stride, long long per_frame) {
+__global__ __launch_bounds__(256) void activation_kernel(float* __restrict__ x, long long batch_stride, long long per_frame,
+                                                         unsigned* __restrict__ out_absmax) {
     float* xn = x + (long long)blockIdx.y * batch_stride;
     const long long step = (long long)gridDim.x * 256;
+    float m = 0.f;   // max |act(v)| of this thread's elements: the frame's slot takes the activated tensor's maximum (kbn_common.h)
     if constexpr (VEC) {
         const long long quads = per_frame >> 2;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < quads; i += step) {
             float4 v = reinterpret_cast<float4*>(xn)[i];
             v.x = act_apply<KIND>(v.x); v.y = act_apply<KIND>(v.y); v.z = act_apply<KIND>(v.z); v.w = act_apply<KIND>(v.w);
             reinterpret_cast<float4*>(xn)[i] = v;
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
-        for (long long i = (quads << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < per_frame; i += step) xn[i] = act_apply<KIND>(xn[i]);
+        for (long long i = (quads << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < per_frame; i += step) {
+            const float v = act_apply<KIND>(xn[i]);
+            xn[i] = v;
+            m = fmaxf(m, fabsf(v));
+        }
     } else {
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_frame; i += step) xn[i] = act_apply<KIND>(xn[i]);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_frame; i += step) {
+            const float v = act_apply<KIND>(xn[i]);
+            xn[i] = v;
+            m = fmaxf(m, fabsf(v));
+        }
     }
+    if (out_absmax) absmax_commit(out_absmax + blockIdx.y, m);
 }
 
 __global__ __launch_bounds__(256) void scale_planes_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ z, long long z_bs,
@@ -51,7 +64,8 @@ __global__ __launch_bounds__(256) void scale_planes_kernel(const float* __restri
 
 extern "C" {
 
-int kbn_activation_forward(float* x, long long batch_stride, int n, long long per_frame, int kind, kbn_stream_t stream) {
+int kbn_activation_forward(float* x, long long batch_stride, int n, long long per_frame, int kind, unsigned* out_absmax,
+                           kbn_stream_t stream) {
     using namespace kbn;
     if (!x || n < 1 || per_frame < 1 || (kind != KBN_ACT_ELU && kind != KBN_ACT_SIGMOID)) return KBN_ERR_INVALID_ARGUMENT;
     if (n > 65535) return KBN_ERR_UNSUPPORTED;
@@ -60,11 +74,11 @@ int kbn_activation_forward(float* x, long long batch_stride, int n, long long pe
     const dim3 grid(blocks, n);
     hipStream_t st = (hipStream_t)stream;
     if (kind == KBN_ACT_ELU) {
-        if (vec) hipLaunchKernelGGL((activation_kernel<1, true>), grid, dim3(256), 0, st, x, batch_stride, per_frame);
-        else hipLaunchKernelGGL((activation_kernel<1, false>), grid, dim3(256), 0, st, x, batch_stride, per_frame);
+        if (vec) hipLaunchKernelGGL((activation_kernel<1, true>), grid, dim3(256), 0, st, x, batch_stride, per_frame, out_absmax);
+        else hipLaunchKernelGGL((activation_kernel<1, false>), grid, dim3(256), 0, st, x, batch_stride, per_frame, out_absmax);
     } else {
-        if (vec) hipLaunchKernelGGL((activation_kernel<2, true>), grid, dim3(256), 0, st, x, batch_stride, per_frame);
-        else hipLaunchKernelGGL((activation_kernel<2, false>), grid, dim3(256), 0, st, x, batch_stride, per_frame);
+        if (vec) hipLaunchKernelGGL((activation_kernel<2, true>), grid, dim3(256), 0, st, x, batch_stride, per_frame, out_absmax);
+        else hipLaunchKernelGGL((activation_kernel<2, false>), grid, dim3(256), 0, st, x, batch_stride, per_frame, out_absmax);
     }
     KBN_CHECK_LAUNCH();
     return KBN_OK;

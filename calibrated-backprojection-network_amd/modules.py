@@ -70,12 +70,12 @@ def _post(act) -> Optional[str]:
     return None
 
 
-def _finish(layer, out, out_absmax, stats):
-    """The activation pass of a layer whose activation the kernels do not fuse; the slot its conv was NOT given stays unfilled."""
+def _finish(layer, out, out_absmax, stats=None):
+    """The activation pass of a layer whose activation the kernels do not fuse (ELU, sigmoid); it folds max |out| per frame into the
+    tensor's slot -- the conv in front of it was given none -- so that split-operand convs downstream place their fp16 windows on
+    the activated values."""
     if layer._post is not None:
-        ops.activation_(out, layer._post)
-        if stats is not None:
-            stats.skip(out_absmax)
+        ops.activation_(out, layer._post, out_absmax)
     return out
 
 
@@ -182,7 +182,7 @@ def _run_split(layer, weight, srcs, n, h, w, out=None, up2x=False, out_absmax=No
     kinds_ok = all((s.kind == _lib.KBN_SRC_TENSOR or (i == 0 and s.kind == _lib.KBN_SRC_PAIR)) and s.channels % 16 == 0
                    for i, s in enumerate(srcs))
     if (not layer.split or layer.kernel_size != 3 or (up2x and w % 4) or len(srcs) > 2 or (up2x and layer.stride != 1)
-            or not kinds_ok):
+            or not kinds_ok or (pair_out and layer._post is not None)):   # (a pair tensor holds what the KERNEL wrote: no ELU / sigmoid behind it)
         return None
     # narrow layers stay on the fp32 kernels (a 64-filter tile would be mostly padding) -- except the folded up-conv,
     # which has 16-filter tiles for them (deconv0's 64 -> 12 at full resolution)
@@ -204,8 +204,9 @@ def _run_split(layer, weight, srcs, n, h, w, out=None, up2x=False, out_absmax=No
         out = torch.empty((n, layer.out_channels, h, w), device=dev, dtype=torch.float32)
     packed = (layer._packed_split_up.get(weight, 1, up2x="split_up_t" if transposed else "split_up") if up2x
               else layer._packed_split.get(weight, layer.stride, up2x="split"))
-    return ops.conv3x3_split(srcs, packed, n, layer.out_channels, h, w, out, up2x=up2x, negative_slope=layer._slope,
-                             stride=layer.stride, folded_up2x=up2x, out_absmax=out_absmax, transposed=transposed)
+    res = ops.conv3x3_split(srcs, packed, n, layer.out_channels, h, w, out, up2x=up2x, negative_slope=layer._slope,
+                            stride=layer.stride, folded_up2x=up2x, out_absmax=None if layer._post else out_absmax, transposed=transposed)
+    return res if res is None else _finish(layer, res, out_absmax)
 
 
 class Conv2d(torch.nn.Module):
@@ -237,9 +238,7 @@ class Conv2d(torch.nn.Module):
         # KITTI frames); at KB2's 96 filters the layer is bound by its stride-2 HBM reads either way (365 vs 342 us)
         self.split_fused_min_filters = 192
         self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
-        # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies; not behind an ELU / sigmoid layer, whose kernels
-        # would fold max |out| BEFORE the activation into the slot their consumers place their fp16 windows on
-        self.split = self._post is None
+        self.split = True   # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies
         # the folded up-conv of a layer with at most 16 filters has 16-filter tiles (upconv2x_split16_kernel): deconv0's
         # 64 -> 12 up-conv.  Level with the fp32 9-product kernel on random operands (650 vs 640 us per 32 KITTI frames),
         # 8-11 % faster inside the forward (660-690 vs 745 us, tools/layer_profile.py)
@@ -308,7 +307,11 @@ class Conv2d(torch.nn.Module):
         if cin != self.in_channels:   # the packed blob carries no size: a wrong count would read past the weight panel
             raise KbnError(f"expected {self.in_channels} input channels in total, got {cin}")
         oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)
-        if self._post is not None:   # ELU / sigmoid: the fp32 conv without activation, then the activation in place
+        if self._post is not None:   # ELU / sigmoid: the conv without activation (split operands where the shape qualifies), then the activation in place
+            if not resize and not self.bf16:
+                res = self.run_split(srcs, n, oh, ow, out=out, out_absmax=out_absmax, stats=stats)   # (_run_split finishes the layer)
+                if res is not None:
+                    return res
             if out is None:
                 out = torch.empty((n, self.out_channels, oh, ow), device=self.conv.weight.device, dtype=torch.float32)
             res = ops.conv2d(srcs, self.packed(), n, self.out_channels, self.kernel_size, self.stride, in_h, in_w, out,
@@ -486,7 +489,7 @@ class TransposeConv2d(torch.nn.Module):
         self._packed_split = None                         # (never used: the layer has no plain-conv form)
         self._packed_split_up = _PackedWeight()
         self._packed_up2x = _PackedWeight()
-        self.split = self._post is None                   # (as Conv2d.split)
+        self.split = True
         self.split_narrow_up = True
         self.bf16 = False                                 # no bf16 leg for this layer
 
@@ -744,7 +747,7 @@ class DecoderBlock(torch.nn.Module):
         ops.PairTensor and `pair_out` asks for one (the decoder's chain of split-operand kernels, MultiScaleDecoder);
         None when the pair kernels decline a shape (the caller repeats the block in fp32)."""
         if pair_out and (self.conv.bf16 or self.deconv.bf16 or not self.conv.split or self.conv.out_channels < 48
-                         or self.conv.out_channels % 8 or self.conv.kernel_size != 3):
+                         or self.conv.out_channels % 8 or self.conv.kernel_size != 3 or self.conv._post is not None):
             return None   # declined before anything is launched
         if self.deconv_type == "transpose":
             # the transposed conv fixes the size (reference :1468-1469: `shape` and the skip's size are not consulted); a skip of
@@ -1190,7 +1193,7 @@ class MultiScaleDecoder(torch.nn.Module):
         d0 = self.deconv0
         x, amax = self.features_level1(x, skips, amax_x, amax_skips, stats, allow_pair=d0.skip_channels == 0)
         if d0.skip_channels == 0:
-            packed = self._packed_tail.get(d0.conv.conv.weight) if d0.conv.split else None
+            packed = self._packed_tail.get(d0.conv.conv.weight) if (d0.conv.split and d0.conv._post is None) else None
             up = None
             if packed is not None and self.pair_tail and self.pair_chain and d0.conv.out_channels <= 12 and not d0.conv.bf16:
                 # deconv0's up-conv hands the tail a PairTensor too (16 channels for KBNet's 12)

@@ -480,15 +480,15 @@ ACT_KINDS = {"elu": _lib.KBN_ACT_ELU, "sigmoid": _lib.KBN_ACT_SIGMOID}
 
 
 @_on_tensor_device
-def activation_(t: torch.Tensor, kind: str) -> torch.Tensor:
+def activation_(t: torch.Tensor, kind: str, out_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """t <- ELU(t) / sigmoid(t) in place (kbn_activation_forward): the activation of a conv that was launched without one, for
     the activations the fused kernels do not carry (reference src/net_utils.py:38-43).  `t`: a dense N x C x H x W tensor or a
-    channel slice of one."""
+    channel slice of one.  `out_absmax`: the tensor's per-frame max |a| slot (ActStats), filled with the maxima of the activated values."""
     lib = _lib.load()
     tptr, tbs = _planes(t, "t")
     n = t.shape[0]
     per = t.shape[1] * t.shape[2] * t.shape[3]
-    check(_launch("activation", 0.0, lambda: lib.kbn_activation_forward(tptr, tbs, n, per, ACT_KINDS[kind], _stream()),
+    check(_launch("activation", 0.0, lambda: lib.kbn_activation_forward(tptr, tbs, n, per, ACT_KINDS[kind], _slot_ptr(out_absmax, n), _stream()),
                   nbytes=8.0 * n * per), "kbn_activation_forward")
     return t
 

@@ -204,10 +204,13 @@ int kbn_conv2d_forward(const kbn_conv_src* srcs, int n_src, const float* packed_
  * (apply_activation = 0) and followed by kbn_activation_forward in place; the KB block's z = act(proj_depth . depth)
  * (:1352-1355) is then a tensor of its own and xyz = coordinates * z (:1357-1359) one kbn_scale_planes_forward.
  *   kbn_activation_forward    x: n frames of per_frame contiguous floats, batch_stride apart; kind KBN_ACT_ELU (v > 0 ? v :
- *                             expm1(v), alpha = 1) or KBN_ACT_SIGMOID (1 / (1 + exp(-v)))
+ *                             expm1(v), alpha = 1) or KBN_ACT_SIGMOID (1 / (1 + exp(-v))); out_absmax (may be NULL): the per-frame
+ *                             max |a| slots of the tensor (above), which receive the maxima of the ACTIVATED values -- the convs in
+ *                             front of this pass are given no slot
  *   kbn_scale_planes_forward  out[n, c, y, x] = x[n, c, y, x] * z[n, 0, y, x], c < channels; dense planes, frames *_batch_stride apart */
 enum { KBN_ACT_ELU = 1, KBN_ACT_SIGMOID = 2 };
-int kbn_activation_forward(float* x, long long batch_stride, int n, long long per_frame, int kind, kbn_stream_t stream);
+int kbn_activation_forward(float* x, long long batch_stride, int n, long long per_frame, int kind, unsigned* out_absmax,
+                           kbn_stream_t stream);
 int kbn_scale_planes_forward(const float* x, long long x_batch_stride, const float* z, long long z_batch_stride, float* out,
                              long long out_batch_stride, int n, int channels, int height, int width, kbn_stream_t stream);
 

@@ -458,8 +458,11 @@ def test_activation_pass_vs_torch(dev, kind, shape):
     x = 4.0 * torch.randn(*shape, generator=g)
     x[0, 0, 0, :3] = torch.tensor([0.0, -1e-8, 30.0])[:min(3, shape[3])]
     ref = torch.nn.functional.elu(x) if kind == "elu" else torch.sigmoid(x)
-    got = kb.ops.activation_(x.to(dev).clone(), kind)
+    stats = kb.ops.ActStats(shape[0], dev)
+    slot = stats.new()
+    got = kb.ops.activation_(x.to(dev).clone(), kind, slot)
     assert float((got.cpu() - ref).abs().max()) < 2e-7 and rel_err(got, ref) < 2e-6
+    assert torch.equal(kb.ops.slot_values(slot), got.abs().amax(dim=(1, 2, 3)))   # the slot takes the ACTIVATED tensor's maxima
     big = torch.cat([x, x, x], dim=1).to(dev)
     c = shape[1]
     kb.ops.activation_(big[:, c:2 * c], kind)
