@@ -550,7 +550,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
 
     # The reference's other architecture switches (run_kbnet.py --deconv_type transpose, --activation_func relu | elu) at the headline's
     # batch and size: what a user of those options gets -- the transposed decoder on the folded up-conv's split kernels, relu in the
-    # shipped kernels (slope 0), elu layer by layer on the fp32-MFMA kernels.  Side measurements, forward only.
+    # shipped kernels (slope 0), elu layer by layer (activation passes of their own; the wide 3x3 convs still on the split-operand kernels).  Side measurements, forward only.
     options_fps = None
     if not args.no_options and not args.eager:
         import dataclasses
