@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkbnet_hip.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["abi.hip", "s2d.hip", "conv_igemm.hip", "conv_dma.hip", "conv_dma_t1.hip", "conv_dma_t2.hip", "conv_dma_t4.hip", "conv_up2x.hip", "conv_wino.hip", "tune.hip", "kb.hip", "kb_pair.hip", "kb_pair_nb3.hip", "kb_pair_nb4.hip", "head.hip", "conv_bf16.hip", "conv_split.hip", "front.hip", "tail.hip", "pre_eval.hip", "unpack.hip", "io_png.hip", "elementwise.hip"]
+SOURCES = ["abi.hip", "s2d.hip", "conv_igemm.hip", "conv_dma.hip", "conv_dma_t1.hip", "conv_dma_t2.hip", "conv_dma_t4.hip", "conv_up2x.hip", "conv_wino.hip", "tune.hip", "kb.hip", "kb_pair.hip", "kb_pair_nb3.hip", "kb_pair_nb4.hip", "head.hip", "conv_split.hip", "front.hip", "tail.hip", "pre_eval.hip", "unpack.hip", "io_png.hip", "elementwise.hip"]
 HEADERS = ["kbn_common.h", "conv_common.h", "conv_dma_impl.h", "kb_pair_impl.h", "front_common.h", "s2d_pools.h", "s2d_stage.h", "conv_split_body.inc", "upconv64_split_body.inc", os.path.join("..", "..", "include", "kbnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function"]

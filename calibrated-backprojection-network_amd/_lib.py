@@ -22,7 +22,7 @@ KBN_SRC_TENSOR, KBN_SRC_COORDS, KBN_SRC_XYZ, KBN_SRC_PAIR = 0, 1, 2, 3
 KBN_ACT_ELU, KBN_ACT_SIGMOID = 1, 2
 KBN_RESIZE_NONE, KBN_RESIZE_NEAREST = 0, 1
 KBN_MAX_SRC = 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class KbnError(RuntimeError):
@@ -112,9 +112,6 @@ SIGNATURES = {
     "kbn_conv1x1s2_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "kbn_conv1x1s2_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "kbn_kb_xyz_s2_forward": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _F, _P, _L, _I, _P]),
-    "kbn_conv3x3_bf16_packed_weight_bytes": (C.c_size_t, [_I, _I]),
-    "kbn_conv3x3_bf16_pack_weight": (_I, [_P, _P, _I, _I, _P]),
-    "kbn_conv3x3_bf16_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P]),
     "kbn_png_info": (_I, [_P, C.c_size_t, _P, _P, _P, _P]),
     "kbn_png_decode": (_I, [_P, C.c_size_t, _P, C.c_size_t]),
     "kbn_png_decode_batch": (_I, [_P, _P, _P, _P, _I, _I, _P]),

@@ -381,220 +381,6 @@ __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const Spli
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// MODE 0 (the concat convs) on v_mfma_f32_16x16x32_f16.  A whole-chip stream of v_mfma_f32_32x32x16_f16 on real data is
-// held at 1.22 PFLOP/s -- exactly what conv3x3_split_kernel<0> executes -- while the 16x16x32 shape sustains 1.83
-// (tools/probe/mfma_power_probe.hip).  Same tile (16 rows x 32 pixels x 64 filters, eight waves of two rows), same LDS
-// layouts for A ([part][k-group][pixel][8 fp16]) and for the weights of a chunk ([tap][part][k-group][64 filters][8]), same
-// packed blob, same staging code; what changes is how a chunk's 16 channels x 9 taps fill the K = 32 of an MFMA:
-//   small terms, one MFMA per tap:    A = [h1 | h2] (channels 0-15 of each),  B = [w2 2^11 | w1]   -> h1 (w2 2^11) + h2 w1
-//   main term,   one MFMA per TWO taps: A = [h1 at tap t | h1 at tap t'],     B = [w1(t) | w1(t')]  -> pairs (0,1) (3,4) (6,7)
-//                                      (next pixel), (2,5) (next row), (8, a tap of zero weights behind the nine)
-// 14 MFMA K-steps of 16 clk per 16 x 16 block and chunk instead of 27 of 32 clk per 32 x 32 block: 4 % more pipe time, one
-// rounding of the main accumulator per 32 products.  A lane of a fragment read is (pixel or filter p = lane & 15,
-// k-slot kq = lane >> 4): the k-slot picks the part / the tap of the pair, so every variant is ONE per-lane base
-// pointer plus compile-time offsets.  D block: filter = lane & 15, pixels 4 (lane >> 4) + r: a float4 per block and lane.
-__global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_k32_kernel(const SplitConvParams p) {
-    constexpr int TH = 16, MB = 2, NT = 64, ROWS = TH + 2, COLS = SP_TW + 2, NPIX = ROWS * COLS, PR = (NPIX + 255) / 256;
-    constexpr int A_PART = 2 * NPIX * 16, A_BYTES = 2 * A_PART;
-    constexpr int B_TAP = 2 * 2 * NT * 16, B_CHUNK = 9 * B_TAP, B_LDS = 10 * B_TAP;   // a tenth tap of zeros behind the nine
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals (see conv3x3_split_kernel)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = rows MB rg, MB rg + 1 of the tile
-    const int lp = lane & 15, kq = lane >> 4, hi = kq >> 1, kg = kq & 1;
-    int bid = xcd_remap(blockIdx.x, p.nblocks);
-    const int nt = bid % p.nTilesN;
-    bid /= p.nTilesN;
-    const int tx = bid % p.tilesX;
-    bid /= p.tilesX;
-    const int ty = bid % p.tilesY;
-    const int n = bid / p.tilesY;
-    const int oy0 = ty * TH, ox0 = tx * SP_TW;
-    const int H = p.H, W = p.W, sH = p.sH, sW = p.sW;
-    const long long plane = (long long)sH * sW;
-    const int nchunks = p.Cin / SP_CK;
-    float prescale, unscale;
-    sp_act_scale(p, n, prescale, unscale);
-
-    const int kg_st = rg >> 2, t256 = tid & 255;
-    int goff[PR];
-#pragma unroll
-    for (int u = 0; u < PR; ++u) {
-        const int pix = u * 256 + t256;
-        const int r = pix / COLS, c = pix - r * COLS;
-        const int Y = oy0 - 1 + r, X = ox0 - 1 + c;
-        goff[u] = (pix < NPIX && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (Y * sW + X) * 4 : -1;
-    }
-    const _Float16* wp_nt = p.wp + (long long)nt * nchunks * (B_CHUNK / 2);
-
-    float va[PR][8];
-    auto load_chunk = [&](int chunk) {
-        int c = chunk * SP_CK, s = 0;
-        if (p.nsrc > 1 && c >= p.srcC[0]) { c -= p.srcC[0]; s = 1; }
-        const float* base = p.src[s] + (long long)n * p.src_bstride[s] + (long long)(c + kg_st * 8) * plane;
-#pragma unroll
-        for (int u = 0; u < PR; ++u) {
-            const unsigned voff = goff[u] < 0 ? 0u : (unsigned)goff[u];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float* sb = base + (long long)k * plane;   // wave-uniform
-                asm volatile("global_load_dword %0, %1, %2" : "=v"(va[u][k]) : "v"(voff), "s"(sb) : "memory");
-            }
-        }
-    };
-    auto store_round = [&](int buf, int u) {
-        unsigned char* A = smem + buf * A_BYTES + kg_st * NPIX * 16;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(va[u][k]));
-        const int pix = u * 256 + t256;
-        if (pix < NPIX) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = goff[u] >= 0 ? va[u][k] : 0.f;
-            sph8 h1, h2;
-            sp_split8(v, prescale, h1, h2);
-            *reinterpret_cast<sph8*>(A + pix * 16) = h1;
-            *reinterpret_cast<sph8*>(A + A_PART + pix * 16) = h2;
-        }
-    };
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
-    auto stage_b = [&](int bbuf, int chunk) {
-        const float* src = reinterpret_cast<const float*>(wp_nt + (long long)chunk * (B_CHUNK / 2));
-        const unsigned dst = lds0 + (unsigned)(2 * A_BYTES + bbuf * B_LDS);
-        constexpr int n4 = B_CHUNK / 16;
-#pragma unroll
-        for (int e0 = 0; e0 < n4; e0 += SP_THREADS) {
-            const int eb = e0 + rg * 64;
-            if (eb + lane < n4) lds_dma16_s(src + eb * 4, (unsigned)(lane * 16), dst + eb * 16);
-        }
-    };
-    // the zero tap of both weight buffers (the DMA never touches it)
-    for (int e = tid; e < 2 * (B_TAP / 16); e += SP_THREADS) {
-        const int b = e / (B_TAP / 16), w = e - b * (B_TAP / 16);
-        *reinterpret_cast<f32x4*>(smem + 2 * A_BYTES + b * B_LDS + B_CHUNK + w * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    spf4 acc[MB][2][4], lo[MB][2][4];   // [row][16-pixel half][16-filter quarter]
-#pragma unroll
-    for (int i = 0; i < MB * 8; ++i) {
-        acc[i >> 3][(i >> 2) & 1][i & 3] = (spf4){0.f, 0.f, 0.f, 0.f};
-        lo[i >> 3][(i >> 2) & 1][i & 3] = (spf4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    // per-lane fragment bases (bytes): the k-slot kq = 2 hi + kg selects the split term / the tap of a pair
-    const int apix = (kg * NPIX + MB * rg * COLS + lp) * 16;
-    const unsigned char* const a_s = smem + hi * A_PART + apix;          // [h1 | h2]
-    const unsigned char* const a_dx = smem + apix + hi * 16;             // [h1 | h1 of the next pixel]
-    const unsigned char* const a_dy = smem + apix + hi * COLS * 16;      // [h1 | h1 of the next row]
-    const unsigned char* const a_0 = smem + apix;                        // [h1 | h1] (against [w1 | 0])
-    const int bfil = (kg * NT + lp) * 16;
-    const unsigned char* const bbase = smem + 2 * A_BYTES;
-    const unsigned char* const b_s = bbase + (1 - hi) * 2 * NT * 16 + bfil;   // [w2 2^11 | w1]
-    const unsigned char* const b_dx = bbase + hi * B_TAP + bfil;              // [w1(t) | w1(t + 1)]
-    const unsigned char* const b_dy = bbase + hi * 3 * B_TAP + bfil;          // [w1(t) | w1(t + 3)]
-
-    // K-steps of a chunk: s < 5 main pairs, then the nine small-term steps
-    struct KStep { int ky, kx, tap, akind, bkind, small; };   // akind: 0 a_s 1 a_dx 2 a_dy 3 a_0; bkind: 0 b_s 1 b_dx 2 b_dy
-    auto kstep = [](int s) constexpr -> KStep {
-        if (s == 0) return KStep{0, 0, 0, 1, 1, 0};
-        if (s == 1) return KStep{1, 0, 3, 1, 1, 0};
-        if (s == 2) return KStep{2, 0, 6, 1, 1, 0};
-        if (s == 3) return KStep{0, 2, 2, 2, 2, 0};
-        if (s == 4) return KStep{2, 2, 8, 3, 1, 0};
-        return KStep{(s - 5) / 3, (s - 5) % 3, s - 5, 0, 0, 1};
-    };
-    const bool wave_live = oy0 + MB * rg < H;   // wave-uniform
-    constexpr int NSTEP = 14, WAIT_STEP = 7;
-    static_assert(WAIT_STEP + PR <= NSTEP, "the staging rounds follow the wait inside the chunk");
-
-    auto body = [&](int c, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        const int abuf = (c & 1) * A_BYTES, bbuf = (c & 1) * B_LDS;
-        if (MORE) {
-            stage_b((c & 1) ^ 1, c + 1);
-            load_chunk(c + 1);
-        }
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            constexpr int dummy = 0; (void)dummy;
-            const KStep ks = kstep(s);
-            const unsigned char* ab = ks.akind == 0 ? a_s : ks.akind == 1 ? a_dx : ks.akind == 2 ? a_dy : a_0;
-            const unsigned char* bb = ks.bkind == 0 ? b_s : ks.bkind == 1 ? b_dx : b_dy;
-            sph8 a[MB][2], b[4];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int ph = 0; ph < 2; ++ph)
-                    a[mb][ph] = *reinterpret_cast<const sph8*>(ab + abuf + ((mb + ks.ky) * COLS + 16 * ph + ks.kx) * 16);
-#pragma unroll
-            for (int fq = 0; fq < 4; ++fq) b[fq] = *reinterpret_cast<const sph8*>(bb + bbuf + ks.tap * B_TAP + fq * 16 * 16);
-            if (MORE && s == WAIT_STEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's weights (DMA) and inputs
-            if (wave_live) {   // a wave whose rows lie below the map (22 rows in 16-row tiles) only stages: one branch per K-step
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-                        for (int fq = 0; fq < 4; ++fq) {
-                            spf4& d = ks.small ? lo[mb][ph][fq] : acc[mb][ph][fq];
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][ph], b[fq], d, 0, 0, 0);
-                        }
-            }
-            if (MORE && s >= WAIT_STEP && s - WAIT_STEP < PR) store_round((c & 1) ^ 1, s - WAIT_STEP);
-        }
-        __syncthreads();
-    };
-
-    load_chunk(0);
-    stage_b(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < PR; ++u) store_round(0, u);
-    __syncthreads();
-    for (int c = 0; c + 1 < nchunks; ++c) body(c, std::true_type{});
-    body(nchunks - 1, std::false_type{});
-
-    // ---- epilogue: block [mb][ph][fq]: filter 16 fq + lp, pixels x = 16 ph + 4 kq + r of row MB rg + mb
-    const long long oplane = (long long)H * W;
-    float* outn = p.out + (long long)n * p.out_bstride;
-    const float slope = p.act ? p.slope : 1.f;
-    const bool vec4 = p.vec4 != 0;
-    float amax = 0.f;
-#pragma unroll
-    for (int fq = 0; fq < 4; ++fq) {
-        const int oc = nt * NT + fq * 16 + lp;
-        const float inv = p.inv_scale[oc] * unscale;               // the table is padded to whole n-tiles
-        if (oc >= p.OC) continue;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int Y = oy0 + MB * rg + mb;
-            if (Y >= H) continue;
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
-                const int X = ox0 + 16 * ph + 4 * kq;
-                if (X >= W) continue;
-                float* o = outn + (long long)oc * oplane + (long long)Y * W + X;
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float t = __builtin_fmaf(lo[mb][ph][fq][j], 0.00048828125f, acc[mb][ph][fq][j]) * inv;   // main + 2^-11 small
-                    v[j] = t > 0.f ? t : t * slope;
-                }
-                if (vec4) {
-                    *reinterpret_cast<f32x4*>(o) = v;
-                    amax = sp_amax4(amax, v);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (X + j < W) { o[j] = v[j]; amax = fmaxf(amax, fabsf(v[j])); }
-                }
-            }
-        }
-    }
-    if (p.out_amax) absmax_commit(p.out_amax + n, amax);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // Nearest-2x up-conv in its FOLDED form on split operands (MODE 3 of the entry point).  An output pixel (2Y+py, 2X+px)
 // of conv3x3(upsample2x(x)) only sees the 2 x 2 low-resolution pixels (Y+py-1+dy, X+px-1+dx), dy, dx in {0, 1}, with
 // the 3 x 3 weights summed over the taps that land on the same source pixel (rows: py 0 -> {0}, {1,2}; py 1 -> {0,1},
@@ -1668,7 +1454,7 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
         if (s == 0) { p.sH = a.src_height; p.sW = a.src_width; }
         if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
         if (pair) {   // source 0 of the concat conv / the input of a folded up-conv, written by a split-operand producer
-            if (s != 0 || mode == 1 || (knob(KNOB_DEBUG) & (16 | 64))) return KBN_ERR_UNSUPPORTED;
+            if (s != 0 || mode == 1 || (knob(KNOB_DEBUG) & 16)) return KBN_ERR_UNSUPPORTED;
             if (mode == 2 && n_src != 1) return KBN_ERR_UNSUPPORTED;
             // the concat kernel's K loop: a pair source beside an fp32 one, at least two 16-channel chunks each
             if (mode == 0 && (n_src != 2 || a.channels < 2 * SP_CK || srcs[1].kind != KBN_SRC_TENSOR || srcs[1].channels < 2 * SP_CK))
@@ -1705,7 +1491,7 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     if (pair_out) {   // the output as a pair tensor: concat convs and the 64-filter folded up-convs; its 2^k needs every source's slot
         // the narrow up-conv writes 16 channels (two k-groups, zeros past out_channels): its pair tensor feeds the decoder tail
         const bool narrow = mode == 3 && uf_narrow(out_channels, cin) && !(knob(KNOB_DEBUG) & 128);
-        const bool kernel_ok = (mode == 0 && !(knob(KNOB_DEBUG) & 64)) || (mode == 3 && ntf == U64_NT && !uf_narrow(out_channels, cin)) ||
+        const bool kernel_ok = (mode == 0) || (mode == 3 && ntf == U64_NT && !uf_narrow(out_channels, cin)) ||
                                (mode == 2 && n_src == 1) || narrow;
         if (!kernel_ok || (!narrow && (out_channels & 7))) return KBN_ERR_UNSUPPORTED;
         const int pair_channels = narrow ? U16_NT : out_channels;
@@ -1800,14 +1586,9 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     }
     switch (mode) {
         case 0:
-            // KBN_DEBUG & 64: the 16x16x32 form.  On random operands (tools/split_bench.py) it is 2-15 % faster than the
-            // 32x32x16 kernel; on the network's own activations the 32x32x16 kernel runs 12-20 % faster than on random ones
-            // (its limit is the power its data draws) and the 16x16x32 form does not (673 / 538 / 1369 / 1565 us against
-            // 629 / 539 / 1334 / 1469 us for deconv4 .. deconv1's convs inside a KITTI forward): off.
-            if (knob(KNOB_DEBUG) & 64) {
-                static DeviceOnce ok32;
-                rc = launch(conv3x3_split_k32_kernel, SpGeom<0>::LDS + 2 * 10 * 2 * 2 * 64 * 16, ok32);
-            } else {
+            // (a 16x16x32 form of this kernel was built and measured in round 2 -- profiles/r02/HISTORY.md: 1-7 % slower
+            // inside the forward -- and removed in round 6)
+            {
                 constexpr size_t lds0 = SpGeom<0>::LDS + 2 * 9 * 2 * 2 * 64 * 16;
                 // a map whose width leaves 1-16 columns behind the whole 32-column tiles: that column goes to a launch of
                 // transposed tiles (32 rows x 16 columns), half the MFMAs of the tiles it replaces (KBN_DEBUG & 512: off)

@@ -106,9 +106,7 @@ class _PackedWeight:
     def get(self, weight: torch.Tensor, stride: int, up2x: bool = False) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, weight.device, stride, up2x)
         if key != self._key:
-            if up2x == "bf16":      # throughput-only bf16 leg (ops.conv3x3_bf16)
-                self._packed = ops.pack_conv3x3_bf16_weight(weight, out=self._packed)
-            elif up2x == "split":   # fp32-grade products on the 16-bit matrix core (ops.conv3x3_split)
+            if up2x == "split":   # fp32-grade products on the 16-bit matrix core (ops.conv3x3_split)
                 self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, stride=stride)
             elif up2x == "split_up":   # the same for the folded nearest-2x up-conv
                 self._packed = ops.pack_conv3x3_split_weight(weight, out=self._packed, folded_up2x=True)
@@ -230,14 +228,12 @@ class Conv2d(torch.nn.Module):
         self._slope = _slope(activation_func)
         self._post = _post(activation_func)
         self._packed = _PackedWeight()
-        self._packed_bf16 = _PackedWeight()
         self._packed_split = _PackedWeight()
         self._packed_split_up = _PackedWeight()
         self._packed_split_1x1 = _PackedWeight()
         # conv_fused on split operands from this width on: KB3 / KB4 (192 / 384 filters: 239 vs 285 and 152 vs 253 us per 32
         # KITTI frames); at KB2's 96 filters the layer is bound by its stride-2 HBM reads either way (365 vs 342 us)
         self.split_fused_min_filters = 192
-        self.bf16 = False   # throughput-only bf16 MFMA leg (MultiScaleDecoder.set_bf16); never the parity-gated path
         self.split = True   # fp32-grade 3x3 convs on the 16-bit matrix core where the shape qualifies
         # the folded up-conv of a layer with at most 16 filters has 16-filter tiles (upconv2x_split16_kernel): deconv0's
         # 64 -> 12 up-conv.  Level with the fp32 9-product kernel on random operands (650 vs 640 us per 32 KITTI frames),
@@ -289,17 +285,6 @@ class Conv2d(torch.nn.Module):
     def packed(self):
         return self._packed.get(self.conv.weight, self.stride)
 
-    def run_bf16(self, srcs, n, h, w, out=None, up2x=False):
-        """3x3 conv with bf16 MFMA operands (ops.conv3x3_bf16); `h` x `w` is the OUTPUT size.  None when the layer or
-        the shape does not qualify (kernel 3, input channels of every source % 16, output width % 4)."""
-        if (not self.bf16 or self.kernel_size != 3 or w % 4 or len(srcs) > 2 or any(s.channels % 16 for s in srcs)
-                or (up2x and self.stride != 1)):
-            return None
-        if out is None:
-            out = torch.empty((n, self.out_channels, h, w), device=self.conv.weight.device, dtype=torch.float32)
-        return ops.conv3x3_bf16(srcs, self._packed_bf16.get(self.conv.weight, 1, up2x="bf16"), n, self.out_channels, h, w,
-                                out, up2x=up2x, negative_slope=self._slope, stride=self.stride)
-
     def run(self, srcs, n, in_h, in_w, out=None, resize=False, out_absmax=None, stats=None):
         """`out_absmax`: slot (ops.ActStats) that receives max |out| per frame; `stats`: where slots for unmeasured
         inputs come from (split-operand launches only)."""
@@ -308,7 +293,7 @@ class Conv2d(torch.nn.Module):
             raise KbnError(f"expected {self.in_channels} input channels in total, got {cin}")
         oh, ow = -(-in_h // self.stride), -(-in_w // self.stride)
         if self._post is not None:   # ELU / sigmoid: the conv without activation (split operands where the shape qualifies), then the activation in place
-            if not resize and not self.bf16:
+            if not resize:
                 res = self.run_split(srcs, n, oh, ow, out=out, out_absmax=out_absmax, stats=stats)   # (_run_split finishes the layer)
                 if res is not None:
                     return res
@@ -317,12 +302,6 @@ class Conv2d(torch.nn.Module):
             res = ops.conv2d(srcs, self.packed(), n, self.out_channels, self.kernel_size, self.stride, in_h, in_w, out,
                              resize=resize, negative_slope=None)
             return _finish(self, res, out_absmax, stats)
-        if self.bf16 and not resize:
-            res = self.run_bf16(srcs, n, oh, ow, out=out)
-            if res is not None:
-                if stats is not None:
-                    stats.skip(out_absmax)   # the bf16 kernels fold no maxima
-                return res
         if not resize:
             res = self.run_split(srcs, n, oh, ow, out=out, out_absmax=out_absmax, stats=stats)
             if res is not None:
@@ -422,7 +401,6 @@ class UpConv2d(torch.nn.Module):
         self._packed_up2x = _PackedWeight()
         self.split_up = True    # folded 16-product form on split operands (ops.conv3x3_split(folded_up2x=True))
 
-    bf16 = property(lambda self: self.conv.bf16)
     out_channels = property(lambda self: self.conv.out_channels)
 
     def forward(self, x, shape, amax=None, out_absmax=None, stats=None, pair_out=False):
@@ -438,7 +416,7 @@ class UpConv2d(torch.nn.Module):
                 x = x if _dense(x) else x.contiguous()
             n, _, h, w = x.shape
             oh, ow = int(shape[0]), int(shape[1])
-            if (oh, ow) != (2 * h, 2 * w) or self.conv.kernel_size != 3 or self.conv.bf16 or not self.split_up:
+            if (oh, ow) != (2 * h, 2 * w) or self.conv.kernel_size != 3 or not self.split_up:
                 return None
             src = ops.pair_src(x, "x") if pair_in else ops.tensor_src(x, "x", amax)
             return self.conv.run_split([src], n, oh, ow, up2x=True, out_absmax=out_absmax, stats=stats, pair_out=pair_out)
@@ -446,12 +424,6 @@ class UpConv2d(torch.nn.Module):
         n, _, h, w = x.shape
         oh, ow = int(shape[0]), int(shape[1])
         if (oh, ow) == (2 * h, 2 * w) and self.conv.kernel_size == 3:
-            if self.conv.bf16:
-                res = self.conv.run_bf16([ops.tensor_src(x, "x")], n, oh, ow, up2x=True)
-                if res is not None:
-                    if stats is not None:
-                        stats.skip(out_absmax)
-                    return res
             if self.split_up:
                 res = self.conv.run_split([ops.tensor_src(x, "x", amax)], n, oh, ow, up2x=True, out_absmax=out_absmax, stats=stats)
                 if res is not None:
@@ -491,7 +463,6 @@ class TransposeConv2d(torch.nn.Module):
         self._packed_up2x = _PackedWeight()
         self.split = True
         self.split_narrow_up = True
-        self.bf16 = False                                 # no bf16 leg for this layer
 
     def forward(self, x, shape=None, amax=None, out_absmax=None, stats=None, pair_out=False):
         """`shape` is accepted and ignored, as in the reference's DecoderBlock (:1468-1469: the transposed conv fixes the size).
@@ -590,7 +561,7 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         # as one: the encoder's chain of stride-2 split convs (KBNetEncoder.encode); None when the pair kernels decline
         pair_in = isinstance(image, ops.PairTensor)
         if (pair_in or pair_image_out) and not (self.conv_image.conv_block[0].split and self.split_image and self.split_fused
-                                                and coordinates.dim() == 3 and not self.conv_image.conv_block[0].bf16 and stats is not None
+                                                and coordinates.dim() == 3 and stats is not None
                                                 and not self.stacked and not self.layerwise):
             return None
         n, ci, h, w = image.shape
@@ -614,20 +585,6 @@ class CalibratedBackprojectionBlock(torch.nn.Module):
         else:
             coords = coordinates.contiguous()
         ci_conv = self.conv_image.conv_block[0]
-        if ci_conv.bf16 and kinv is not None:
-            # THROUGHPUT-ONLY bf16 leg: conv_image (most of the block's FLOPs) on bf16 MFMAs; conv_depth and conv_fused --
-            # their inputs are synthesized in-kernel (K^-1 [x y 1]^T, backprojection) -- stay on the fp32 conv kernels.
-            res = ci_conv.run_bf16([ops.tensor_src(image, "image")], n, oh, ow, out=out_image)
-            if res is not None:
-                if stats is not None:
-                    stats.skip(out_amax_image)
-                self.conv_depth.conv_block[0].run([ops.tensor_src(depth, "depth"), ops.coords_src(kinv)], n, h, w, out=out_depth,
-                                                  out_absmax=out_amax_skip)
-                srcs = [ops.tensor_src(image, "image"), ops.xyz_src(depth, self.proj_depth.conv.weight, kinv)]
-                if fused is not None:
-                    srcs.append(ops.tensor_src(fused, "fused"))
-                self.conv_fused.run(srcs, n, h, w, out=out_fused, out_absmax=out_amax_skip)
-                return out_image, out_depth, out_fused
         if ci_conv.split and self.split_image and kinv is not None:
             # conv_image (most of the block's FLOPs) on the 16-bit matrix core (fp32-grade split operands); conv_depth and
             # conv_fused -- their inputs are synthesized in-kernel (K^-1 [x y 1]^T, backprojection) -- on the fp32 kernels
@@ -746,7 +703,7 @@ class DecoderBlock(torch.nn.Module):
         for the result and the slot pool of the forward (ops.ActStats); missing input slots are measured.  `x` may be an
         ops.PairTensor and `pair_out` asks for one (the decoder's chain of split-operand kernels, MultiScaleDecoder);
         None when the pair kernels decline a shape (the caller repeats the block in fp32)."""
-        if pair_out and (self.conv.bf16 or self.deconv.bf16 or not self.conv.split or self.conv.out_channels < 48
+        if pair_out and (not self.conv.split or self.conv.out_channels < 48
                          or self.conv.out_channels % 8 or self.conv.kernel_size != 3 or self.conv._post is not None):
             return None   # declined before anything is launched
         if self.deconv_type == "transpose":
@@ -766,8 +723,7 @@ class DecoderBlock(torch.nn.Module):
         # inside the pair chain the up-conv's output goes to the concat conv as a PairTensor too (that kernel wants at least
         # two 16-channel chunks from each of its two sources)
         deconv = None
-        if (pair_out and self.pair_mid and skip is not None and self.skip_channels >= 32 and self.deconv.out_channels >= 32
-                and not self.conv.bf16):
+        if (pair_out and self.pair_mid and skip is not None and self.skip_channels >= 32 and self.deconv.out_channels >= 32):
             deconv = self.deconv(x, shape=shape, amax=amax_x, out_absmax=amax_deconv, stats=stats, pair_out=True)
         if deconv is None:
             deconv = self.deconv(x, shape=shape, amax=amax_x, out_absmax=amax_deconv, stats=stats)
@@ -778,8 +734,6 @@ class DecoderBlock(torch.nn.Module):
             skip = skip if _dense(skip) else skip.contiguous()
             srcs.append(ops.tensor_src(skip, "skip", amax_skip))  # torch.cat([deconv, skip]) fused into the K loop
         if pair_out:
-            if self.conv.bf16:
-                return None
             return self.conv.run_split(srcs, x.shape[0], int(shape[0]), int(shape[1]), out_absmax=out_absmax, stats=stats, pair_out=True)
         return self.conv.run(srcs, x.shape[0], int(shape[0]), int(shape[1]), out_absmax=out_absmax, stats=stats)
 
@@ -911,7 +865,7 @@ class KBNetEncoder(torch.nn.Module):
         blk = self.calibrated_backprojection1
         ci, cf, cd = blk.conv_image.conv_block[0], blk.conv_fused, blk.conv_depth.conv_block[0]
         c0 = self.conv0_image
-        if (not self.front or not c0.split or not ci.split or ci.bf16 or c0._slope is None or blk.proj_depth._slope is None
+        if (not self.front or not c0.split or not ci.split or c0._slope is None or blk.proj_depth._slope is None
                 or cf.in_channels != c0.out_channels + 3 or not _dense(image) or blk.stacked):
             return None
         n, _, h, w = image.shape
@@ -961,7 +915,7 @@ class KBNetEncoder(torch.nn.Module):
         nxt, nxt_info = None, None
         blk2 = getattr(self, "calibrated_backprojection2", None) if 1 in self.resolutions_backprojection else None
         if (self.front_next and blk2 is not None and kinv_next is not None and not blk2.stacked and blk2.split_image
-                and blk2.conv_image.conv_block[0].split and not blk2.conv_image.conv_block[0].bf16
+                and blk2.conv_image.conv_block[0].split
                 and blk2.conv_fused.in_channels == ci.out_channels + 3 + cf.out_channels and blk2.proj_depth._slope is not None
                 and ops.kb1_front_next_supported(image.shape[1], c0.out_channels, ci.out_channels, blk2.n_filter_fused, h, w, c0._slope)):
             packed_n = self._packed_front_next.get(blk2.conv_fused.conv.weight)
@@ -977,15 +931,6 @@ class KBNetEncoder(torch.nn.Module):
                          c0._slope, blk._slope, a_img, a_skip, next_fused=nxt) is None:
             raise KbnError("kb1_front declined a problem kbn_kb1_front_query accepted")
         return skip, out_image, out_depth, out_fused, a_img, a_skip, nxt_info
-
-    def set_bf16(self, enabled: bool = True):
-        """THROUGHPUT-ONLY switch (see MultiScaleDecoder.set_bf16): the stride-2 image convs of the KB blocks and both
-        convs of level 4 run with bf16 MFMA operands; conv0, conv_depth and conv_fused (narrow or synthesized inputs)
-        stay on the fp32 kernels."""
-        for name, m in self.named_modules():
-            if isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 2 and m.in_channels % 16 == 0:
-                m.bf16 = bool(enabled)
-        return self
 
     def forward(self, image, depth, intrinsics):
         latent, skips, _, _ = self.encode(image, depth, intrinsics)
@@ -1140,15 +1085,6 @@ class MultiScaleDecoder(torch.nn.Module):
         self.output0 = Conv2d(n_filters[4], output_channels, 3, 1, weight_initializer, None)
         self._packed_tail = _PackedTail()
 
-    def set_bf16(self, enabled: bool = True):
-        """THROUGHPUT-ONLY switch (BASELINE configs[2]'s bf16 figure): the decoder's 3x3 stride-1 convs with at least 16
-        input channels run with bf16 MFMA operands and fp32 accumulation (csrc/conv_bf16.hip).  Misses the 1e-4 parity
-        bar by construction; bench.py reports its rate and measured error under separate keys."""
-        for m in self.modules():
-            if isinstance(m, Conv2d):
-                m.bf16 = bool(enabled)
-        return self
-
     def features(self, x, skips, shape):
         """Everything up to (not including) output0."""
         stats = ops.ActStats(x.shape[0], x.device)
@@ -1195,7 +1131,7 @@ class MultiScaleDecoder(torch.nn.Module):
         if d0.skip_channels == 0:
             packed = self._packed_tail.get(d0.conv.conv.weight) if (d0.conv.split and d0.conv._post is None) else None
             up = None
-            if packed is not None and self.pair_tail and self.pair_chain and d0.conv.out_channels <= 12 and not d0.conv.bf16:
+            if packed is not None and self.pair_tail and self.pair_chain and d0.conv.out_channels <= 12:
                 # deconv0's up-conv hands the tail a PairTensor too (16 channels for KBNet's 12)
                 up = d0.deconv(x, shape=tuple(shape)[-2:], amax=amax, stats=stats, pair_out=True)
                 if up is not None:
@@ -1462,14 +1398,6 @@ class KBNetModel(object):
         return self.decoder.depth(latent, skips, shape, self.min_predict_depth, self.max_predict_depth,
                                   return_logits=return_logits, out=out, amax_x=amax_latent, amax_skips=amax_skips, stats=stats)
 
-    def set_bf16(self, enabled: bool = True):
-        """THROUGHPUT-ONLY bf16 leg (BASELINE configs[2]): every 3x3 conv with at least 16 (a multiple of 16) input channels
-        per source -- the decoder's up-convs and concat convs, the stride-2 image convs of the encoder -- on bf16 MFMAs
-        with fp32 accumulation.  Misses the 1e-4 parity bar by construction; never the default."""
-        self.encoder.set_bf16(enabled)
-        self.decoder.set_bf16(enabled)
-        return self
-
     def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1, split_graphs=False):
         """Captures one forward of this batch shape into a HIP graph and returns a callable
         `replay(image, sparse_depth, validity_map_depth, intrinsics) -> depth` (inputs are copied
@@ -1489,7 +1417,6 @@ class KBNetModel(object):
             for sub in m.modules():
                 if isinstance(sub, Conv2d):
                     sub._packed.refresh(sub.conv.weight)
-                    sub._packed_bf16.refresh(sub.conv.weight)
                     sub._packed_split.refresh(sub.conv.weight)
                     sub._packed_split_up.refresh(sub.conv.weight)
                     sub._packed_split_1x1.refresh(sub.conv.weight)

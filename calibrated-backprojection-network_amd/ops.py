@@ -77,11 +77,11 @@ def autotune(enabled: bool = True):
 # issues on the matrix cores (Winograd / phase-decomposed up-convs execute fewer; tile and channel padding
 # execute more), None for byte-bound launches; `pipe` names the pipe those MFMAs run on -- "fp32"
 # (v_mfma_f32_*_f32: the vector datapath's 157.3 TFLOP/s), "fp16" (split-operand kernels: three fp16 MFMAs per fp32
-# product on the 2.5 PFLOP/s matrix core), "bf16" (the throughput-only leg) -- so that whoever prices `executed`
+# product on the 2.5 PFLOP/s matrix core) -- so that whoever prices `executed`
 # uses the right peak; `nbytes` the launch's ALGORITHMIC HBM bytes (every input read once + every output written once).
 PROFILE = None
-PIPE_PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0, "bf16": 2500.0}    # MI355X_MICROARCH.md, dense
-PIPE_PRODUCTS = {"fp32": 1.0, "fp16": 3.0, "bf16": 1.0}              # MFMA products issued per product of the reference
+PIPE_PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0}    # MI355X_MICROARCH.md, dense
+PIPE_PRODUCTS = {"fp32": 1.0, "fp16": 3.0}    # MFMA products issued per product of the reference
 
 
 def _launch(name: str, work: float, fn, executed=None, pipe: Optional[str] = None, nbytes: Optional[float] = None):
@@ -183,7 +183,7 @@ class ActStats:
     def __init__(self, n: int, device, capacity: int = 40):
         self.buf = torch.zeros((capacity, n), device=device, dtype=torch.int32)
         self.n, self.used = n, 0
-        self.unfilled = set()   # data_ptr of slots handed to a launch that does not fill them (the throughput-only bf16 kernels)
+        self.unfilled = set()   # data_ptr of slots handed to a launch that does not fill them (a layer-by-layer activation pass in between)
 
     def skip(self, slot: Optional[torch.Tensor]):
         """A producer that writes (part of) the slot's tensor without folding its maxima: consumers measure the tensor."""
@@ -1216,55 +1216,6 @@ def s2d_depth_front(x: torch.Tensor, kinv: torch.Tensor, packed_s2d: torch.Tenso
         return None
     check(status, "kbn_s2d_depth_front_forward")
     return out_depth, xyz
-
-
-# ----------------------------------------------------- bf16 leg (throughput-only)
-@_on_tensor_device
-def pack_conv3x3_bf16_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """OIHW fp32 3x3 weight -> bf16 MFMA blob for `conv3x3_bf16` (in_channels % 16 == 0)."""
-    lib = _lib.load()
-    w = weight.detach().contiguous()
-    _require(w, "weight", 4)
-    oc, cin, kh, kw = w.shape
-    nbytes = lib.kbn_conv3x3_bf16_packed_weight_bytes(oc, cin) if (kh, kw) == (3, 3) else 0
-    if nbytes == 0:
-        raise KbnError(f"conv3x3_bf16 needs a 3x3 weight with in_channels % 16 == 0, got {tuple(w.shape)}")
-    packed = out if _reusable(out, nbytes // 4, w) else torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    check(lib.kbn_conv3x3_bf16_pack_weight(w.data_ptr(), packed.data_ptr(), oc, cin, _stream()), "kbn_conv3x3_bf16_pack_weight")
-    return packed
-
-
-@_on_tensor_device
-def conv3x3_bf16(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
-                 out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1):
-    """THROUGHPUT-ONLY: 3x3 conv (+ LeakyReLU) of up to two concatenated sources with bf16 MFMA operands and fp32
-    accumulation (kbn_conv3x3_bf16_forward); `height` x `width` is the OUTPUT size; `up2x`: the single source is
-    nearest-upsampled by 2 first; `stride` 2: sources are the (2x larger) input planes.  Returns None when the shape does
-    not qualify (the caller then stays on the fp32 kernels)."""
-    lib = _lib.load()
-    arr = (ConvSrc * len(srcs))(*srcs)
-    optr, obs = _planes(out, "out")
-    if tuple(out.shape) != (n, out_channels, height, width):
-        raise KbnError(f"out has shape {tuple(out.shape)}, expected {(n, out_channels, height, width)}")
-    cin = sum(s.channels for s in srcs)
-    flops = 2.0 * n * height * width * cin * 9 * out_channels
-    if up2x and stride != 1:
-        raise KbnError("conv3x3_bf16: up2x and stride 2 are mutually exclusive")
-    status = _launch("conv_bf16", flops,
-                     lambda: lib.kbn_conv3x3_bf16_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
-                                                          out_channels, height, width, 1 if up2x else (2 if stride == 2 else 0),
-                                                          0 if negative_slope is None else 1,
-                                                          0.0 if negative_slope is None else float(negative_slope),
-                                                          _stream()),
-                     # 16 x 32 pixels x 64 filters per workgroup (csrc/conv_bf16.hip): tile padding is issued
-                     executed=2.0 * n * (-(-height // 16) * 16) * (-(-width // 32) * 32) * cin * 9 * (-(-out_channels // 64) * 64),
-                     pipe="bf16", nbytes=_src_bytes(srcs, n) + 4.0 * n * height * width * out_channels)
-    if status == _lib.KBN_ERR_UNSUPPORTED:
-        if PROFILE is not None:
-            PROFILE.pop()
-        return None
-    check(status, "kbn_conv3x3_bf16_forward")
-    return out
 
 
 # ------------------------------------------------------- pre-model stage / evaluation

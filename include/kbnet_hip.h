@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KBN_ABI_VERSION 6
+#define KBN_ABI_VERSION 7
 
 typedef void* kbn_stream_t; /* hipStream_t */
 
@@ -324,28 +324,6 @@ int kbn_kb_xyz_s2_forward(const float* depth, long long depth_batch_stride, int 
                           const float* proj_weight, const float* kinv, int apply_activation, float negative_slope, float* xyz,
                           long long xyz_batch_stride, int n, kbn_stream_t stream);
 
-
-/* ---------------------------------------------------- bf16 leg (THROUGHPUT-ONLY) ------
- * BASELINE.json configs[2] asks for a bf16 figure next to the fp32 one.  bf16 convolutions miss the
- * 1e-4 parity bar by two orders of magnitude, so nothing on the parity-gated path uses
- * these entry points; they exist to MEASURE the alternative: a 3x3 conv (+ LeakyReLU) with bf16 MFMA
- * operands and fp32 accumulation, the shape of both convs of a DecoderBlock (reference
- * src/net_utils.py:484-499: nearest-2x then conv; :1483-1487: conv over cat[deconv, skip]) and of the
- * stride-2 image convs of the encoder.  Tensors stay fp32 NCHW like everywhere else; inputs and
- * weights are rounded to bf16 (nearest even) on their way into the matrix cores.
- *   mode      0: 3x3 stride 1 (height x width source planes); 1: nearest-2x up-conv (ONE source with (height/2) x
- *             (width/2) planes); 2: 3x3 stride 2 (source planes h x w with ceil(h/2) = height, ceil(w/2) = width: the
- *             image convs of the KB blocks and conv5, reference src/net_utils.py:1348, src/networks.py:521-525)
- *   srcs      1 or 2 KBN_SRC_TENSOR sources, each a multiple of 16 channels
- *   packed    from kbn_conv3x3_bf16_pack_weight (OIHW fp32 3x3 weight in)
- *   out       N x out_channels x height x width, frames out_batch_stride elements apart
- * KBN_ERR_UNSUPPORTED unless width % 4 == 0 and `out` is 16-byte aligned. */
-size_t kbn_conv3x3_bf16_packed_weight_bytes(int out_channels, int in_channels);
-int kbn_conv3x3_bf16_pack_weight(const float* weight, void* packed, int out_channels, int in_channels,
-                                 kbn_stream_t stream);
-int kbn_conv3x3_bf16_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
-                             long long out_batch_stride, int n, int out_channels, int height, int width,
-                             int mode, int apply_activation, float negative_slope, kbn_stream_t stream);
 
 /* Which kernel variant / tile geometry kbn_conv2d_forward picks for a problem (diagnostics,
  * profiling): info[8] = {CK, NB, MW, TWB, TH, workgroups, staged positions per thread, kernel};

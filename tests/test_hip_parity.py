@@ -710,7 +710,6 @@ def test_conv_tail_kernel(dev, kenv, c, shape, amag):
     kenv.delenv("KBN_NO_SPLIT")
 
 
-# ------------------------------------------------- bf16 leg (throughput-only, never parity-gated)
 @pytest.mark.parametrize("cins,cout,hw,kind", [((32,), 48, (16, 64), "plain"), ((64, 64), 64, (22, 76), "plain"),
                                                ((128,), 64, (20, 36), "up2x"), ((16, 32), 130, (9, 40), "plain"),
                                                ((256, 512), 256, (22, 76), "plain"), ((64,), 96, (36, 72), "up2x"),
@@ -1016,38 +1015,6 @@ def test_pair_tensor_chain_of_stride2_convs(dev, c0, c1, c2, hw):
         assert kb.ops.conv1x1s2_split([kb.ops.tensor_src(pt.sub, "image", pt.absmax), kb.ops.tensor_src(fused, "fused", fslot)], pf, xyz,
                                       n, c2, oh, ow, sub, negative_slope=0.2) is not None
         assert torch.equal(sub, full), "same values fetched from the side output: same bits"
-
-
-@pytest.mark.parametrize("cins,cout,hw", [((64, 64), 64, (22, 76)), ((32,), 48, (16, 64)), ((16, 32), 130, (9, 40)), ((128, 128), 128, (37, 52))])
-def test_conv3x3_split_k32_form(dev, kenv, cins, cout, hw):
-    """The 16x16x32 form of the concat-conv kernel (conv3x3_split_k32_kernel, KBN_DEBUG=64; off by default: slower on the
-    network's activations): same packed blob, same bars against fp64, and the 32x32x16 kernel's result within the suite's
-    single-op tolerance (the two sum in different orders)."""
-    h, w = hw
-    g = torch.Generator().manual_seed(sum(cins) + cout + h)
-    n = 2
-    xs = [torch.nn.functional.leaky_relu(torch.randn(n, c, h, w, generator=g), 0.2) for c in cins]
-    cin = sum(cins)
-    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
-    wt[1] *= 1e-3
-    ref64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.cat(xs, 1).double(), wt.double(), padding=1), 0.2)
-    srcs_t = [x.to(dev) for x in xs]
-    stats = kb.ops.ActStats(n, dev)
-    srcs = [kb.ops.tensor_src(x, "x", stats.measure(x)) for x in srcs_t]
-    packed = kb.ops.pack_conv3x3_split_weight(wt.to(dev))
-    base = torch.empty(n, cout, h, w, device=dev)
-    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, base, negative_slope=0.2) is not None
-    kenv.setenv("KBN_DEBUG", "64")
-    out = torch.empty_like(base)
-    slot = stats.new()
-    assert kb.ops.conv3x3_split(srcs, packed, n, cout, h, w, out, negative_slope=0.2, out_absmax=slot) is not None
-    assert torch.equal(kb.ops.slot_values(slot), out.abs().amax(dim=(1, 2, 3)))
-    kenv.delenv("KBN_DEBUG")
-    assert not torch.equal(out, base), "the knob selected the other kernel"
-    rms = ref64.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()
-    e = ((out.cpu().double() - ref64) / rms).abs()
-    assert float(e.pow(2).mean().sqrt()) < 1.5e-6 and float(e.max()) < 2e-5
-    assert rel_err(out, base) < TIGHT
 
 
 @pytest.mark.parametrize("ci,cf,cd,cout,hw", [(48, 48, 16, 96, (35, 70)), (96, 96, 32, 192, (19, 44)), (192, 192, 64, 384, (11, 38)),
@@ -1464,62 +1431,6 @@ def test_kb_block_split_fused(dev, ci, cd, cf, fi, fd, h, w):
     fp32 = run()
     for a, b, r in zip(got, fp32, ref):
         assert rel_err(a, r) < TIGHT and rel_err(a, b) < TIGHT
-
-
-@pytest.mark.parametrize("cins,cout,hw,up2x", [((32,), 48, (16, 64), False), ((64, 64), 64, (22, 76), False),
-                                               ((128,), 64, (20, 36), True), ((16, 32), 12, (9, 40), False),
-                                               ((256, 512), 256, (22, 76), False), ((64,), 12, (36, 72), True),
-                                               ((48,), 96, (23, 44), "s2"), ((192,), 384, (22, 76), "s2"), ((16,), 16, (5, 8), "s2")])
-def test_conv3x3_bf16_kernel(dev, cins, cout, hw, up2x):
-    """The bf16 MFMA conv of the throughput-only leg: against the oracle's conv on bf16-ROUNDED inputs and weights the
-    only difference is fp32 summation order (2e-5, max norm) -- the kernel computes what it claims to; against the
-    fp32 conv the error is bf16's (~1e-2), which is why this leg is never on the parity-gated path."""
-    h, w = hw                                   # output size
-    g = torch.Generator().manual_seed(sum(cins) + cout + h)
-    n = 2
-    stride = 2 if up2x == "s2" else 1
-    up2x = up2x is True
-    sh, sw = (h // 2, w // 2) if up2x else ((2 * h - 1, 2 * w) if stride == 2 else (h, w))   # odd input height: ceil(in / 2) rows
-    xs = [torch.randn(n, c, sh, sw, generator=g) for c in cins]
-    cin = sum(cins)
-    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
-    xcat = torch.cat(xs, 1)
-    if up2x:
-        xcat = torch.nn.functional.interpolate(xcat, size=(h, w), mode="nearest")
-    rb = lambda t: t.bfloat16().float()
-    ref_bf16 = orc.conv2d(rb(xcat), rb(wt), stride, 0.2)
-    ref_fp32 = orc.conv2d(xcat, wt, stride, 0.2)
-    assert tuple(ref_fp32.shape[-2:]) == (h, w)
-    xd = [x.to(dev) for x in xs]
-    out = torch.empty(n, cout, h, w, device=dev)
-    res = kb.ops.conv3x3_bf16([kb.ops.tensor_src(x) for x in xd], kb.ops.pack_conv3x3_bf16_weight(wt.to(dev)), n, cout, h, w,
-                              out, up2x=up2x, negative_slope=0.2, stride=stride)
-    assert res is not None
-    assert rel_err(out, ref_bf16) < TIGHT
-    assert 1e-4 < rel_err(out, ref_fp32) < 3e-2   # bf16 operands: two orders of magnitude off the fp32 bar
-
-
-def test_bf16_leg_error_is_reported_not_gated(dev):
-    """KBNetModel.set_bf16(): the whole forward with the decoder's wide 3x3 convs and the encoder's stride-2 image convs
-    on bf16 MFMAs.  The result is close to the fp32 forward in the bf16 sense (mean relative error < 2e-2) and NOT within
-    the 1e-4 parity bar -- the reason bench.py reports this leg under its own keys."""
-    cfg = kb.kitti_config()
-    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
-    frames = to(dev, *kb.synthetic.make_frames(2, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1))
-    m = kb.modules.KBNetModel.from_config(cfg, dev)
-    m.load_state_dicts(*sds)
-    ref = m.forward(*frames).clone()
-    m.decoder.set_bf16(True)
-    out_dec = m.forward(*frames).clone()
-    m.set_bf16(True)
-    out = m.forward(*frames)
-    m.set_bf16(False)
-    assert torch.equal(m.forward(*frames), ref), "switching the leg off restores the fp32 path bit for bit"
-    err_dec = ((out_dec - ref).abs() / ref.abs())
-    err = ((out - ref).abs() / ref.abs())
-    print(f"bf16 leg vs fp32 path: decoder only max rel {float(err_dec.max()):.3e}, mean rel {float(err_dec.mean()):.3e}; "
-          f"encoder image convs + decoder max rel {float(err.max()):.3e}, mean rel {float(err.mean()):.3e}")
-    assert float(err.mean()) < 2e-2 and float(err.max()) > 1e-4
 
 
 # --------------------------------------------------------------------- full forward
