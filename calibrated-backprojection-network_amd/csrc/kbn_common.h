@@ -38,6 +38,9 @@ __device__ __forceinline__ float leaky_relu(float v, float slope) { return v > 0
 // distance -- six registers that hipcc computes in a kernel's prologue, and in a kernel at its register limit SPILLS, so that every
 // step of the reduction became scratch_load + s_waitcnt vmcnt(0), i.e. a wait for all the stores the epilogue had just issued
 // (kb1_front_kernel<.., NEXT>: + 330 us per 32 KITTI frames, round 5).
+// PRECONDITION: the whole wave is active at the call (EXEC = all ones).  v_readlane of an inactive lane returns whatever its register
+// holds, and lanes 0 / 16 / 32 / 48 are read unconditionally.  Every call site sits in wave-convergent code (after the epilogue's loops,
+// with out-of-image lanes contributing 0 instead of leaving); a caller inside divergent control flow must reduce another way.
 __device__ __forceinline__ unsigned wave_max_bits(float m) {
 #define KBN_DPP_MAX(ctrl) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), ctrl, 0xf, 0xf, true)))
     KBN_DPP_MAX(0xB1);    // quad_perm [1, 0, 3, 2]

@@ -59,7 +59,9 @@ class ShardedRunner:
 
     Lifetime of returned tensors: they are views of the runner's own buffers.  `step()` / `step_mixed()`
     results are overwritten by the next call with the same output shape; `step_pipelined()` results by the
-    next-but-one call.  Clone what must live longer."""
+    next-but-one call when a collective runs (they live in the runner's two gather buffers) -- and by the NEXT call
+    without one (a single rank: the result is then the forward's own output tensor, which with rotating graph outputs
+    is the tensor the next replay writes).  Clone what must live longer."""
 
     def __init__(self, forward_fn: Callable, rank: int, world: int, gather_single: bool = False):
         """`gather_single`: run the collectives even with one rank (a one-rank RCCL group is legal): lets a single-GPU

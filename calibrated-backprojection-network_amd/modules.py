@@ -891,7 +891,8 @@ class KBNetEncoder(torch.nn.Module):
         packed_d = self._packed_depth_front.get(c0d.conv.weight, cd.conv.weight, blk.proj_depth.conv.weight) if depth_front_ok else None
         if depth is None:
             s2d_mod, s2d_x = s2d
-            if (self.fuse_s2d and packed_d is not None and s2d_x.shape[1] == 2 and _dense(s2d_x) and len(s2d_mod.pool_convs) == 3
+            if (self.fuse_s2d and packed_d is not None and not s2d_mod.layerwise and s2d_mod._slope is not None
+                    and s2d_x.shape[1] == 2 and _dense(s2d_x) and len(s2d_mod.pool_convs) == 3
                     and ops.s2d_depth_front_supported(s2d_x.shape[1], s2d_mod.min_pool_sizes, s2d_mod.max_pool_sizes, len(s2d_mod.pool_convs),
                                                       s2d_mod.conv.out_channels, c0d.out_channels, cd.out_channels, h, w, s2d_mod._slope, c0d._slope)):
                 packed_s = self._packed_s2d_front.get(*[c.conv.weight for c in s2d_mod.pool_convs], s2d_mod.conv.conv.weight)

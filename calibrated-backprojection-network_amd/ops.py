@@ -1224,10 +1224,12 @@ def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5
                normalized_image_range=(0, 1)):
     """Validity map + outlier removal (+ image normalisation): what reference src/kbnet.py:899-912 does
     before calling the model.  `normalized_image_range` as run_kbnet.py --normalized_image_range (reference
-    src/transforms.py:185-214): [0, 1] image / 255, [-1, 1] 2 (image / 255) - 1, [0, 255] untouched (like normalize_image=False),
-    anything else ValueError.  Returns (image_normalized or None, filtered_validity, filtered_sparse)."""
+    src/transforms.py:185-214): [0, 1] image / 255, [-1, 1] 2 (image / 255) - 1, [0, 255] the image as it came (the reference returns
+    its input for that range), anything else ValueError.  Returns (image, filtered_validity, filtered_sparse); image is None only
+    with normalize_image=False (the caller keeps its own tensor) or when none was passed."""
     rng = [float(v) for v in normalized_image_range]
-    if rng == [0.0, 255.0]:
+    untouched = rng == [0.0, 255.0]
+    if untouched:
         normalize_image = False
     elif rng not in ([0.0, 1.0], [-1.0, 1.0]):
         raise ValueError("Unsupported normalization range: {}".format(list(normalized_image_range)))
@@ -1249,6 +1251,8 @@ def preprocess(image, sparse_depth, kernel_size: int = 7, threshold: float = 1.5
                                      out_img.data_ptr() if out_img is not None else None, validity.data_ptr(),
                                      filtered.data_ptr(), ws.data_ptr(), 4, n, c, h, w, int(kernel_size),
                                      float(threshold), 1 if rng == [-1.0, 1.0] else 0, _stream()), "kbn_preprocess_forward")
+    if untouched and image is not None:
+        out_img = image.contiguous()
     return out_img, validity, filtered
 
 

@@ -12,8 +12,35 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--slow", action="store_true", default=False,
+                     help="also run the tests marked `slow` (wide seed sweeps, the full fuzz / perturbation / depth-front matrices); "
+                          "the builder runs `pytest tests -m gpu --slow` and keeps the log under profiles/")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: the wide form of a test whose representative cases run without it (run with --slow)")
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(config, items):
+    """`slow` items leave the collection unless --slow is given: `-m gpu` (the driver's command) then runs one representative of
+    every matrix and stays inside its time limit."""
+    if config.getoption("--slow"):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("slow") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
+
+
+@pytest.fixture(scope="session")
+def slow(request):
+    """True under --slow: tests that loop over seeds widen their lists."""
+    return bool(request.config.getoption("--slow"))
 
 
 def load_golden(name):

@@ -1289,9 +1289,14 @@ def test_kb1_depth_front_kernel(dev, hw, amag):
             assert rel_err(got[i], r32[i]) < TIGHT, (name, i)
 
 
-@pytest.mark.parametrize("preset,hw", [("kitti", (64, 96)), ("kitti", (35, 70)), ("kitti", (16, 32)), ("kitti", (52, 100)), ("kitti", (33, 47)),
-                                        ("void", (48, 80)), ("void", (37, 45)), ("void_train", (40, 64))])
-@pytest.mark.parametrize("zmag,density", [(1.0, 0.05), (1.0, 0.6), (1e-2, 0.3), (1.0, 0.0)])
+_DF_HW = [("kitti", (64, 96)), ("kitti", (35, 70)), ("kitti", (16, 32)), ("kitti", (52, 100)), ("kitti", (33, 47)),
+          ("void", (48, 80)), ("void", (37, 45)), ("void_train", (40, 64))]
+_DF_Z = [(1.0, 0.05), (1.0, 0.6), (1e-2, 0.3), (1.0, 0.0)]
+_DF_FAST = {(("kitti", (35, 70)), (1.0, 0.05)), (("kitti", (33, 47)), (1e-2, 0.3)), (("void", (37, 45)), (1.0, 0.6)), (("void_train", (40, 64)), (1.0, 0.0))}
+
+
+@pytest.mark.parametrize("preset,hw,zmag,density", [(*a, *b) if (a, b) in _DF_FAST else pytest.param(*a, *b, marks=pytest.mark.slow)
+                                                    for a in _DF_HW for b in _DF_Z])
 def test_s2d_depth_front_kernel(dev, preset, hw, zmag, density):
     """kbn_s2d_depth_front_forward: SparseToDensePool -> conv0_depth -> conv_depth / xyz of the level-0 KB block
     in ONE launch, the S2D tensor kept on the CU (csrc/s2d_stage.h).  Against the oracle's composition of the three layers and
@@ -1603,9 +1608,11 @@ def _compare_with_oracle(dev, cfg, n, h, w, seed, gain, check_graph=True):
         assert torch.equal(m.capture(*to(dev, *frames))(*to(dev, *frames)), out)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("KBN_FUZZ_SEEDS", "48"))))
+FUZZ_FAST = (1, 2, 8, 11, 21, 25, 34, 44)   # without --slow: eight seeds covering both deconv types, the five activations, odd sizes, level 4, S2D widths 4 / 8 / 16
+@pytest.mark.parametrize("seed", [s_ if s_ in FUZZ_FAST else pytest.param(s_, marks=pytest.mark.slow)
+                                  for s_ in range(int(os.environ.get("KBN_FUZZ_SEEDS", "48")))])
 def test_random_configurations_vs_oracle(dev, seed):
-    """48 (KBN_FUZZ_SEEDS) random architectures off the shipped presets -- each a combination of run_kbnet.py switches nobody wrote a
+    """48 (KBN_FUZZ_SEEDS; eight of them without --slow) random architectures off the shipped presets -- each a combination of run_kbnet.py switches nobody wrote a
     kernel for -- through KBNetModel.from_config against the oracle."""
     cfg, (h, w), n = _random_configuration(seed)
     _compare_with_oracle(dev, cfg, n, h, w, seed, gain=1.2)
@@ -1686,7 +1693,8 @@ PRESET_PERTURBATIONS = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(PRESET_PERTURBATIONS))
+PERTURB_FAST = ("odd_frame_353x1217", "batch_3", "kb_levels_01234", "decoder_odd_widths", "s2d_16_filters", "elu_transpose", "void_pools")
+@pytest.mark.parametrize("name", [n_ if n_ in PERTURB_FAST else pytest.param(n_, marks=pytest.mark.slow) for n_ in sorted(PRESET_PERTURBATIONS)])
 def test_preset_perturbations_vs_oracle(dev, name):
     import dataclasses
     changes, (h, w), n = PRESET_PERTURBATIONS[name]
@@ -1743,7 +1751,7 @@ def test_forward_batch8_full_size_vs_oracle(dev):
     assert worst < TOL, f"max relative error {worst:.3e}"
 
 
-def test_forward_follows_input_scale_without_calibration(dev):
+def test_forward_follows_input_scale_without_calibration(dev, slow):
     """The forward is a function of its inputs and weights alone (reference src/net_utils.py:120-141: a conv holds no
     state).  The split-operand convs take their fp16 windows from per-frame absmax slots that every producer fills on
     the device (ops.ActStats), so ONE captured graph, recorded on KITTI-statistics frames, must stay as close to the
@@ -1791,10 +1799,12 @@ def test_forward_follows_input_scale_without_calibration(dev):
                                            torch.cat([valid[:1], torch.zeros_like(valid[1:])]), k),
         "VOID statistics": (vi, vs, vv, vk),
     }
+    # without --slow the oracle pair (fp32 + fp64, 6 s) runs for the frames that carry a scale of their own; the graph replays every case
+    checked = {"recorded frames": (0,), "image x 255 | depth x 10": (0, 1), "depth x 0.1 | empty sparse map": (0, 1), "VOID statistics": (1,)}
     for name, fr in cases.items():
         out = replay(*to(dev, *fr)).clone()
         assert torch.isfinite(out).all(), name
-        for i in range(2):
+        for i in ((0, 1) if slow else checked[name]):
             check(f"{name}, frame {i}", out[i:i + 1], [f[i:i + 1] for f in fr])
         assert torch.equal(m.forward(*to(dev, *[f[1:2] for f in fr])), out[1:2]), "a frame alone gives the bits it gave in the batch"
     # first encoder convs x 2^14, last decoder conv x 2^-14 (LeakyReLU is positively homogeneous: the same network function
@@ -1811,14 +1821,14 @@ def test_forward_follows_input_scale_without_calibration(dev):
 
 
 @pytest.mark.parametrize("preset,shape", [("kitti", (352, 1216)), ("void", (480, 640)), ("nyu_v2", (416, 576))])
-def test_forward_full_size_seed_sweep(dev, preset, shape):
-    """Parity margin: seven weight / input seeds per preset at BASELINE's sizes (4 and 6 are the worst KITTI seeds of the
-    16-seed runs, profiles/r02/parity_margin_v29.txt).  Two assertions per seed: the worst element-wise relative error
+def test_forward_full_size_seed_sweep(dev, slow, preset, shape):
+    """Parity margin: seven weight / input seeds per preset at BASELINE's sizes under --slow, the two worst KITTI seeds (4 and 6
+    of the 16-seed runs, profiles/r02/parity_margin_v29.txt) and one seed of the other presets without it.  Two assertions per seed: the worst element-wise relative error
     against the fp32 oracle stays below north_star's 1e-4, and -- the one that discriminates: two fp32 evaluation orders
     of a 35-conv network cannot agree better with each other than each agrees with the truth -- against an fp64
     evaluation of the same network the HIP path is at most 2x as far from the exact result as the fp32 oracle is."""
     cfg = kb.PRESETS[preset]()
-    seeds = (0, 3, 4, 6, 7, 11, 19)
+    seeds = (0, 3, 4, 6, 7, 11, 19) if slow else ((4, 6) if preset == "kitti" else (4,))
     per_seed, vs64 = [], []
     for seed in seeds:
         sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=kb.synthetic.PARITY_GAIN[preset])
@@ -1854,8 +1864,71 @@ def _fp64_forward(cfg, sds, frames):
         torch.set_default_dtype(torch.float32)
 
 
+def test_forward_full_size_saturated_logits_keep_the_fp64_criterion(dev):
+    """the gate that does not depend on the chosen gain.  At gain 1.3 the KITTI logits have std 6-11 (most pixels
+    saturated) and the fp32 ORACLE itself is up to 7.7e-5 from an fp64 evaluation (tests/analysis/gain_study.py), which is why the 1e-4
+    tests moved to gain 1.1 in round 5 -- but `HIP vs fp64 <= 2 x (fp32 oracle vs fp64)` is conditioning-independent and must hold there
+    too: four KITTI seeds (4 and 6 were the worst of rounds 2-4) at full size through the split-operand kernels."""
+    cfg = kb.kitti_config()
+    rows = []
+    for seed in (0, 4, 6, 11):
+        sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3)
+        frames = kb.synthetic.make_frames(1, 352, 1216, "kitti", seed=1 + seed, jitter_intrinsics=0.1)
+        m = kb.modules.KBNetModel.from_config(cfg, dev)
+        m.load_state_dicts(*sds)
+        out, logits = m.forward(*to(dev, *frames), return_logits=True)
+        ref = orc.kbnet_forward(*frames, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+        ref64 = _fp64_forward(cfg, sds, frames)
+        hip64 = float(((out.cpu().double() - ref64).abs() / ref64.abs()).max())
+        orc64 = float(((ref.double() - ref64).abs() / ref64.abs()).max())
+        rows.append((seed, hip64, orc64, float(logits.std()), float(logits.abs().max())))
+    for seed, hip64, orc64, lstd, lmax in rows:
+        print(f"gain 1.3 seed {seed}: logits std {lstd:.1f} |max| {lmax:.0f}; vs fp64: HIP {hip64:.2e}, fp32 oracle {orc64:.2e}")
+    assert max(r[3] for r in rows) > 3.0, "gain 1.3 is meant to saturate the head"
+    for seed, hip64, orc64, _, _ in rows:
+        assert hip64 <= 2.0 * orc64, f"seed {seed}: HIP {hip64:.3e} from the exact result, the fp32 oracle {orc64:.3e}"
+
+
+def test_forward_full_size_intra_frame_dynamic_range(dev):
+    """a large dynamic range INSIDE one frame.  The fp16 windows of the split-operand convs sit on the per-frame
+    maximum and keep 22 bits for 29 binades below it (csrc/conv_split.hip:15-22); every `amag` case of the op tests scales a whole
+    tensor.  Here one KITTI frame carries a handful of image pixels 1e4 x the rest (a saturated sensor patch before normalisation) and a
+    sparse depth map that mixes 0.004 m and 655 m returns (the 16-bit PNG's extremes, src/data_utils.py:109-112) with ordinary ones.
+    Bars: <= 1e-4 against the oracle wherever the oracle is itself within 4e-5 of fp64, and never more than 2 x as far from fp64."""
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=2, gain=kb.synthetic.PARITY_GAIN["kitti"])
+    image, sparse, valid, k = kb.synthetic.make_frames(2, 352, 1216, "kitti", seed=5, jitter_intrinsics=0.1)
+    g = torch.Generator().manual_seed(17)
+    image, sparse = image.clone(), sparse.clone()
+    ys, xs = torch.randint(0, 352, (12,), generator=g), torch.randint(0, 1216, (12,), generator=g)
+    image[0, :, ys, xs] = image[0, :, ys, xs] * 1e4 + 50.0                  # outlier pixels, frame 0 only (frame 1: the same frame without them)
+    hit = valid[0, 0].nonzero()
+    pick = hit[torch.randperm(hit.shape[0], generator=g)[:40]]
+    sparse[0, 0, pick[:20, 0], pick[:20, 1]] = 0.004
+    sparse[0, 0, pick[20:, 0], pick[20:, 1]] = 655.0
+    image[1], sparse[1], valid[1], k[1] = image[0], sparse[0], valid[0], k[0]
+    image[1, :, ys, xs] = image[1, :, ys, xs].clamp(max=1.0)
+    frames = (image, sparse, valid, k)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    out = m.forward(*to(dev, *frames))
+    assert torch.isfinite(out).all()
+    for i in (0, 1):
+        fr = [f[i:i + 1] for f in frames]
+        ref = orc.kbnet_forward(*fr, *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+        ref64 = _fp64_forward(cfg, sds, fr)
+        err32 = _worst_rel(out[i:i + 1], ref)
+        hip64 = float(((out[i:i + 1].cpu().double() - ref64).abs() / ref64.abs()).max())
+        orc64 = float(((ref.double() - ref64).abs() / ref64.abs()).max())
+        print(f"intra-frame range, frame {i} ({'outliers' if i == 0 else 'clamped'}): vs oracle {err32:.2e}; vs fp64: HIP {hip64:.2e}, fp32 oracle {orc64:.2e}")
+        assert hip64 <= 2.0 * orc64 + 5e-7, f"frame {i}: HIP {hip64:.3e} from the exact result, the fp32 oracle {orc64:.3e}"
+        if orc64 < 4e-5:
+            assert err32 < TOL, f"frame {i}: {err32:.3e} vs the fp32 oracle"
+
+
 @pytest.mark.parametrize("fuse_s2d", [False, True])
-@pytest.mark.parametrize("preset,shape,seeds", [("kitti", (352, 1216), (0, 1, 2)), ("void", (480, 640), (0, 5))])
+@pytest.mark.parametrize("preset,shape,seeds", [("kitti", (352, 1216), (1,)), pytest.param("kitti", (352, 1216), (0, 2), marks=pytest.mark.slow),
+                                                pytest.param("void", (480, 640), (0, 5), marks=pytest.mark.slow)])
 def test_forward_full_size_trained_like_weights(dev, preset, shape, seeds, fuse_s2d):
     """the pretrained checkpoints are external files, and xavier noise has none of what trained weights do to
     an fp16 window -- so the full-size forward is stressed with TRAINED-LIKE statistics (synthetic.make_state_dicts(
@@ -2217,7 +2290,8 @@ def test_preprocess_golden_bit_exact(dev):
     # run_kbnet.py --normalized_image_range -1 1 / 0 255 (reference src/transforms.py:205-210)
     img_m, valid_m, _ = kb.ops.preprocess(g["image"].to(dev), g["sparse_depth"].to(dev), normalized_image_range=[-1, 1])
     assert torch.equal(img_m.cpu(), g["image_normalized_m1_1"]) and torch.equal(valid_m, valid)
-    assert kb.ops.preprocess(g["image"].to(dev), g["sparse_depth"].to(dev), normalized_image_range=[0, 255])[0] is None
+    img_255 = g["image"].to(dev)
+    assert torch.equal(kb.ops.preprocess(img_255, g["sparse_depth"].to(dev), normalized_image_range=[0, 255])[0], img_255)   # the reference returns its input
     with pytest.raises(ValueError):
         kb.ops.preprocess(g["image"].to(dev), g["sparse_depth"].to(dev), normalized_image_range=[0, 2])
 
