@@ -385,16 +385,76 @@ def timed_steps(runner, step_inputs, steps: int, warmup: int, dev):
         runner.step_pipelined(step_inputs)
     out = runner.drain()
     device_sync(dev)
+    local = time.perf_counter() - t0      # this rank's own K steps (its last gather drained), before it waits for the others
     kb.dist.barrier()
     elapsed = time.perf_counter() - t0
+    timed_steps.local_seconds = kb.dist.gather_over_ranks(local, dev)   # rank order; read by main() for `config.multi_gpu`
     return kb.dist.max_over_ranks(elapsed, dev), out
+
+
+def multi_gpu_report(forward, step_inputs, gathered_like, per, world, rank, dev, fps, local_seconds, steps, reps=20):
+    """`config.multi_gpu`: what explains an N-rank figure without a second run.
+      per_rank_frames_per_s   every rank's own rate over the timed steps (its clock stops when its last gather has drained)
+      forward_only            all ranks replay their graph at once, no collective: per-rank rates, min / max
+      allgather_ms            the step's collective alone: a loop of nothing but all_gather_into_tensor of the N x 1 x H x W maps
+      rank0_alone             rank 0 replays while the other ranks wait at a barrier: the N = 1 rate of THIS job's build / box
+      scaling_efficiency      value / (N x rank0_alone) -- the driver computes its own from the per-N runs; this one needs no history
+    Every rank runs this (the loops hold collectives)."""
+    import torch.distributed as tdist
+    rep = {"per_rank_frames_per_s": [round(per * steps / t, 1) for t in local_seconds]}
+    rep["per_rank_min_max"] = [min(rep["per_rank_frames_per_s"]), max(rep["per_rank_frames_per_s"])]
+
+    def forward_loop():
+        for _ in range(3):
+            forward(*step_inputs)
+        device_sync(dev)
+        t = time.perf_counter()
+        for _ in range(reps):
+            forward(*step_inputs)
+        device_sync(dev)
+        return time.perf_counter() - t
+
+    kb.dist.barrier()
+    rates = [round(per * reps / t, 1) for t in kb.dist.gather_over_ranks(forward_loop(), dev)]
+    rep["forward_only"] = {"per_rank_frames_per_s": rates, "min": min(rates), "max": max(rates), "sum": round(sum(rates), 1),
+                           "what": f"{reps} graph replays per rank, all ranks at once, no collective"}
+    if world > 1 and tdist.is_initialized():
+        src = forward(*step_inputs)
+        dst = torch.empty_like(gathered_like)
+        for _ in range(3):
+            tdist.all_gather_into_tensor(dst, src)
+        device_sync(dev)
+        kb.dist.barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            tdist.all_gather_into_tensor(dst, src)
+        device_sync(dev)
+        ag = kb.dist.max_over_ranks(time.perf_counter() - t, dev) / reps
+        nbytes = dst.numel() * dst.element_size()
+        rep["allgather_ms"] = round(1e3 * ag, 4)
+        rep["allgather"] = {"bytes_gathered_per_rank": nbytes, "algbw_GBps": round(nbytes / ag / 1e9, 2),
+                            "what": f"{reps} blocking all_gather_into_tensor calls of {per} x 1 x {HEIGHT} x {WIDTH} fp32 per rank, nothing else running; "
+                                    "in the timed step the same collective runs under the next step's forward"}
+        del dst
+    else:
+        rep["allgather_ms"] = None
+    kb.dist.barrier()
+    alone = forward_loop() if rank == 0 else None
+    kb.dist.barrier()
+    alone = kb.dist.gather_over_ranks(alone or 0.0, dev)[0]
+    rep["rank0_alone_frames_per_s"] = round(per * reps / alone, 1)
+    rep["scaling_efficiency"] = round(fps / (world * per * reps / alone), 4)
+    rep["scaling_efficiency_what"] = "value / (n_gpus x rank0_alone_frames_per_s), same process, same build, same minute"
+    return rep
 
 
 def base_result(fps, world, steps, warmup, ms_per_step):
     """The keys the driver's contract names, in one place."""
     return {"metric": "depth-completion frames/sec at 352x1216", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            # the pipe behind "f32": tensors / accumulators / results fp32; the wide 3x3 convs form each fp32 product from three fp16 MFMAs
+            "pipe": "fp16x3-split", "data": "synthetic"}
 
 
 def emit(result, rank: int):
@@ -456,8 +516,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         if bad:
             raise SystemExit(f"bench.py: {', '.join(bad)} set in the environment -- the timed region would not be the parity-gated "
                              "path; unset it (the bench runs those modes itself as side legs)")
-    if world > 1 and not args.side:
-        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = args.no_mixed = args.no_batch1 = args.no_options = True
+    if world > 1 and not args.side:   # (the mixed-shape stream stays: configs[4] is an N-rank workload)
+        args.no_void = args.no_side_batch = args.no_bf16 = args.no_fp32_mfma = args.no_fp16 = args.no_batch1 = args.no_options = True
     per = args.frames_per_gpu
     # rank r holds frames [r*per, (r+1)*per) of the global batch (seed 1+rank; frame 0 of
     # rank 0 is the frame the CPU oracle sees)
@@ -467,7 +527,10 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
         runner = kb.dist.ShardedRunner(forward_factory(rank, dev, frames), rank, world)
         elapsed, out = timed_steps(runner, frames, args.steps, args.warmup, dev)
         result = base_result(per * world * args.steps / elapsed, world, args.steps, args.warmup, 1e3 * elapsed / args.steps)
+        multi_gpu = multi_gpu_report(runner.forward_fn, frames, out, per, world, rank, dev, result["value"], list(timed_steps.local_seconds),
+                                     args.steps, reps=3)
         result["config"] = {"workload": "stand-in forward (plumbing test)", "frames_per_gpu": per, "global_batch": per * world,
+                            "multi_gpu": multi_gpu,
                             "gathered_frames": int(out.shape[0]), "rank_seeds": [1 + r for r in range(world)],
                             "n_ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                             "backend": backend}
@@ -495,6 +558,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     step_inputs = forward.static_in if hasattr(forward, "static_in") else frames
 
     elapsed, out = timed_steps(runner, step_inputs, args.steps, args.warmup, dev)
+    local_seconds = list(timed_steps.local_seconds)
     out = out.clone()
     # this rank's slice of the gathered tensor must be the bits its own forward produces (the gather reads the graph's output in place)
     gather_ok = bool(torch.equal(out[rank * per:(rank + 1) * per], forward(*step_inputs)))
@@ -660,6 +724,9 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
             fps = sustained["frames_per_s"]
             ms_per_step = 1e3 * per * world / fps
     gflop_frame = conv_gflop_per_frame(cfg, HEIGHT, WIDTH)
+    multi_gpu = None
+    if not args.eager:
+        multi_gpu = multi_gpu_report(forward, step_inputs, out, per, world, rank, dev, fps, local_seconds, args.steps)
 
     # ---- roofline of the dominant kernel (this rank's launches; rank 0 prints) ----
     groups = summarise_profile(prof, args.steps)
@@ -743,6 +810,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    "collective_backend": backend + (" (TEST MODE: all ranks share cuda:0, gloo collectives -- not a scaling point)" if backend == "gloo-cuda" else ""),
                    "gathered_frames": int(out.shape[0]), "gather_matches_local_forward_rank0": gather_ok,
                    "rccl_version": rccl_version(),
+                   # per-rank rates, the collective alone, rank 0 alone and value / (N x rank 0 alone): an N-rank line that explains itself
+                   "multi_gpu": multi_gpu,
                    "launch": "eager" if args.eager else
                              f"HIP graph replay, {getattr(forward, 'branches', 1)} concurrent sub-batch branch(es)"
                              + (", one graph per branch on its own stream" if getattr(forward, "split_graphs", False) else ""),

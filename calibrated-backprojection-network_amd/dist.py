@@ -224,6 +224,17 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(value: float, device) -> list:
+    """`value` of every rank, rank order (a one-element list without a process group): per-rank rates of a run."""
+    if not dist.is_initialized():
+        return [float(value)]
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[dist.get_rank()] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
 def sum_over_ranks(values: torch.Tensor) -> torch.Tensor:
     """Element-wise sum of a small tensor over all ranks (in place; identity without a process group)."""
     if dist.is_initialized():

@@ -321,6 +321,45 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(dev):
     assert d["value"] > 0 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert c["sustained"]["steps"] >= 300 and d["roofline"]["frac"] > 0
     assert "gloo" in c["collective_backend"]
+    _check_multi_gpu_fields(d, 2)
+
+
+def _check_multi_gpu_fields(d, world):
+    """The fields that make an N-rank line explain itself: per-rank rates, the collective alone, rank 0 alone, the
+    efficiency against it, and configs[4]'s mixed-shape stream under the same ranks."""
+    c, mg = d["config"], d["config"]["multi_gpu"]
+    assert c["n_ranks_seen"] == world == d["n_gpus"]
+    assert len(mg["per_rank_frames_per_s"]) == world and min(mg["per_rank_frames_per_s"]) > 0
+    assert len(mg["forward_only"]["per_rank_frames_per_s"]) == world
+    assert mg["allgather_ms"] > 0 and mg["allgather"]["bytes_gathered_per_rank"] == world * c["frames_per_gpu"] * 352 * 1216 * 4
+    assert mg["rank0_alone_frames_per_s"] > 0 and 0 < mg["scaling_efficiency"] < 1.5
+    assert c["mixed_shape_stream_frames_per_s"] > 0, "configs[4] in miniature runs under the N ranks"
+    assert d["pipe"] == "fp16x3-split"
+
+
+def test_bench_all_visible_gpus_over_rccl():
+    """The driver's command line on every visible device with the REAL backend: `python bench.py --gpus N` (N = device count >= 2), RCCL
+    all-gather over xGMI.  One-GPU leases skip it -- with the reason in the report (-rs), never silently; the gloo-cuda test above runs the
+    same code path there."""
+    import json
+    import subprocess
+    import sys
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n < 2:
+        pytest.skip(f"{n} visible device(s): an N > 1 RCCL run needs two (SCALE_rNN is the driver's 8-GPU run of this command)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KBN_BENCH_TEST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "10", "--warmup", "3"],
+                       capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["collective_backend"] == "nccl" and d["config"]["gather_matches_local_forward_rank0"] is True
+    _check_multi_gpu_fields(d, n)
+    print(json.dumps(d["config"]["multi_gpu"]))
 
 
 def _rccl_worker(rank, world, port, q):

@@ -279,6 +279,10 @@ def _bench_worker(rank, world, port, outdir, q):
         ok = ok and line["cpu_baseline"] is None and line["vs_baseline"] is None and line["higher_is_better"] is True
         ok = ok and line["config"]["global_batch"] == 4 * world and line["config"]["gathered_frames"] == 4 * world
         ok = ok and abs(line["value"] - 4 * world * 3 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]
+        mg = line["config"]["multi_gpu"]      # the self-explaining N-rank fields
+        ok = ok and len(mg["per_rank_frames_per_s"]) == world and len(mg["forward_only"]["per_rank_frames_per_s"]) == world
+        ok = ok and mg["allgather_ms"] > 0 and mg["rank0_alone_frames_per_s"] > 0 and mg["scaling_efficiency"] > 0
+        ok = ok and line["pipe"] == "fp16x3-split" and line["dtype"] == "f32"
     else:
         ok = ok and not lines                  # only rank 0 prints
     q.put((rank, ok, seen["first"]))
@@ -329,6 +333,8 @@ def test_bench_plain_python_launch_spawns_its_ranks():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["config"]["n_ranks_seen"] == 2 and line["config"]["gathered_frames"] == 8
     assert line["cpu_baseline"] is None
+    mg = line["config"]["multi_gpu"]
+    assert len(mg["per_rank_frames_per_s"]) == 2 and mg["allgather_ms"] > 0 and 0 < mg["scaling_efficiency"]
     # failing ranks' exit code comes back (here: zero timed steps cannot be averaged)
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "0", "--warmup", "0",
                           "--frames-per-gpu", "2"], env=env, capture_output=True, text=True, timeout=240)
