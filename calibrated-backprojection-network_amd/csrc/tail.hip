@@ -77,7 +77,7 @@ template <bool PIN, bool ONE = false>
 __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailParams p) {
     constexpr int IN_KG = TL_NP0 * 16, IN_PART = 2 * IN_KG, IN_BYTES = 2 * IN_PART;   // [term][k-group][pixel][8 ch] fp16
     constexpr int OFF_F = IN_BYTES;                                                    // [C][TL_FP] fp32
-    static_assert(OFF_F + 12 * TL_FP * 4 <= 80 * 1024, "two workgroups per CU at KBNet's 12 channels");
+    static_assert(OFF_F + 12 * TL_FP * 4 + 12 * 9 * 4 <= 80 * 1024, "two workgroups per CU at KBNet's 12 channels");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0");   // fp16 results flush subnormals (see conv3x3_split_kernel)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,6 +92,11 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
     const int H = p.H, W = p.W, C = p.C;
     const long long plane = (long long)H * W;
     float* const F = reinterpret_cast<float*>(smem + OFF_F);
+    // output0's weights (C x 9) behind the feature planes: the head reads them per lane (channel = lane & 3 + 4 i) -- from global
+    // memory that was a latency chain of 27 vector loads inside the channel loop (hoisting them cost the registers that keep two
+    // workgroups per CU: round 5); from LDS they cost a broadcast read each
+    float* const WO = F + C * TL_FP;
+    if (tid < C * 9) WO[tid] = p.wout[tid];   // published by the barrier that ends stage A
     // the conv's A fragments (weights, 10 KB shared by every tile): requested FIRST, so that their L2 / L1 latency runs under the
     // tile's input DMA instead of behind the barrier that ends it (hipcc otherwise sinks the loads to their first use)
     th8 a1[5], a2[5];
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
                     const float win[6] = {a[0], a[1], a[2], a[3], b[0], b[1]};
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const float w = p.wout[c * 9 + ky * 3 + kx];
+                        const float w = WO[c * 9 + ky * 3 + kx];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(w, win[i + kx], acc[i]);
                     }
@@ -361,7 +366,7 @@ static int conv_tail_launch(const float* x, long long x_batch_stride, const void
     p.slope = apply_activation ? negative_slope : 1.f;
     p.dmin = min_predict_depth;
     p.ratio = (float)((double)min_predict_depth / (double)max_predict_depth);   // evaluated in double like the reference's scalar
-    const size_t lds = (size_t)2 * 2 * TL_NP0 * 16 + (size_t)channels * TL_FP * 4;
+    const size_t lds = (size_t)2 * 2 * TL_NP0 * 16 + (size_t)channels * TL_FP * 4 + (size_t)channels * 9 * 4;
     static DeviceOnce once, oncep, once1, oncep1;
     const bool one_term = knob(KNOB_FP16_ONE_TERM) != 0;   // THROUGHPUT-ONLY: h1 w1 alone
     auto go = [&](auto kern, DeviceOnce& o) -> int {

@@ -9,7 +9,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     cfg = kb.PRESETS[preset]()
     h, w = (352, 1216) if preset == "kitti" else (480, 640)
     dev = torch.device("cuda:0")
-    _, sp, va, _ = kb.synthetic.make_frames(8, h, w, preset, seed=1)
+    nb = int(os.environ.get("S2D_BATCH", "8"))
+    _, sp, va, _ = kb.synthetic.make_frames(nb, h, w, preset, seed=1)
     x = torch.cat([sp, va], 1).to(dev)
     sd = kb.synthetic.make_state_dicts(cfg, seed=0)[0]
     ws = [sd[f"pool_convs.{i}.conv.weight"].to(dev) for i in range(3)]
@@ -22,9 +23,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     for _ in range(10): f()
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 100
-    print(json.dumps({"us": round(us, 1), "GBps": round(8 * h * w * 40 / us / 1e3, 1)}))
+    print(json.dumps({"us": round(us, 1), "GBps": round(nb * h * w * 40 / us / 1e3, 1), "batch": nb}))
     sys.exit(0)
-for dbg, tag in ((0, "full"), (16, "no z staging"), (1, "no vertical pass"), (2, "no horizontal pass"), (4, "no 1x1 chain"), (8, "no 3x3 conv"), (12, "no convs"), (31, "skeleton only"), (15, "staging+stores only")):
-    r = subprocess.run([sys.executable, __file__, "--one"], env=dict(os.environ, KBN_S2D_DEBUG=str(dbg)), capture_output=True, text=True)
+base = int(os.environ.get("S2D_BASE", "0"))   # 32: the fp32 form
+cases = ((0, "full"), (16, "no z staging"), (1, "no vertical pass"), (2, "no horizontal pass"), (4, "no 1x1 chain"), (8, "no 3x3 conv"), (12, "no convs"),
+         (64, "no input split (P3b)"), (128, "no stores"), (12 + 64, "no convs, no split"), (12 + 64 + 128, "no convs, split, stores"), (31 + 64 + 128, "skeleton only"))
+for dbg, tag in cases:
+    if base and dbg >= 64: continue
+    r = subprocess.run([sys.executable, __file__, "--one"], env=dict(os.environ, KBN_S2D_DEBUG=str(dbg | base)), capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    print(f"{tag:22s}", line[-1] if line else r.stderr[-300:], flush=True)
+    print(f"{tag:26s}", line[-1] if line else r.stderr[-300:], flush=True)
