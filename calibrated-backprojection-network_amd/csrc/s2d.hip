@@ -939,8 +939,8 @@ static int s2d_launch(S2DParams& p, const int* min_pool_sizes, int n_min, const 
         return KBN_OK;
     };
     static DeviceOnce set_kitti, set_void, set_voidtrain, set_dyn, setm_kitti, setm_void, setm_voidtrain;
-    // KBNet's own S2D shape on a compiled pool preset: the convolutions on the 16-bit matrix core (s2d_mfma_kernel); KBN_S2D_DEBUG & 32: the fp32 form (A/B, tests)
-    const bool mfma = !p.pyramid && p.nf == 8 && p.nconv == 3 && p.inC == 2 && !(p.dbg & 32);
+    // KBNet's own S2D shape on a compiled pool preset: the convolutions on the 16-bit matrix core (s2d_mfma_kernel); opt-in, KBN_S2D_DEBUG & 256 (round 6: parity green, level with the fp32 form in time -- profiles/r06/v82_s2d_mfma_form_ablation.txt)
+    const bool mfma = !p.pyramid && p.nf == 8 && p.nconv == 3 && p.inC == 2 && (p.dbg & 256);
     auto launch_mfma = [&](auto kern, DeviceOnce& once, size_t lds_m) -> int {
         if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
         int cus = device_cu_count();

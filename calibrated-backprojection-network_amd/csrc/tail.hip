@@ -94,7 +94,7 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
     float* const F = reinterpret_cast<float*>(smem + OFF_F);
     // output0's weights (C x 9) behind the feature planes: the head reads them per lane (channel = lane & 3 + 4 i) -- from global
     // memory that was a latency chain of 27 vector loads inside the channel loop (hoisting them cost the registers that keep two
-    // workgroups per CU: round 5); from LDS they cost a broadcast read each
+    // workgroups per CU: round 5); from LDS they cost a broadcast read each (489 -> 467 us per 32 KITTI frames, same box: profiles/r06/v83_ab_tail_wout_lds.txt)
     float* const WO = F + C * TL_FP;
     if (tid < C * 9) WO[tid] = p.wout[tid];   // published by the barrier that ends stage A
     // the conv's A fragments (weights, 10 KB shared by every tile): requested FIRST, so that their L2 / L1 latency runs under the
