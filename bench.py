@@ -651,7 +651,19 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
             oreplay(img1, one[1], valid1, one[3])
         torch.cuda.synchronize()
         ref_region_ms = 1e3 * (time.perf_counter() - t9) / 200
-        batch1 = {"ms_per_frame": round(1e3 / rate1, 4), "reference_style_region_ms_per_frame": round(ref_region_ms, 4),
+        # the latency form (KBNetModel.set_latency_mode: split-K on the launches one frame cannot fill the chip with; another summation
+        # order than the default form, same 1e-4 bar): its own graph of the same frame
+        model.set_latency_mode(True)
+        try:
+            lreplay = model.capture(*one)
+            lrate1, lout = replay_rate(lreplay, lreplay.static_in, 200, 20, 1, 1, dev)
+            lrel = float(((lout - oreplay(*one)).abs() / oreplay(*one).abs()).max())
+            del lreplay
+        finally:
+            model.set_latency_mode(False)
+        batch1 = {"ms_per_frame": round(1e3 / rate1, 4), "latency_mode_ms_per_frame": round(1e3 / lrate1, 4),
+                  "latency_mode_max_rel_diff_vs_default_form": lrel,
+                  "reference_style_region_ms_per_frame": round(ref_region_ms, 4),
                   "reference_readme_ms_per_frame": README_KITTI_MS_PER_FRAME,
                   "note": "graph replay of one KITTI 352x1216 frame; the reference's 15.19 ms (README.md:232) is on its own GPU and "
                           "includes the pre-model stage without a device sync: context, not a same-hardware comparison"}

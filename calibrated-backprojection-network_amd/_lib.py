@@ -108,6 +108,7 @@ SIGNATURES = {
     "kbn_conv3x3_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_conv3x3_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "kbn_conv3x3_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _L, _P, _P]),
+    "kbn_conv3x3_split_forward_ksplit": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P]),
     "kbn_conv1x1s2_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_conv1x1s2_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "kbn_conv1x1s2_split_forward": (_I, [C.POINTER(ConvSrc), _I, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

@@ -115,6 +115,9 @@ struct SplitConvParams {
     const float* xyz;           // N x 3 x H x W (output size), or null
     long long xyz_bstride;
     const float* wxyz;          // out_channels x 3 fp32
+    // split-K (KSPLIT kernels): workgroups per tile, elements between the partial sums' plane sets (p.out is the workspace then)
+    int ksplit;
+    long long ks_stride;
 };
 
 // two-term split of 8 floats: h1 = fp16(a 2^k), h2 = fp16((a 2^k - h1) 2^11)
@@ -365,7 +368,7 @@ __device__ __forceinline__ void sp_wait_b(f32x4 (&b)[NBX][2]) {   // vmcnt(N), t
 // ONE: the THROUGHPUT-ONLY one-term mode (KBN_FP16_ONE_TERM=1; BASELINE configs[2]'s 16-bit leg and the ablation "same skeleton, a
 // third of the MFMAs"): only h1 w1 is issued -- plain fp16 operands, fp32 accumulation -- and the h2 halves of the staged tiles
 // are neither fetched (pair sources, weights through LDS) nor read.  Never on the parity-gated path.
-template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2, bool PIN0 = false, bool POUT = false, bool MIXED = false, bool ONE = false>   // NBW: 32-filter blocks per wave
+template <int MODE, int RG, bool APART, bool BLDS, int NBW = 2, bool PIN0 = false, bool POUT = false, bool MIXED = false, bool ONE = false, bool KSPLIT = false>   // NBW: 32-filter blocks per wave
 __global__ __launch_bounds__(SP_THREADS, 1) void conv3x3_split_kernel(const SplitConvParams p) {
     static_assert(!MIXED || (MODE == 0 && BLDS), "transposed tiles: the concat kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1114,7 +1117,7 @@ __global__ void uf64_pack_kernel(const float* __restrict__ w, const float* __res
 // PIN: the input is a pair tensor (staged by LDS-DMA, nothing to split); POUT: the output is written as one (the MFMA
 // operands swap roles, so that a lane's accumulator registers run over FILTERS of one pixel: four consecutive channels
 // = half a granule per store).
-template <bool PIN, bool POUT, bool MIXED = false, bool ONE = false>   // MIXED: p.nblocks whole tiles, then p.tp_nblocks transposed ones; ONE: see conv3x3_split_kernel
+template <bool PIN, bool POUT, bool MIXED = false, bool ONE = false, bool KSPLIT = false>   // MIXED: p.nblocks whole tiles, then p.tp_nblocks transposed ones; ONE, KSPLIT: see conv3x3_split_kernel
 __global__ __launch_bounds__(SP_THREADS, 1) void upconv2x_split64_kernel(const SplitConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!MIXED || (int)blockIdx.x < p.nblocks) {
@@ -1360,6 +1363,45 @@ __global__ void kb_xyz_s2_kernel(const float* __restrict__ depth, long long dbs,
         o[(long long)j * oh * ow] = (fmaf(ki[j * 3 + 1], (float)Y, ki[j * 3 + 0] * (float)X) + ki[j * 3 + 2]) * z;
 }
 
+// Sum of the split-K partial planes (conv3x3_split_kernel<.., KSPLIT>), in split order, + activation + the frame's max |out|:
+// ws [ksplit][n][OC][H W] -> out (frames out_bstride apart).  A thread owns `kr` items of four consecutive pixels (VEC) or of one, 256
+// threads apart (the launcher keeps about 512 blocks per frame, at most 8 items per thread); the block's maximum meets in LDS so that
+// ONE wave per block touches the frame's slot (a commit per wave is 13 k agent-scope accesses of one address for deconv2's conv: 110 us
+// of a 60 us launch).
+template <bool VEC>
+__global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float* __restrict__ ws, long long ks_stride, int ksplit, float* __restrict__ out,
+                                                            long long out_bstride, long long per_frame, float slope, unsigned* __restrict__ out_amax, int kr) {
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    float m = 0.f;
+    for (int r = 0; r < kr; ++r) {
+        const long long i = (((long long)blockIdx.x * kr + r) * 256 + threadIdx.x) * (VEC ? 4 : 1);
+        if (i < per_frame) {
+            const float* src = ws + (long long)n * per_frame + i;
+            if constexpr (VEC) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(src);
+                for (int k = 1; k < ksplit; ++k) a += *reinterpret_cast<const f32x4*>(src + (long long)k * ks_stride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = a[j] > 0.f ? a[j] : a[j] * slope;
+                *reinterpret_cast<f32x4*>(out + (long long)n * out_bstride + i) = a;
+                m = sp_amax4(m, a);
+            } else {
+                float a = src[0];
+                for (int k = 1; k < ksplit; ++k) a += src[(long long)k * ks_stride];
+                a = a > 0.f ? a : a * slope;
+                out[(long long)n * out_bstride + i] = a;
+                m = fmaxf(m, fabsf(a));
+            }
+        }
+    }
+    if (out_amax) {   // launch-uniform
+        const unsigned b = wave_max_bits(m);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __uint_as_float(b);
+        __syncthreads();
+        absmax_commit(out_amax + n, threadIdx.x < 64 ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : 0.f);
+    }
+}
+
 __global__ void copy_wxyz_kernel(const float* __restrict__ w, float* __restrict__ wxyz, int OC, int cin_total, int xyz_offset) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < OC * 3) wxyz[e] = w[(long long)(e / 3) * cin_total + xyz_offset + e % 3];
@@ -1431,10 +1473,11 @@ int kbn_absmax_frames(const float* x, long long batch_stride, int n, long long p
     return kbn::absmax_frames_launch(x, batch_stride, n, per_frame, slots, (hipStream_t)stream);
 }
 
-int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
+static int conv3x3_split_impl(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
                               long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
                               int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
-                              void* pair_out, long long pair_out_batch_stride, float* pair_out_scale, kbn_stream_t stream) {
+                              void* pair_out, long long pair_out_batch_stride, float* pair_out_scale, int ksplit, float* workspace,
+                              kbn_stream_t stream) {
     using namespace kbn;
     if (act_exponent < -60 || act_exponent > 60) return KBN_ERR_INVALID_ARGUMENT;
     if (!srcs || n_src < 1 || n_src > 2 || !packed_weight || (!out && !pair_out) || n < 1 || out_channels < 1 || height < 1 || width < 1)
@@ -1512,6 +1555,54 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     p.act = apply_activation ? 1 : 0; p.slope = negative_slope;
     p.prescale = ldexpf(1.f, act_exponent); p.unscale = ldexpf(1.f, -act_exponent);
     p.vec4 = vec4 ? 1 : 0;
+    p.ksplit = 1;
+    if (ksplit > 1) {
+        // The latency form: a layer whose tiles cannot fill the chip (deconv4's conv on ONE KITTI frame: 24 workgroups of 48 chunks each)
+        // spreads every tile's K loop over `ksplit` workgroups; partial sums go to `workspace` [ksplit][n][out_channels][height x width]
+        // and ksplit_reduce_kernel adds them in split order.  Another summation order than the one-workgroup form: same 1e-4 parity,
+        // other low bits -- opt-in (KBNetModel.latency_mode), never mixed with the default form inside one model.
+        const bool up64 = mode == 3 && ntf == U64_NT && !uf_narrow(out_channels, cin);   // the 64-filter folded up-conv
+        if ((mode != 0 && mode != 2 && !up64) || p.pair_src || pair_out || !workspace || !out || knob(KNOB_FP16_ONE_TERM)) return KBN_ERR_UNSUPPORTED;
+        const int nchunks = cin / SP_CK;
+        if (ksplit > nchunks || (long long)(ceil_div(nchunks, ksplit)) * (ksplit - 1) >= nchunks) return KBN_ERR_INVALID_ARGUMENT;   // an empty range
+        if (blocks * ksplit > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+        const long long per_frame = (long long)out_channels * height * width;
+        SplitConvParams q = p;
+        q.ksplit = ksplit;
+        q.out = workspace; q.out_bstride = per_frame; q.ks_stride = per_frame * n;
+        q.out_amax = nullptr; q.act = 0;
+        q.vec4 = !((width & 3) || (reinterpret_cast<uintptr_t>(workspace) & 15)) ? 1 : 0;
+        q.nblocks = (int)(blocks * ksplit);
+        static DeviceOnce ok0, ok2, ok3;
+        if (up64) {   // 8 x 32 low-resolution pixels x 64 filters per workgroup, whole tiles only
+            q.tilesX = ceil_div(p.sW, 32); q.tilesY = ceil_div(p.sH, 8);
+            const long long b64 = (long long)q.tilesX * q.tilesY * n * p.nTilesN * ksplit;
+            if (b64 > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
+            q.nblocks = (int)b64;
+            auto kern = upconv2x_split64_kernel<false, false, false, false, true>;
+            if (int r = set_max_dynamic_lds(ok3, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
+            hipLaunchKernelGGL(kern, dim3(q.nblocks), dim3(SP_THREADS), 2 * (2 * 2 * 10 * 34 * 16) + 2 * (8 * 2 * 2 * 64 * 16), (hipStream_t)stream, q);
+        } else if (mode == 0) {
+            auto kern = conv3x3_split_kernel<0, 8, true, true, 2, false, false, false, false, true>;
+            if (int r = set_max_dynamic_lds(ok0, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
+            hipLaunchKernelGGL(kern, dim3(q.nblocks), dim3(SP_THREADS), SpGeom<0>::LDS + 2 * 9 * 2 * 2 * 64 * 16, (hipStream_t)stream, q);
+        } else {
+            auto kern = conv3x3_split_kernel<2, 2, true, false, 1, false, false, false, false, true>;
+            if (int r = set_max_dynamic_lds(ok2, reinterpret_cast<const void*>(kern), 160 * 1024)) return r;
+            hipLaunchKernelGGL(kern, dim3(q.nblocks), dim3(SP_THREADS), SpGeom<2>::LDS, (hipStream_t)stream, q);
+        }
+        KBN_CHECK_LAUNCH();
+        const float slope = apply_activation ? negative_slope : 1.f;
+        const bool vec = !(per_frame & 3) && !(out_batch_stride & 3) && !((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(workspace)) & 15);
+        const long long items = vec ? per_frame / 4 : per_frame;
+        long long kr = items / (256LL * 512);
+        kr = kr < 1 ? 1 : (kr > 8 ? 8 : kr);
+        const dim3 grid((unsigned)((items + 256 * kr - 1) / (256 * kr)), (unsigned)n);
+        if (vec) hipLaunchKernelGGL(ksplit_reduce_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, workspace, q.ks_stride, ksplit, out, out_batch_stride, per_frame, slope, out_absmax, (int)kr);
+        else hipLaunchKernelGGL(ksplit_reduce_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, workspace, q.ks_stride, ksplit, out, out_batch_stride, per_frame, slope, out_absmax, (int)kr);
+        KBN_CHECK_LAUNCH();
+        return KBN_OK;
+    }
     // THROUGHPUT-ONLY (KBN_FP16_ONE_TERM=1): the concat convs, the 64-filter folded up-convs and the stride-2 convs issue h1 w1 alone
     const bool one_term = knob(KNOB_FP16_ONE_TERM) != 0;
     auto launch = [&](auto kern, size_t lds, DeviceOnce& once) -> int {
@@ -1653,6 +1744,24 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
     if (rc != KBN_OK) return rc;
     KBN_CHECK_LAUNCH();
     return KBN_OK;
+}
+
+
+int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
+                              long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
+                              int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
+                              void* pair_out, long long pair_out_batch_stride, float* pair_out_scale, kbn_stream_t stream) {
+    return conv3x3_split_impl(srcs, n_src, packed_weight, out, out_batch_stride, n, out_channels, height, width, mode, act_exponent,
+                              apply_activation, negative_slope, out_absmax, pair_out, pair_out_batch_stride, pair_out_scale, 1, nullptr, stream);
+}
+
+int kbn_conv3x3_split_forward_ksplit(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
+                                     long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
+                                     int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
+                                     int ksplit, float* workspace, kbn_stream_t stream) {
+    if (ksplit < 1) return KBN_ERR_INVALID_ARGUMENT;
+    return conv3x3_split_impl(srcs, n_src, packed_weight, out, out_batch_stride, n, out_channels, height, width, mode, act_exponent,
+                              apply_activation, negative_slope, out_absmax, nullptr, 0, nullptr, ksplit, workspace, stream);
 }
 
 

@@ -202,8 +202,15 @@ def _run_split(layer, weight, srcs, n, h, w, out=None, up2x=False, out_absmax=No
         out = torch.empty((n, layer.out_channels, h, w), device=dev, dtype=torch.float32)
     packed = (layer._packed_split_up.get(weight, 1, up2x="split_up_t" if transposed else "split_up") if up2x
               else layer._packed_split.get(weight, layer.stride, up2x="split"))
-    res = ops.conv3x3_split(srcs, packed, n, layer.out_channels, h, w, out, up2x=up2x, negative_slope=layer._slope,
-                            stride=layer.stride, folded_up2x=up2x, out_absmax=None if layer._post else out_absmax, transposed=transposed)
+    # the latency form (KBNetModel.set_latency_mode): a launch too small for the chip spreads every tile's K loop over several workgroups
+    ks = 1
+    if getattr(layer, "latency", False) and not pair_out and all(s.kind == _lib.KBN_SRC_TENSOR for s in srcs):
+        ks = ops.ksplit_for(sum(s.channels for s in srcs), layer.out_channels, h, w, layer.stride, up2x=up2x)
+    kw = dict(up2x=up2x, negative_slope=layer._slope, stride=layer.stride, folded_up2x=up2x, out_absmax=None if layer._post else out_absmax,
+              transposed=transposed)
+    res = ops.conv3x3_split(srcs, packed, n, layer.out_channels, h, w, out, ksplit=ks, **kw) if ks > 1 else None
+    if res is None:
+        res = ops.conv3x3_split(srcs, packed, n, layer.out_channels, h, w, out, **kw)
     return res if res is None else _finish(layer, res, out_absmax)
 
 
@@ -1398,6 +1405,23 @@ class KBNetModel(object):
         # decoder; its tail (deconv0's second conv + output0 + sigmoid + d_min / (s + d_min/d_max)) is one kernel
         return self.decoder.depth(latent, skips, shape, self.min_predict_depth, self.max_predict_depth,
                                   return_logits=return_logits, out=out, amax_x=amax_latent, amax_skips=amax_skips, stats=stats)
+
+    def set_latency_mode(self, enabled: bool = True):
+        """The LATENCY form of the forward, for batches of one or two frames (the reference's own run loop is batch 1:
+        src/kbnet.py:764-772, 887).  One KITTI frame gives the low-resolution layers 6-30 workgroups for 256 CUs -- deconv4's conv runs
+        24 workgroups of 48 K-chunks each -- so every split-operand 3x3 conv whose launch cannot fill half the chip spreads each tile's K
+        loop over up to 16 workgroups and a second kernel adds the partial sums (kbn_conv3x3_split_forward_ksplit, ops.ksplit_for); the
+        tensors between the layers stay fp32 (the pair-tensor chains serve the power-bound large-batch kernels, not this regime).
+        Same 1e-4 parity as the default form, ANOTHER summation order: a model is in one mode throughout, and a frame's bits are
+        those of the mode (eager = graph replay = frame alone or in a batch, within the mode).  Off by default."""
+        for top in self.modules():
+            for m in top.modules():
+                if isinstance(m, (Conv2d, TransposeConv2d)):
+                    m.latency = bool(enabled)
+        self.decoder.pair_chain = False if enabled else None      # None: back to the KBN_NO_PAIR switches
+        self.encoder.pair_chain = False if enabled else None
+        self.latency_mode = bool(enabled)
+        return self
 
     def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1, split_graphs=False):
         """Captures one forward of this batch shape into a HIP graph and returns a callable

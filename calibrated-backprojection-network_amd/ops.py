@@ -828,8 +828,10 @@ def conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride=1, 
 def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_channels: int, height: int, width: int,
                   out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1,
                   act_exponent: int = -6, folded_up2x: bool = False, out_absmax: Optional[torch.Tensor] = None,
-                  transposed: bool = False):
-    """3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
+                  transposed: bool = False, ksplit: int = 1):
+    """`ksplit` > 1: the latency form of the plain and the stride-2 conv (kbn_conv3x3_split_forward_ksplit): every tile's K loop spread
+    over `ksplit` workgroups, partial sums added by a second kernel -- for launches too small to fill the chip; see ksplit_for().
+    3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
     `stride` 2: sources are the 2x larger input planes), fp32 in / fp32 out, every product taken as three fp16 MFMAs
     over two-term splits of both operands (kbn_conv3x3_split_forward): fp32-grade accuracy at 3/16 of the fp32 MFMA's
     time.  `height` x `width` is the OUTPUT size.  The fp16 window follows the data when every source carries its absmax
@@ -858,6 +860,23 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     cin = sum(s.channels for s in srcs)
     flops = 2.0 * n * height * width * cin * 9 * out_channels / (4 if transposed else 1)   # transposed: nine taps per SOURCE pixel
     mode = (4 if transposed else (3 if folded_up2x else 1)) if up2x else (2 if stride == 2 else 0)
+    if ksplit > 1:
+        if pair or mode == 1:
+            raise KbnError("conv3x3_split: ksplit goes with the plain / stride-2 / folded up-conv forms and an fp32 output")
+        ws = torch.empty((ksplit, n, out_channels, height, width), device=out.device, dtype=torch.float32)
+        status = _launch(("conv_split", "", "conv_split_s2", "conv_split_upfold", "conv_split_upfold")[mode], flops,
+                         lambda: lib.kbn_conv3x3_split_forward_ksplit(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n, out_channels, height, width,
+                                                                      mode, max(-60, min(60, int(act_exponent))), 0 if negative_slope is None else 1,
+                                                                      0.0 if negative_slope is None else float(negative_slope),
+                                                                      _slot_ptr(out_absmax, n), int(ksplit), ws.data_ptr(), _stream()),
+                         executed=conv3x3_split_executed_flops(n, cin, out_channels, height, width, stride, up2x and folded_up2x),
+                         pipe="fp16", nbytes=_src_bytes(srcs, n) + 4.0 * n * height * width * out_channels * (1 + 2 * ksplit))
+        if status == _lib.KBN_ERR_UNSUPPORTED:
+            if PROFILE is not None:
+                PROFILE.pop()
+            return None
+        check(status, "kbn_conv3x3_split_forward_ksplit")
+        return out
     status = _launch(("conv_split", "conv_split_up", "conv_split_s2", "conv_split_upfold", "conv_split_upfold")[mode], flops,
                      lambda: lib.kbn_conv3x3_split_forward(arr, len(srcs), packed_weight.data_ptr(), optr, obs, n,
                                                            out_channels, height, width,
@@ -877,6 +896,24 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
         return None
     check(status, "kbn_conv3x3_split_forward")
     return out
+
+
+def ksplit_for(cin: int, out_channels: int, height: int, width: int, stride: int = 1, cus: int = 256, up2x: bool = False) -> int:
+    """How many workgroups share a tile's K loop in the latency form (KBNetModel.set_latency_mode): as many as bring ONE FRAME's launch
+    to about one workgroup per CU -- every range at least two 16-channel chunks long, at most 16 -- and 1 when one frame's tiles
+    already fill a quarter of the chip or its output is large (the partial planes cost HBM traffic: 2 x ksplit x the output).  A function
+    of the layer alone, not of the batch: inside the mode a frame's bits do not depend on what runs beside it."""
+    if up2x:   # the folded up-conv: 8 x 32 low-resolution pixels x 64 filters per workgroup
+        tiles = -(-(width // 2) // 32) * (-(-(height // 2) // 8)) * (-(-out_channels // 64))
+    else:
+        tiles = -(-width // 32) * (-(-height // (8 if stride == 2 else 16))) * (-(-out_channels // (128 if stride == 2 else 64)))
+    chunks = cin // 16
+    if tiles * 2 > cus or chunks < 4 or 4 * out_channels * height * width > (16 << 20):
+        return 1
+    ks = min(16, chunks // 2, max(1, cus // tiles))
+    while ks > 1 and -(-chunks // ks) * (ks - 1) >= chunks:   # no empty range
+        ks -= 1
+    return ks
 
 
 # ----------------------------------------------------- KB block: conv_fused on split operands

@@ -300,6 +300,18 @@ int kbn_conv3x3_split_forward(const kbn_conv_src* srcs, int n_src, const void* p
                               long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
                               int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
                               void* pair_out, long long pair_out_batch_stride, float* pair_out_scale, kbn_stream_t stream);
+/* The LATENCY form of modes 0 and 2 (round 6): the same conv (reference src/net_utils.py:1483-1487 / :1348, net_utils.Conv2d.forward
+ * :120-141) for launches whose tiles cannot fill the chip -- one KITTI frame gives deconv4's conv (768 -> 256 at 22 x 76) 24 workgroups
+ * of 48 K-chunks each on 256 CUs.  `ksplit` workgroups share every tile, each summing a contiguous range of the 16-channel chunks
+ * into a plane set of its own in `workspace` (ksplit x n x out_channels x height x width floats, 16-byte aligned), and a second kernel
+ * adds the sets in split order, applies the activation and fills out_absmax.  fp32 KBN_SRC_TENSOR sources only, no pair output.
+ * The result differs from kbn_conv3x3_split_forward's in summation order (same 1e-4 bar, other low bits), so a model uses one form
+ * throughout (KBNetModel.latency_mode).  ksplit = 1 is kbn_conv3x3_split_forward; 1 <= ksplit <= in_channels / 16 with no empty range
+ * (ceil(chunks / ksplit) * (ksplit - 1) < chunks), else KBN_ERR_INVALID_ARGUMENT. */
+int kbn_conv3x3_split_forward_ksplit(const kbn_conv_src* srcs, int n_src, const void* packed_weight, float* out,
+                                     long long out_batch_stride, int n, int out_channels, int height, int width, int mode,
+                                     int act_exponent, int apply_activation, float negative_slope, unsigned* out_absmax,
+                                     int ksplit, float* workspace, kbn_stream_t stream);
 
 /* conv_fused of the KB block on split operands -- reference src/net_utils.py:1337-1343 (Conv2d(in_channels_fused + 3,
  * n_filter_fused, kernel_size=1, stride=2)) applied to cat[image, xyz, fused] (:1352-1368).  The tensor channels
