@@ -56,7 +56,7 @@ __host__ __device__ inline ConvPlan make_plan(int oc, int cin, int ks, int strid
     // conv0_depth, deconv0's 12 -> 12) also take 4: no K padding (12 = 3 x 4) and staging of chunk c+1
     // overlaps the MFMAs of chunk c even in a two- or three-chunk loop (-8 % / -20 % on those layers).
     pl.CK = (ks == 1) ? 16 : ((cin <= 16 || stride == 2) ? 4 : 8);
-    if (force_ck == 4 && ks == 3) pl.CK = 4;  // experiment hook (KBN_FORCE_CK)
+    if (force_ck == 4 && ks == 3) pl.CK = 4;  // (experiment hook of rounds 1-5; no caller passes it any more)
     if (force_ck == 8 && ks == 3 && cin > 4) pl.CK = 8;
     int nblk = ceil_div(oc, 16);
     // pick NB in 1..4 minimising padded n-blocks, ties -> larger NB

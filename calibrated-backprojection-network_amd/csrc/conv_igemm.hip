@@ -432,7 +432,7 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
     }
     for (int s = n_src; s < KBN_MAX_SRC; ++s) p.src[s] = p.src[0];
 
-    const ConvPlan pl = make_plan(out_channels, ctot, kernel_size, stride, knob(KNOB_FORCE_CK));
+    const ConvPlan pl = make_plan(out_channels, ctot, kernel_size, stride, 0);
     p.nsrc = n_src; p.N = n; p.OC = out_channels; p.Ctot = ctot; p.Cpad = pl.Cpad;
     p.wp = packed_weight; p.out = out; p.out_bstride = out_batch_stride;
     p.inH = in_height; p.inW = in_width;
@@ -455,7 +455,7 @@ int conv2d_launch(const kbn_conv_src* srcs, int n_src, const float* packed_weigh
             rc = absmax_frames_launch(out, out_batch_stride, n, (long long)out_channels * p.outH * p.outW, out_absmax, stream);
         if (rc != KBN_ERR_UNSUPPORTED) return rc;
     }
-    if (!knob(KNOB_NO_DMA)) {  // fast path: LDS-DMA staging (aligned tensor sources, no resize)
+    {  // fast path: LDS-DMA staging (aligned tensor sources, no resize)
         const bool forced = knob(KNOB_FORCE_MW) || knob(KNOB_FORCE_TWB);
         int sig = n_src;
         for (int s = 0; s < n_src; ++s) sig = sig * 4 + srcs[s].kind;
@@ -508,7 +508,7 @@ extern "C" {
 size_t kbn_conv2d_packed_weight_bytes(int out_channels, int in_channels, int kernel_size, int stride) {
     if (out_channels < 1 || in_channels < 1 || (kernel_size != 1 && kernel_size != 3)) return 0;
     if (stride != 1 && stride != 2) return 0;
-    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::knob(kbn::KNOB_FORCE_CK));
+    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, 0);
     return sizeof(float) * ((size_t)pl.nTilesN * pl.Cpad * kernel_size * kernel_size * pl.NT +
                             (size_t)kbn::wino_packed_floats(out_channels, in_channels, kernel_size, stride));
 }
@@ -517,7 +517,7 @@ int kbn_conv2d_pack_weight(const float* weight, float* packed, int out_channels,
                            int kernel_size, int stride, kbn_stream_t stream) {
     if (!weight || !packed || out_channels < 1 || in_channels < 1) return KBN_ERR_INVALID_ARGUMENT;
     if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
-    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, kbn::knob(kbn::KNOB_FORCE_CK));
+    kbn::ConvPlan pl = kbn::make_plan(out_channels, in_channels, kernel_size, stride, 0);
     int taps = kernel_size * kernel_size;
     long long total = (long long)pl.nTilesN * pl.Cpad * taps * pl.NT;
     int blocks = (int)((total + 255) / 256);
@@ -535,7 +535,7 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
     if (!info || n < 1 || out_channels < 1 || in_channels < 1 || in_height < 1 || in_width < 1)
         return KBN_ERR_INVALID_ARGUMENT;
     if ((kernel_size != 1 && kernel_size != 3) || (stride != 1 && stride != 2)) return KBN_ERR_UNSUPPORTED;
-    const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size, stride, knob(KNOB_FORCE_CK));
+    const ConvPlan pl = make_plan(out_channels, in_channels, kernel_size, stride, 0);
     const int outH = ceil_div(in_height, stride), outW = ceil_div(in_width, stride);
     TileChoice tc = choose_tile(outH, outW, n, pl.nTilesN, kernel_size, stride, pl.MW, pl.CK, pl.NT);
     {   // a tuned choice, if this shape has run already (tensor sources only: the common signatures)
@@ -554,7 +554,7 @@ int kbn_conv2d_query(int n, int out_channels, int in_channels, int kernel_size, 
     info[5] = ceil_div(outW, tw) * ceil_div(outH, th) * n * pl.nTilesN;
     info[6] = maxpos;
     // 2: conv_dma_kernel (assuming 16-byte aligned planes), 1: conv_igemm_kernel pipelined, 0: not pipelined
-    info[7] = (!resize && (in_width & 3) == 0 && !knob(KNOB_NO_DMA)) ? 2 : ((maxpos * pl.CK <= 48) ? 1 : 0);
+    info[7] = (!resize && (in_width & 3) == 0) ? 2 : ((maxpos * pl.CK <= 48) ? 1 : 0);
     if (kernel_size == 3 && stride == 1 && !resize && !knob(KNOB_NO_WINO)) {
         int rt = 0, ct = 0;
         const int wgs = wino_query(n, out_channels, in_channels, in_height, in_width, &rt, &ct);

@@ -1497,7 +1497,7 @@ static int conv3x3_split_impl(const kbn_conv_src* srcs, int n_src, const void* p
         if (s == 0) { p.sH = a.src_height; p.sW = a.src_width; }
         if (a.src_height != p.sH || a.src_width != p.sW) return KBN_ERR_INVALID_ARGUMENT;
         if (pair) {   // source 0 of the concat conv / the input of a folded up-conv, written by a split-operand producer
-            if (s != 0 || mode == 1 || (knob(KNOB_DEBUG) & 16)) return KBN_ERR_UNSUPPORTED;
+            if (s != 0 || mode == 1) return KBN_ERR_UNSUPPORTED;
             if (mode == 2 && n_src != 1) return KBN_ERR_UNSUPPORTED;
             // the concat kernel's K loop: a pair source beside an fp32 one, at least two 16-channel chunks each
             if (mode == 0 && (n_src != 2 || a.channels < 2 * SP_CK || srcs[1].kind != KBN_SRC_TENSOR || srcs[1].channels < 2 * SP_CK))
@@ -1714,7 +1714,7 @@ static int conv3x3_split_impl(const kbn_conv_src* srcs, int n_src, const void* p
                 rc = one_term ? pick0(std::true_type{}) : pick0(std::false_type{});
             }
             break;
-        case 1: rc = launch(conv3x3_split_kernel<1, 8, true, false>, SpGeom<1>::LDS, o[1]); break;
+        case 1: return KBN_ERR_UNSUPPORTED;   // the nine-tap up-conv form (rounds 2-5; superseded by the folded form, mode 3) is no longer built
         case 2:
             // 2 row groups x 4 filter groups of waves (a wave: 4 rows x ONE 32-filter block): every weight fragment is fetched from
             // L2 by two waves instead of four -- half the vector-memory traffic of a chunk -- for twice the A fragment reads
@@ -1733,12 +1733,8 @@ static int conv3x3_split_impl(const kbn_conv_src* srcs, int n_src, const void* p
             }
             break;
         default:
-            if (knob(KNOB_DEBUG) & 16) {   // weights fetched per set into registers (the form before the LDS stage), for A/B runs
-                static DeviceOnce o3r;
-                rc = launch(upconv2x_split_kernel<false>, 2 * 2 * 2 * 18 * 34 * 16 * 2, o3r);
-            } else {   // two A buffers (18 x 34 pixels x 16 channels x two fp16 terms) + two buffers of sixteen weight sets
-                rc = launch(upconv2x_split_kernel<true>, 2 * (2 * 2 * 18 * 34 * 16) + 2 * UF_ITEMS * (2 * 2 * UF_NT * 16), o[3]);
-            }
+            // two A buffers (18 x 34 pixels x 16 channels x two fp16 terms) + two buffers of sixteen weight sets
+            rc = launch(upconv2x_split_kernel<true>, 2 * (2 * 2 * 18 * 34 * 16) + 2 * UF_ITEMS * (2 * 2 * UF_NT * 16), o[3]);
             break;
     }
     if (rc != KBN_OK) return rc;

@@ -896,7 +896,7 @@ static int upconv2x_forward_impl(const float* src, long long src_batch_stride, c
     // fast path: LDS-DMA staging, compile-time tile geometry
     const bool aligned = (src_width & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
                          (src_batch_stride & 3) == 0 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad;
-    if (aligned && !knob(KNOB_NO_UP2X_DMA)) {
+    if (aligned) {
         const int ftw = knob(KNOB_FORCE_TWB);
         int twb = 1;   // 16-wide tiles unless 32-wide ones waste fewer pixels / fill the rounds better
         {
@@ -938,8 +938,7 @@ static int upconv2x_forward_impl(const float* src, long long src_batch_stride, c
         return launch(cand);
     }
     // maps whose rows are not 16-byte aligned: the same kernel with dword DMA granules (wide outputs only)
-    if (!aligned && pl.NB >= 3 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad && !knob(KNOB_NO_UP2X_DMA) &&
-        !knob(KNOB_UP_MW)) {
+    if (!aligned && pl.NB >= 3 && (pl.Cpad / 8) % 2 == 0 && in_channels == pl.Cpad) {
         const int t3 = (knob(KNOB_NO_UP2X3) || plain) ? 0 : 1;
         auto launch = [&](int cand) -> int {   // candidate = (TWB - 1) + 2 * (half-size tile)
             Up2xParams q = p;
@@ -958,7 +957,7 @@ static int upconv2x_forward_impl(const float* src, long long src_batch_stride, c
     {
         const long long tiles2 = (long long)ceil_div(src_width, 16) * ceil_div(src_height, 4 * pl.MW) * n * pl.nTilesN * 2;
         if (pl.NB >= 3 && tiles2 <= 512) mw = 1;
-        const int fm = knob(KNOB_UP_MW);
+        const int fm = 0;
         if (fm && pl.NB >= 3) mw = fm == 1 ? 1 : pl.MW;
     }
     const int mblocks = 4 * mw;
@@ -1036,14 +1035,14 @@ int kbn_upconv2x_query(int n, int in_channels, int out_channels, int src_height,
     const bool aligned = (src_width & 3) == 0 && chunks_ok;   // plus 16-byte aligned planes, which torch tensors are
     const int t3 = knob(KNOB_NO_UP2X3) ? 0 : 1;
     info[0] = 16; info[1] = pl.nTilesN * pl.NT; info[2] = pl.Cpad; info[3] = 0;
-    if (aligned && !knob(KNOB_NO_UP2X_DMA)) {
+    if (aligned) {
         if (up2x9_eligible(out_channels) && !knob(KNOB_NO_UP2X9) && t3) {
             const Up2x9Plan q9 = make_up2x9_plan(out_channels);
             info[0] = 9; info[1] = q9.nTilesN * q9.NT;
         } else {
             info[0] = t3 ? 12 : 16;
         }
-    } else if (!aligned && pl.NB >= 3 && chunks_ok && !knob(KNOB_NO_UP2X_DMA) && !knob(KNOB_UP_MW)) {
+    } else if (!aligned && pl.NB >= 3 && chunks_ok) {
         info[0] = t3 ? 12 : 16;
     }
     return KBN_OK;

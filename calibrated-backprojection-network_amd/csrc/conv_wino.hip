@@ -486,11 +486,7 @@ static int wino_variant(const WinoParams& p, size_t lds, hipStream_t stream) {
     if (int rc = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv_wino_kernel<DBG>), 160 * 1024)) return rc;
     int n_cu = device_cu_count();   // persistent workgroups: one per CU of the current device
     if (n_cu < 1) n_cu = 256;
-    int grid = p.nblocks < n_cu ? p.nblocks : n_cu;
-    if (const int v = knob(KNOB_WINO_GRID)) {   // experiment hook: -1 = one workgroup per tile, N = N persistent workgroups
-        if (v < 0) grid = p.nblocks;
-        else grid = p.nblocks < v ? p.nblocks : v;
-    }
+    const int grid = p.nblocks < n_cu ? p.nblocks : n_cu;
     hipLaunchKernelGGL(conv_wino_kernel<DBG>, dim3(grid), dim3(512), lds, stream, p);
     KBN_CHECK_LAUNCH();
     return KBN_OK;

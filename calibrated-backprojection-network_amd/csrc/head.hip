@@ -160,7 +160,7 @@ extern "C" int kbn_depth_head_forward(const float* x, const float* weight, float
     float ratio = (float)((double)min_predict_depth / (double)max_predict_depth);
     const bool aligned = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(depth) & 15) == 0 && (!logits || (reinterpret_cast<uintptr_t>(logits) & 15) == 0);
-    if (aligned && !kbn::knob(kbn::KNOB_NO_HEAD_DMA)) {
+    if (aligned) {
         const int tilesX = ceil_div(width, HQ_TW), tilesY = ceil_div(height, HQ_TH);
         const long long blocks = (long long)tilesX * tilesY * n;
         if (blocks > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;

@@ -94,8 +94,8 @@ int device_cu_count();   // abi.hip: compute units of the current device (cached
 // Read from the environment ONCE when the library is loaded (and again by kbn_reload_env(), which tests
 // and the ablation tools call after changing a variable): no getenv on any launch path.
 enum Knob {
-    KNOB_DEBUG, KNOB_FORCE_MW, KNOB_FORCE_TWB, KNOB_FORCE_CK, KNOB_EPI_LDS, KNOB_NO_WINO, KNOB_NO_DMA,
-    KNOB_NO_UP2X_DMA, KNOB_NO_UP2X9, KNOB_NO_UP2X3, KNOB_UP_MW, KNOB_WINO_RT, KNOB_WINO_GRID, KNOB_NO_HEAD_DMA,
+    KNOB_DEBUG, KNOB_FORCE_MW, KNOB_FORCE_TWB, KNOB_EPI_LDS, KNOB_NO_WINO,
+    KNOB_NO_UP2X9, KNOB_NO_UP2X3, KNOB_WINO_RT,
     KNOB_NO_KB_PAIR, KNOB_NO_KB_DEPTH_FUSION, KNOB_PAIR_CAND, KNOB_S2D_DEBUG, KNOB_AUTOTUNE,
     KNOB_NO_HEAD_FUSION, KNOB_NO_SPLIT,
     // switches of the host mirror (modules.py asks kbn_knob(): one reading of the environment for both sides)

@@ -25,11 +25,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     us = s.elapsed_time(e) * 100
     print(json.dumps({"us": round(us, 1), "GBps": round(nb * h * w * 40 / us / 1e3, 1), "batch": nb}))
     sys.exit(0)
-base = int(os.environ.get("S2D_BASE", "0"))   # 32: the fp32 form
-cases = ((0, "full"), (16, "no z staging"), (1, "no vertical pass"), (2, "no horizontal pass"), (4, "no 1x1 chain"), (8, "no 3x3 conv"), (12, "no convs"),
-         (64, "no input split (P3b)"), (128, "no stores"), (12 + 64, "no convs, no split"), (12 + 64 + 128, "no convs, split, stores"), (31 + 64 + 128, "skeleton only"))
+cases = ((0, "full"), (16, "no z staging"), (1, "no vertical pass"), (2, "no horizontal pass"), (4, "no 1x1 chain"), (8, "no 3x3 conv"), (12, "no convs"), (31, "skeleton only"))
 for dbg, tag in cases:
-    if base and dbg >= 64: continue
-    r = subprocess.run([sys.executable, __file__, "--one"], env=dict(os.environ, KBN_S2D_DEBUG=str(dbg | base)), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, __file__, "--one"], env=dict(os.environ, KBN_S2D_DEBUG=str(dbg)), capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     print(f"{tag:26s}", line[-1] if line else r.stderr[-300:], flush=True)
