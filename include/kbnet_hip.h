@@ -274,8 +274,8 @@ int kbn_deconv2x_forward(const float* src, long long src_batch_stride, const flo
  *             with slots on every source the kernel derives k per frame from the data, max |a| 2^k in [2^14, 2^15)
  *             (the Python mirror always provides slots; a static k is for callers that know their range: -6
  *             covers 0.0039 .. 4.2e6).  Range -60 .. 60.
- *   mode      0: 3x3 stride 1 over height x width sources; 1: nearest-2x up-conv (ONE source with
- *             (height/2) x (width/2) planes); 2: 3x3 stride 2 (source planes h x w with ceil(h/2) = height,
+ *   mode      0: 3x3 stride 1 over height x width sources; 1: nearest-2x up-conv in its nine-tap form (ONE source with
+ *             (height/2) x (width/2) planes; no longer built since ABI 7: KBN_ERR_UNSUPPORTED, use mode 3); 2: 3x3 stride 2 (source planes h x w with ceil(h/2) = height,
  *             ceil(w/2) = width: the image convs of the KB blocks, reference src/net_utils.py:1348); 3: mode 1 in its folded
  *             form (four 2x2 convs on the low-resolution source, 16 instead of 36 channel products per source pixel: what the
  *             decoder runs); 4: ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1) -- deconv_type='transpose',
