@@ -1197,6 +1197,14 @@ def new_depth_input_pair(n, height, width, device):
     return pair[:, 0:1], pair[:, 1:2]
 
 
+# Stream capture in THREAD-LOCAL error mode: under the default ("global") mode a HIP call that is illegal during capture fails the capture
+# when ANY thread makes it -- and ProcessGroupNCCL's watchdog thread polls the events of recent collectives (hipEventQuery) all the time.
+# A capture() after the first all-gather of a process (bench.py's side legs, the mixed-shape stream, a second batch shape) then died one
+# run in four with "operation not permitted when stream is capturing" thrown on the WATCHDOG thread, which terminates the process
+# (round 6, profiles/r06/v99_rccl_child_failure.err).  Nothing on the capturing thread needs the global check.
+_CAPTURE_MODE = "thread_local"
+
+
 class GraphedForward:
     """HIP-graph replay of `KBNetModel.forward` for a fixed batch shape (torch.cuda.CUDAGraph is
     the plumbing: capture, private memory pool, replay; every node is one of our kernels or a
@@ -1266,14 +1274,14 @@ class GraphedForward:
                 row = []
                 for i in range(branches):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=self.graphs[0][i].pool() if self.graphs else None):
+                    with torch.cuda.graph(g, pool=self.graphs[0][i].pool() if self.graphs else None, capture_error_mode=_CAPTURE_MODE):
                         model.forward(*parts[i], out=self.static_outs[k][i * per:(i + 1) * per])
                     row.append(g)
                 self.graphs.append(row)
                 continue
             graph = torch.cuda.CUDAGraph()
             # one memory pool for all copies: they replay one after the other on one stream, never concurrently
-            with torch.cuda.graph(graph, pool=self.graphs[0].pool() if self.graphs else None):
+            with torch.cuda.graph(graph, pool=self.graphs[0].pool() if self.graphs else None, capture_error_mode=_CAPTURE_MODE):
                 self._record(model, parts, branches, per, self.static_outs[k])
             self.graphs.append(graph)
         self.graph, self.static_out = self.graphs[0], self.static_outs[0]

@@ -1626,7 +1626,7 @@ def _random_configuration(seed):
         activation_func=r.choice(["leaky_relu", "leaky_relu", "relu", "elu", "sigmoid", "linear"])), shape, r.choice([1, 2, 3])
 
 
-def _compare_with_oracle(dev, cfg, n, h, w, seed, gain, check_graph=True):
+def _compare_with_oracle(dev, cfg, n, h, w, seed, gain, check_graph=True, latency=False):
     """One forward of a KBNetModel built from `cfg` against the oracle: the LOGITS in units of their largest magnitude (random widths and
     activations leave the sigmoid head anywhere between flat and saturated, where the depth map would hide an error), the depth map,
     the state_dict layout, and the captured graph against the eager bits."""
@@ -1644,6 +1644,8 @@ def _compare_with_oracle(dev, cfg, n, h, w, seed, gain, check_graph=True):
     assert {k: tuple(v.shape) for k, v in m.encoder.state_dict().items()} == kb.config.encoder_param_shapes(cfg)
     assert {k: tuple(v.shape) for k, v in m.decoder.state_dict().items()} == kb.config.decoder_param_shapes(cfg)
     m.load_state_dicts(*sds)
+    if latency:
+        m.set_latency_mode(True)
     out, logits = m.forward(*to(dev, *frames), return_logits=True)
     scale = float(ref_logits.abs().max())
     err = float((logits.cpu() - ref_logits).abs().max()) / scale
@@ -1748,6 +1750,22 @@ def test_preset_perturbations_vs_oracle(dev, name):
     changes, (h, w), n = PRESET_PERTURBATIONS[name]
     cfg = dataclasses.replace(kb.kitti_config(), name=name, **changes)
     _compare_with_oracle(dev, cfg, n, h, w, seed=11, gain=kb.synthetic.PARITY_GAIN["kitti"])
+
+
+@pytest.mark.parametrize("name", ["kb_levels_01234", "decoder_odd_widths", "transpose", "elu_transpose", "encoder_image_64", "batch_3"])
+def test_preset_perturbations_latency_mode(dev, name):
+    """KBNetModel.set_latency_mode() off the shipped preset: the split-K launches under other widths, the transposed decoder (the
+    folded up-conv's kernels, mode 4), ELU layers (activation pass behind the reduce kernel), a KB layer at level 4, three frames."""
+    import dataclasses
+    changes, (h, w), n = PRESET_PERTURBATIONS[name]
+    cfg = dataclasses.replace(kb.kitti_config(), name=name, **changes)
+    _compare_with_oracle(dev, cfg, n, h, w, seed=11, gain=kb.synthetic.PARITY_GAIN["kitti"], latency=True)
+
+
+@pytest.mark.parametrize("seed", [1, 8, 21, 25, 34])
+def test_random_configurations_latency_mode(dev, seed):
+    cfg, (h, w), n = _random_configuration(seed)
+    _compare_with_oracle(dev, cfg, n, h, w, seed, gain=1.2, latency=True)
 
 
 def _worst_rel(out, ref):
