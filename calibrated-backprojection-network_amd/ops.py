@@ -829,9 +829,7 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
                   out: torch.Tensor, up2x: bool = False, negative_slope: Optional[float] = 0.2, stride: int = 1,
                   act_exponent: int = -6, folded_up2x: bool = False, out_absmax: Optional[torch.Tensor] = None,
                   transposed: bool = False, ksplit: int = 1):
-    """`ksplit` > 1: the latency form of the plain and the stride-2 conv (kbn_conv3x3_split_forward_ksplit): every tile's K loop spread
-    over `ksplit` workgroups, partial sums added by a second kernel -- for launches too small to fill the chip; see ksplit_for().
-    3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
+    """3x3 conv (+ LeakyReLU) of up to two concatenated tensor sources (`up2x`: of ONE source upsampled 2x, nearest;
     `stride` 2: sources are the 2x larger input planes), fp32 in / fp32 out, every product taken as three fp16 MFMAs
     over two-term splits of both operands (kbn_conv3x3_split_forward): fp32-grade accuracy at 3/16 of the fp32 MFMA's
     time.  `height` x `width` is the OUTPUT size.  The fp16 window follows the data when every source carries its absmax
@@ -839,8 +837,11 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     `act_exponent` k (|a| 2^k < 65504).  `out_absmax`: slot that receives max |out| per frame.
     `folded_up2x` (with `up2x`): the folded 16-product form, weights from
     pack_conv3x3_split_weight(folded_up2x=True).  `transposed` (with both): the layer is a ConvTranspose2d(kernel 3, stride 2,
-    padding 1, output_padding 1) instead -- same kernels, blob from pack_conv3x3_split_weight(transposed=True).  Returns None
-    when the shape does not qualify (the caller stays on the fp32-MFMA kernels)."""
+    padding 1, output_padding 1) instead -- same kernels, blob from pack_conv3x3_split_weight(transposed=True).
+    `ksplit` > 1: the latency form of the plain, the stride-2 and the wide folded up-conv (kbn_conv3x3_split_forward_ksplit): every
+    tile's K loop spread over `ksplit` workgroups, their partial sums added in split order by a second kernel -- for launches too small
+    to fill the chip (ksplit_for); fp32 sources and an fp32 output only.  Returns None when the shape does not qualify (the caller
+    stays on the fp32-MFMA kernels)."""
     if transposed and not (up2x and folded_up2x):
         raise KbnError("conv3x3_split: transposed goes with up2x and folded_up2x")
     if up2x and stride != 1:

@@ -1899,7 +1899,7 @@ def test_forward_follows_input_scale_without_calibration(dev, slow):
         "VOID statistics": (vi, vs, vv, vk),
     }
     # without --slow the oracle pair (fp32 + fp64, 6 s) runs for the frames that carry a scale of their own; the graph replays every case
-    checked = {"recorded frames": (0,), "image x 255 | depth x 10": (0, 1), "depth x 0.1 | empty sparse map": (0, 1), "VOID statistics": (1,)}
+    checked = {"recorded frames": (), "image x 255 | depth x 10": (0, 1), "depth x 0.1 | empty sparse map": (1,), "VOID statistics": ()}
     for name, fr in cases.items():
         out = replay(*to(dev, *fr)).clone()
         assert torch.isfinite(out).all(), name
@@ -1963,14 +1963,14 @@ def _fp64_forward(cfg, sds, frames):
         torch.set_default_dtype(torch.float32)
 
 
-def test_forward_full_size_saturated_logits_keep_the_fp64_criterion(dev):
+def test_forward_full_size_saturated_logits_keep_the_fp64_criterion(dev, slow):
     """the gate that does not depend on the chosen gain.  At gain 1.3 the KITTI logits have std 6-11 (most pixels
     saturated) and the fp32 ORACLE itself is up to 7.7e-5 from an fp64 evaluation (tests/analysis/gain_study.py), which is why the 1e-4
     tests moved to gain 1.1 in round 5 -- but `HIP vs fp64 <= 2 x (fp32 oracle vs fp64)` is conditioning-independent and must hold there
-    too: four KITTI seeds (4 and 6 were the worst of rounds 2-4) at full size through the split-operand kernels."""
+    too: four KITTI seeds under --slow, the two worst of rounds 2-4 without it, at full size through the split-operand kernels."""
     cfg = kb.kitti_config()
     rows = []
-    for seed in (0, 4, 6, 11):
+    for seed in ((0, 4, 6, 11) if slow else (4, 6)):   # (4 and 6: the worst seeds of rounds 2-4)
         sds = kb.synthetic.make_state_dicts(cfg, seed=seed, gain=1.3)
         frames = kb.synthetic.make_frames(1, 352, 1216, "kitti", seed=1 + seed, jitter_intrinsics=0.1)
         m = kb.modules.KBNetModel.from_config(cfg, dev)
