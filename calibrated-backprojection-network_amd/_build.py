@@ -16,7 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkbnet_hip.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["abi.hip", "s2d.hip", "conv_igemm.hip", "conv_dma.hip", "conv_dma_t1.hip", "conv_dma_t2.hip", "conv_dma_t4.hip", "conv_up2x.hip", "conv_wino.hip", "tune.hip", "kb.hip", "kb_pair.hip", "kb_pair_nb3.hip", "kb_pair_nb4.hip", "head.hip", "conv_split.hip", "front.hip", "tail.hip", "pre_eval.hip", "unpack.hip", "io_png.hip", "elementwise.hip"]
+# longest translation units first (conv_split.hip alone takes 100-110 s): the pool then ends with the short ones
+SOURCES = ["conv_split.hip", "conv_igemm.hip", "conv_dma_t1.hip", "conv_dma_t2.hip", "conv_dma_t4.hip", "conv_up2x.hip", "front.hip", "kb_pair_nb3.hip",
+           "kb_pair_nb4.hip", "conv_wino.hip", "s2d.hip", "kb_pair.hip", "head.hip", "tail.hip", "kb.hip", "conv_dma.hip", "tune.hip", "abi.hip", "pre_eval.hip",
+           "unpack.hip", "io_png.hip", "elementwise.hip"]
 HEADERS = ["kbn_common.h", "conv_common.h", "conv_dma_impl.h", "kb_pair_impl.h", "front_common.h", "s2d_pools.h", "s2d_stage.h", "conv_split_body.inc", "upconv64_split_body.inc", os.path.join("..", "..", "include", "kbnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function"]
@@ -61,7 +64,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 4))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"])
