@@ -630,11 +630,20 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
             del oreplay, omodel
 
     # configs[1] (batch 8 per GPU, the round-1 headline) as a side measurement on the same weights
-    side_fps = None
+    side_fps = side_latency_fps = None
     if not args.no_side_batch and per != SIDE_BATCH:
-        sreplay = model.capture(*[f[:SIDE_BATCH].contiguous() for f in frames])
+        sframes = [f[:SIDE_BATCH].contiguous() for f in frames]
+        sreplay = model.capture(*sframes)
         side_fps, _ = replay_rate(sreplay, sreplay.static_in, 20, 3, SIDE_BATCH, world, dev)
         del sreplay
+        # the same batch in the latency form sized for its launches (two graph branches of four frames: set_latency_mode(frames=4))
+        model.set_latency_mode(True, frames=SIDE_BATCH // 2)
+        try:
+            sreplay = model.capture(*sframes)
+            side_latency_fps, _ = replay_rate(sreplay, sreplay.static_in, 20, 3, SIDE_BATCH, world, dev)
+            del sreplay
+        finally:
+            model.set_latency_mode(False)
 
     # Batch-1 latency (graph replay of ONE frame, the encoder's level side branches on): the figure that sits beside the reference's
     # README.md:232 "15.19 ms per KITTI sample" (its GPU, batch 1, its timed region src/kbnet.py:896-921 incl. the pre-model stage)
@@ -840,6 +849,8 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
                    "reference_options_frames_per_s": options_fps,
                    # side measurement: BASELINE configs[1] (batch 8 per GPU), forward only
                    "batch8_frames_per_s": None if side_fps is None else round(side_fps, 1),
+                   # ... and in the latency form sized for four-frame launches (split-K where four frames cannot fill the chip; another summation order, opt-in)
+                   "batch8_latency_mode_frames_per_s": None if side_latency_fps is None else round(side_latency_fps, 1),
                    # side measurement: the forward without the one conv of the reference's graph whose result nothing reads
                    "unused_image_conv_skipped": dead_conv_fps,
                    # side measurement: the same batch with every conv on the fp32 MFMAs (KBN_NO_SPLIT=1), graph replay

@@ -23,7 +23,7 @@
 // is why this kernel sits on the parity-gated path (tests/test_hip_parity.py holds it to the same 1e-4 bar).
 //
 // Direct 3x3 conv (+ LeakyReLU) over one or two NCHW fp32 sources -- MODE 0: the concat convs of the decoder, reference
-// src/net_utils.py:1483-1487; MODE 1: nearest-2x up-conv with nine taps, :484-499 (superseded by the folded form at the
+// src/net_utils.py:1483-1487; MODE 1: nearest-2x up-conv with nine taps, :484-499 (no longer instantiated since round 6: superseded by the folded form at the
 // end of this file); MODE 2: stride 2, the image convs of the KB blocks, :1348 -- as an implicit GEMM with M = 32 output
 // pixels of a row, N = 32 filters, K = 16 channels per v_mfma_f32_32x32x16_f16.  Workgroup = 512 threads = 8 waves = RG
 // row groups x 8/RG filter groups; a wave owns MB rows (m-blocks) x two 32-filter n-blocks and keeps TWO accumulators

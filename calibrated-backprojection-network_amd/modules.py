@@ -204,8 +204,8 @@ def _run_split(layer, weight, srcs, n, h, w, out=None, up2x=False, out_absmax=No
               else layer._packed_split.get(weight, layer.stride, up2x="split"))
     # the latency form (KBNetModel.set_latency_mode): a launch too small for the chip spreads every tile's K loop over several workgroups
     ks = 1
-    if getattr(layer, "latency", False) and not pair_out and all(s.kind == _lib.KBN_SRC_TENSOR for s in srcs):
-        ks = ops.ksplit_for(sum(s.channels for s in srcs), layer.out_channels, h, w, layer.stride, up2x=up2x)
+    if getattr(layer, "latency", 0) and not pair_out and all(s.kind == _lib.KBN_SRC_TENSOR for s in srcs):
+        ks = ops.ksplit_for(sum(s.channels for s in srcs), layer.out_channels, h, w, layer.stride, up2x=up2x, frames=layer.latency)
     kw = dict(up2x=up2x, negative_slope=layer._slope, stride=layer.stride, folded_up2x=up2x, out_absmax=None if layer._post else out_absmax,
               transposed=transposed)
     res = ops.conv3x3_split(srcs, packed, n, layer.out_channels, h, w, out, ksplit=ks, **kw) if ks > 1 else None
@@ -705,6 +705,16 @@ class DecoderBlock(torch.nn.Module):
         self.conv = Conv2d(skip_channels + out_channels, out_channels, 3, 1, weight_initializer,
                            activation_func, use_batch_norm, use_instance_norm)
 
+    def latency_splitk(self, h, w):
+        """In the latency form (KBNetModel.set_latency_mode): would this block's up-conv (input h x w) or its concat conv launch
+        split-K?  Such a block runs on fp32 tensors."""
+        frames = getattr(self.conv, "latency", 0)
+        if not frames:
+            return False
+        up = self.deconv.conv if isinstance(self.deconv, UpConv2d) else self.deconv
+        return (ops.ksplit_for(up.in_channels, up.out_channels, 2 * h, 2 * w, 1, up2x=True, frames=frames) > 1
+                or ops.ksplit_for(self.conv.in_channels, self.conv.out_channels, 2 * h, 2 * w, 1, frames=frames) > 1)
+
     def forward(self, x, skip=None, shape=None, amax_x=None, amax_skip=None, out_absmax=None, stats=None, pair_out=False):
         """amax_x / amax_skip / out_absmax / stats (extensions): per-frame max |a| slots of the inputs, the slot to fill
         for the result and the slot pool of the forward (ops.ActStats); missing input slots are measured.  `x` may be an
@@ -940,6 +950,15 @@ class KBNetEncoder(torch.nn.Module):
             raise KbnError("kb1_front declined a problem kbn_kb1_front_query accepted")
         return skip, out_image, out_depth, out_fused, a_img, a_skip, nxt_info
 
+    def _image_splitk(self, level, h, w):
+        """In the latency form: would KB level `level`'s stride-2 image conv (input h x w) launch split-K?"""
+        blk = getattr(self, f"calibrated_backprojection{level + 1}", None)
+        if blk is None:
+            return False
+        ci = blk.conv_image.conv_block[0]
+        frames = getattr(ci, "latency", 0)
+        return bool(frames) and ops.ksplit_for(ci.in_channels, ci.out_channels, (h + 1) // 2, (w + 1) // 2, 2, frames=frames) > 1
+
     def forward(self, image, depth, intrinsics):
         latent, skips, _, _ = self.encode(image, depth, intrinsics)
         return latent, skips
@@ -1002,6 +1021,8 @@ class KBNetEncoder(torch.nn.Module):
                 # conv_image of a KB level is read by the next KB level only -- its stride-2 split conv_image and, at the even
                 # pixels, its conv_fused: it travels as an ops.PairTensor (+ the fp32 even-pixel side output) from level 1 on
                 want_pair = self.pair_chain and 1 <= level < 3 and (level + 1) in self.resolutions_backprojection
+                if want_pair and self._image_splitk(level + 1, oh, ow):
+                    want_pair = False   # the latency form: the next level's image conv runs split-K, on an fp32 source
                 res = None
                 if want_pair or isinstance(conv_image, ops.PairTensor):
                     res = blk.run(conv_image, conv_depth, kinv, conv_fused, None, out_depth, out_fused,
@@ -1111,8 +1132,12 @@ class MultiScaleDecoder(torch.nn.Module):
             a_out = stats.new()
             # the concat conv's output is read by the next block's up-conv only: as a PairTensor when that kernel takes one
             y = None
+            # the latency form: a block whose up-conv or concat conv would run split-K takes and returns fp32 tensors (the split-K
+            # kernels read fp32 sources); the pair chain starts behind the last such block
+            if not isinstance(x, ops.PairTensor) and blk.latency_splitk(x.shape[2], x.shape[3]):
+                y = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats)
             # (not with KBN_NO_SPLIT=1: every split-operand launch would decline, after the block's up-conv had already run in fp32)
-            if self.pair_chain and (allow_pair or i > 0) and ops.split_enabled():
+            if y is None and self.pair_chain and (allow_pair or i > 0) and ops.split_enabled():
                 y = blk(x, skips[i], amax_x=amax, amax_skip=amax_skips[i], out_absmax=a_out, stats=stats, pair_out=True)
             if y is None and isinstance(x, ops.PairTensor):
                 # a pair tensor in, an fp32 tensor out (the block's up-conv stages the pair source by DMA, mode "pair in /
@@ -1414,21 +1439,24 @@ class KBNetModel(object):
         return self.decoder.depth(latent, skips, shape, self.min_predict_depth, self.max_predict_depth,
                                   return_logits=return_logits, out=out, amax_x=amax_latent, amax_skips=amax_skips, stats=stats)
 
-    def set_latency_mode(self, enabled: bool = True):
-        """The LATENCY form of the forward, for batches of one or two frames (the reference's own run loop is batch 1:
-        src/kbnet.py:764-772, 887).  One KITTI frame gives the low-resolution layers 6-30 workgroups for 256 CUs -- deconv4's conv runs
-        24 workgroups of 48 K-chunks each -- so every split-operand 3x3 conv whose launch cannot fill half the chip spreads each tile's K
-        loop over up to 16 workgroups and a second kernel adds the partial sums (kbn_conv3x3_split_forward_ksplit, ops.ksplit_for); the
-        tensors between the layers stay fp32 (the pair-tensor chains serve the power-bound large-batch kernels, not this regime).
-        Same 1e-4 parity as the default form, ANOTHER summation order: a model is in one mode throughout, and a frame's bits are
-        those of the mode (eager = graph replay = frame alone or in a batch, within the mode).  Off by default."""
+    def set_latency_mode(self, enabled: bool = True, frames: int = 1):
+        """The LATENCY form of the forward, for launches of a few frames (the reference's own run loop is batch 1: src/kbnet.py:764-772,
+        887).  One KITTI frame gives the low-resolution layers 6-30 workgroups for 256 CUs -- deconv4's conv runs 24 workgroups of 48
+        K-chunks each -- so every split-operand 3x3 conv whose launch of `frames` frames cannot fill half the chip spreads each tile's K
+        loop over up to 16 workgroups and a second kernel adds the partial sums (kbn_conv3x3_split_forward_ksplit, ops.ksplit_for).  The
+        split-K kernels read and write fp32 tensors, so the decoder blocks / KB levels that use them leave the pair-tensor chains; the
+        chains start behind the last of them.  `frames`: the frames ONE LAUNCH carries -- 1 for the run loop (and for batch 2), 4 for a
+        batch-8 graph (two branches of four frames) -- a property of the mode, not read off the tensors, so that inside a mode a frame's
+        bits do not depend on how it is run (eager = graph replay = alone or in a batch).  Same 1e-4 parity as the default form, ANOTHER
+        summation order.  Off by default; from 16 frames per launch on no layer qualifies any more."""
+        frames = int(frames) if enabled else 0
+        if enabled and frames < 1:
+            raise KbnError("set_latency_mode: frames must be at least 1")
         for top in self.modules():
             for m in top.modules():
                 if isinstance(m, (Conv2d, TransposeConv2d)):
-                    m.latency = bool(enabled)
-        self.decoder.pair_chain = False if enabled else None      # None: back to the KBN_NO_PAIR switches
-        self.encoder.pair_chain = False if enabled else None
-        self.latency_mode = bool(enabled)
+                    m.latency = frames
+        self.latency_mode = frames
         return self
 
     def capture(self, image, sparse_depth, validity_map_depth, intrinsics, branches=None, tune=True, outputs=1, split_graphs=False):

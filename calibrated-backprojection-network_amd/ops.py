@@ -899,17 +899,19 @@ def conv3x3_split(srcs: List[ConvSrc], packed_weight: torch.Tensor, n: int, out_
     return out
 
 
-def ksplit_for(cin: int, out_channels: int, height: int, width: int, stride: int = 1, cus: int = 256, up2x: bool = False) -> int:
-    """How many workgroups share a tile's K loop in the latency form (KBNetModel.set_latency_mode): as many as bring ONE FRAME's launch
-    to about one workgroup per CU -- every range at least two 16-channel chunks long, at most 16 -- and 1 when one frame's tiles
-    already fill a quarter of the chip or its output is large (the partial planes cost HBM traffic: 2 x ksplit x the output).  A function
-    of the layer alone, not of the batch: inside the mode a frame's bits do not depend on what runs beside it."""
+def ksplit_for(cin: int, out_channels: int, height: int, width: int, stride: int = 1, cus: int = 256, up2x: bool = False, frames: int = 1) -> int:
+    """How many workgroups share a tile's K loop in the latency form (KBNetModel.set_latency_mode(frames=)): as many as bring a launch
+    of `frames` frames to about one workgroup per CU -- every range at least two 16-channel chunks long, at most 16 -- and 1 when
+    its tiles already fill half the chip or the output is large (the partial planes cost HBM traffic: 2 x ksplit x the output).  A
+    function of the layer and of the MODE's `frames`, never of the batch a call happens to carry: inside a mode a frame's bits do not
+    depend on what runs beside it."""
     if up2x:   # the folded up-conv: 8 x 32 low-resolution pixels x 64 filters per workgroup
         tiles = -(-(width // 2) // 32) * (-(-(height // 2) // 8)) * (-(-out_channels // 64))
     else:
         tiles = -(-width // 32) * (-(-height // (8 if stride == 2 else 16))) * (-(-out_channels // (128 if stride == 2 else 64)))
+    tiles *= max(1, int(frames))
     chunks = cin // 16
-    if tiles * 2 > cus or chunks < 4 or 4 * out_channels * height * width > (16 << 20):
+    if tiles * 2 > cus or chunks < 4 or 4 * out_channels * height * width * max(1, int(frames)) > (16 << 20):
         return 1
     ks = min(16, chunks // 2, max(1, cus // tiles))
     while ks > 1 and -(-chunks // ks) * (ks - 1) >= chunks:   # no empty range

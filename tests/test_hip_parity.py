@@ -1827,6 +1827,37 @@ def test_forward_latency_mode_full_size(dev, preset, shape):
     assert torch.equal(m.forward(*dframes), default), "switching the mode off restores the default form bit for bit"
 
 
+def test_forward_latency_mode_batch8_graph(dev):
+    """set_latency_mode(frames=4): BASELINE configs[1]'s batch of 8 as the graph of two four-frame branches, with split-K where FOUR
+    frames cannot fill the chip (deconv4 / deconv3, KB level 3's image conv, conv5) and the pair-tensor chains everywhere else.  The
+    mode's `frames` is a property of the model, not read off the tensors: the eager batch of 8, the 2 x 4 graph and a frame alone
+    give the same bits; frames 0 and 7 within 1e-4 of the oracle."""
+    cfg = kb.kitti_config()
+    sds = kb.synthetic.make_state_dicts(cfg, seed=0, gain=kb.synthetic.PARITY_GAIN["kitti"])
+    frames = kb.synthetic.make_frames(8, 352, 1216, "kitti", seed=1, jitter_intrinsics=0.1)
+    m = kb.modules.KBNetModel.from_config(cfg, dev)
+    m.load_state_dicts(*sds)
+    dframes = to(dev, *frames)
+    default = m.forward(*dframes).clone()
+    m.set_latency_mode(True, frames=4)
+    kb.ops.PROFILE = []
+    try:
+        out = m.forward(*dframes).clone()
+    finally:
+        prof, kb.ops.PROFILE = kb.ops.PROFILE, None
+    names = [r[0] for r in prof]
+    assert names.count("conv_split") == 4 and names.count("conv_split_upfold") == 5, "the decoder stayed on the split-operand kernels"
+    assert not torch.equal(out, default)
+    replay = m.capture(*dframes)
+    assert replay.branches == 2 and torch.equal(replay(*dframes), out), "graph replay (2 x 4 frames) = the eager batch"
+    assert torch.equal(m.forward(*[f[7:8] for f in dframes]), out[7:8]), "a frame alone gives the bits it gave in the batch"
+    for i in (0, 7):
+        ref = orc.kbnet_forward(*[f[i:i + 1] for f in frames], *sds, cfg.min_pools, cfg.max_pools, cfg.min_predict_depth, cfg.max_predict_depth)
+        assert _worst_rel(out[i:i + 1], ref) < TOL
+    m.set_latency_mode(False)
+    assert torch.equal(m.forward(*dframes), default)
+
+
 def test_forward_batch8_full_size_vs_oracle(dev):
     """BASELINE configs[1]'s workload -- KITTI 352x1216, batch 8, fp32, one GPU -- in the all-HIP form: eager, and as the graph
     bench.py's `batch8_frames_per_s` replays (two branches of 4 frames: other tuned tile choices and another graph than batch 32's).
