@@ -104,7 +104,6 @@ SIGNATURES = {
     "kbn_conv_tail_pack_weight": (_I, [_P, _P, _I, _P]),
     "kbn_conv_tail_forward": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P]),
     "kbn_conv_tail_forward_pair": (_I, [_P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P]),
-    "kbn_deconv0_tail_forward": (_I, [_P, _L, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _F, _F, _P]),
     "kbn_absmax_frames": (_I, [_P, _L, _I, _L, _P, _P]),
     "kbn_conv3x3_split_packed_weight_bytes": (C.c_size_t, [_I, _I, _I]),
     "kbn_conv3x3_split_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),

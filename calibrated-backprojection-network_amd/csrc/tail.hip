@@ -49,11 +49,6 @@ struct TailParams {
     const float* tab;        // TL_TAB floats
     const _Float16* wp;      // [5 k-steps][term][4 k-groups][16 filters][8]: k-group g = 4 ks + kq = (tap g >> 1, channels 8 (g & 1) + j)
     const float* wout;       // 1 x C x 3 x 3 (raw)
-    // FUSE (conv_tail_kernel<.., FUSE>, kbn_deconv0_tail_forward): deconv0's up-conv in front -- the input is the PAIR tensor of the
-    // half-resolution features (64 channels at (H/2) x (W/2)) in xp / xp_bstride / xscale, and
-    const float* up_inv;     // 2^-e per filter of the folded up-conv (16 floats: the blob of kbn_conv3x3_split_pack_weight, mode 3, <= 16 filters)
-    const _Float16* up_wp;   // its weights [chunk of 32 channels][set (16)][part (w1, w2)][k-group (4)][16 filters][8] fp16 (uf16_pack_kernel)
-    float up_slope;          // the up-conv's LeakyReLU slope (1: linear)
     float* depth;
     float* logits;           // or null
     int N, C, H, W, tilesX, tilesY, ntiles;
@@ -78,20 +73,8 @@ __device__ __forceinline__ void tl_split8(const float (&v)[8], float pre, th8& h
 // registers, no tile maximum, no splitting; the window is the producer's
 // ONE: the THROUGHPUT-ONLY one-term mode (KBN_FP16_ONE_TERM=1, BASELINE configs[2]'s 16-bit leg): h1 w1 alone -- plain fp16 operands,
 // fp32 accumulation, a third of the MFMAs; the h2 planes of a pair input are neither fetched nor read
-// FUSE: deconv0's nearest-2x up-conv (reference src/net_utils.py:484-499; 64 -> C <= 12 filters, the folded four-parity form of
-// csrc/conv_split.hip) evaluated HERE for the 20 x 36 pixels the tile reads, from the half-resolution PAIR tensor: the 16-channel
-// full-resolution tensor between the two kernels (27 MB written + 34 MB read per KITTI frame) never exists.  Stage A becomes:
-//   A0  the (10 + 2) x (18 + 2) low-resolution pixels x 64 channels by LDS-DMA: channels 0-31 into the (still idle) feature planes,
-//       32-63 into the (still idle) IN area -- 61 KB in flight, nothing double buffered
-//   A1  D[filter][position] on v_mfma_f32_16x16x32_f16 per output parity (py, px): position = (r, c) of the 10 x 18 low-resolution grid,
-//       output pixel (2 r + py, 2 c + px) of IN; K = (tap (dy, dx), 32 channels): the B fragment of a lane is ONE granule at staged pixel
-//       (r + py + dy, c + px + dx); wave w takes parity w & 3 and six of its twelve 16-position blocks; the 16 x 32 weight fragments
-//       (1 KiB per set and part) come straight from L2 / L1, one K step ahead; one accumulator per block (K = 256 per output)
-//   A2  scale, LeakyReLU, zero outside the image, the tile's maximum -> window; split; v_permlane16_swap hands lanes kq = 0 / 2 the
-//       whole h1 granule of their k-group and kq = 1 / 3 the h2 granule -> IN [term][k-group][pixel][8]
-template <bool PIN, bool ONE = false, bool FUSE = false>
+template <bool PIN, bool ONE = false>
 __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailParams p) {
-    static_assert(!FUSE || (PIN && !ONE), "the fused form reads a pair tensor and has no one-term mode");
     constexpr int IN_KG = TL_NP0 * 16, IN_PART = 2 * IN_KG, IN_BYTES = 2 * IN_PART;   // [term][k-group][pixel][8 ch] fp16
     constexpr int OFF_F = IN_BYTES;                                                    // [C][TL_FP] fp32
     static_assert(OFF_F + 12 * TL_FP * 4 + 12 * 9 * 4 <= 80 * 1024, "two workgroups per CU at KBNet's 12 channels");
@@ -112,157 +95,21 @@ __global__ __launch_bounds__(TL_THREADS, 2) void conv_tail_kernel(const TailPara
     // output0's weights (C x 9) behind the feature planes: the head reads them per lane (channel = lane & 3 + 4 i) -- from global
     // memory that was a latency chain of 27 vector loads inside the channel loop (hoisting them cost the registers that keep two
     // workgroups per CU: round 5); from LDS they cost a broadcast read each (489 -> 467 us per 32 KITTI frames, same box: profiles/r06/v83_ab_tail_wout_lds.txt)
-    float* const WO = F + (FUSE ? 12 : C) * TL_FP;   // (FUSE: chunk 0 of the staged tile lies in the 12 planes' bytes whatever C is)
+    float* const WO = F + C * TL_FP;
     if (tid < C * 9) WO[tid] = p.wout[tid];   // published by the barrier that ends stage A
     // the conv's A fragments (weights, 10 KB shared by every tile): requested FIRST, so that their L2 / L1 latency runs under the
     // tile's input DMA instead of behind the barrier that ends it (hipcc otherwise sinks the loads to their first use)
     th8 a1[5], a2[5];
-    if constexpr (!FUSE) {
 #pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-            a1[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 0) * 512 + lane * 8);
-            a2[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 1) * 512 + lane * 8);
-        }
-        asm volatile("" ::: "memory");   // keeps the requests above the DMA issue below
+    for (int ks = 0; ks < 5; ++ks) {
+        a1[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 0) * 512 + lane * 8);
+        a2[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 1) * 512 + lane * 8);
     }
+    asm volatile("" ::: "memory");   // keeps the requests above the DMA issue below
 
     // ---- A: input tile -> split granules; the fp16 window is the tile's own (max |x| over the pixels loaded here)
     float un_in;
-    if constexpr (FUSE) {
-        constexpr int LR = TL_R0H / 2 + 2, LC = TL_R0W / 2 + 2, LNP = LR * LC;     // staged low-resolution pixels: 12 x 20
-        constexpr int XKG = LNP * 16, XPART = 4 * XKG, XCHUNK = 2 * XPART;         // [term][k-group (4)][pixel][8 ch] of one 32-channel chunk
-        static_assert(XCHUNK <= 12 * TL_FP * 4 && XCHUNK <= IN_BYTES, "chunk 0 in the feature planes, chunk 1 in the IN area");
-        constexpr int PR = TL_R0H / 2, PC = TL_R0W / 2, NPOS = PR * PC, NBLK = (NPOS + 15) / 16, BPW = NBLK / 2;   // 10 x 18 positions, 12 blocks, 6 per wave
-        static_assert(NBLK % 2 == 0, "two waves per parity");
-        const int sH = H >> 1, sW = W >> 1;
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(smem)));
-        const long long pplane = pair_plane_halves(sH, sW);
-        const _Float16* pn = p.xp + (long long)n * p.xp_bstride;
-        // ---- A0: both chunks by DMA (wave-wide id = chunk * 32 + plane * 4 + round; wave w issues ids w, w + 8, ..)
-        constexpr int NRD = (LNP + 63) / 64, NDMA = 2 * 8 * NRD;
-        static_assert(NDMA % 8 == 0, "whole rounds of the eight waves");
-#pragma unroll
-        for (int i = 0; i < NDMA / 8; ++i) {
-            const int id = wave + 8 * i, ch = id / (8 * NRD), pl = (id / NRD) % 8, j = id % NRD;
-            const int t = pl >> 2, kgl = pl & 3;
-            const int pix = j * 64 + lane;
-            const int r = pix / LC, c = pix - r * LC;
-            const int Y = (oy0 >> 1) - 2 + r, X = (ox0 >> 1) - 2 + c;
-            const unsigned voff = (pix < LNP && Y >= 0 && Y < sH && X >= 0 && X < sW) ? (unsigned)(Y * sW + X) * 16u : (unsigned)(sH * sW) * 16u;
-            const unsigned long long mask = (j == NRD - 1 && (LNP & 63)) ? ((1ull << (LNP & 63)) - 1) : ~0ull;
-            lds_dma16_sm(reinterpret_cast<const float*>(pn + (long long)((ch * 4 + kgl) * 2 + t) * pplane), voff,
-                         lds0 + (unsigned)((ch == 0 ? OFF_F : 0) + t * XPART + kgl * XKG + j * 64 * 16), mask);
-        }
-        // ---- A1: the folded up-conv.  wave -> (parity, half of the parity's blocks)
-        const int par = wave & 3, py = par >> 1, px = par & 1, bh = wave >> 2;
-        int boff[BPW];          // byte offset of position (r, c) + (py, px) in a staged plane, per block
-        bool live[BPW];
-#pragma unroll
-        for (int u = 0; u < BPW; ++u) {
-            const int q = 16 * (bh * BPW + u) + l15;
-            live[u] = q < NPOS;
-            const int qc = live[u] ? q : NPOS - 1;
-            const int r = qc / PC, c = qc - r * PC;
-            boff[u] = ((r + py) * LC + (c + px)) * 16 + kq * XKG;
-        }
-        tf4 acc[BPW];
-#pragma unroll
-        for (int u = 0; u < BPW; ++u) acc[u] = (tf4){0.f, 0.f, 0.f, 0.f};
-        // set index of (py, dy, px, dx) in uf_item's visiting order (csrc/conv_split.hip): ox = px + dx major, then 2 py + dy, then px
-        auto item_of = [&](int dy, int dx) {
-            const int ox = px + dx, row = 2 * py + dy;
-            return ox == 0 ? row : (ox == 1 ? 4 + 2 * row + px : 12 + row);
-        };
-        auto wfrag = [&](int ch, int tap, int part) {
-            return *reinterpret_cast<const th8*>(p.up_wp + ((long long)((ch * 16 + item_of(tap >> 1, tap & 1)) * 2 + part) * 64 + lane) * 8);
-        };
-        th8 w1n = wfrag(0, 0, 0), w2n = wfrag(0, 0, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();        // the staged tile is complete
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int ch = ks >> 2, tap = ks & 3;
-            const th8 w1 = w1n, w2 = w2n;
-#ifndef KBN_FUSE_ABL_NOW
-            if (ks + 1 < 8) { w1n = wfrag((ks + 1) >> 2, (ks + 1) & 3, 0); w2n = wfrag((ks + 1) >> 2, (ks + 1) & 3, 1); }
-#endif
-            const th8 w1s = w1 * (_Float16)0.00048828125f;     // w1 2^-11: the partner of the scaled residual h2
-            const unsigned char* xb = smem + (ch == 0 ? OFF_F : 0) + ((tap >> 1) * LC + (tap & 1)) * 16;
-#pragma unroll
-            for (int u = 0; u < BPW; ++u) {
-                const th8 b1 = *reinterpret_cast<const th8*>(xb + boff[u]);
-                const th8 b2 = *reinterpret_cast<const th8*>(xb + XPART + boff[u]);
-#ifdef KBN_FUSE_ABL_NOMFMA
-                acc[u][0] += (float)b1[0] * (float)w1[0] + (float)b2[1] * (float)w2[0] + (float)w1s[0];
-#else
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b1, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, b1, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1s, b2, acc[u], 0, 0, 0);
-#endif
-            }
-        }
-        // ---- A2: values of this lane's four filters at its positions; the tile's maximum places IN's window
-        const float unx = 1.f / p.xscale[n];
-        tf4 sc = *reinterpret_cast<const tf4*>(p.up_inv + 4 * kq);
-        sc *= unx;
-        int ipix[BPW];
-        float tm = 0.f;
-#pragma unroll
-        for (int u = 0; u < BPW; ++u) {
-            const int q = 16 * (bh * BPW + u) + l15;
-            const int qc = live[u] ? q : NPOS - 1;
-            const int r = qc / PC, c = qc - r * PC;
-            const int iy = 2 * r + py, ix = 2 * c + px;
-            const int Y = oy0 - 2 + iy, X = ox0 - 2 + ix;
-            ipix[u] = iy * TL_R0W + ix;
-            tf4 v = acc[u] * sc;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], v[k] * p.up_slope);
-            if (!(Y >= 0 && Y < H && X >= 0 && X < W)) v = (tf4){0.f, 0.f, 0.f, 0.f};    // the conv's zero padding
-            acc[u] = v;
-            tm = fmaxf(fmaxf(tm, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        }
-        tm = __uint_as_float(wave_max_bits(tm));
-        __syncthreads();        // every fragment read of the staged tile is done: the reduction scratch and IN overlay it
-        if (lane == 0) F[wave] = tm;
-        __syncthreads();
-        tm = fmaxf(fmaxf(fmaxf(F[0], F[1]), fmaxf(F[2], F[3])), fmaxf(fmaxf(F[4], F[5]), fmaxf(F[6], F[7])));
-        const unsigned abits = __builtin_amdgcn_readfirstlane(__float_as_uint(tm));
-        int k2 = 14 + 127 - (int)(abits >> 23);
-        k2 = k2 > 100 ? 100 : (k2 < -100 ? -100 : k2);
-        const float pre_in = __uint_as_float((unsigned)(127 + k2) << 23);
-        un_in = __uint_as_float((unsigned)(127 - k2) << 23);
-        typedef unsigned tu2 __attribute__((ext_vector_type(2)));
-        typedef unsigned tu4 __attribute__((ext_vector_type(4)));
-        typedef _Float16 th4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int u = 0; u < BPW; ++u) {
-            const tf4 v = acc[u] * pre_in;
-            th4 h1, h2;
-#pragma unroll
-            for (int k = 0; k < 4; k += 2) {
-                const f32x2 a = {v[k], v[k + 1]};
-                const th2 c1 = __builtin_convertvector(a, th2);
-                const f32x2 f = {(float)c1[0], (float)c1[1]};
-                const f32x2 hi = a * 2048.f;
-                const f32x2 rr = {__builtin_fmaf(f[0], -2048.f, hi[0]), __builtin_fmaf(f[1], -2048.f, hi[1])};
-                const th2 c2 = __builtin_convertvector(rr, th2);
-                h1[k] = c1[0]; h1[k + 1] = c1[1];
-                h2[k] = c2[0]; h2[k + 1] = c2[1];
-            }
-            // lane kq holds channels 4 kq .. 4 kq + 3 of its pixel: kq = 0 / 2 take the whole h1 granule of k-group kq >> 1, kq = 1 / 3 its h2 granule
-            const tu2 H1 = __builtin_bit_cast(tu2, h1), H2 = __builtin_bit_cast(tu2, h2);
-            const auto r0 = __builtin_amdgcn_permlane16_swap(H1[0], H2[0], false, false);
-            const auto r1 = __builtin_amdgcn_permlane16_swap(H1[1], H2[1], false, false);
-            const tu4 g4 = {r0[0], r1[0], r0[1], r1[1]};
-            if (live[u]) *reinterpret_cast<tu4*>(smem + (kq & 1) * IN_PART + (kq >> 1) * IN_KG + ipix[u] * 16) = g4;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-            a1[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 0) * 512 + lane * 8);
-            a2[ks] = *reinterpret_cast<const th8*>(p.wp + (ks * 2 + 1) * 512 + lane * 8);
-        }
-    } else if constexpr (PIN) {
+    if constexpr (PIN) {
         constexpr int NR = (TL_NP0 + 63) / 64, NDMA = (ONE ? 2 : 4) * NR, DPW = NDMA / 8;   // 4 planes (term, k-group; ONE: the two h1 planes) x 12 rounds of 64 pixels
         static_assert(NDMA % 8 == 0, "whole rounds of the eight waves");
         un_in = 1.f / p.xscale[n];
@@ -540,49 +387,6 @@ int kbn_conv_tail_forward(const float* x, long long x_batch_stride, const void* 
     if (!x) return KBN_ERR_INVALID_ARGUMENT;
     return conv_tail_launch(x, x_batch_stride, nullptr, 0, nullptr, packed_w_conv, w_out, depth, logits, n, channels, height, width,
                             apply_activation, negative_slope, min_predict_depth, max_predict_depth, stream);
-}
-
-int kbn_deconv0_tail_forward(const void* x_pair, long long x_pair_batch_stride, const float* x_pair_scale, int in_channels,
-                             const void* packed_up, const void* packed_w_conv, const float* w_out, float* depth, float* logits, int n,
-                             int channels, int height, int width, int up_apply_activation, float up_negative_slope, int apply_activation,
-                             float negative_slope, float min_predict_depth, float max_predict_depth, kbn_stream_t stream) {
-    using namespace kbn;
-    if (!x_pair || !x_pair_scale || !packed_up || !packed_w_conv || !w_out || !depth || n < 1 || channels < 1 || height < 1 || width < 1)
-        return KBN_ERR_INVALID_ARGUMENT;
-    // KBNet's deconv0: 64 half-resolution channels (two 32-channel chunks: both resident in LDS), at most 12 filters, an exact 2x target
-    if (in_channels != 64 || channels > 12 || (height & 1) || (width & 1) || knob(KNOB_NO_SPLIT) || knob(KNOB_NO_HEAD_FUSION) || knob(KNOB_FP16_ONE_TERM) ||
-        (knob(KNOB_DEBUG) & 1024))   // KBN_DEBUG & 1024: the two-launch form (A/B runs)
-        return KBN_ERR_UNSUPPORTED;
-    const int sh = height / 2, sw = width / 2;
-    if ((reinterpret_cast<uintptr_t>(x_pair) & 15) || (x_pair_batch_stride & 7) || x_pair_batch_stride < (long long)(in_channels / 8) * 2 * pair_plane_halves(sh, sw))
-        return KBN_ERR_INVALID_ARGUMENT;
-    if ((long long)height * width > 0x1fffffffLL || (long long)sh * sw >= 0x0fffffffLL) return KBN_ERR_UNSUPPORTED;
-    if ((up_apply_activation && !(up_negative_slope >= 0.f && up_negative_slope <= 1.f)) ||
-        (apply_activation && !(negative_slope >= 0.f && negative_slope <= 1.f))) return KBN_ERR_UNSUPPORTED;
-    TailParams p{};
-    p.xp = static_cast<const _Float16*>(x_pair); p.xp_bstride = x_pair_batch_stride; p.xscale = x_pair_scale;
-    p.up_inv = static_cast<const float*>(packed_up);
-    p.up_wp = reinterpret_cast<const _Float16*>(p.up_inv + 16);     // (ocpad = 16 floats of 2^-e in front of the panel: kbn_conv3x3_split_pack_weight)
-    p.up_slope = up_apply_activation ? up_negative_slope : 1.f;
-    p.tab = static_cast<const float*>(packed_w_conv);
-    p.wp = reinterpret_cast<const _Float16*>(p.tab + TL_TAB);
-    p.wout = w_out; p.depth = depth; p.logits = logits;
-    p.N = n; p.C = channels; p.H = height; p.W = width;
-    p.tilesX = ceil_div(width, TL_TW); p.tilesY = ceil_div(height, TL_TH);
-    const long long tiles = (long long)p.tilesX * p.tilesY * n;
-    if (tiles > 0x7fffffffLL) return KBN_ERR_UNSUPPORTED;
-    p.ntiles = (int)tiles;
-    p.slope = apply_activation ? negative_slope : 1.f;
-    p.dmin = min_predict_depth;
-    p.ratio = (float)((double)min_predict_depth / (double)max_predict_depth);
-    // IN + the feature planes sized for 12 channels (chunk 0 of the staged tile lies there whatever `channels` is) + output0's weights
-    const size_t lds = (size_t)2 * 2 * TL_NP0 * 16 + (size_t)12 * TL_FP * 4 + (size_t)12 * 9 * 4;
-    static DeviceOnce oncef;
-    auto kern = conv_tail_kernel<true, false, true>;
-    if (int rc = set_max_dynamic_lds(oncef, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(TL_THREADS), lds, (hipStream_t)stream, p);
-    KBN_CHECK_LAUNCH();
-    return KBN_OK;
 }
 
 int kbn_conv_tail_forward_pair(const void* x_pair, long long x_pair_batch_stride, const float* x_pair_scale, const void* packed_w_conv,

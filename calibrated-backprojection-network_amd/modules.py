@@ -1165,15 +1165,6 @@ class MultiScaleDecoder(torch.nn.Module):
             packed = self._packed_tail.get(d0.conv.conv.weight) if (d0.conv.split and d0.conv._post is None) else None
             up = None
             if packed is not None and self.pair_tail and self.pair_chain and d0.conv.out_channels <= 12:
-                # the whole block in ONE launch where it fits (64 half-resolution channels as a PairTensor, an exact 2x target): the
-                # up-conv is evaluated per tile inside the tail kernel and its full-resolution output never reaches HBM
-                upc = d0.deconv.conv if isinstance(d0.deconv, UpConv2d) else None
-                if (upc is not None and isinstance(x, ops.PairTensor) and x.shape[1] == 64 and upc._post is None and upc.split
-                        and upc.split_narrow_up and upc.kernel_size == 3 and tuple(int(v) for v in tuple(shape)[-2:]) == (2 * x.shape[2], 2 * x.shape[3])):
-                    res = ops.deconv0_tail(x, upc._packed_split_up.get(upc.conv.weight, 1, up2x="split_up"), packed, self.output0.conv.weight,
-                                           min_predict_depth, max_predict_depth, upc._slope, d0.conv._slope, return_logits=return_logits, out=out)
-                    if res is not None:
-                        return res
                 # deconv0's up-conv hands the tail a PairTensor too (16 channels for KBNet's 12)
                 up = d0.deconv(x, shape=tuple(shape)[-2:], amax=amax, stats=stats, pair_out=True)
                 if up is not None:

@@ -767,51 +767,6 @@ def conv_tail(x, packed_w_conv, w_out, min_predict_depth: float, max_predict_dep
     return (depth, logits) if return_logits else depth
 
 
-@_on_tensor_device
-def deconv0_tail(x: "PairTensor", packed_up, packed_w_conv, w_out, min_predict_depth: float, max_predict_depth: float,
-                 up_negative_slope: Optional[float] = 0.2, negative_slope: Optional[float] = 0.2, return_logits=False, out=None):
-    """deconv0 in ONE launch (kbn_deconv0_tail_forward): nearest-2x up-conv of the half-resolution PairTensor `x` (64 channels) per tile,
-    then the channels -> channels conv, output0 and the depth mapping of conv_tail -- the full-resolution tensor between the block's two
-    convs never reaches HBM.  packed_up: pack_conv3x3_split_weight(folded_up2x=True) of the up-conv's weight (at most 12 filters).
-    Returns None when the shape does not qualify (the caller runs the up-conv and conv_tail)."""
-    lib = _lib.load()
-    wo = w_out.detach().contiguous()
-    _require(wo, "w_out", 4)
-    if not isinstance(x, PairTensor):
-        return None
-    n, cin, sh, sw = x.shape
-    c = wo.shape[1]
-    h, wd = 2 * sh, 2 * sw
-    if tuple(wo.shape) != (1, c, 3, 3):
-        raise KbnError(f"deconv0_tail: w_out must be 1 x {c} x 3 x 3")
-    if out is None:
-        depth = torch.empty((n, 1, h, wd), device=x.data.device, dtype=torch.float32)
-    else:
-        _require(out, "out", 4)
-        if tuple(out.shape) != (n, 1, h, wd) or not out.is_contiguous():
-            raise KbnError(f"out must be a contiguous {(n, 1, h, wd)} tensor")
-        depth = out
-    logits = torch.empty_like(depth) if return_logits else None
-    tiles = n * (-(-h // 16)) * (-(-wd // 32))
-    flops = 2.0 * n * h * wd * (cin * 9 * c + c * 9 * c)
-    status = _launch("deconv0_tail", flops,
-                     lambda: lib.kbn_deconv0_tail_forward(x.data.data_ptr(), x.data.stride(0), x.scale.data_ptr(), cin, packed_up.data_ptr(),
-                                                          packed_w_conv.data_ptr(), wo.data_ptr(), depth.data_ptr(),
-                                                          logits.data_ptr() if return_logits else None, n, c, h, wd,
-                                                          0 if up_negative_slope is None else 1, 0.0 if up_negative_slope is None else float(up_negative_slope),
-                                                          0 if negative_slope is None else 1, 0.0 if negative_slope is None else float(negative_slope),
-                                                          float(min_predict_depth), float(max_predict_depth), _stream()),
-                     # per tile: 48 position blocks x 24 MFMAs (up-conv on 20 x 36 pixels) + 39 x 15 (the conv), 16 x 16 x 32 each
-                     executed=tiles * (48 * 24 + 39 * 15) * 2.0 * 16 * 16 * 32,
-                     pipe="fp16", nbytes=4.0 * n * (sh * sw * cin + h * wd))
-    if status == _lib.KBN_ERR_UNSUPPORTED:
-        if PROFILE is not None:
-            PROFILE.pop()
-        return None
-    check(status, "kbn_deconv0_tail_forward")
-    return (depth, logits) if return_logits else depth
-
-
 # ----------------------------------------------------- fp32-grade convs on the 16-bit matrix core (split operands)
 @_on_tensor_device
 def pack_conv3x3_split_weight(weight: torch.Tensor, out: Optional[torch.Tensor] = None, stride: int = 1,

@@ -524,20 +524,6 @@ int kbn_conv_tail_forward_pair(const void* x_pair, long long x_pair_batch_stride
                                int apply_activation, float negative_slope, float min_predict_depth, float max_predict_depth,
                                kbn_stream_t stream);
 
-/* deconv0 WHOLE in one launch (round 6): the block's nearest-2x up-conv (reference src/net_utils.py:484-499, as called by
- * DecoderBlock.forward :1468-1481 with no skip: src/networks.py:1966-1983) in FRONT of kbn_conv_tail_forward_pair's fusion (second conv
- * :1485-1487 + MultiScaleDecoder.output0 src/networks.py:1985 + the depth mapping src/kbnet_model.py:181-184).  The input is the PAIR
- * tensor of the half-resolution features (in_channels = 64 at (height / 2) x (width / 2): deconv1's concat-conv output); the up-conv is
- * evaluated per tile for the 20 x 36 pixels the tile reads (the folded four-parity form, fp32-grade split products), so the
- * full-resolution tensor between the two kernels -- 27 MB written and 34 MB read back per KITTI frame -- never reaches HBM.
- *   packed_up      from kbn_conv3x3_split_pack_weight(mode 3) of the up-conv's channels x 64 x 3 x 3 weight (channels <= 12: the 16-filter layout)
- *   packed_w_conv  from kbn_conv_tail_pack_weight; w_out raw
- * KBN_ERR_UNSUPPORTED unless in_channels == 64, channels <= 12 and height, width even (the caller runs the two launches). */
-int kbn_deconv0_tail_forward(const void* x_pair, long long x_pair_batch_stride, const float* x_pair_scale, int in_channels,
-                             const void* packed_up, const void* packed_w_conv, const float* w_out, float* depth, float* logits, int n,
-                             int channels, int height, int width, int up_apply_activation, float up_negative_slope, int apply_activation,
-                             float negative_slope, float min_predict_depth, float max_predict_depth, kbn_stream_t stream);
-
 /* ------------------------------------------------- pre-model stage --
  * What the reference's run loop does between the host->device copy and the model call:
  *   validity = where(sparse > 0, 1, sparse)                        reference src/kbnet.py:899-902
