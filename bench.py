@@ -369,7 +369,7 @@ def device_sync(dev):
         torch.cuda.synchronize(dev)
 
 
-def timed_steps(runner, step_inputs, steps: int, warmup: int, dev):
+def timed_steps(runner, step_inputs, steps: int, warmup: int, dev, per_rank: bool = False):
     """The contract's timed region: W untimed steps, then EXACTLY K steps bracketed by barrier + device synchronise on
     both sides; returns (seconds = MAX over ranks, gathered output of the last step).  A step = forward of this rank's
     frames + the asynchronous all-gather of the depth maps (the gather of step i overlaps step i+1's forward; the last
@@ -388,7 +388,8 @@ def timed_steps(runner, step_inputs, steps: int, warmup: int, dev):
     local = time.perf_counter() - t0      # this rank's own K steps (its last gather drained), before it waits for the others
     kb.dist.barrier()
     elapsed = time.perf_counter() - t0
-    timed_steps.local_seconds = kb.dist.gather_over_ranks(local, dev)   # rank order; read by main() for `config.multi_gpu`
+    if per_rank:   # + every rank's own seconds, rank order (`config.multi_gpu.per_rank_frames_per_s`)
+        return kb.dist.max_over_ranks(elapsed, dev), out, kb.dist.gather_over_ranks(local, dev)
     return kb.dist.max_over_ranks(elapsed, dev), out
 
 
@@ -525,10 +526,9 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     frames = [f.to(dev) for f in frames]
     if forward_factory is not None:   # test hook: the plumbing alone
         runner = kb.dist.ShardedRunner(forward_factory(rank, dev, frames), rank, world)
-        elapsed, out = timed_steps(runner, frames, args.steps, args.warmup, dev)
+        elapsed, out, local_seconds = timed_steps(runner, frames, args.steps, args.warmup, dev, per_rank=True)
         result = base_result(per * world * args.steps / elapsed, world, args.steps, args.warmup, 1e3 * elapsed / args.steps)
-        multi_gpu = multi_gpu_report(runner.forward_fn, frames, out, per, world, rank, dev, result["value"], list(timed_steps.local_seconds),
-                                     args.steps, reps=3)
+        multi_gpu = multi_gpu_report(runner.forward_fn, frames, out, per, world, rank, dev, result["value"], local_seconds, args.steps, reps=3)
         result["config"] = {"workload": "stand-in forward (plumbing test)", "frames_per_gpu": per, "global_batch": per * world,
                             "multi_gpu": multi_gpu,
                             "gathered_frames": int(out.shape[0]), "rank_seeds": [1 + r for r in range(world)],
@@ -557,8 +557,7 @@ def main(argv=None, backend: str = "nccl", forward_factory=None):
     # loader.InferenceFrameLoader writes there directly, so a step has no input copy.  Eager mode: the frames.
     step_inputs = forward.static_in if hasattr(forward, "static_in") else frames
 
-    elapsed, out = timed_steps(runner, step_inputs, args.steps, args.warmup, dev)
-    local_seconds = list(timed_steps.local_seconds)
+    elapsed, out, local_seconds = timed_steps(runner, step_inputs, args.steps, args.warmup, dev, per_rank=True)
     out = out.clone()
     # this rank's slice of the gathered tensor must be the bits its own forward produces (the gather reads the graph's output in place)
     gather_ok = bool(torch.equal(out[rank * per:(rank + 1) * per], forward(*step_inputs)))
