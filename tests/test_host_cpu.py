@@ -284,3 +284,38 @@ def test_front_queries_answer_without_a_gpu():
     finally:
         del os.environ["KBN_NO_SPLIT"]
         kb.ops.reload_env()
+
+
+def test_latency_mode_host_logic():
+    """KBNetModel.set_latency_mode (round 6) is host logic until a launch happens: the split-K rule is a function of the LAYER and of the
+    mode's `frames` (never of a call's batch: a frame's bits inside a mode do not depend on how it is run), its ranges are never empty,
+    the decoder blocks / KB levels that would launch split-K are the low-resolution ones, and switching the mode off leaves nothing behind."""
+    import torch
+    for cin in (64, 96, 128, 384, 768, 1024):
+        for oc in (48, 64, 128, 256, 384):
+            for hw in ((11, 38), (22, 76), (44, 152), (88, 304), (176, 608), (15, 20), (30, 40)):
+                for stride, up in ((1, False), (2, False), (1, True)):
+                    for frames in (1, 2, 4, 16):
+                        ks = kb.ops.ksplit_for(cin, oc, hw[0], hw[1], stride, up2x=up, frames=frames)
+                        chunks = cin // 16
+                        assert 1 <= ks <= 16 and ks <= max(1, chunks // 2)
+                        assert ks == 1 or -(-chunks // ks) * (ks - 1) < chunks, "no empty chunk range"
+                        assert ks == kb.ops.ksplit_for(cin, oc, hw[0], hw[1], stride, up2x=up, frames=frames), "deterministic"
+    assert kb.ops.ksplit_for(768, 256, 22, 76) > 1 and kb.ops.ksplit_for(768, 256, 22, 76, frames=16) == 1
+    assert kb.ops.ksplit_for(128, 64, 176, 608) == 1, "a full-resolution layer fills the chip on its own"
+    m = kb.modules.KBNetModel.from_config(kb.kitti_config(), torch.device("cpu"))
+    d, e = m.decoder, m.encoder
+    blocks = ((d.deconv4, (11, 38)), (d.deconv3, (22, 76)), (d.deconv2, (44, 152)), (d.deconv1, (88, 304)))
+    levels = ((1, (176, 608)), (2, (88, 304)), (3, (44, 152)))
+    assert not any(b.latency_splitk(*hw) for b, hw in blocks) and not any(e._image_splitk(l, *hw) for l, hw in levels), "off by default"
+    m.set_latency_mode(True)
+    assert [b.latency_splitk(*hw) for b, hw in blocks] == [True, True, True, False]
+    assert [e._image_splitk(l, *hw) for l, hw in levels] == [False, True, True]
+    m.set_latency_mode(True, frames=4)
+    assert [b.latency_splitk(*hw) for b, hw in blocks] == [True, True, False, False]
+    assert [e._image_splitk(l, *hw) for l, hw in levels] == [False, False, True]
+    with pytest.raises(kb._lib.KbnError):
+        m.set_latency_mode(True, frames=0)
+    m.set_latency_mode(False)
+    assert not any(b.latency_splitk(*hw) for b, hw in blocks) and m.latency_mode == 0
+    assert all(getattr(c, "latency", 0) == 0 for top in m.modules() for c in top.modules())
