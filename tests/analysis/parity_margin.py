@@ -12,7 +12,7 @@ and the largest window slack of the forward's pair tensors (binades between the 
 from its BOUND and the maximum it then measured).  Two fp32 evaluation orders of a 35-conv network cannot agree better
 with each other than each agrees with the exact result: the fp64 columns are what discriminates.
 
-usage: parity_margin.py [--seeds N] [--trained] [--out FILE] [--presets kitti,void,nyu_v2] [--deconv-type transpose] [--activation elu]
+usage: parity_margin.py [--seeds N] [--trained] [--out FILE] [--presets kitti,void,nyu_v2] [--deconv-type transpose] [--activation elu] [--latency-frames 1]
 """
 import argparse
 import os
@@ -32,6 +32,7 @@ ap.add_argument("--out", default=None)
 ap.add_argument("--presets", default="kitti,void,nyu_v2")
 ap.add_argument("--deconv-type", default="up", help="run_kbnet.py --deconv_type (up | transpose)")
 ap.add_argument("--activation", default="leaky_relu", help="run_kbnet.py --activation_func (leaky_relu | relu | elu | sigmoid | linear)")
+ap.add_argument("--latency-frames", type=int, default=0, help="the shipped-path columns in the latency form: KBNetModel.set_latency_mode(True, frames=N)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -59,6 +60,8 @@ def hip_forward(cfg, sds, frames, no_split):
     try:
         m = kb.modules.KBNetModel.from_config(cfg, dev)
         m.load_state_dicts(*sds)
+        if args.latency_frames and not no_split:
+            m.set_latency_mode(True, frames=args.latency_frames)
         kb.ops.PairTensor.LOG = log = []
         out = m.forward(*[f.to(dev) for f in frames]).cpu()
         slack = max((float(t.window_slack_log2().max()) for t in log), default=float("nan"))
@@ -69,7 +72,7 @@ def hip_forward(cfg, sds, frames, no_split):
         kb.ops.reload_env()
 
 
-say(f"# parity margin: {args.seeds} seeds x presets {args.presets}; deconv_type {args.deconv_type}, activation {args.activation}; weights {'trained-like (t3 entries, 2^7 filter spread, 10 % dead)' if args.trained else 'xavier'}; "
+say(f"# parity margin: {args.seeds} seeds x presets {args.presets}; {'LATENCY FORM (frames = %d); ' % args.latency_frames if args.latency_frames else ''}deconv_type {args.deconv_type}, activation {args.activation}; weights {'trained-like (t3 entries, 2^7 filter spread, 10 % dead)' if args.trained else 'xavier'}; "
     f"device {torch.cuda.get_device_name(0)}; columns: max element-wise relative error of the depth map")
 say("# preset seed | hip_vs_oracle hip_vs_fp64 | nosplit_vs_oracle nosplit_vs_fp64 | oracle_vs_fp64 | max pair-window slack (binades), pair tensors")
 t_all = time.time()
